@@ -1,0 +1,141 @@
+"""ctypes binding of oracle/liboracle.so (TEST INFRASTRUCTURE ONLY - see oracle/oracle.c).
+
+Importable only from tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(_HERE, "liboracle.so")
+_U64P = C.POINTER(C.c_uint64)
+
+
+def build(force: bool = False) -> str:
+    src = os.path.join(_HERE, "oracle.c")
+    if force or not os.path.exists(_LIB) or os.path.getmtime(_LIB) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-s", "-C", _HERE, "-B", "liboracle.so"])
+    return _LIB
+
+
+def _load():
+    lib = C.CDLL(build())
+    lib.orc_ctx_create.argtypes = [C.POINTER(C.c_void_p), C.c_uint32, C.c_uint32, _U64P, _U64P]
+    lib.orc_ctx_create.restype = C.c_int
+    lib.orc_ctx_destroy.argtypes = [C.c_void_p]
+    lib.orc_get_root_powers.argtypes = [C.c_void_p, C.c_uint32, _U64P, _U64P]
+    lib.orc_schoolbook_negacyclic.argtypes = [_U64P, _U64P, _U64P, C.c_uint64, C.c_uint64]
+    lib.orc_max_threads.restype = C.c_int
+    lib.orc_ntt_fwd.argtypes = [C.c_void_p, _U64P, C.c_size_t, C.c_int]
+    lib.orc_ntt_inv.argtypes = [C.c_void_p, _U64P, C.c_size_t, C.c_int]
+    lib.orc_dyadic.argtypes = [C.c_void_p, C.c_int, _U64P, _U64P, _U64P, C.c_size_t, C.c_int]
+    lib.orc_ct_mul.argtypes = [C.c_void_p, _U64P, _U64P, _U64P, C.c_size_t, C.c_int]
+    lib.orc_ct_mul_schoolbook.argtypes = [C.c_void_p, _U64P, _U64P, _U64P, C.c_size_t, C.c_int]
+    lib.orc_matvec_plain.argtypes = [C.c_void_p, _U64P, _U64P, _U64P, C.c_size_t, C.c_size_t, C.c_size_t, C.c_int]
+    lib.orc_reduce_sum.argtypes = [C.c_void_p, _U64P, _U64P, C.c_size_t, C.c_size_t]
+    lib.orc_fill_splitmix.argtypes = [C.c_void_p, _U64P, C.c_size_t, C.c_uint64]
+    for f in ("orc_ctx_destroy", "orc_get_root_powers", "orc_schoolbook_negacyclic", "orc_ntt_fwd", "orc_ntt_inv",
+              "orc_dyadic", "orc_ct_mul", "orc_ct_mul_schoolbook", "orc_matvec_plain", "orc_reduce_sum", "orc_fill_splitmix"):
+        getattr(lib, f).restype = None
+    return lib
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        _lib = _load()
+    return _lib
+
+
+def _p(a: np.ndarray):
+    assert a.dtype == np.uint64 and a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(_U64P)
+
+
+class Oracle:
+    """CPU evaluator over numpy uint64 arrays laid out [batch][component][limb][N]."""
+
+    DYADIC = {"mul": 0, "mul_add": 1, "add": 2, "sub": 3, "negate": 4}
+
+    def __init__(self, log2_n: int, moduli, psi):
+        self.log2_n, self.n, self.L = log2_n, 1 << log2_n, len(moduli)
+        self.moduli, self.psi = tuple(int(q) for q in moduli), tuple(int(w) for w in psi)
+        m = (C.c_uint64 * self.L)(*self.moduli)
+        w = (C.c_uint64 * self.L)(*self.psi)
+        h = C.c_void_p()
+        rc = lib().orc_ctx_create(C.byref(h), log2_n, self.L, m, w)
+        if rc:
+            raise ValueError(f"orc_ctx_create failed rc={rc}")
+        self._h = h
+
+    @classmethod
+    def from_params(cls, p):
+        return cls(p.log2_n, p.moduli, p.psi)
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().orc_ctx_destroy(self._h)
+            self._h = None
+
+    def max_threads(self) -> int:
+        return lib().orc_max_threads()
+
+    def root_powers(self, limb: int):
+        rp, irp = np.empty(self.n, np.uint64), np.empty(self.n, np.uint64)
+        lib().orc_get_root_powers(self._h, limb, _p(rp), _p(irp))
+        return rp, irp
+
+    def schoolbook(self, a, b, q):
+        out = np.empty_like(a)
+        lib().orc_schoolbook_negacyclic(_p(out), _p(a), _p(b), a.size, int(q))
+        return out
+
+    def _npolys(self, a):
+        assert a.size % (self.L * self.n) == 0
+        return a.size // (self.L * self.n)
+
+    def ntt_fwd(self, a, threads=1):
+        out = np.ascontiguousarray(a).copy()
+        lib().orc_ntt_fwd(self._h, _p(out), self._npolys(out), threads)
+        return out
+
+    def ntt_inv(self, a, threads=1):
+        out = np.ascontiguousarray(a).copy()
+        lib().orc_ntt_inv(self._h, _p(out), self._npolys(out), threads)
+        return out
+
+    def dyadic(self, op, a, b=None, acc=None, threads=1):
+        out = np.empty_like(a) if acc is None else np.ascontiguousarray(acc).copy()
+        lib().orc_dyadic(self._h, self.DYADIC[op], _p(out), _p(a), _p(b) if b is not None else None, self._npolys(a), threads)
+        return out
+
+    def ct_mul(self, a2, b2, threads=1, schoolbook=False):
+        batch = a2.size // (2 * self.L * self.n)
+        out = np.empty(batch * 3 * self.L * self.n, np.uint64)
+        f = lib().orc_ct_mul_schoolbook if schoolbook else lib().orc_ct_mul
+        f(self._h, _p(out), _p(a2), _p(b2), batch, threads)
+        return out.reshape(batch, 3, self.L, self.n)
+
+    def matvec_plain(self, W, x, rows, cols, comps=2, threads=1):
+        y = np.empty(rows * comps * self.L * self.n, np.uint64)
+        lib().orc_matvec_plain(self._h, _p(y), _p(W), _p(x), rows, cols, comps, threads)
+        return y.reshape(rows, comps, self.L, self.n)
+
+    def reduce_sum(self, cts, comps):
+        words = comps * self.L * self.n
+        count = cts.size // words
+        out = np.empty(words, np.uint64)
+        lib().orc_reduce_sum(self._h, _p(out), _p(cts), count, comps)
+        return out.reshape(comps, self.L, self.n)
+
+    def fill(self, n_rns_polys: int, seed: int):
+        out = np.empty(n_rns_polys * self.L * self.n, np.uint64)
+        lib().orc_fill_splitmix(self._h, _p(out), n_rns_polys, seed)
+        return out.reshape(n_rns_polys, self.L, self.n)

@@ -1,0 +1,379 @@
+/*
+ * oracle.c - CPU restatement of the RLWE ciphertext-arithmetic hot path.  TEST INFRASTRUCTURE ONLY.
+ *
+ * PARITY UNPINNED BY THE REFERENCE.  deeppowers/deeppowers holds no FHE code to restate (SURVEY.md
+ * section 0: no NTT / modular arithmetic / Ciphertext / Evaluator anywhere under /root/reference;
+ * FHE is README prose only, /root/reference/README.md:42,93,197).  What this file follows instead:
+ *
+ *   (1) orc_schoolbook_negacyclic - the mathematical definition c = a*b in Z_q[X]/(X^N+1) with
+ *       canonical residues (unique answer; 128-bit accumulation).  This is the ground truth.
+ *   (2) the "build CPU evaluator" of BASELINE.md section 3: radix-2 Harvey lazy-reduction
+ *       negacyclic NTT / inverse NTT with Shoup twiddles (published algorithm: D. Harvey, "Faster
+ *       arithmetic for number-theoretic transforms", J. Symb. Comp. 2014; ordering convention of
+ *       SURVEY.md section 8(a) A1/A2), Barrett dyadic multiply, and the ct x ct tensor product
+ *       built from them.  It doubles as the timed CPU baseline (bench.py cpu_baseline, kind "port").
+ *
+ * It is pinned against oracle/pyoracle.py (Python big ints) and the known answers of SURVEY.md
+ * Appendix B in tests/test_oracle_*.py.  Only tests/, __graft_entry__.smoke() and bench.py's
+ * cpu_baseline leg may load the library built from this file; the product path never does.
+ *
+ * Layout everywhere: [batch][component][limb][N] little-endian u64 words, canonical residues.
+ */
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+typedef unsigned __int128 u128;
+
+typedef struct {
+    uint32_t log2n;
+    uint64_t n, q, psi;
+    uint64_t *rp, *rp_sh;   /* psi^brv(i),            floor(rp[i]  * 2^64 / q) */
+    uint64_t *irp, *irp_sh; /* psi^-brv(i),           Shoup companions         */
+    uint64_t ninv, ninv_sh; /* N^-1 mod q                                      */
+    uint64_t br_hi, br_lo;  /* floor(2^128 / q) as two words (Barrett)         */
+} orc_limb;
+
+typedef struct {
+    uint32_t log2n, n_limbs;
+    orc_limb* limb;
+} orc_ctx;
+
+/* ------------------------------------------------------------------ scalar modular arithmetic */
+static inline uint64_t mulmod_slow(uint64_t a, uint64_t b, uint64_t q) { return (uint64_t)((u128)a * b % q); }
+
+static uint64_t powmod(uint64_t b, uint64_t e, uint64_t q) {
+    uint64_t r = 1;
+    b %= q;
+    while (e) {
+        if (e & 1) r = mulmod_slow(r, b, q);
+        b = mulmod_slow(b, b, q);
+        e >>= 1;
+    }
+    return r;
+}
+
+static inline uint64_t shoup_of(uint64_t w, uint64_t q) { return (uint64_t)(((u128)w << 64) / q); }
+
+/* w*y mod q in [0, 2q) for any y < 2^64 (Harvey); w < q, wsh = floor(w*2^64/q) */
+static inline uint64_t mul_shoup_lazy(uint64_t y, uint64_t w, uint64_t wsh, uint64_t q) {
+    uint64_t hi = (uint64_t)(((u128)y * wsh) >> 64);
+    return y * w - hi * q;
+}
+
+/* Barrett reduction of a 128-bit value with the two-word ratio floor(2^128/q); out in [0,q) */
+static inline uint64_t barrett128(u128 z, const orc_limb* t) {
+    uint64_t z0 = (uint64_t)z, z1 = (uint64_t)(z >> 64);
+    /* floor(z * ratio / 2^128), dropping only the z0*br_lo low word (error <= 2 quotients) */
+    uint64_t carry = (uint64_t)(((u128)z0 * t->br_lo) >> 64);
+    u128 t1 = (u128)z0 * t->br_hi + carry;
+    u128 t2 = (u128)z1 * t->br_lo + (uint64_t)t1;
+    uint64_t qhat = z1 * t->br_hi + (uint64_t)(t1 >> 64) + (uint64_t)(t2 >> 64);
+    uint64_t r = z0 - qhat * t->q;
+    while (r >= t->q) r -= t->q;
+    return r;
+}
+
+static inline uint64_t mulmod_barrett(uint64_t a, uint64_t b, const orc_limb* t) { return barrett128((u128)a * b, t); }
+
+static uint32_t brv(uint32_t x, uint32_t bits) {
+    uint32_t r = 0;
+    for (uint32_t i = 0; i < bits; ++i) { r = (r << 1) | (x & 1); x >>= 1; }
+    return r;
+}
+
+/* ------------------------------------------------------------------ context */
+static int limb_init(orc_limb* t, uint32_t log2n, uint64_t q, uint64_t psi) {
+    uint64_t n = 1ull << log2n;
+    memset(t, 0, sizeof *t);
+    if (q < 3 || (q >> 62) || (q - 1) % (2 * n) != 0) return 2000;
+    if (psi == 0 || psi >= q || powmod(psi, n, q) != q - 1) return 2000;
+    t->log2n = log2n; t->n = n; t->q = q; t->psi = psi;
+    t->rp = malloc(4 * n * sizeof(uint64_t));
+    if (!t->rp) return 1001;
+    t->rp_sh = t->rp + n; t->irp = t->rp + 2 * n; t->irp_sh = t->rp + 3 * n;
+    uint64_t ipsi = powmod(psi, q - 2, q);
+    uint64_t pw = 1, ipw = 1;
+    for (uint64_t i = 0; i < n; ++i) { /* natural powers scattered to bit-reversed slots */
+        uint32_t r = brv((uint32_t)i, log2n);
+        t->rp[r] = pw;   t->rp_sh[r] = shoup_of(pw, q);
+        t->irp[r] = ipw; t->irp_sh[r] = shoup_of(ipw, q);
+        pw = mulmod_slow(pw, psi, q); ipw = mulmod_slow(ipw, ipsi, q);
+    }
+    t->ninv = powmod(n % q, q - 2, q);
+    t->ninv_sh = shoup_of(t->ninv, q);
+    u128 ratio = (~(u128)0) / q; /* floor((2^128-1)/q) == floor(2^128/q) since q is not a power of two */
+    t->br_hi = (uint64_t)(ratio >> 64); t->br_lo = (uint64_t)ratio;
+    return 0;
+}
+
+int orc_ctx_create(orc_ctx** out, uint32_t log2n, uint32_t n_limbs, const uint64_t* moduli, const uint64_t* psi) {
+    if (!out || !moduli || !psi || n_limbs == 0 || log2n < 1 || log2n > 20) return 2000;
+    orc_ctx* c = calloc(1, sizeof *c);
+    if (!c) return 1001;
+    c->log2n = log2n; c->n_limbs = n_limbs;
+    c->limb = calloc(n_limbs, sizeof(orc_limb));
+    if (!c->limb) { free(c); return 1001; }
+    for (uint32_t l = 0; l < n_limbs; ++l) {
+        int rc = limb_init(&c->limb[l], log2n, moduli[l], psi[l]);
+        if (rc) {
+            for (uint32_t k = 0; k <= l; ++k) free(c->limb[k].rp);
+            free(c->limb); free(c);
+            return rc;
+        }
+    }
+    *out = c;
+    return 0;
+}
+
+void orc_ctx_destroy(orc_ctx* c) {
+    if (!c) return;
+    for (uint32_t l = 0; l < c->n_limbs; ++l) free(c->limb[l].rp);
+    free(c->limb); free(c);
+}
+
+/* copies rp (forward table, psi^brv(i)) of one limb out - lets tests pin the table itself */
+void orc_get_root_powers(const orc_ctx* c, uint32_t limb, uint64_t* out_rp, uint64_t* out_irp) {
+    const orc_limb* t = &c->limb[limb];
+    if (out_rp) memcpy(out_rp, t->rp, t->n * sizeof(uint64_t));
+    if (out_irp) memcpy(out_irp, t->irp, t->n * sizeof(uint64_t));
+}
+
+/* ------------------------------------------------------------------ ground truth */
+void orc_schoolbook_negacyclic(uint64_t* out, const uint64_t* a, const uint64_t* b, uint64_t n, uint64_t q) {
+    /* positive (i+j = k) and negative (i+j = k+N, X^N = -1) parts accumulated separately in 128 bits;
+     * `lim` raw products (each < q^2) fit a u128 next to an already reduced value, then we fold mod q. */
+    int bits = 64 - __builtin_clzll(q);
+    int sh = 127 - 2 * bits;
+    uint64_t lim = sh <= 0 ? 1 : (sh > 20 ? (1ull << 20) : (1ull << sh));
+    for (uint64_t k = 0; k < n; ++k) {
+        u128 pos = 0, neg = 0;
+        uint64_t cnt = 0;
+        for (uint64_t i = 0; i <= k; ++i) {
+            pos += (u128)a[i] * b[k - i];
+            if (++cnt == lim) { pos %= q; cnt = 0; }
+        }
+        cnt = 0;
+        for (uint64_t i = k + 1; i < n; ++i) {
+            neg += (u128)a[i] * b[n + k - i];
+            if (++cnt == lim) { neg %= q; cnt = 0; }
+        }
+        uint64_t p = (uint64_t)(pos % q), m = (uint64_t)(neg % q);
+        out[k] = p >= m ? p - m : p + q - m;
+    }
+}
+
+/* ------------------------------------------------------------------ Harvey NTT (one residue polynomial) */
+static void ntt_fwd_poly(const orc_limb* T, uint64_t* a) {
+    const uint64_t q = T->q, two_q = 2 * q, n = T->n;
+    uint64_t t = n;
+    for (uint64_t m = 1; m < n; m <<= 1) {
+        t >>= 1;
+        for (uint64_t i = 0; i < m; ++i) {
+            const uint64_t w = T->rp[m + i], wsh = T->rp_sh[m + i];
+            uint64_t* x = a + 2 * i * t;
+            uint64_t* y = x + t;
+            for (uint64_t j = 0; j < t; ++j) {
+                uint64_t u = x[j];                  /* [0,4q) */
+                u -= (u >= two_q) ? two_q : 0;      /* [0,2q) */
+                uint64_t v = mul_shoup_lazy(y[j], w, wsh, q); /* [0,2q) */
+                x[j] = u + v;                       /* [0,4q) */
+                y[j] = u - v + two_q;               /* [0,4q) */
+            }
+        }
+    }
+    for (uint64_t j = 0; j < n; ++j) {
+        uint64_t u = a[j];
+        u -= (u >= two_q) ? two_q : 0;
+        u -= (u >= q) ? q : 0;
+        a[j] = u;
+    }
+}
+
+static void ntt_inv_poly(const orc_limb* T, uint64_t* a) {
+    const uint64_t q = T->q, two_q = 2 * q, n = T->n;
+    uint64_t t = 1;
+    for (uint64_t m = n; m > 1; m >>= 1) {
+        const uint64_t h = m >> 1;
+        uint64_t* x = a;
+        for (uint64_t i = 0; i < h; ++i, x += 2 * t) {
+            const uint64_t w = T->irp[h + i], wsh = T->irp_sh[h + i];
+            uint64_t* y = x + t;
+            for (uint64_t j = 0; j < t; ++j) {
+                uint64_t u = x[j], v = y[j];        /* both [0,2q) */
+                uint64_t s = u + v;                 /* [0,4q) */
+                s -= (s >= two_q) ? two_q : 0;
+                x[j] = s;                           /* [0,2q) */
+                y[j] = mul_shoup_lazy(u - v + two_q, w, wsh, q); /* [0,2q) */
+            }
+        }
+        t <<= 1;
+    }
+    for (uint64_t j = 0; j < n; ++j) {
+        uint64_t u = mul_shoup_lazy(a[j], T->ninv, T->ninv_sh, q);
+        a[j] = u - ((u >= q) ? q : 0);
+    }
+}
+
+/* ------------------------------------------------------------------ batched public entry points */
+static int clamp_threads(int threads) {
+#ifdef _OPENMP
+    int mx = omp_get_max_threads();
+    if (threads <= 0 || threads > mx) threads = mx;
+    return threads;
+#else
+    (void)threads;
+    return 1;
+#endif
+}
+
+int orc_max_threads(void) { return clamp_threads(0); }
+
+void orc_ntt_fwd(const orc_ctx* c, uint64_t* io, size_t n_rns_polys, int threads) {
+    const size_t n = 1ull << c->log2n, L = c->n_limbs;
+    threads = clamp_threads(threads);
+#pragma omp parallel for num_threads(threads) schedule(static)
+    for (long long p = 0; p < (long long)(n_rns_polys * L); ++p) ntt_fwd_poly(&c->limb[p % L], io + (size_t)p * n);
+}
+
+void orc_ntt_inv(const orc_ctx* c, uint64_t* io, size_t n_rns_polys, int threads) {
+    const size_t n = 1ull << c->log2n, L = c->n_limbs;
+    threads = clamp_threads(threads);
+#pragma omp parallel for num_threads(threads) schedule(static)
+    for (long long p = 0; p < (long long)(n_rns_polys * L); ++p) ntt_inv_poly(&c->limb[p % L], io + (size_t)p * n);
+}
+
+/* op: 0 mul, 1 mul_add (out += a*b), 2 add, 3 sub, 4 negate (b ignored) */
+void orc_dyadic(const orc_ctx* c, int op, uint64_t* out, const uint64_t* a, const uint64_t* b, size_t n_rns_polys, int threads) {
+    const size_t n = 1ull << c->log2n, L = c->n_limbs;
+    threads = clamp_threads(threads);
+#pragma omp parallel for num_threads(threads) schedule(static)
+    for (long long p = 0; p < (long long)(n_rns_polys * L); ++p) {
+        const orc_limb* T = &c->limb[p % L];
+        const uint64_t q = T->q;
+        const size_t o = (size_t)p * n;
+        for (size_t j = 0; j < n; ++j) {
+            uint64_t x = a[o + j], y = b ? b[o + j] : 0, r;
+            switch (op) {
+                case 0: r = mulmod_barrett(x, y, T); break;
+                case 1: r = mulmod_barrett(x, y, T) + out[o + j]; r -= (r >= q) ? q : 0; break;
+                case 2: r = x + y; r -= (r >= q) ? q : 0; break;
+                case 3: r = x >= y ? x - y : x + q - y; break;
+                default: r = x ? q - x : 0; break;
+            }
+            out[o + j] = r;
+        }
+    }
+}
+
+/* ct x ct, coefficient domain in/out, through the NTT path.  a2,b2: [batch][2][L][N]; out3: [batch][3][L][N] */
+void orc_ct_mul(const orc_ctx* c, uint64_t* out3, const uint64_t* a2, const uint64_t* b2, size_t batch, int threads) {
+    const size_t n = 1ull << c->log2n, L = c->n_limbs;
+    threads = clamp_threads(threads);
+#pragma omp parallel num_threads(threads)
+    {
+        uint64_t* w = malloc(4 * n * sizeof(uint64_t));
+#pragma omp for schedule(static)
+        for (long long it = 0; it < (long long)(batch * L); ++it) {
+            const size_t bi = (size_t)it / L, l = (size_t)it % L;
+            const orc_limb* T = &c->limb[l];
+            const uint64_t q = T->q;
+            uint64_t *A0 = w, *A1 = w + n, *B0 = w + 2 * n, *B1 = w + 3 * n;
+            memcpy(A0, a2 + ((bi * 2 + 0) * L + l) * n, n * 8);
+            memcpy(A1, a2 + ((bi * 2 + 1) * L + l) * n, n * 8);
+            memcpy(B0, b2 + ((bi * 2 + 0) * L + l) * n, n * 8);
+            memcpy(B1, b2 + ((bi * 2 + 1) * L + l) * n, n * 8);
+            ntt_fwd_poly(T, A0); ntt_fwd_poly(T, A1); ntt_fwd_poly(T, B0); ntt_fwd_poly(T, B1);
+            uint64_t* c0 = out3 + ((bi * 3 + 0) * L + l) * n;
+            uint64_t* c1 = out3 + ((bi * 3 + 1) * L + l) * n;
+            uint64_t* c2 = out3 + ((bi * 3 + 2) * L + l) * n;
+            for (size_t j = 0; j < n; ++j) {
+                c0[j] = mulmod_barrett(A0[j], B0[j], T);
+                uint64_t s = mulmod_barrett(A0[j], B1[j], T) + mulmod_barrett(A1[j], B0[j], T);
+                c1[j] = s - ((s >= q) ? q : 0);
+                c2[j] = mulmod_barrett(A1[j], B1[j], T);
+            }
+            ntt_inv_poly(T, c0); ntt_inv_poly(T, c1); ntt_inv_poly(T, c2);
+        }
+        free(w);
+    }
+}
+
+/* same tensor product by schoolbook convolution (ground truth; O(N^2), small sizes only) */
+void orc_ct_mul_schoolbook(const orc_ctx* c, uint64_t* out3, const uint64_t* a2, const uint64_t* b2, size_t batch, int threads) {
+    const size_t n = 1ull << c->log2n, L = c->n_limbs;
+    threads = clamp_threads(threads);
+#pragma omp parallel num_threads(threads)
+    {
+        uint64_t* w = malloc(n * sizeof(uint64_t));
+#pragma omp for schedule(static)
+        for (long long it = 0; it < (long long)(batch * L); ++it) {
+            const size_t bi = (size_t)it / L, l = (size_t)it % L;
+            const uint64_t q = c->limb[l].q;
+            const uint64_t* a0 = a2 + ((bi * 2 + 0) * L + l) * n;
+            const uint64_t* a1 = a2 + ((bi * 2 + 1) * L + l) * n;
+            const uint64_t* b0 = b2 + ((bi * 2 + 0) * L + l) * n;
+            const uint64_t* b1 = b2 + ((bi * 2 + 1) * L + l) * n;
+            uint64_t* c0 = out3 + ((bi * 3 + 0) * L + l) * n;
+            uint64_t* c1 = out3 + ((bi * 3 + 1) * L + l) * n;
+            uint64_t* c2 = out3 + ((bi * 3 + 2) * L + l) * n;
+            orc_schoolbook_negacyclic(c0, a0, b0, n, q);
+            orc_schoolbook_negacyclic(c1, a0, b1, n, q);
+            orc_schoolbook_negacyclic(w, a1, b0, n, q);
+            for (size_t j = 0; j < n; ++j) { uint64_t s = c1[j] + w[j]; c1[j] = s - ((s >= q) ? q : 0); }
+            orc_schoolbook_negacyclic(c2, a1, b1, n, q);
+        }
+        free(w);
+    }
+}
+
+/* y[rows][comps][L][N] = sum_j W[rows][cols][L][N] (.) x[cols][comps][L][N]   (all NTT domain) */
+void orc_matvec_plain(const orc_ctx* c, uint64_t* y, const uint64_t* W, const uint64_t* x, size_t rows, size_t cols, size_t comps, int threads) {
+    const size_t n = 1ull << c->log2n, L = c->n_limbs;
+    threads = clamp_threads(threads);
+#pragma omp parallel for num_threads(threads) schedule(static)
+    for (long long it = 0; it < (long long)(rows * comps * L); ++it) {
+        const size_t i = (size_t)it / (comps * L), cc = ((size_t)it / L) % comps, l = (size_t)it % L;
+        const orc_limb* T = &c->limb[l];
+        uint64_t* yo = y + ((i * comps + cc) * L + l) * n;
+        for (size_t k = 0; k < n; ++k) {
+            uint64_t acc = 0;
+            for (size_t j = 0; j < cols; ++j) {
+                uint64_t p = mulmod_barrett(W[((i * cols + j) * L + l) * n + k], x[((j * comps + cc) * L + l) * n + k], T);
+                acc += p; acc -= (acc >= T->q) ? T->q : 0;
+            }
+            yo[k] = acc;
+        }
+    }
+}
+
+/* sum of `count` ciphertexts of `comps` components into one (A8 local_reduce) */
+void orc_reduce_sum(const orc_ctx* c, uint64_t* out, const uint64_t* in, size_t count, size_t comps) {
+    const size_t n = 1ull << c->log2n, L = c->n_limbs, words = comps * L * n;
+    for (size_t w = 0; w < words; ++w) {
+        const uint64_t q = c->limb[(w / n) % L].q;
+        uint64_t acc = 0;
+        for (size_t i = 0; i < count; ++i) { acc += in[i * words + w]; acc -= (acc >= q) ? q : 0; }
+        out[w] = acc;
+    }
+}
+
+/* splitmix64 stream of words uniform-ish in [0, q_limb): layout [n_rns_polys][L][N] (SURVEY.md App. B generator) */
+void orc_fill_splitmix(const orc_ctx* c, uint64_t* out, size_t n_rns_polys, uint64_t seed) {
+    const size_t n = 1ull << c->log2n, L = c->n_limbs;
+    uint64_t s = seed;
+    for (size_t p = 0; p < n_rns_polys * L; ++p) {
+        const uint64_t q = c->limb[p % L].q;
+        for (size_t j = 0; j < n; ++j) {
+            s += 0x9E3779B97F4A7C15ull;
+            uint64_t z = s;
+            z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+            z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+            z ^= z >> 31;
+            out[p * n + j] = z % q;
+        }
+    }
+}
