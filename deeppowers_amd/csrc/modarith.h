@@ -1,0 +1,122 @@
+// modarith.h - 64-bit modular arithmetic for the RLWE hot path (host + gfx950 device).
+//
+// No reference counterpart: deeppowers/deeppowers has no modular arithmetic (SURVEY.md section 0;
+// its widest integer type is INT32, /root/reference/src/core/hal/hal.hpp:27-33).  Two policies:
+//
+//   ShoupArith - any prime q < 2^60.  Harvey lazy butterflies with Shoup companions
+//                (w' = floor(w 2^64 / q)):  10 32x32 multiplies per butterfly.
+//   FoldArith  - primes just below 2^60, q = 2^60 - d with d < 2^24 (every prime of SURVEY.md
+//                Appendix A has d < 2^20).  2^60 = d (mod q), so a 124-bit product is folded with
+//                three small multiplies instead of a quotient estimate:  7 multiplies per
+//                butterfly, no companion table, and a 3-instruction partial reduction that lets
+//                butterflies run without per-stage corrections (static bound plans in ntt_core.h).
+//
+// Everything is written on 32-bit halves through mad32(a,b,c) = a*b + c, which is exactly one
+// v_mad_u64_u32 on gfx950 (there is no 64x64 vector multiply on CDNA4).
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define DPF_HD __host__ __device__ __forceinline__
+#else
+#define DPF_HD inline __attribute__((always_inline))
+#endif
+
+namespace dpfhe {
+
+typedef uint64_t u64;
+typedef uint32_t u32;
+
+struct LimbConst {  // one per RNS limb, read through scalar loads (limb index is workgroup-uniform)
+    u64 q;
+    u64 d;          // 2^60 - q (FoldArith only; 0 when not applicable)
+    u64 ninv;       // N^-1 mod q
+    u64 ninv_sh;    // floor(ninv 2^64 / q)
+    u64 br_hi;      // floor(2^128 / q), high word   (generic Barrett)
+    u64 br_lo;      //                   low word
+    u64 pad0, pad1;
+};
+
+DPF_HD u64 mad32(u32 a, u32 b, u64 c) { return (u64)a * b + c; }
+
+DPF_HD u64 mulhi64(u64 a, u64 b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __umul64hi(a, b);
+#else
+    return (u64)(((unsigned __int128)a * b) >> 64);
+#endif
+}
+
+// x >= m ? x - m : x
+DPF_HD u64 csub(u64 x, u64 m) {
+    u64 t = x - m;
+    return x >= m ? t : x;
+}
+
+// -------------------------------------------------------------------------------------------------
+struct alignas(16) TwShoup {
+    u64 w, wsh;
+};
+struct TwFold {
+    u64 w;
+};
+
+struct ShoupArith {
+    typedef TwShoup Tw;
+    static constexpr bool kFold = false;
+    // w*y mod q, result in [0, 2q), for ANY y < 2^64 (w < q, wsh = floor(w 2^64/q))
+    static DPF_HD u64 mul_tw(u64 y, const Tw& t, const LimbConst& c) {
+        u64 hi = mulhi64(y, t.wsh);
+        return y * t.w - hi * c.q;
+    }
+    // a*b mod q, canonical, a,b < 2^64 with a*b < 2^124 (generic 128-bit Barrett, ratio = floor(2^128/q))
+    static DPF_HD u64 mul_var(u64 a, u64 b, const LimbConst& c) {
+        u64 z0 = a * b, z1 = mulhi64(a, b);
+        u64 carry = mulhi64(z0, c.br_lo);
+        u64 t1lo = z0 * c.br_hi, t1hi = mulhi64(z0, c.br_hi);
+        u64 s = t1lo + carry;
+        t1hi += (s < t1lo);
+        u64 t2lo = z1 * c.br_lo, t2hi = mulhi64(z1, c.br_lo);
+        u64 s2 = t2lo + s;
+        t2hi += (s2 < t2lo);
+        u64 qhat = z1 * c.br_hi + t1hi + t2hi;
+        u64 r = z0 - qhat * c.q;
+        r = csub(r, 2 * c.q);
+        return csub(r, c.q);
+    }
+};
+
+struct FoldArith {
+    typedef TwFold Tw;
+    static constexpr bool kFold = true;
+    // y*w mod q for y < 2^64, w < 2^60; result < 2^60 + 2^53 (< 2q), typically < q + 2^45
+    static DPF_HD u64 mul60(u64 y, u64 w, u32 d) {
+        const u32 y0 = (u32)y, y1 = (u32)(y >> 32), w0 = (u32)w, w1 = (u32)(w >> 32);
+        u64 p = mad32(y0, w0, 0);
+        u64 m = mad32(y0, w1, p >> 32);
+        u64 n = mad32(y1, w0, (u32)m);
+        u64 r = mad32(y1, w1, (n >> 32) + (m >> 32));  // P = [p.lo, n.lo, r.lo, r.hi] < 2^124
+        u64 xl = (u64)(u32)p | ((u64)((u32)n & 0x0fffffffu) << 32);
+        u64 xh = (r << 4) | ((u32)n >> 28);            // P >> 60
+        u64 A = mad32((u32)xh, d, xl);
+        u64 B = mad32((u32)(xh >> 32), d, A >> 32);    // R = xl + xh*d = [A.lo, B.lo, B.hi] < 2^89
+        u32 yh = (u32)(B >> 28);                       // R >> 60
+        u64 yl = (u64)(u32)A | ((u64)((u32)B & 0x0fffffffu) << 32);
+        return mad32(yh, d, yl);
+    }
+    static DPF_HD u64 mul_tw(u64 y, const Tw& t, const LimbConst& c) { return mul60(y, t.w, (u32)c.d); }
+    // any x < 2^64  ->  x mod q representative < 2^60 + 16 d
+    static DPF_HD u64 reduce(u64 x, const LimbConst& c) {
+        return mad32((u32)(x >> 60), (u32)c.d, x & 0x0fffffffffffffffull);
+    }
+    static DPF_HD u64 canon(u64 x, const LimbConst& c) { return csub(reduce(x, c), c.q); }
+    // a*b mod q, canonical; a < 2^64, b < 2^60
+    static DPF_HD u64 mul_var(u64 a, u64 b, const LimbConst& c) { return csub(mul60(a, b, (u32)c.d), c.q); }
+};
+
+// canonical add / sub / negate (inputs canonical)
+DPF_HD u64 add_mod(u64 a, u64 b, u64 q) { return csub(a + b, q); }
+DPF_HD u64 sub_mod(u64 a, u64 b, u64 q) { return a >= b ? a - b : a + q - b; }
+DPF_HD u64 neg_mod(u64 a, u64 q) { return a ? q - a : 0; }
+
+}  // namespace dpfhe

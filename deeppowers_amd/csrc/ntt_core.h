@@ -1,0 +1,332 @@
+// ntt_core.h - the register/LDS-tiled negacyclic NTT of one residue polynomial (host + device).
+//
+// SURVEY.md section 8(a) rows A1/A2 (no reference counterpart - section 0).  One workgroup owns one
+// residue polynomial.  Each of T = N/E threads holds E = 2^LOGE coefficients in registers and runs
+// up to LOGE radix-2 stages per "phase" without touching memory; between phases the polynomial is
+// re-tiled through one padded LDS buffer.  N=4096: E=16, 256 threads, phases of 4+4+4 stages, two
+// LDS round trips, one HBM read and one HBM write in total.
+//
+// The forward transform is Cooley-Tukey (natural in -> bit-reversed out), the inverse is
+// Gentleman-Sande (bit-reversed in -> natural out, N^-1 folded into the last stage); the inverse
+// walks the same phase list backwards, so the forward OUTPUT register mapping equals the inverse
+// INPUT mapping and a fused ct x ct multiply never leaves registers between them.
+//
+// Every function takes `tid` explicitly and LDS as a plain pointer, so tools/emulate.cpp can run
+// the very same code thread-by-thread on the CPU and compare with the oracle.
+#pragma once
+#include "modarith.h"
+
+namespace dpfhe {
+
+// tools/emulate.cpp defines DPFHE_EMU_CHECK to count 64-bit wrap-arounds in the lazy arithmetic
+#if defined(DPFHE_EMU_CHECK) && !defined(__HIPCC__)
+extern long g_emu_overflows;
+inline u64 chk_add(u64 a, u64 b) { if ((unsigned __int128)a + b >> 64) ++g_emu_overflows; return a + b; }
+inline u64 chk_sub_add(u64 a, u64 b, u64 off) {  // a - b + off must stay in [0, 2^64)
+    __int128 v = (__int128)a - (__int128)b + (__int128)off;
+    if (v < 0 || (v >> 64)) ++g_emu_overflows;
+    return a - b + off;
+}
+#else
+DPF_HD u64 chk_add(u64 a, u64 b) { return a + b; }
+DPF_HD u64 chk_sub_add(u64 a, u64 b, u64 off) { return a - b + off; }
+#endif
+
+// ------------------------------------------------------------------------------------------------
+// geometry
+// ------------------------------------------------------------------------------------------------
+struct Phase {
+    int c;   // window start: the thread-local index k occupies bits [c, c+LOGE) of the coefficient index
+    int b;   // butterfly bits of this phase are [b, b+r)  (a sub-range of the window)
+    int r;   // number of radix-2 stages
+};
+
+template <int LOGN_, int LOGE_>
+struct Geo {
+    static constexpr int LOGN = LOGN_, LOGE = LOGE_;
+    static constexpr int N = 1 << LOGN, E = 1 << LOGE, T = N / E;
+    static constexpr int NPH = (LOGN + LOGE - 1) / LOGE;
+    static_assert(LOGN >= LOGE && LOGE >= 1, "bad geometry");
+
+    // forward phase p handles bits [b, b+r) going DOWN from the top; balanced split of LOGN
+    static constexpr Phase phase(int p) {
+        int rem = LOGN, top = LOGN, r = 0;
+        for (int i = 0; i <= p; ++i) {
+            int left = NPH - i;
+            r = (rem + left - 1) / left;
+            top = rem;
+            rem -= r;
+        }
+        int b = top - r;
+        int c = b < (LOGN - LOGE) ? b : (LOGN - LOGE);
+        return Phase{c, b, r};
+    }
+    // coefficient index of local element k of thread tid in a phase with window start c
+    static DPF_HD int index(int c, int tid, int k) {
+        return ((tid >> c) << (c + LOGE)) | (k << c) | (tid & ((1 << c) - 1));
+    }
+    // LDS padding of the exchange between windows clo < chi.  Bijective for any choice (monotone);
+    // chosen so that both access patterns of the N=4096 / N=8192 kernels are bank-conflict free:
+    //  * window 0 side: a thread touches E consecutive words with 16-byte accesses; a lane stride of
+    //    E+2 words spreads a ds_read/write_b128 lane group over all 16-byte slots;
+    //  * window chi side: lanes are 2^chi-word runs at a 2^(chi+LOGE)-word stride; +16 words per
+    //    stride puts the two runs of a 32-lane ds_read_b64 group on opposite halves of the bank row.
+    template <int CLO, int CHI, bool FWD>
+    static DPF_HD int lds_addr(int j) {
+        int a = j;
+        if (CLO == 0) a += (j >> LOGE) << 1;
+        if (CLO != 0 || !FWD) a += (j >> (CHI + LOGE)) << 4;
+        return a;
+    }
+    static constexpr int lds_words() {  // largest padded address over all exchanges (+ slack)
+        int mx = N;
+        for (int p = 0; p + 1 < NPH; ++p) {
+            const int chi = phase(p).c, clo = phase(p + 1).c;
+            int a = N - 1;
+            if (clo == 0) a += ((N - 1) >> LOGE) << 1;
+            a += ((N - 1) >> (chi + LOGE)) << 4;
+            if (a + 1 > mx) mx = a + 1;
+        }
+        return (mx + 15) & ~15;
+    }
+};
+
+// twiddle table index of the butterfly whose lower element is local k, at global bit position `pos`
+// (distance 2^pos): table[(N >> (pos+1)) + (j >> (pos+1))], split into thread part + constant part.
+template <class G>
+DPF_HD int tw_index(int c, int th /* = tid >> c */, int k, int pos) {
+    const int lb = pos - c;
+    return (1 << (G::LOGN - 1 - pos)) + (th << (G::LOGE - 1 - lb)) + (k >> (lb + 1));
+}
+// tid >> c, forced to the constant 0 for the top window (all its twiddles are workgroup-uniform and
+// are fetched with scalar loads)
+template <class G>
+DPF_HD int tid_high(int c, int tid) { return (c + G::LOGE >= G::LOGN) ? 0 : (tid >> c); }
+
+// ------------------------------------------------------------------------------------------------
+// static bound plans (FoldArith).  Bounds are in units of q/1024.  A value with bound B is < B q/1024.
+// All data words stay below 2^64 > 16 q.
+// ------------------------------------------------------------------------------------------------
+constexpr int kUnit = 1024;
+constexpr int kMulB = kUnit + 9;    // mul60 output  < q + 2^53           (q > 2^59.99)
+constexpr int kRedB = kUnit + 1;    // reduce output < 2^60 + 16d
+constexpr int kLimit = 16 * kUnit;  // 16 q < 2^64
+
+template <int LOGE>
+struct GsPlan {  // one Gentleman-Sande phase on E local elements, up to LOGE stages
+    bool red[LOGE][1 << LOGE];   // reduce element k before stage u
+    int off[LOGE][1 << LOGE];    // butterfly with lower element k at stage u: y' = (x - y + off q) w
+    bool red_end[1 << LOGE];     // reduce element k after the last stage (normalise to <= out bound)
+    int out_bound;
+};
+
+// lb0 = local bit of the first stage, r stages (local bits ascending), every input < in_bound
+template <int LOGE>
+constexpr GsPlan<LOGE> make_gs_plan(int lb0, int r, int in_bound, int out_bound, bool last_all_mul) {
+    GsPlan<LOGE> p{};
+    constexpr int E = 1 << LOGE;
+    int bnd[E] = {};
+    for (int k = 0; k < E; ++k) bnd[k] = in_bound;
+    for (int u = 0; u < r; ++u) {
+        const int bit = 1 << (lb0 + u);
+        for (int k = 0; k < E; ++k) {
+            if (k & bit) continue;
+            int bx = bnd[k], by = bnd[k | bit];
+            int offq = (by + kUnit - 1) / kUnit;
+            if (bx + by > kLimit || bx + offq * kUnit > kLimit) {
+                if (bx > kRedB) { p.red[u][k] = true; bx = kRedB; }
+                if (by > kRedB) { p.red[u][k | bit] = true; by = kRedB; }
+                offq = (by + kUnit - 1) / kUnit;
+            }
+            p.off[u][k] = offq;
+            const bool final_stage = last_all_mul && (u == r - 1);
+            bnd[k] = final_stage ? kMulB : bx + by;   // last inverse stage multiplies x' by N^-1 too
+            bnd[k | bit] = kMulB;
+        }
+    }
+    for (int k = 0; k < E; ++k) {
+        p.red_end[k] = bnd[k] > out_bound;
+        if (p.red_end[k]) bnd[k] = kRedB;
+    }
+    p.out_bound = out_bound;
+    return p;
+}
+
+struct CtPlan {  // Cooley-Tukey: bounds are uniform over the polynomial, one flag per global stage
+    bool red[32];
+    int out_bound;
+};
+constexpr CtPlan make_ct_plan(int logn, int in_bound) {
+    CtPlan p{};
+    int b = in_bound;
+    for (int s = 0; s < logn; ++s) {
+        if (b + 2 * kUnit > kLimit) { p.red[s] = true; b = kRedB; }
+        b += 2 * kUnit;   // x' = x + t, y' = x - t + 2q with t < 2q
+    }
+    p.out_bound = b;
+    return p;
+}
+
+// ------------------------------------------------------------------------------------------------
+// per-thread transform body
+// ------------------------------------------------------------------------------------------------
+template <class Arith, int LOGN, int LOGE>
+struct NttBody {
+    typedef Geo<LOGN, LOGE> G;
+    typedef typename Arith::Tw Tw;
+    static constexpr int E = G::E, T = G::T, NPH = G::NPH;
+
+    // ---------------- global <-> registers ----------------
+    // window-top mapping (forward input / inverse output): word j = k*T + tid, 8 B per lane, coalesced
+    static DPF_HD void load_top(int tid, u64 (&x)[E], const u64* g) {
+#pragma unroll
+        for (int k = 0; k < E; ++k) x[k] = g[k * T + tid];
+    }
+    static DPF_HD void store_top(int tid, const u64 (&x)[E], u64* g) {
+#pragma unroll
+        for (int k = 0; k < E; ++k) g[k * T + tid] = x[k];
+    }
+    // window-0 mapping (forward output / inverse input): thread owns words [tid*E, tid*E + E)
+    struct alignas(16) V2 {
+        u64 a, b;
+    };
+    static DPF_HD void load_bot(int tid, u64 (&x)[E], const u64* g) {
+        const V2* p = reinterpret_cast<const V2*>(g + tid * E);
+#pragma unroll
+        for (int k = 0; k < E / 2; ++k) { V2 v = p[k]; x[2 * k] = v.a; x[2 * k + 1] = v.b; }
+    }
+    static DPF_HD void store_bot(int tid, const u64 (&x)[E], u64* g) {
+        V2* p = reinterpret_cast<V2*>(g + tid * E);
+#pragma unroll
+        for (int k = 0; k < E / 2; ++k) p[k] = V2{x[2 * k], x[2 * k + 1]};
+    }
+
+    // ---------------- LDS exchange between forward phases P and P+1 ----------------
+    // side = the phase whose register mapping is used for this access
+    template <int P, int SIDE, bool FWD>
+    static DPF_HD int xaddr(int tid, int k) {
+        constexpr int chi = G::phase(P).c, clo = G::phase(P + 1).c;
+        constexpr int c = (SIDE == P) ? chi : clo;
+        return G::template lds_addr<clo, chi, FWD>(G::index(c, tid, k));
+    }
+    template <int P, int SIDE, bool FWD>
+    static DPF_HD void lds_write(int tid, const u64 (&x)[E], u64* lds) {
+        constexpr int c = G::phase(SIDE).c;
+        if (c == 0) {
+            V2* p = reinterpret_cast<V2*>(lds + xaddr<P, SIDE, FWD>(tid, 0));
+#pragma unroll
+            for (int k = 0; k < E / 2; ++k) p[k] = V2{x[2 * k], x[2 * k + 1]};
+        } else {
+#pragma unroll
+            for (int k = 0; k < E; ++k) lds[xaddr<P, SIDE, FWD>(tid, k)] = x[k];
+        }
+    }
+    template <int P, int SIDE, bool FWD>
+    static DPF_HD void lds_read(int tid, u64 (&x)[E], const u64* lds) {
+        constexpr int c = G::phase(SIDE).c;
+        if (c == 0) {
+            const V2* p = reinterpret_cast<const V2*>(lds + xaddr<P, SIDE, FWD>(tid, 0));
+#pragma unroll
+            for (int k = 0; k < E / 2; ++k) { V2 v = p[k]; x[2 * k] = v.a; x[2 * k + 1] = v.b; }
+        } else {
+#pragma unroll
+            for (int k = 0; k < E; ++k) x[k] = lds[xaddr<P, SIDE, FWD>(tid, k)];
+        }
+    }
+
+    // ---------------- forward (Cooley-Tukey) phase ----------------
+    template <int P>
+    static DPF_HD void fwd_phase(int tid, u64 (&x)[E], const Tw* tw, const LimbConst& lc) {
+        constexpr Phase ph = G::phase(P);
+        constexpr CtPlan kCt = make_ct_plan(LOGN, kUnit);  // canonical input
+        const u64 two_q = 2 * lc.q;
+        const int th = tid_high<G>(ph.c, tid);
+#pragma unroll
+        for (int u = 0; u < ph.r; ++u) {
+            const int pos = ph.b + ph.r - 1 - u;        // bit position = distance exponent
+            const int sigma = LOGN - 1 - pos;           // global stage number
+            const int lb = pos - ph.c;
+            if (Arith::kFold && kCt.red[sigma]) {
+#pragma unroll
+                for (int k = 0; k < E; ++k)
+                    if (!(k & (1 << lb))) x[k] = FoldArith::reduce(x[k], lc);
+            }
+#pragma unroll
+            for (int k = 0; k < E; ++k) {
+                if (k & (1 << lb)) continue;
+                const Tw w = tw[tw_index<G>(ph.c, th, k, pos)];
+                u64 a = x[k];
+                if (!Arith::kFold) a = csub(a, two_q);  // Harvey: [0,4q) -> [0,2q)
+                const u64 t = Arith::mul_tw(x[k | (1 << lb)], w, lc);
+                x[k] = chk_add(a, t);
+                x[k | (1 << lb)] = chk_sub_add(a, t, two_q);
+            }
+        }
+    }
+    // forward output -> canonical residues
+    static DPF_HD void fwd_canon(u64 (&x)[E], const LimbConst& lc) {
+#pragma unroll
+        for (int k = 0; k < E; ++k) {
+            if (Arith::kFold) x[k] = FoldArith::canon(x[k], lc);
+            else x[k] = csub(csub(x[k], 2 * lc.q), lc.q);
+        }
+    }
+
+    // ---------------- inverse (Gentleman-Sande) phase; forward phase list walked backwards -------
+    // IN = static bound of every input word of the whole inverse transform (units of q/1024)
+    static constexpr int kGsMid = 2 * kMulB;  // uniform bound re-established at every phase boundary
+    template <int P, int IN>
+    static constexpr GsPlan<LOGE> gs_plan() {
+        constexpr Phase ph = G::phase(P);
+        return make_gs_plan<LOGE>(ph.b - ph.c, ph.r, (P == NPH - 1) ? IN : kGsMid, (P == 0) ? kLimit : kGsMid, P == 0);
+    }
+
+    template <int P, int IN>
+    static DPF_HD void inv_phase(int tid, u64 (&x)[E], const Tw* tw, const Tw& w_last, const Tw& w_ninv, const LimbConst& lc) {
+        constexpr Phase ph = G::phase(P);
+        constexpr GsPlan<LOGE> plan = gs_plan<P, IN>();
+        const u64 q = lc.q, two_q = 2 * lc.q;
+        const int th = tid_high<G>(ph.c, tid);
+#pragma unroll
+        for (int u = 0; u < ph.r; ++u) {
+            const int pos = ph.b + u;
+            const int lb = pos - ph.c;
+            const bool last = (pos == LOGN - 1);
+#pragma unroll
+            for (int k = 0; k < E; ++k) {
+                if (k & (1 << lb)) continue;
+                const int kk = k | (1 << lb);
+                u64 a = x[k], b = x[kk];
+                u64 s, dlt;
+                if (Arith::kFold) {
+                    if (plan.red[u][k]) a = FoldArith::reduce(a, lc);
+                    if (plan.red[u][kk]) b = FoldArith::reduce(b, lc);
+                    s = chk_add(a, b);
+                    dlt = chk_sub_add(a, b, (u64)plan.off[u][k] * q);
+                } else {  // Harvey: inputs in [0,2q)
+                    s = csub(a + b, two_q);
+                    dlt = a - b + two_q;
+                }
+                if (last) {  // N^-1 folded into the last stage: x' = (a+b) N^-1, y' = (a-b) w N^-1
+                    x[k] = Arith::mul_tw(s, w_ninv, lc);
+                    x[kk] = Arith::mul_tw(dlt, w_last, lc);
+                } else {
+                    x[k] = s;
+                    x[kk] = Arith::mul_tw(dlt, tw[tw_index<G>(ph.c, th, k, pos)], lc);
+                }
+            }
+        }
+        if (Arith::kFold) {
+#pragma unroll
+            for (int k = 0; k < E; ++k)
+                if (plan.red_end[k]) x[k] = FoldArith::reduce(x[k], lc);
+        }
+    }
+    // inverse output (all words are outputs of the last-stage multiplies, < 2q) -> canonical
+    static DPF_HD void inv_canon(u64 (&x)[E], const LimbConst& lc) {
+#pragma unroll
+        for (int k = 0; k < E; ++k) x[k] = csub(x[k], lc.q);
+    }
+};
+
+}  // namespace dpfhe

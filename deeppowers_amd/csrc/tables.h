@@ -1,0 +1,67 @@
+// tables.h - host-side construction of the per-limb constants and twiddle tables (A0 of SURVEY.md
+// section 8a).  Plain C++17, no HIP: shared by the C-ABI (dpfhe_cabi.hip) and tools/emulate.cpp.
+#pragma once
+#include <vector>
+
+#include "modarith.h"
+
+namespace dpfhe {
+
+typedef unsigned __int128 u128;
+
+inline u64 h_mulmod(u64 a, u64 b, u64 q) { return (u64)((u128)a * b % q); }
+inline u64 h_powmod(u64 b, u64 e, u64 q) {
+    u64 r = 1;
+    b %= q;
+    for (; e; e >>= 1) {
+        if (e & 1) r = h_mulmod(r, b, q);
+        b = h_mulmod(b, b, q);
+    }
+    return r;
+}
+inline u64 h_shoup(u64 w, u64 q) { return (u64)(((u128)w << 64) / q); }
+inline u32 h_brv(u32 x, int bits) {
+    u32 r = 0;
+    for (int i = 0; i < bits; ++i) { r = (r << 1) | (x & 1); x >>= 1; }
+    return r;
+}
+
+// q = 2^60 - d with d < 2^24: eligible for FoldArith
+inline bool fold_eligible(u64 q) { return q < (1ull << 60) && ((1ull << 60) - q) < (1ull << 24); }
+
+struct HostLimbTables {
+    LimbConst lc;
+    std::vector<u64> rp, irp;        // psi^brv(i), psi^-brv(i)           (index m + i of a CT/GS walk)
+    std::vector<u64> rp_sh, irp_sh;  // Shoup companions
+    u64 w_last, w_last_sh;           // irp[1] * N^-1  (last inverse stage, N^-1 folded in)
+};
+
+// returns 0, or a deeppowers::common::ErrorCode number (INVALID_ARGUMENT = 2000)
+inline int build_limb_tables(int log2n, u64 q, u64 psi, HostLimbTables& t) {
+    const u64 n = 1ull << log2n;
+    if (log2n < 1 || log2n > 20) return 2000;
+    if (q < 3 || (q >> 60) || (q - 1) % (2 * n) != 0) return 2000;
+    if (psi == 0 || psi >= q || h_powmod(psi, n, q) != q - 1) return 2000;  // order exactly 2N
+    t.rp.assign(n, 0); t.irp.assign(n, 0); t.rp_sh.assign(n, 0); t.irp_sh.assign(n, 0);
+    const u64 ipsi = h_powmod(psi, q - 2, q);
+    u64 pw = 1, ipw = 1;
+    for (u64 i = 0; i < n; ++i) {
+        const u32 r = h_brv((u32)i, log2n);
+        t.rp[r] = pw; t.rp_sh[r] = h_shoup(pw, q);
+        t.irp[r] = ipw; t.irp_sh[r] = h_shoup(ipw, q);
+        pw = h_mulmod(pw, psi, q); ipw = h_mulmod(ipw, ipsi, q);
+    }
+    LimbConst& c = t.lc;
+    c.q = q;
+    c.d = fold_eligible(q) ? (1ull << 60) - q : 0;
+    c.ninv = h_powmod(n % q, q - 2, q);
+    c.ninv_sh = h_shoup(c.ninv, q);
+    const u128 ratio = (~(u128)0) / q;
+    c.br_hi = (u64)(ratio >> 64); c.br_lo = (u64)ratio;
+    c.pad0 = c.pad1 = 0;
+    t.w_last = h_mulmod(t.irp[1], c.ninv, q);
+    t.w_last_sh = h_shoup(t.w_last, q);
+    return 0;
+}
+
+}  // namespace dpfhe

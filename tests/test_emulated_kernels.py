@@ -1,0 +1,69 @@
+"""CPU: runs the per-thread code of the HIP NTT kernels (deeppowers_amd/csrc/ntt_core.h) in a
+thread-by-thread emulator (tools/emulate.cpp) and checks it bit for bit against the oracle.
+Covers every geometry the C-ABI dispatches, both arithmetic policies, both directions, extreme
+inputs, and counts 64-bit wrap-arounds of the lazy (uncorrected) arithmetic - must be zero."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from deeppowers_amd.params import PRIMES_60, PRIME_30, PSI_30_N1024
+from oracle.cbind import Oracle
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+U = C.POINTER(C.c_uint64)
+
+
+@pytest.fixture(scope="module")
+def emu():
+    so = os.path.join(ROOT, "tools", "libemu.so")
+    src = os.path.join(ROOT, "tools", "emulate.cpp")
+    deps = [src] + [os.path.join(ROOT, "deeppowers_amd", "csrc", f) for f in ("ntt_core.h", "modarith.h", "tables.h")]
+    if not os.path.exists(so) or any(os.path.getmtime(d) > os.path.getmtime(so) for d in deps):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-o", so, src])
+    lib = C.CDLL(so)
+    lib.emu_ntt.argtypes = [C.c_int] * 4 + [C.c_uint64, C.c_uint64, U, U]
+    lib.emu_overflows.restype = C.c_long
+    return lib
+
+
+def run(emu, arith, ln, le, inv, q, psi, a):
+    a = np.ascontiguousarray(a, dtype=np.uint64)
+    out = np.zeros_like(a)
+    rc = emu.emu_ntt(arith, ln, le, inv, q, psi, a.ctypes.data_as(U), out.ctypes.data_as(U))
+    return rc, out
+
+
+GEOS = [(8, 4), (10, 4), (11, 4), (12, 4), (13, 5)]
+
+
+@pytest.mark.parametrize("ln,le", GEOS)
+@pytest.mark.parametrize("arith", [0, 1], ids=["shoup", "fold"])
+def test_emulated_ntt_matches_oracle(emu, ln, le, arith):
+    n = 1 << ln
+    before = emu.emu_overflows()
+    for limb in (0, 3, 5):
+        q = PRIMES_60[limb][0]
+        psi = pow(PRIMES_60[limb][2], 8192 // n, q)
+        orc = Oracle(ln, [q], [psi])
+        pats = [orc.fill(1, 77 + limb).ravel().copy(), np.full(n, q - 1, np.uint64), np.zeros(n, np.uint64),
+                np.where(np.arange(n) % 2 == 0, q - 1, 0).astype(np.uint64),
+                np.where(np.arange(n) < n // 2, q - 1, 1).astype(np.uint64)]
+        for a in pats:
+            rc, got = run(emu, arith, ln, le, 0, q, psi, a)
+            assert rc == 0 and np.array_equal(got, orc.ntt_fwd(a))
+            rc, got = run(emu, arith, ln, le, 1, q, psi, a)
+            assert rc == 0 and np.array_equal(got, orc.ntt_inv(a))
+    assert emu.emu_overflows() == before, "lazy arithmetic wrapped around 2^64"
+
+
+def test_emulated_30bit_prime_uses_shoup_only(emu):
+    orc = Oracle(10, [PRIME_30], [PSI_30_N1024])
+    a = orc.fill(1, 1).ravel().copy()
+    rc, got = run(emu, 0, 10, 4, 0, PRIME_30, PSI_30_N1024, a)
+    assert rc == 0 and np.array_equal(got, orc.ntt_fwd(a))
+    rc, back = run(emu, 0, 10, 4, 1, PRIME_30, PSI_30_N1024, got)
+    assert rc == 0 and np.array_equal(back, a)
+    assert run(emu, 1, 10, 4, 0, PRIME_30, PSI_30_N1024, a)[0] == 2000  # not fold-eligible

@@ -1,0 +1,105 @@
+// emulate.cpp - CPU emulation of the HIP NTT kernels (TEST INFRASTRUCTURE).
+//
+// Runs the exact per-thread code of deeppowers_amd/csrc/ntt_core.h for every thread id of one
+// workgroup, step by step between barriers, with LDS as a plain array.  tests/test_emulated_kernels.py
+// compares the result with the oracle, so index/twiddle/padding/bound-plan logic is proven on the CPU
+// before any GPU minute is spent.  Built by tests (g++), never shipped, never on the product path.
+#define DPFHE_EMU_CHECK 1
+#include <cstring>
+#include <vector>
+
+#include "../deeppowers_amd/csrc/ntt_core.h"
+#include "../deeppowers_amd/csrc/tables.h"
+
+namespace dpfhe { long g_emu_overflows = 0; }
+using namespace dpfhe;
+extern "C" long emu_overflows() { return g_emu_overflows; }
+
+template <class Arith> struct TwTab;
+template <> struct TwTab<ShoupArith> {
+    static std::vector<TwShoup> make(const std::vector<u64>& w, const std::vector<u64>& sh) {
+        std::vector<TwShoup> v(w.size());
+        for (size_t i = 0; i < w.size(); ++i) v[i] = TwShoup{w[i], sh[i]};
+        return v;
+    }
+    static TwShoup one(u64 w, u64 sh) { return TwShoup{w, sh}; }
+};
+template <> struct TwTab<FoldArith> {
+    static std::vector<TwFold> make(const std::vector<u64>& w, const std::vector<u64>&) {
+        std::vector<TwFold> v(w.size());
+        for (size_t i = 0; i < w.size(); ++i) v[i] = TwFold{w[i]};
+        return v;
+    }
+    static TwFold one(u64 w, u64) { return TwFold{w}; }
+};
+
+template <class B, int P>
+struct FwdSteps {
+    static void run(std::vector<u64>& regs, std::vector<u64>& lds, const typename B::Tw* tw, const LimbConst& lc) {
+        constexpr int E = B::E, T = B::T;
+        auto X = [&](int tid) -> u64(&)[E] { return *reinterpret_cast<u64(*)[E]>(&regs[(size_t)tid * E]); };
+        for (int tid = 0; tid < T; ++tid) B::template fwd_phase<P>(tid, X(tid), tw, lc);
+        if constexpr (P + 1 < B::NPH) {
+            for (int tid = 0; tid < T; ++tid) B::template lds_write<P, P, true>(tid, X(tid), lds.data());
+            for (int tid = 0; tid < T; ++tid) B::template lds_read<P, P + 1, true>(tid, X(tid), lds.data());
+            FwdSteps<B, P + 1>::run(regs, lds, tw, lc);
+        }
+    }
+};
+
+template <class B, int P, int IN>
+struct InvSteps {
+    static void run(std::vector<u64>& regs, std::vector<u64>& lds, const typename B::Tw* tw, const typename B::Tw& wl,
+                    const typename B::Tw& wn, const LimbConst& lc) {
+        constexpr int E = B::E, T = B::T;
+        auto X = [&](int tid) -> u64(&)[E] { return *reinterpret_cast<u64(*)[E]>(&regs[(size_t)tid * E]); };
+        for (int tid = 0; tid < T; ++tid) B::template inv_phase<P, IN>(tid, X(tid), tw, wl, wn, lc);
+        if constexpr (P > 0) {
+            for (int tid = 0; tid < T; ++tid) B::template lds_write<P - 1, P, false>(tid, X(tid), lds.data());
+            for (int tid = 0; tid < T; ++tid) B::template lds_read<P - 1, P - 1, false>(tid, X(tid), lds.data());
+            InvSteps<B, P - 1, IN>::run(regs, lds, tw, wl, wn, lc);
+        }
+    }
+};
+
+template <class Arith, int LOGN, int LOGE>
+static int emu(int inverse, u64 q, u64 psi, const u64* in, u64* out) {
+    typedef NttBody<Arith, LOGN, LOGE> B;
+    HostLimbTables t;
+    int rc = build_limb_tables(LOGN, q, psi, t);
+    if (rc) return rc;
+    if (Arith::kFold && !fold_eligible(q)) return 2000;
+    constexpr int E = B::E, T = B::T;
+    std::vector<u64> regs((size_t)T * E), lds(B::G::lds_words(), 0xDEADBEEFDEADBEEFull);
+    auto X = [&](int tid) -> u64(&)[E] { return *reinterpret_cast<u64(*)[E]>(&regs[(size_t)tid * E]); };
+    if (!inverse) {
+        auto tw = TwTab<Arith>::make(t.rp, t.rp_sh);
+        for (int tid = 0; tid < T; ++tid) B::load_top(tid, X(tid), in);
+        FwdSteps<B, 0>::run(regs, lds, tw.data(), t.lc);
+        for (int tid = 0; tid < T; ++tid) { B::fwd_canon(X(tid), t.lc); B::store_bot(tid, X(tid), out); }
+    } else {
+        auto tw = TwTab<Arith>::make(t.irp, t.irp_sh);
+        auto wl = TwTab<Arith>::one(t.w_last, t.w_last_sh), wn = TwTab<Arith>::one(t.lc.ninv, t.lc.ninv_sh);
+        for (int tid = 0; tid < T; ++tid) B::load_bot(tid, X(tid), in);
+        InvSteps<B, B::NPH - 1, kUnit>::run(regs, lds, tw.data(), wl, wn, t.lc);
+        for (int tid = 0; tid < T; ++tid) { B::inv_canon(X(tid), t.lc); B::store_top(tid, X(tid), out); }
+    }
+    return 0;
+}
+
+// arith: 0 Shoup, 1 Fold.  `in`/`out` must be 16-byte aligned.  returns 0, 2000 bad args, -1 unsupported geometry
+extern "C" int emu_ntt(int arith, int log2n, int loge, int inverse, u64 q, u64 psi, const u64* in, u64* out) {
+#define CASE(LN, LE)                                                                     \
+    if (log2n == LN && loge == LE)                                                       \
+        return arith ? emu<FoldArith, LN, LE>(inverse, q, psi, in, out) : emu<ShoupArith, LN, LE>(inverse, q, psi, in, out);
+    CASE(8, 4) CASE(10, 4) CASE(11, 4) CASE(12, 4) CASE(13, 5) CASE(14, 5) CASE(12, 3) CASE(12, 5) CASE(13, 4) CASE(6, 3)
+#undef CASE
+    return -1;
+}
+
+extern "C" int emu_lds_words(int log2n, int loge) {
+    if (log2n == 12 && loge == 4) return Geo<12, 4>::lds_words();
+    if (log2n == 13 && loge == 5) return Geo<13, 5>::lds_words();
+    if (log2n == 10 && loge == 4) return Geo<10, 4>::lds_words();
+    return -1;
+}
