@@ -1,0 +1,199 @@
+#!/usr/bin/env python3
+"""bench.py - ciphertext-mul/s at N=4096, 4 RNS limbs (BASELINE.json metric) on N GPUs of one node.
+
+A "step" = one pass of the hot path over this rank's shard of synthetic ciphertext pairs:
+    fused ct x ct multiply (coefficient domain in/out)  ->  shard-local modular sum to ONE partial
+    ciphertext  ->  (N>1) RCCL all-gather of the partials  ->  local sum of the gathered partials.
+Weak scaling: --batch-per-gpu ciphertext pairs per GPU (default 8192 = BASELINE configs[3] per-GPU
+share of 65536), inputs resident in HBM before the timed region.  `value` = ct-muls by all ranks / time.
+
+Extra objects on the JSON line:
+  roofline     - the dominant kernel of the timed region (ct_mul_kernel): algorithmic bytes
+                 (7*L*N*8 = 917504 B per ct-mul) / HIP-event launch duration / 8 TB/s.
+  ntt          - BASELINE configs[1] (batch = 1024 RNS polys x 4 limbs, N=4096): forward / inverse NTT
+                 kernel time and fraction of HBM peak (2*N*8 algorithmic bytes per residue polynomial).
+  cpu_baseline - the CPU oracle ("port": reference has no CPU evaluator) timed on
+                 this host's cores on a bounded sample of the same workload (rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK = 8.0e12  # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch-per-gpu", type=int, default=8192)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU-baseline sample duration")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    from deeppowers_amd.evaluator import Ciphertext, Context, Evaluator, to_host
+    from deeppowers_amd.params import FheParams
+    from deeppowers_amd.sharding import allgather_partials
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run --nproc-per-node N")
+        args.gpus = world
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    params = FheParams.n4096_l4()
+    L, N = params.n_limbs, params.n
+    B = args.batch_per_gpu
+    ctx = Context(params, local_rank)
+    ev = Evaluator(ctx)
+    dev = ctx.device
+
+    # synthetic inputs: uniform residues, generated on the device, resident in HBM before timing
+    g = torch.Generator(device=dev).manual_seed(1000 + rank)
+    q = torch.tensor(params.moduli, dtype=torch.int64, device=dev).view(1, 1, L, 1)
+    a = Ciphertext(torch.randint(0, 2**62, (B, 2, L, N), generator=g, dtype=torch.int64, device=dev) % q)
+    b = Ciphertext(torch.randint(0, 2**62, (B, 2, L, N), generator=g, dtype=torch.int64, device=dev) % q)
+    out = ctx.empty(B, components=3)
+    partial = ctx.empty(components=3)
+    total = ctx.empty(components=3)
+
+    ev_start = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+    ev_end = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+
+    def step(i=None):
+        if i is not None:
+            ev_start[i].record()
+        c = ev.multiply(a, b, out=out)           # launches on torch's current stream
+        if i is not None:
+            ev_end[i].record()
+        p = ev.reduce_sum(c, out=partial)
+        gathered = allgather_partials(p.data)     # RCCL all-gather of one partial per rank (no-op at N=1)
+        return ev.reduce_sum(Ciphertext(gathered), out=total)
+
+    for _ in range(args.warmup):
+        step()
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    fence()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    kernel_ms = [s.elapsed_time(e) for s, e in zip(ev_start, ev_end)]
+    k_avg = sum(kernel_ms) / len(kernel_ms) * 1e-3
+    alg_bytes = 7 * L * N * 8 * B
+    achieved = alg_bytes / k_avg
+
+    result = {
+        "metric": "ciphertext-mul/s (N=4096, 4 RNS limbs)",
+        "value": world * B * args.steps / elapsed,
+        "unit": "ct-mul/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "u64",
+        "data": "synthetic",
+        "config": {
+            "workload": f"ct x ct multiply (tensor product, coeff domain in/out), N=4096, L=4 x 60-bit limbs, "
+                        f"{B} ciphertext pairs per GPU (BASELINE configs[3] per-GPU shard), shard-local reduce + "
+                        f"all-gather of one partial ct per GPU",
+            "log2_n": 12, "n_limbs": 4, "batch_per_gpu": B, "global_batch": B * world,
+            "parallelism": f"batch-sharded x{world}, one process per GPU" + (", RCCL all-gather" if world > 1 else ""),
+            "arith": "fold(2^60-d)" if ctx.uses_fold else "shoup",
+        },
+        "roofline": {
+            "kernel": "ct_mul_kernel<FoldArith,12,4>", "bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+            "frac": achieved / HBM_PEAK, "traffic": None,
+            "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": k_avg * 1e3,
+        },
+    }
+
+    if rank == 0:
+        # correctness of the timed output on a sample (bit-exact vs the oracle)
+        from oracle.cbind import Oracle
+        orc = Oracle.from_params(params)
+        idx = [0, B // 2, B - 1]
+        want = orc.ct_mul(to_host(a.data[idx]), to_host(b.data[idx]), threads=0)
+        result["bit_exact_sample"] = bool(np.array_equal(to_host(out[idx]), want))
+
+    if world == 1:
+        # BASELINE configs[1]: NTT / INTT HBM-roofline run, batch 1024 RNS polys x 4 limbs
+        nb = 1024
+        x = torch.randint(0, 2**62, (nb, L, N), generator=g, dtype=torch.int64, device=dev) % q.view(1, L, 1)
+        y = torch.empty_like(x)
+        ntt = {}
+        for name, fn in (("fwd", ev.ntt_forward), ("inv", ev.ntt_inverse)):
+            for _ in range(5):
+                fn(x, out=y)
+            ts = []
+            for _ in range(30):
+                s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                s.record(); fn(x, out=y); e.record()
+                e.synchronize()
+                ts.append(s.elapsed_time(e) * 1e-3)
+            ts.sort()
+            med = ts[len(ts) // 2]
+            nbytes = 2 * N * 8 * nb * L
+            ntt[name] = {"median_us": med * 1e6, "min_us": ts[0] * 1e6, "GBps": nbytes / med / 1e9, "frac_of_hbm_peak": nbytes / med / HBM_PEAK}
+        ntt["algorithmic_bytes"] = 2 * N * 8 * nb * L
+        ntt["workload"] = "BASELINE configs[1]: batch=1024 RNS polys x 4 limbs, N=4096, out-of-place"
+        result["ntt"] = ntt
+
+        if not args.no_cpu_baseline:
+            from oracle.cbind import Oracle
+            orc = Oracle.from_params(params)
+            cores = orc.max_threads()
+            probe = max(cores, 4)
+            ah, bh = to_host(a.data[:probe]), to_host(b.data[:probe])
+            t1 = time.perf_counter(); orc.ct_mul(ah, bh, threads=cores); t_probe = time.perf_counter() - t1
+            n_s = int(min(B, max(probe, probe * args.cpu_seconds / max(t_probe, 1e-6))))
+            ah, bh = to_host(a.data[:n_s]), to_host(b.data[:n_s])
+            t1 = time.perf_counter(); orc.ct_mul(ah, bh, threads=cores); t_all = time.perf_counter() - t1
+            n_1 = max(1, n_s // cores)
+            t1 = time.perf_counter(); orc.ct_mul(ah[:n_1], bh[:n_1], threads=1); t_one = time.perf_counter() - t1
+            result["cpu_baseline"] = {
+                "value": n_s / t_all, "unit": "ct-mul/s", "cores": cores, "kind": "port",
+                "sample": f"first {n_s} ciphertext pairs of the same batch, oracle/oracle.c Harvey-NTT evaluator, OpenMP over "
+                          f"{cores} threads, {t_all:.1f} s (reference has no CPU evaluator: build CPU evaluator)",
+                "single_thread_value": n_1 / t_one,
+            }
+            result["gpu_over_cpu"] = result["value"] / result["cpu_baseline"]["value"]
+
+    if rank == 0:
+        print(json.dumps(result))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

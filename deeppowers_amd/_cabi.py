@@ -1,0 +1,75 @@
+"""ctypes binding of libdpfhe_hip.so (include/dpfhe.h).  Fails LOUDLY when the HIP library is missing:
+there is no CPU fallback on the product path."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdpfhe_hip.so")
+_U64P = C.c_void_p  # device pointers travel as integers
+
+SYMBOLS = {
+    "dpfhe_ctx_create": ([C.POINTER(C.c_void_p), C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_int], C.c_int),
+    "dpfhe_ctx_destroy": ([C.c_void_p], C.c_int),
+    "dpfhe_ctx_log2n": ([C.c_void_p], C.c_uint32),
+    "dpfhe_ctx_limbs": ([C.c_void_p], C.c_uint32),
+    "dpfhe_ctx_uses_fold": ([C.c_void_p], C.c_int),
+    "dpfhe_ntt_fwd": ([C.c_void_p, _U64P, C.c_size_t, C.c_void_p], C.c_int),
+    "dpfhe_ntt_inv": ([C.c_void_p, _U64P, C.c_size_t, C.c_void_p], C.c_int),
+    "dpfhe_ntt_fwd_oop": ([C.c_void_p, _U64P, _U64P, C.c_size_t, C.c_void_p], C.c_int),
+    "dpfhe_ntt_inv_oop": ([C.c_void_p, _U64P, _U64P, C.c_size_t, C.c_void_p], C.c_int),
+    "dpfhe_dyadic_mul": ([C.c_void_p, _U64P, _U64P, _U64P, C.c_size_t, C.c_void_p], C.c_int),
+    "dpfhe_dyadic_mul_add": ([C.c_void_p, _U64P, _U64P, _U64P, C.c_size_t, C.c_void_p], C.c_int),
+    "dpfhe_add": ([C.c_void_p, _U64P, _U64P, _U64P, C.c_size_t, C.c_void_p], C.c_int),
+    "dpfhe_sub": ([C.c_void_p, _U64P, _U64P, _U64P, C.c_size_t, C.c_void_p], C.c_int),
+    "dpfhe_negate": ([C.c_void_p, _U64P, _U64P, C.c_size_t, C.c_void_p], C.c_int),
+    "dpfhe_ct_mul": ([C.c_void_p, _U64P, _U64P, _U64P, C.c_size_t, C.c_uint32, C.c_void_p], C.c_int),
+    "dpfhe_matvec_plain": ([C.c_void_p, _U64P, _U64P, _U64P, C.c_size_t, C.c_size_t, C.c_void_p], C.c_int),
+    "dpfhe_reduce_sum": ([C.c_void_p, _U64P, _U64P, C.c_size_t, C.c_size_t, C.c_void_p], C.c_int),
+    "dpfhe_comm_unique_id": ([C.POINTER(C.c_uint8)], C.c_int),
+    "dpfhe_comm_create": ([C.POINTER(C.c_void_p), C.POINTER(C.c_uint8), C.c_int, C.c_int, C.c_int], C.c_int),
+    "dpfhe_comm_destroy": ([C.c_void_p], C.c_int),
+    "dpfhe_comm_allgather": ([C.c_void_p, _U64P, _U64P, C.c_size_t, C.c_void_p], C.c_int),
+    "dpfhe_strerror": ([C.c_int], C.c_char_p),
+    "dpfhe_last_error": ([], C.c_char_p),
+}
+
+IN_NTT, OUT_NTT = 1, 2
+
+
+class DpfheError(RuntimeError):
+    """Mirrors deeppowers::common::Exception{ErrorCode} (/root/reference/src/common/error.hpp:42-53)."""
+
+    def __init__(self, code: int, message: str):
+        super().__init__(f"[{code}] {message}")
+        self.code = code
+
+
+_lib = None
+
+
+def load():
+    """Loads the HIP library.  torch is imported first so that ONE HIP runtime (the one torch bundles,
+    same soname libamdhip64.so.7) serves both torch's allocator/streams and our kernels."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950).  There is no CPU fallback for the FHE hot path.")
+    import torch  # noqa: F401  (loads libamdhip64 before our library resolves it)
+    lib = C.CDLL(LIB_PATH)
+    for name, (argtypes, restype) in SYMBOLS.items():
+        fn = getattr(lib, name)  # AttributeError if the ABI drifted from include/dpfhe.h
+        fn.argtypes, fn.restype = argtypes, restype
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str = ""):
+    if rc != 0:
+        lib = load()
+        detail = lib.dpfhe_last_error().decode() or lib.dpfhe_strerror(rc).decode()
+        raise DpfheError(rc, f"{what}: {detail}" if what else detail)

@@ -1,0 +1,387 @@
+// dpfhe_cabi.hip - libdpfhe_hip.so: the C ABI declared in include/dpfhe.h over the gfx950 kernels.
+//
+// Reference seam this stands in for: none exists.  Conventions follow the
+// reference's HAL: device chosen by id (/root/reference/src/api/cpp/src/deeppowers.cpp:15), raw device
+// pointers (/root/reference/src/core/hal/hal.hpp:44-48), optional stream last (hal.hpp:95), errors as
+// deeppowers::common::ErrorCode numbers (/root/reference/src/common/error.hpp:10-40).
+// Unlike /root/reference/src/core/distributed/distributed_context.cpp:88,109 nothing here allocates,
+// creates streams or synchronises per call.
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/dpfhe.h"
+#include "kernels.h"
+#include "tables.h"
+
+using namespace dpfhe;
+
+static thread_local std::string g_last_error;
+
+static int fail(int code, const char* what, const char* detail) {
+    g_last_error = std::string(what) + ": " + (detail ? detail : "");
+    return code;
+}
+#define HIP_TRY(expr)                                                                  \
+    do {                                                                               \
+        hipError_t _e = (expr);                                                        \
+        if (_e != hipSuccess)                                                          \
+            return fail(_e == hipErrorOutOfMemory ? DPFHE_OUT_OF_MEMORY : DPFHE_DEVICE_ERROR, #expr, hipGetErrorString(_e)); \
+    } while (0)
+
+struct dpfhe_ctx {
+    uint32_t log2n = 0, n_limbs = 0;
+    int device = 0;
+    bool fold = false;
+    void* d_blob = nullptr;  // one allocation: LimbConst[L] | fwd | inv | last  (both arithmetic layouts share it)
+    DevTables<ShoupArith> shoup{};
+    DevTables<FoldArith> foldt{};
+};
+
+// ------------------------------------------------------------------------------------------------
+extern "C" int dpfhe_ctx_create(dpfhe_ctx** out, uint32_t log2_n, uint32_t n_limbs, const uint64_t* moduli,
+                                const uint64_t* psi, int device_id) {
+    if (!out || !moduli || !psi) return fail(DPFHE_INVALID_ARGUMENT, "dpfhe_ctx_create", "null argument");
+    if (log2_n < 8 || log2_n > 13) return fail(DPFHE_INVALID_ARGUMENT, "dpfhe_ctx_create", "log2_n must be in [8, 13]");
+    if (n_limbs == 0 || n_limbs > 1024) return fail(DPFHE_INVALID_ARGUMENT, "dpfhe_ctx_create", "n_limbs must be in [1, 1024]");
+    const size_t n = (size_t)1 << log2_n, L = n_limbs;
+    std::vector<HostLimbTables> ht(L);
+    bool fold = true;
+    for (size_t l = 0; l < L; ++l) {
+        int rc = build_limb_tables((int)log2_n, moduli[l], psi[l], ht[l]);
+        if (rc) return fail(rc, "dpfhe_ctx_create", "modulus must be < 2^60 and 1 mod 2N, psi a primitive 2N-th root");
+        fold = fold && fold_eligible(moduli[l]);
+    }
+    int ndev = 0;
+    HIP_TRY(hipGetDeviceCount(&ndev));
+    if (device_id < 0 || device_id >= ndev) return fail(DPFHE_INVALID_ARGUMENT, "dpfhe_ctx_create", "no such device");
+    int prev = 0;
+    HIP_TRY(hipGetDevice(&prev));
+    HIP_TRY(hipSetDevice(device_id));
+
+    dpfhe_ctx* c = new (std::nothrow) dpfhe_ctx;
+    if (!c) return fail(DPFHE_OUT_OF_MEMORY, "dpfhe_ctx_create", "host allocation");
+    c->log2n = log2_n; c->n_limbs = n_limbs; c->device = device_id; c->fold = fold;
+
+    // blob layout (all 256-byte aligned sections)
+    auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    const size_t tw_sz = fold ? sizeof(TwFold) : sizeof(TwShoup);
+    const size_t o_lc = 0, o_fwd = up(o_lc + L * sizeof(LimbConst)), o_inv = up(o_fwd + L * n * tw_sz),
+                 o_last = up(o_inv + L * n * tw_sz), total = up(o_last + L * 2 * tw_sz);
+    std::vector<unsigned char> blob(total, 0);
+    for (size_t l = 0; l < L; ++l) {
+        std::memcpy(&blob[o_lc + l * sizeof(LimbConst)], &ht[l].lc, sizeof(LimbConst));
+        if (fold) {
+            TwFold* f = reinterpret_cast<TwFold*>(&blob[o_fwd]) + l * n;
+            TwFold* v = reinterpret_cast<TwFold*>(&blob[o_inv]) + l * n;
+            for (size_t i = 0; i < n; ++i) { f[i].w = ht[l].rp[i]; v[i].w = ht[l].irp[i]; }
+            InvLast<TwFold>* s = reinterpret_cast<InvLast<TwFold>*>(&blob[o_last]) + l;
+            s->w_last.w = ht[l].w_last; s->w_ninv.w = ht[l].lc.ninv;
+        } else {
+            TwShoup* f = reinterpret_cast<TwShoup*>(&blob[o_fwd]) + l * n;
+            TwShoup* v = reinterpret_cast<TwShoup*>(&blob[o_inv]) + l * n;
+            for (size_t i = 0; i < n; ++i) {
+                f[i].w = ht[l].rp[i]; f[i].wsh = ht[l].rp_sh[i];
+                v[i].w = ht[l].irp[i]; v[i].wsh = ht[l].irp_sh[i];
+            }
+            InvLast<TwShoup>* s = reinterpret_cast<InvLast<TwShoup>*>(&blob[o_last]) + l;
+            s->w_last.w = ht[l].w_last; s->w_last.wsh = ht[l].w_last_sh;
+            s->w_ninv.w = ht[l].lc.ninv; s->w_ninv.wsh = ht[l].lc.ninv_sh;
+        }
+    }
+    hipError_t e = hipMalloc(&c->d_blob, total);
+    if (e == hipSuccess) e = hipMemcpy(c->d_blob, blob.data(), total, hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        if (c->d_blob) (void)hipFree(c->d_blob);
+        delete c;
+        (void)hipSetDevice(prev);
+        return fail(e == hipErrorOutOfMemory ? DPFHE_OUT_OF_MEMORY : DPFHE_DEVICE_ERROR, "dpfhe_ctx_create: table upload", hipGetErrorString(e));
+    }
+    unsigned char* d = static_cast<unsigned char*>(c->d_blob);
+    if (fold) {
+        c->foldt.lc = reinterpret_cast<const LimbConst*>(d + o_lc);
+        c->foldt.fwd = reinterpret_cast<const TwFold*>(d + o_fwd);
+        c->foldt.inv = reinterpret_cast<const TwFold*>(d + o_inv);
+        c->foldt.last = reinterpret_cast<const InvLast<TwFold>*>(d + o_last);
+        c->foldt.n_limbs = (int)n_limbs;
+    } else {
+        c->shoup.lc = reinterpret_cast<const LimbConst*>(d + o_lc);
+        c->shoup.fwd = reinterpret_cast<const TwShoup*>(d + o_fwd);
+        c->shoup.inv = reinterpret_cast<const TwShoup*>(d + o_inv);
+        c->shoup.last = reinterpret_cast<const InvLast<TwShoup>*>(d + o_last);
+        c->shoup.n_limbs = (int)n_limbs;
+    }
+    (void)hipSetDevice(prev);
+    *out = c;
+    return DPFHE_SUCCESS;
+}
+
+extern "C" int dpfhe_ctx_destroy(dpfhe_ctx* c) {
+    if (!c) return DPFHE_SUCCESS;
+    if (c->d_blob) (void)hipFree(c->d_blob);
+    delete c;
+    return DPFHE_SUCCESS;
+}
+extern "C" uint32_t dpfhe_ctx_log2n(const dpfhe_ctx* c) { return c ? c->log2n : 0; }
+extern "C" uint32_t dpfhe_ctx_limbs(const dpfhe_ctx* c) { return c ? c->n_limbs : 0; }
+extern "C" int dpfhe_ctx_uses_fold(const dpfhe_ctx* c) { return c && c->fold ? 1 : 0; }
+
+// ------------------------------------------------------------------------------------------------
+static inline bool misaligned(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) != 0; }
+static const size_t kMaxGrid = 0x7fffffff;
+
+static int check_launch(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(DPFHE_DEVICE_ERROR, what, hipGetErrorString(e));
+    return DPFHE_SUCCESS;
+}
+
+template <class Arith>
+static const DevTables<Arith>& tables_of(const dpfhe_ctx* c);
+template <>
+const DevTables<ShoupArith>& tables_of<ShoupArith>(const dpfhe_ctx* c) { return c->shoup; }
+template <>
+const DevTables<FoldArith>& tables_of<FoldArith>(const dpfhe_ctx* c) { return c->foldt; }
+
+// geometry dispatch: (log2n -> LOGE) pairs proven by tests/test_emulated_kernels.py
+#define DPFHE_GEO_SWITCH(log2n, MACRO)        \
+    switch (log2n) {                          \
+        case 8: MACRO(8, 4); break;           \
+        case 9: MACRO(9, 4); break;           \
+        case 10: MACRO(10, 4); break;         \
+        case 11: MACRO(11, 4); break;         \
+        case 12: MACRO(12, 4); break;         \
+        case 13: MACRO(13, 5); break;         \
+        default: return fail(DPFHE_INVALID_STATE, "geometry", "unsupported log2_n"); \
+    }
+
+template <class Arith>
+static int launch_ntt(dpfhe_ctx* c, bool inverse, u64* out, const u64* in, size_t npolys, hipStream_t s) {
+    const DevTables<Arith>& tb = tables_of<Arith>(c);
+#define NTT_CASE(LN, LE)                                                                                   \
+    if (inverse) hipLaunchKernelGGL((ntt_inv_kernel<Arith, LN, LE>), dim3((unsigned)npolys), dim3(Geo<LN, LE>::T), 0, s, out, in, tb); \
+    else hipLaunchKernelGGL((ntt_fwd_kernel<Arith, LN, LE>), dim3((unsigned)npolys), dim3(Geo<LN, LE>::T), 0, s, out, in, tb)
+    DPFHE_GEO_SWITCH(c->log2n, NTT_CASE)
+#undef NTT_CASE
+    return check_launch("ntt kernel launch");
+}
+
+static int ntt_entry(dpfhe_ctx* c, bool inverse, uint64_t* out, const uint64_t* in, size_t n_rns_polys, void* stream) {
+    if (!c) return fail(DPFHE_INVALID_ARGUMENT, "ntt", "null context");
+    if (n_rns_polys == 0) return DPFHE_SUCCESS;
+    if (!out || !in || misaligned(out) || misaligned(in)) return fail(DPFHE_INVALID_ARGUMENT, "ntt", "null or misaligned buffer");
+    const size_t npolys = n_rns_polys * c->n_limbs;
+    if (npolys > kMaxGrid) return fail(DPFHE_INVALID_ARGUMENT, "ntt", "batch too large for one launch");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    return c->fold ? launch_ntt<FoldArith>(c, inverse, out, in, npolys, s) : launch_ntt<ShoupArith>(c, inverse, out, in, npolys, s);
+}
+
+extern "C" int dpfhe_ntt_fwd(dpfhe_ctx* c, uint64_t* d_io, size_t n, void* s) { return ntt_entry(c, false, d_io, d_io, n, s); }
+extern "C" int dpfhe_ntt_inv(dpfhe_ctx* c, uint64_t* d_io, size_t n, void* s) { return ntt_entry(c, true, d_io, d_io, n, s); }
+extern "C" int dpfhe_ntt_fwd_oop(dpfhe_ctx* c, uint64_t* o, const uint64_t* i, size_t n, void* s) { return ntt_entry(c, false, o, i, n, s); }
+extern "C" int dpfhe_ntt_inv_oop(dpfhe_ctx* c, uint64_t* o, const uint64_t* i, size_t n, void* s) { return ntt_entry(c, true, o, i, n, s); }
+
+// ------------------------------------------------------------------------------------------------
+template <class Arith, int OP>
+static void launch_dy(dpfhe_ctx* c, u64* out, const u64* a, const u64* b, size_t npolys, hipStream_t s) {
+    hipLaunchKernelGGL((dyadic_kernel<Arith, OP>), dim3((unsigned)npolys), dim3(256), 0, s, out, a, b, tables_of<Arith>(c).lc,
+                       (int)c->n_limbs, 1 << c->log2n);
+}
+
+static int dyadic_entry(dpfhe_ctx* c, int op, uint64_t* out, const uint64_t* a, const uint64_t* b, size_t n_rns_polys, void* stream) {
+    if (!c) return fail(DPFHE_INVALID_ARGUMENT, "dyadic", "null context");
+    if (n_rns_polys == 0) return DPFHE_SUCCESS;
+    if (!out || !a || (op != DY_NEG && !b) || misaligned(out) || misaligned(a) || misaligned(b))
+        return fail(DPFHE_INVALID_ARGUMENT, "dyadic", "null or misaligned buffer");
+    const size_t npolys = n_rns_polys * c->n_limbs;
+    if (npolys > kMaxGrid) return fail(DPFHE_INVALID_ARGUMENT, "dyadic", "batch too large for one launch");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (op == DY_NEG) b = a;
+#define DY_CASE(OP)                                                   \
+    case OP:                                                          \
+        if (c->fold) launch_dy<FoldArith, OP>(c, out, a, b, npolys, s); \
+        else launch_dy<ShoupArith, OP>(c, out, a, b, npolys, s);      \
+        break
+    switch (op) {
+        DY_CASE(DY_MUL); DY_CASE(DY_MUL_ADD); DY_CASE(DY_ADD); DY_CASE(DY_SUB); DY_CASE(DY_NEG);
+        default: return fail(DPFHE_INVALID_ARGUMENT, "dyadic", "bad op");
+    }
+#undef DY_CASE
+    return check_launch("dyadic kernel launch");
+}
+
+extern "C" int dpfhe_dyadic_mul(dpfhe_ctx* c, uint64_t* o, const uint64_t* a, const uint64_t* b, size_t n, void* s) { return dyadic_entry(c, DY_MUL, o, a, b, n, s); }
+extern "C" int dpfhe_dyadic_mul_add(dpfhe_ctx* c, uint64_t* acc, const uint64_t* a, const uint64_t* b, size_t n, void* s) { return dyadic_entry(c, DY_MUL_ADD, acc, a, b, n, s); }
+extern "C" int dpfhe_add(dpfhe_ctx* c, uint64_t* o, const uint64_t* a, const uint64_t* b, size_t n, void* s) { return dyadic_entry(c, DY_ADD, o, a, b, n, s); }
+extern "C" int dpfhe_sub(dpfhe_ctx* c, uint64_t* o, const uint64_t* a, const uint64_t* b, size_t n, void* s) { return dyadic_entry(c, DY_SUB, o, a, b, n, s); }
+extern "C" int dpfhe_negate(dpfhe_ctx* c, uint64_t* o, const uint64_t* a, size_t n, void* s) { return dyadic_entry(c, DY_NEG, o, a, nullptr, n, s); }
+
+// ------------------------------------------------------------------------------------------------
+template <class Arith, bool IN_NTT, bool OUT_NTT>
+static int launch_ct_mul(dpfhe_ctx* c, u64* out3, const u64* a2, const u64* b2, size_t blocks, hipStream_t s) {
+    const DevTables<Arith>& tb = tables_of<Arith>(c);
+    // the fused kernel keeps four transformed polynomials in registers: always E = 16 words per thread
+#define CT_CASE(LN, LE) \
+    hipLaunchKernelGGL((ct_mul_kernel<Arith, LN, 4, IN_NTT, OUT_NTT>), dim3((unsigned)blocks), dim3(Geo<LN, 4>::T), 0, s, out3, a2, b2, tb)
+    DPFHE_GEO_SWITCH(c->log2n, CT_CASE)
+#undef CT_CASE
+    return check_launch("ct_mul kernel launch");
+}
+
+template <class Arith>
+static int ct_mul_flags(dpfhe_ctx* c, u64* o, const u64* a, const u64* b, size_t blocks, uint32_t flags, hipStream_t s) {
+    switch (flags) {
+        case 0: return launch_ct_mul<Arith, false, false>(c, o, a, b, blocks, s);
+        case DPFHE_IN_NTT: return launch_ct_mul<Arith, true, false>(c, o, a, b, blocks, s);
+        case DPFHE_OUT_NTT: return launch_ct_mul<Arith, false, true>(c, o, a, b, blocks, s);
+        default: return launch_ct_mul<Arith, true, true>(c, o, a, b, blocks, s);
+    }
+}
+
+extern "C" int dpfhe_ct_mul(dpfhe_ctx* c, uint64_t* d_out3, const uint64_t* d_a2, const uint64_t* d_b2, size_t batch,
+                            uint32_t flags, void* stream) {
+    if (!c) return fail(DPFHE_INVALID_ARGUMENT, "dpfhe_ct_mul", "null context");
+    if (flags & ~(DPFHE_IN_NTT | DPFHE_OUT_NTT)) return fail(DPFHE_INVALID_ARGUMENT, "dpfhe_ct_mul", "unknown flag");
+    if (batch == 0) return DPFHE_SUCCESS;
+    if (!d_out3 || !d_a2 || !d_b2 || misaligned(d_out3) || misaligned(d_a2) || misaligned(d_b2))
+        return fail(DPFHE_INVALID_ARGUMENT, "dpfhe_ct_mul", "null or misaligned buffer");
+    const size_t blocks = batch * c->n_limbs;
+    if (blocks > kMaxGrid) return fail(DPFHE_INVALID_ARGUMENT, "dpfhe_ct_mul", "batch too large for one launch");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    return c->fold ? ct_mul_flags<FoldArith>(c, d_out3, d_a2, d_b2, blocks, flags, s)
+                   : ct_mul_flags<ShoupArith>(c, d_out3, d_a2, d_b2, blocks, flags, s);
+}
+
+// ------------------------------------------------------------------------------------------------
+extern "C" int dpfhe_matvec_plain(dpfhe_ctx* c, uint64_t* d_y, const uint64_t* d_W, const uint64_t* d_x, size_t rows, size_t cols,
+                                  void* stream) {
+    if (!c) return fail(DPFHE_INVALID_ARGUMENT, "dpfhe_matvec_plain", "null context");
+    if (rows == 0) return DPFHE_SUCCESS;
+    if (cols == 0) return fail(DPFHE_INVALID_ARGUMENT, "dpfhe_matvec_plain", "cols must be > 0");
+    if (!d_y || !d_W || !d_x || misaligned(d_y) || misaligned(d_W) || misaligned(d_x))
+        return fail(DPFHE_INVALID_ARGUMENT, "dpfhe_matvec_plain", "null or misaligned buffer");
+    const size_t blocks = rows * c->n_limbs;
+    if (blocks > kMaxGrid) return fail(DPFHE_INVALID_ARGUMENT, "dpfhe_matvec_plain", "too many rows for one launch");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int n = 1 << c->log2n;
+    if (c->fold) hipLaunchKernelGGL((matvec_kernel<FoldArith>), dim3((unsigned)blocks), dim3(256), 0, s, d_y, d_W, d_x, c->foldt.lc, (int)c->n_limbs, n, cols);
+    else hipLaunchKernelGGL((matvec_kernel<ShoupArith>), dim3((unsigned)blocks), dim3(256), 0, s, d_y, d_W, d_x, c->shoup.lc, (int)c->n_limbs, n, cols);
+    return check_launch("matvec kernel launch");
+}
+
+extern "C" int dpfhe_reduce_sum(dpfhe_ctx* c, uint64_t* d_out, const uint64_t* d_in, size_t count, size_t components, void* stream) {
+    if (!c) return fail(DPFHE_INVALID_ARGUMENT, "dpfhe_reduce_sum", "null context");
+    if (components == 0 || count == 0) return fail(DPFHE_INVALID_ARGUMENT, "dpfhe_reduce_sum", "count and components must be > 0");
+    if (!d_out || !d_in || misaligned(d_out) || misaligned(d_in)) return fail(DPFHE_INVALID_ARGUMENT, "dpfhe_reduce_sum", "null or misaligned buffer");
+    const size_t blocks = components * c->n_limbs;
+    if (blocks > kMaxGrid) return fail(DPFHE_INVALID_ARGUMENT, "dpfhe_reduce_sum", "too many components");
+    const int n = 1 << c->log2n;
+    const LimbConst* lc = c->fold ? c->foldt.lc : c->shoup.lc;
+    hipLaunchKernelGGL(reduce_sum_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), d_out, d_in, lc,
+                       (int)c->n_limbs, n, count, components * c->n_limbs * (size_t)n);
+    return check_launch("reduce_sum kernel launch");
+}
+
+// ------------------------------------------------------------------------------------------------
+// (e) RCCL all-gather.  librccl is opened lazily so that single-GPU users never depend on it.
+// ------------------------------------------------------------------------------------------------
+namespace {
+struct NcclUniqueId { char internal[128]; };
+typedef void* ncclComm_t;
+struct Rccl {
+    void* h = nullptr;
+    int (*GetUniqueId)(NcclUniqueId*) = nullptr;
+    int (*CommInitRank)(ncclComm_t*, int, NcclUniqueId, int) = nullptr;
+    int (*CommDestroy)(ncclComm_t) = nullptr;
+    int (*AllGather)(const void*, void*, size_t, int, ncclComm_t, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+    bool ok = false;
+};
+Rccl& rccl() {
+    static Rccl r = [] {
+        Rccl x;
+        x.h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+        if (!x.h) x.h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!x.h) return x;
+        x.GetUniqueId = reinterpret_cast<decltype(x.GetUniqueId)>(dlsym(x.h, "ncclGetUniqueId"));
+        x.CommInitRank = reinterpret_cast<decltype(x.CommInitRank)>(dlsym(x.h, "ncclCommInitRank"));
+        x.CommDestroy = reinterpret_cast<decltype(x.CommDestroy)>(dlsym(x.h, "ncclCommDestroy"));
+        x.AllGather = reinterpret_cast<decltype(x.AllGather)>(dlsym(x.h, "ncclAllGather"));
+        x.GetErrorString = reinterpret_cast<decltype(x.GetErrorString)>(dlsym(x.h, "ncclGetErrorString"));
+        x.ok = x.GetUniqueId && x.CommInitRank && x.CommDestroy && x.AllGather;
+        return x;
+    }();
+    return r;
+}
+const int kNcclUint64 = 5;  // ncclUint64 in rccl.h's ncclDataType_t
+int rccl_fail(const char* what, int rc) {
+    Rccl& r = rccl();
+    return fail(DPFHE_RUNTIME_ERROR, what, r.GetErrorString ? r.GetErrorString(rc) : "rccl error");
+}
+}  // namespace
+
+struct dpfhe_comm {
+    ncclComm_t comm = nullptr;
+    int rank = 0, world = 1, device = 0;
+};
+
+extern "C" int dpfhe_comm_unique_id(uint8_t out_id[128]) {
+    if (!out_id) return fail(DPFHE_INVALID_ARGUMENT, "dpfhe_comm_unique_id", "null argument");
+    Rccl& r = rccl();
+    if (!r.ok) return fail(DPFHE_RUNTIME_ERROR, "dpfhe_comm_unique_id", "librccl.so.1 not loadable");
+    NcclUniqueId id;
+    int rc = r.GetUniqueId(&id);
+    if (rc) return rccl_fail("ncclGetUniqueId", rc);
+    std::memcpy(out_id, id.internal, 128);
+    return DPFHE_SUCCESS;
+}
+
+extern "C" int dpfhe_comm_create(dpfhe_comm** out, const uint8_t id[128], int rank, int world_size, int device_id) {
+    if (!out || !id || world_size < 1 || rank < 0 || rank >= world_size) return fail(DPFHE_INVALID_ARGUMENT, "dpfhe_comm_create", "bad argument");
+    Rccl& r = rccl();
+    if (!r.ok) return fail(DPFHE_RUNTIME_ERROR, "dpfhe_comm_create", "librccl.so.1 not loadable");
+    HIP_TRY(hipSetDevice(device_id));
+    dpfhe_comm* c = new (std::nothrow) dpfhe_comm;
+    if (!c) return fail(DPFHE_OUT_OF_MEMORY, "dpfhe_comm_create", "host allocation");
+    c->rank = rank; c->world = world_size; c->device = device_id;
+    NcclUniqueId uid;
+    std::memcpy(uid.internal, id, 128);
+    int rc = r.CommInitRank(&c->comm, world_size, uid, rank);
+    if (rc) { delete c; return rccl_fail("ncclCommInitRank", rc); }
+    *out = c;
+    return DPFHE_SUCCESS;
+}
+
+extern "C" int dpfhe_comm_destroy(dpfhe_comm* c) {
+    if (!c) return DPFHE_SUCCESS;
+    if (c->comm) (void)rccl().CommDestroy(c->comm);
+    delete c;
+    return DPFHE_SUCCESS;
+}
+
+extern "C" int dpfhe_comm_allgather(dpfhe_comm* c, uint64_t* d_recv, const uint64_t* d_send, size_t words_per_rank, void* stream) {
+    if (!c || !d_recv || !d_send) return fail(DPFHE_INVALID_ARGUMENT, "dpfhe_comm_allgather", "null argument");
+    if (words_per_rank == 0) return DPFHE_SUCCESS;
+    int rc = rccl().AllGather(d_send, d_recv, words_per_rank, kNcclUint64, c->comm, static_cast<hipStream_t>(stream));
+    if (rc) return rccl_fail("ncclAllGather", rc);
+    return DPFHE_SUCCESS;
+}
+
+// ------------------------------------------------------------------------------------------------
+extern "C" const char* dpfhe_strerror(int code) {
+    switch (code) {
+        case DPFHE_SUCCESS: return "success";
+        case DPFHE_OUT_OF_MEMORY: return "out of memory";
+        case DPFHE_DEVICE_ERROR: return "device error";
+        case DPFHE_INVALID_ARGUMENT: return "invalid argument";
+        case DPFHE_INVALID_STATE: return "invalid state";
+        case DPFHE_RUNTIME_ERROR: return "runtime error";
+        default: return "unknown error";
+    }
+}
+extern "C" const char* dpfhe_last_error(void) { return g_last_error.c_str(); }

@@ -34,7 +34,8 @@ struct LimbConst {  // one per RNS limb, read through scalar loads (limb index i
     u64 ninv_sh;    // floor(ninv 2^64 / q)
     u64 br_hi;      // floor(2^128 / q), high word   (generic Barrett)
     u64 br_lo;      //                   low word
-    u64 pad0, pad1;
+    u64 two64;      // 2^64 mod q
+    u64 pad1;
 };
 
 DPF_HD u64 mad32(u32 a, u32 b, u64 c) { return (u64)a * b + c; }

@@ -58,7 +58,8 @@ inline int build_limb_tables(int log2n, u64 q, u64 psi, HostLimbTables& t) {
     c.ninv_sh = h_shoup(c.ninv, q);
     const u128 ratio = (~(u128)0) / q;
     c.br_hi = (u64)(ratio >> 64); c.br_lo = (u64)ratio;
-    c.pad0 = c.pad1 = 0;
+    c.two64 = (u64)((((u128)1) << 64) % q);
+    c.pad1 = 0;
     t.w_last = h_mulmod(t.irp[1], c.ninv, q);
     t.w_last_sh = h_shoup(t.w_last, q);
     return 0;

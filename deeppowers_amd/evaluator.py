@@ -1,0 +1,249 @@
+"""deeppowers.fhe - Context / Plaintext / Ciphertext / Evaluator over the HIP C ABI (Python mirror).
+
+The reference has no Ciphertext/Evaluator; this mirrors the BUILD-SPEC operator API
+of SURVEY.md section 8(a)/(b), in the reference's house style (the C++ twin is include/deeppowers/fhe.hpp):
+heavy objects own their buffers (/root/reference/src/core/execution/model.hpp:88-89), the device is
+chosen by id (/root/reference/src/api/cpp/src/deeppowers.cpp:15), errors are exceptions carrying a
+deeppowers::common::ErrorCode (/root/reference/src/common/error.hpp:42-53), the stream is optional and last
+(/root/reference/src/core/hal/hal.hpp:95).
+
+PyTorch is used only for device memory and streams; every operation is a HIP kernel launched through
+libdpfhe_hip.so.  Words are u64 residues stored in int64 tensors (bit pattern), layout
+[batch...][component][limb][N].
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _cabi
+from .params import FheParams
+
+
+def _stream_ptr(stream) -> int:
+    s = torch.cuda.current_stream() if stream is None else stream
+    return s.cuda_stream
+
+
+def to_device(words: np.ndarray, device) -> torch.Tensor:
+    """numpy uint64 -> int64 device tensor (same bits)."""
+    a = np.ascontiguousarray(words, dtype=np.uint64)
+    return torch.from_numpy(a.view(np.int64)).to(device)
+
+
+def to_host(t: torch.Tensor) -> np.ndarray:
+    return t.detach().cpu().contiguous().numpy().view(np.uint64)
+
+
+class Context:
+    """A0: immutable per-device tables (twiddles, Shoup/Barrett/fold constants) for one FheParams."""
+
+    def __init__(self, params: FheParams, device_id: int = 0):
+        self.params = params
+        self.device_id = int(device_id)
+        self.device = torch.device("cuda", self.device_id)
+        self._lib = _cabi.load()
+        L = params.n_limbs
+        h = C.c_void_p()
+        m = (C.c_uint64 * L)(*params.moduli)
+        w = (C.c_uint64 * L)(*params.psi)
+        _cabi.check(self._lib.dpfhe_ctx_create(C.byref(h), params.log2_n, L, m, w, self.device_id), "dpfhe_ctx_create")
+        self._h = h
+
+    @property
+    def handle(self):
+        return self._h
+
+    @property
+    def uses_fold(self) -> bool:
+        return bool(self._lib.dpfhe_ctx_uses_fold(self._h))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.dpfhe_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # buffers
+    def empty(self, *lead, components: int) -> torch.Tensor:
+        p = self.params
+        return torch.empty(*lead, components, p.n_limbs, p.n, dtype=torch.int64, device=self.device)
+
+
+class Plaintext:
+    """A5: one RNS polynomial [L][N] (optionally batched), with an is_ntt flag."""
+
+    def __init__(self, data: torch.Tensor, is_ntt: bool = False):
+        self.data, self.is_ntt = data, bool(is_ntt)
+
+
+class Ciphertext:
+    """A4: `size` in {2,3} RNS polynomials, tensor [..., size, L, N] + is_ntt."""
+
+    def __init__(self, data: torch.Tensor, is_ntt: bool = False):
+        if data.dim() < 3 or data.shape[-3] not in (2, 3):
+            raise _cabi.DpfheError(2000, "Ciphertext tensor must be [..., 2|3, L, N]")
+        self.data, self.is_ntt = data, bool(is_ntt)
+
+    @property
+    def size(self) -> int:
+        return self.data.shape[-3]
+
+    @property
+    def batch(self) -> int:
+        return int(np.prod(self.data.shape[:-3])) if self.data.dim() > 3 else 1
+
+
+class Evaluator:
+    """Operator API over one Context.  Every method only enqueues work on `stream` (default: current)."""
+
+    def __init__(self, ctx: Context):
+        self.ctx = ctx
+        self._lib = ctx._lib
+
+    # ---- checks -------------------------------------------------------------------------------------
+    def _chk(self, *tensors):
+        p = self.ctx.params
+        for t in tensors:
+            if t.dtype != torch.int64 or not t.is_cuda or not t.is_contiguous():
+                raise _cabi.DpfheError(2000, "buffers must be contiguous int64 (u64 bits) CUDA tensors")
+            if t.device != self.ctx.device:
+                raise _cabi.DpfheError(2000, f"buffer on {t.device}, context on {self.ctx.device}")
+            if t.dim() < 2 or t.shape[-1] != p.n or t.shape[-2] != p.n_limbs:
+                raise _cabi.DpfheError(2000, f"trailing dims must be [L={p.n_limbs}][N={p.n}]")
+
+    def _npolys(self, t) -> int:
+        return t.numel() // self.ctx.params.words_per_rns_poly()
+
+    # ---- A1 / A2 --------------------------------------------------------------------------------------
+    def ntt_forward_(self, t: torch.Tensor, stream=None) -> torch.Tensor:
+        self._chk(t)
+        _cabi.check(self._lib.dpfhe_ntt_fwd(self.ctx.handle, t.data_ptr(), self._npolys(t), _stream_ptr(stream)), "dpfhe_ntt_fwd")
+        return t
+
+    def ntt_inverse_(self, t: torch.Tensor, stream=None) -> torch.Tensor:
+        self._chk(t)
+        _cabi.check(self._lib.dpfhe_ntt_inv(self.ctx.handle, t.data_ptr(), self._npolys(t), _stream_ptr(stream)), "dpfhe_ntt_inv")
+        return t
+
+    def ntt_forward(self, t: torch.Tensor, out: torch.Tensor | None = None, stream=None) -> torch.Tensor:
+        out = torch.empty_like(t) if out is None else out
+        self._chk(t, out)
+        _cabi.check(self._lib.dpfhe_ntt_fwd_oop(self.ctx.handle, out.data_ptr(), t.data_ptr(), self._npolys(t), _stream_ptr(stream)), "dpfhe_ntt_fwd_oop")
+        return out
+
+    def ntt_inverse(self, t: torch.Tensor, out: torch.Tensor | None = None, stream=None) -> torch.Tensor:
+        out = torch.empty_like(t) if out is None else out
+        self._chk(t, out)
+        _cabi.check(self._lib.dpfhe_ntt_inv_oop(self.ctx.handle, out.data_ptr(), t.data_ptr(), self._npolys(t), _stream_ptr(stream)), "dpfhe_ntt_inv_oop")
+        return out
+
+    def transform_to_ntt_(self, x, stream=None):
+        if not x.is_ntt:
+            self.ntt_forward_(x.data, stream)
+            x.is_ntt = True
+        return x
+
+    def transform_from_ntt_(self, x, stream=None):
+        if x.is_ntt:
+            self.ntt_inverse_(x.data, stream)
+            x.is_ntt = False
+        return x
+
+    # ---- A3 -------------------------------------------------------------------------------------------
+    def _dy(self, fn, name, out, a, b, stream):
+        self._chk(out, a, *(() if b is None else (b,)))
+        if a.shape != out.shape or (b is not None and b.shape != a.shape):
+            raise _cabi.DpfheError(2000, "operand shapes differ")
+        args = (self.ctx.handle, out.data_ptr(), a.data_ptr()) + (() if b is None else (b.data_ptr(),))
+        _cabi.check(fn(*args, self._npolys(a), _stream_ptr(stream)), name)
+        return out
+
+    def dyadic_mul(self, a, b, out=None, stream=None):
+        return self._dy(self._lib.dpfhe_dyadic_mul, "dpfhe_dyadic_mul", torch.empty_like(a) if out is None else out, a, b, stream)
+
+    def dyadic_mul_add_(self, acc, a, b, stream=None):
+        return self._dy(self._lib.dpfhe_dyadic_mul_add, "dpfhe_dyadic_mul_add", acc, a, b, stream)
+
+    def add_words(self, a, b, out=None, stream=None):
+        return self._dy(self._lib.dpfhe_add, "dpfhe_add", torch.empty_like(a) if out is None else out, a, b, stream)
+
+    def sub_words(self, a, b, out=None, stream=None):
+        return self._dy(self._lib.dpfhe_sub, "dpfhe_sub", torch.empty_like(a) if out is None else out, a, b, stream)
+
+    def negate_words(self, a, out=None, stream=None):
+        return self._dy(self._lib.dpfhe_negate, "dpfhe_negate", torch.empty_like(a) if out is None else out, a, None, stream)
+
+    # ---- A8: ciphertext add/sub/negate/reduce --------------------------------------------------------------
+    def add(self, a: Ciphertext, b: Ciphertext, stream=None) -> Ciphertext:
+        self._same_domain(a, b)
+        return Ciphertext(self.add_words(a.data, b.data, stream=stream), a.is_ntt)
+
+    def sub(self, a: Ciphertext, b: Ciphertext, stream=None) -> Ciphertext:
+        self._same_domain(a, b)
+        return Ciphertext(self.sub_words(a.data, b.data, stream=stream), a.is_ntt)
+
+    def negate(self, a: Ciphertext, stream=None) -> Ciphertext:
+        return Ciphertext(self.negate_words(a.data, stream=stream), a.is_ntt)
+
+    def reduce_sum(self, cts: Ciphertext, out: torch.Tensor | None = None, stream=None) -> Ciphertext:
+        """Modular sum over the batch dimension(s) -> one ciphertext (the shard-local partial)."""
+        self._chk(cts.data)
+        comps = cts.size
+        if out is None:
+            out = self.ctx.empty(components=comps)
+        self._chk(out)
+        _cabi.check(self._lib.dpfhe_reduce_sum(self.ctx.handle, out.data_ptr(), cts.data.data_ptr(), cts.batch, comps, _stream_ptr(stream)), "dpfhe_reduce_sum")
+        return Ciphertext(out, cts.is_ntt)
+
+    @staticmethod
+    def _same_domain(a, b):
+        if a.is_ntt != b.is_ntt:
+            raise _cabi.DpfheError(2002, "operands are in different domains (is_ntt mismatch)")
+        if a.data.shape != b.data.shape:
+            raise _cabi.DpfheError(2000, "operand shapes differ")
+
+    # ---- A6: THE METRIC OP -----------------------------------------------------------------------------
+    def multiply(self, a: Ciphertext, b: Ciphertext, out: torch.Tensor | None = None, out_ntt: bool | None = None, stream=None) -> Ciphertext:
+        """(a0,a1) (x) (b0,b1) -> (a0 b0, a0 b1 + a1 b0, a1 b1); no relinearisation.  Batched over leading dims."""
+        self._same_domain(a, b)
+        if a.size != 2 or b.size != 2:
+            raise _cabi.DpfheError(2000, "multiply expects 2-component ciphertexts")
+        self._chk(a.data, b.data)
+        out_ntt = a.is_ntt if out_ntt is None else bool(out_ntt)
+        lead = a.data.shape[:-3]
+        if out is None:
+            out = self.ctx.empty(*lead, components=3)
+        self._chk(out)
+        flags = (_cabi.IN_NTT if a.is_ntt else 0) | (_cabi.OUT_NTT if out_ntt else 0)
+        _cabi.check(self._lib.dpfhe_ct_mul(self.ctx.handle, out.data_ptr(), a.data.data_ptr(), b.data.data_ptr(), a.batch, flags, _stream_ptr(stream)), "dpfhe_ct_mul")
+        return Ciphertext(out, out_ntt)
+
+    # ---- A7 -------------------------------------------------------------------------------------------
+    def multiply_plain(self, a: Ciphertext, p: Plaintext, stream=None) -> Ciphertext:
+        """ct (.) pt, both in the NTT domain: every component times the plaintext polynomial."""
+        if not (a.is_ntt and p.is_ntt):
+            raise _cabi.DpfheError(2002, "multiply_plain needs NTT-domain operands")
+        pt = p.data.expand(a.data.shape).contiguous()
+        return Ciphertext(self.dyadic_mul(a.data, pt, stream=stream), True)
+
+    def matvec_plain(self, W: Plaintext, x: Ciphertext, out: torch.Tensor | None = None, stream=None) -> Ciphertext:
+        """y_i = sum_j W_ij (.) x_j.  W.data: [rows][cols][L][N] (NTT), x.data: [cols][2][L][N] (NTT)."""
+        if not (W.is_ntt and x.is_ntt):
+            raise _cabi.DpfheError(2002, "matvec_plain needs NTT-domain operands")
+        self._chk(W.data, x.data)
+        if W.data.dim() != 4 or x.data.dim() != 4 or x.size != 2 or W.data.shape[1] != x.data.shape[0]:
+            raise _cabi.DpfheError(2000, "matvec_plain: W [rows][cols][L][N], x [cols][2][L][N]")
+        rows, cols = W.data.shape[0], W.data.shape[1]
+        if out is None:
+            out = self.ctx.empty(rows, components=2)
+        self._chk(out)
+        _cabi.check(self._lib.dpfhe_matvec_plain(self.ctx.handle, out.data_ptr(), W.data.data_ptr(), x.data.data_ptr(), rows, cols, _stream_ptr(stream)), "dpfhe_matvec_plain")
+        return Ciphertext(out, True)

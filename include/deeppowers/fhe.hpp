@@ -1,0 +1,136 @@
+// deeppowers/fhe.hpp - C++ operator API of the FHE ciphertext-arithmetic hot path.
+//
+// The reference has no Ciphertext/Evaluator to keep, so this is the BUILD-SPEC
+// API of SURVEY.md section 8(a)/(b), written in the reference's house style so that it reads like the
+// rest of deeppowers:
+//   - namespace deeppowers                     (/root/reference/src/core/hal/hal.hpp:8)
+//   - pimpl with std::unique_ptr<Impl>         (/root/reference/src/api/cpp/include/deeppowers.hpp:73-75)
+//   - heavy objects are non-copyable           (/root/reference/src/core/execution/model.hpp:88-89)
+//   - errors are exceptions carrying ErrorCode (/root/reference/src/common/error.hpp:42-53)
+//   - device chosen by id                      (/root/reference/src/api/cpp/src/deeppowers.cpp:15)
+//   - optional stream as the last argument     (/root/reference/src/core/hal/hal.hpp:95)
+// Host code stays C++; every operation is one call through the C ABI of include/dpfhe.h into HIP kernels.
+// An encrypted linear layer at the reference's matmul sites
+// (/root/reference/src/core/execution/models/gpt_model.cpp:793,848,883) is Evaluator::matvec_plain.
+#pragma once
+
+#include <cstddef>
+#include <cstdint>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+namespace deeppowers {
+namespace fhe {
+
+// numbers of deeppowers::common::ErrorCode (/root/reference/src/common/error.hpp:10-40)
+enum class ErrorCode { SUCCESS = 0, OUT_OF_MEMORY = 1001, DEVICE_ERROR = 1002, INVALID_ARGUMENT = 2000, INVALID_STATE = 2002, RUNTIME_ERROR = 3000 };
+
+class Exception : public std::runtime_error {
+public:
+    Exception(ErrorCode code, const std::string& message) : std::runtime_error(message), code_(code) {}
+    ErrorCode code() const { return code_; }
+
+private:
+    ErrorCode code_;
+};
+
+using Stream = void;  // a hipStream_t; nullptr = the null stream
+
+struct FheParams {
+    uint32_t log2_n = 0;
+    std::vector<uint64_t> moduli;  // primes < 2^60, q = 1 (mod 2N)
+    std::vector<uint64_t> psi;     // primitive 2N-th roots of unity
+    size_t n() const { return size_t(1) << log2_n; }
+    size_t n_limbs() const { return moduli.size(); }
+    static FheParams config1();     // N=1024, one 30-bit limb       (BASELINE.json configs[0])
+    static FheParams n4096_l4();    // N=4096, 4 x 60-bit limbs      (configs[1..3], the metric)
+    static FheParams n8192_l6();    // N=8192, 6 x 60-bit limbs      (configs[4] sizes)
+};
+
+class Context {
+public:
+    explicit Context(const FheParams& params, int device_id = 0);
+    ~Context();
+    Context(const Context&) = delete;
+    Context& operator=(const Context&) = delete;
+
+    const FheParams& params() const;
+    int device_id() const;
+    bool uses_fold() const;
+    void* handle() const;  // dpfhe_ctx*
+    void synchronize() const;
+
+private:
+    class Impl;
+    std::unique_ptr<Impl> impl_;
+};
+
+// Device-resident words [batch][components][L][N]; owner of its buffer.
+class PolyBuffer {
+public:
+    PolyBuffer(const Context& ctx, size_t batch, size_t components, bool is_ntt);
+    ~PolyBuffer();
+    PolyBuffer(PolyBuffer&&) noexcept;
+    PolyBuffer& operator=(PolyBuffer&&) noexcept;
+    PolyBuffer(const PolyBuffer&) = delete;
+    PolyBuffer& operator=(const PolyBuffer&) = delete;
+
+    uint64_t* data();
+    const uint64_t* data() const;
+    size_t batch() const;
+    size_t size() const;   // components per item
+    size_t words() const;  // batch * size * L * N
+    bool is_ntt() const;
+    void set_ntt(bool v);
+    void copy_from_host(const uint64_t* src);  // words() canonical residues
+    void copy_to_host(uint64_t* dst) const;
+
+private:
+    class Impl;
+    std::unique_ptr<Impl> impl_;
+};
+
+class Plaintext : public PolyBuffer {  // A5: one polynomial per item
+public:
+    explicit Plaintext(const Context& ctx, size_t batch = 1, bool is_ntt = false) : PolyBuffer(ctx, batch, 1, is_ntt) {}
+};
+
+class Ciphertext : public PolyBuffer {  // A4: size in {2, 3}
+public:
+    explicit Ciphertext(const Context& ctx, size_t size = 2, size_t batch = 1, bool is_ntt = false);
+};
+
+class Evaluator {
+public:
+    explicit Evaluator(const Context& ctx);
+    ~Evaluator();
+    Evaluator(const Evaluator&) = delete;
+    Evaluator& operator=(const Evaluator&) = delete;
+
+    // A1 / A2 (in place; flips is_ntt)
+    void transform_to_ntt_inplace(PolyBuffer& x, Stream* stream = nullptr) const;
+    void transform_from_ntt_inplace(PolyBuffer& x, Stream* stream = nullptr) const;
+    // A3 / A8 on whole buffers (same shape and domain)
+    void add(const PolyBuffer& a, const PolyBuffer& b, PolyBuffer& out, Stream* stream = nullptr) const;
+    void sub(const PolyBuffer& a, const PolyBuffer& b, PolyBuffer& out, Stream* stream = nullptr) const;
+    void negate(const PolyBuffer& a, PolyBuffer& out, Stream* stream = nullptr) const;
+    void dyadic_multiply(const PolyBuffer& a, const PolyBuffer& b, PolyBuffer& out, Stream* stream = nullptr) const;
+    void dyadic_multiply_add(const PolyBuffer& a, const PolyBuffer& b, PolyBuffer& acc, Stream* stream = nullptr) const;
+    // A6: the metric op.  out must be a 3-component ciphertext of the same batch; its domain flag selects OUT_NTT.
+    void multiply(const Ciphertext& a, const Ciphertext& b, Ciphertext& out, Stream* stream = nullptr) const;
+    // A7: ct (.) pt per component (NTT domain) and the matrix-vector product y_i = sum_j W_ij (.) x_j
+    void multiply_plain(const Ciphertext& a, const Plaintext& p, Ciphertext& out, Stream* stream = nullptr) const;
+    void matvec_plain(const Plaintext& W /* batch = rows*cols */, const Ciphertext& x /* batch = cols */, Ciphertext& y /* batch = rows */,
+                      Stream* stream = nullptr) const;
+    // A8: modular sum over the batch -> one item
+    void reduce_sum(const PolyBuffer& in, PolyBuffer& out, Stream* stream = nullptr) const;
+
+private:
+    class Impl;
+    std::unique_ptr<Impl> impl_;
+};
+
+}  // namespace fhe
+}  // namespace deeppowers

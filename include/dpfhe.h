@@ -1,0 +1,115 @@
+/*
+ * dpfhe.h - C ABI of libdpfhe_hip.so: the MI355X (gfx950) implementation of DeepPowers' FHE
+ * ciphertext-arithmetic hot path (negacyclic NTT / inverse NTT over Z_q, coefficient-wise modular
+ * mul/add, ciphertext x ciphertext and ciphertext x plaintext multiply).
+ *
+ * What each entry point replaces in the reference: NOTHING EXISTS THERE.  deeppowers/deeppowers has no
+ * Ciphertext/Evaluator/NTT code, so there is no FFI surface to bind to.  These are
+ * the entry points SURVEY.md section 8(b) specifies for the path, shaped by the reference's plugin seam
+ * and conventions:
+ *   - device placement + raw device pointers + optional stream last:
+ *       /root/reference/src/core/hal/hal.hpp:36-57 (Device::allocate/memcpy), :95 (launch(cfg, Stream*))
+ *   - error numbers are deeppowers::common::ErrorCode values:
+ *       /root/reference/src/common/error.hpp:10-40 (SUCCESS=0, OUT_OF_MEMORY=1001, DEVICE_ERROR=1002,
+ *       INVALID_ARGUMENT=2000, INVALID_STATE=2002, RUNTIME_ERROR=3000)
+ *   - the encrypted matmul sites an Evaluator would serve (callers of dpfhe_matvec_plain):
+ *       /root/reference/src/core/execution/models/gpt_model.cpp:793 (QKV), :848 (FFN), :883 (logits)
+ *   - the one collective kept (dpfhe_comm_allgather):
+ *       /root/reference/src/core/distributed/distributed_context.cpp:97-122 (ncclAllGather), without its
+ *       per-call cudaMalloc/stream-create (:109, :88).
+ *
+ * Conventions
+ *   - All data buffers are DEVICE pointers owned by the caller, 16-byte aligned, holding little-endian
+ *     u64 words that are canonical residues in [0, q_limb).  Layout: [batch][component][limb][N], contiguous.
+ *     "n_rns_polys" counts RNS polynomials (L limbs x N words each); a 2-component ciphertext is 2 of them.
+ *   - forward NTT: natural order in, BIT-REVERSED order out, ahat[k] = sum_j a[j] psi^((2 brv(k)+1) j);
+ *     inverse NTT: bit-reversed in, natural out, including N^-1.  Outputs are canonical.
+ *   - `stream` is a hipStream_t (NULL = the null stream).  Calls only enqueue work; they never allocate,
+ *     never synchronise.  A dpfhe_ctx is immutable after creation: concurrent calls from different host
+ *     threads on different streams are allowed.
+ *   - No C++ types and no exceptions cross this boundary.
+ */
+#ifndef DPFHE_H
+#define DPFHE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct dpfhe_ctx dpfhe_ctx;
+typedef struct dpfhe_comm dpfhe_comm;
+
+/* deeppowers::common::ErrorCode numbers (/root/reference/src/common/error.hpp:10-40) */
+enum {
+    DPFHE_SUCCESS = 0,
+    DPFHE_OUT_OF_MEMORY = 1001,
+    DPFHE_DEVICE_ERROR = 1002,
+    DPFHE_INVALID_ARGUMENT = 2000,
+    DPFHE_INVALID_STATE = 2002,
+    DPFHE_RUNTIME_ERROR = 3000
+};
+
+/* dpfhe_ct_mul flags: which domain the inputs are in / the output is wanted in */
+enum { DPFHE_IN_NTT = 1u, DPFHE_OUT_NTT = 2u };
+
+/* -- A0: context ----------------------------------------------------------------------------------
+ * log2_n in [8, 14]; n_limbs >= 1; moduli[i] prime < 2^60 with q = 1 (mod 2N); psi[i] a primitive
+ * 2N-th root of unity mod q_i (psi^N = -1).  Builds twiddle / Shoup / Barrett tables on device_id. */
+int dpfhe_ctx_create(dpfhe_ctx** out, uint32_t log2_n, uint32_t n_limbs, const uint64_t* moduli,
+                     const uint64_t* psi, int device_id);
+int dpfhe_ctx_destroy(dpfhe_ctx* ctx);
+uint32_t dpfhe_ctx_log2n(const dpfhe_ctx* ctx);
+uint32_t dpfhe_ctx_limbs(const dpfhe_ctx* ctx);
+/* 1 if every limb is of the form 2^60 - d, d < 2^24, and the fold-reduction kernels are in use */
+int dpfhe_ctx_uses_fold(const dpfhe_ctx* ctx);
+
+/* -- A1 / A2: batched negacyclic NTT, in place and out of place -------------------------------------- */
+int dpfhe_ntt_fwd(dpfhe_ctx* ctx, uint64_t* d_io, size_t n_rns_polys, void* stream);
+int dpfhe_ntt_inv(dpfhe_ctx* ctx, uint64_t* d_io, size_t n_rns_polys, void* stream);
+int dpfhe_ntt_fwd_oop(dpfhe_ctx* ctx, uint64_t* d_out, const uint64_t* d_in, size_t n_rns_polys, void* stream);
+int dpfhe_ntt_inv_oop(dpfhe_ctx* ctx, uint64_t* d_out, const uint64_t* d_in, size_t n_rns_polys, void* stream);
+
+/* -- A3: coefficient-wise modular ops (either domain); out may alias a or b ----------------------------- */
+int dpfhe_dyadic_mul(dpfhe_ctx* ctx, uint64_t* d_out, const uint64_t* d_a, const uint64_t* d_b, size_t n_rns_polys, void* stream);
+int dpfhe_dyadic_mul_add(dpfhe_ctx* ctx, uint64_t* d_acc, const uint64_t* d_a, const uint64_t* d_b, size_t n_rns_polys, void* stream);
+int dpfhe_add(dpfhe_ctx* ctx, uint64_t* d_out, const uint64_t* d_a, const uint64_t* d_b, size_t n_rns_polys, void* stream);
+int dpfhe_sub(dpfhe_ctx* ctx, uint64_t* d_out, const uint64_t* d_a, const uint64_t* d_b, size_t n_rns_polys, void* stream);
+int dpfhe_negate(dpfhe_ctx* ctx, uint64_t* d_out, const uint64_t* d_a, size_t n_rns_polys, void* stream);
+
+/* -- A6: ciphertext x ciphertext tensor product, no relinearisation (THE METRIC OP) -----------------
+ * d_a2, d_b2: [batch][2][L][N];  d_out3: [batch][3][L][N] = (a0 b0, a0 b1 + a1 b0, a1 b1) in R_q.
+ * flags = 0: coefficient domain in and out (4 NTT + 4 dyadic mul + 1 add + 3 inverse NTT per limb, one
+ * fused kernel: 7 residue polynomials of HBM traffic per limb). */
+int dpfhe_ct_mul(dpfhe_ctx* ctx, uint64_t* d_out3, const uint64_t* d_a2, const uint64_t* d_b2, size_t batch,
+                 uint32_t flags, void* stream);
+
+/* -- A7: ciphertext x plaintext matrix-vector product, everything in the NTT domain ------------------
+ * d_W: [rows][cols][L][N] plaintext polys; d_x: [cols][2][L][N]; d_y: [rows][2][L][N],
+ * y_i = sum_j W_ij (.) x_j  with 128-bit lazy accumulation and one reduction at the end. */
+int dpfhe_matvec_plain(dpfhe_ctx* ctx, uint64_t* d_y, const uint64_t* d_W, const uint64_t* d_x, size_t rows,
+                       size_t cols, void* stream);
+
+/* -- A8: modular sum of `count` ciphertexts of `components` RNS polys each into one ------------------
+ * d_in: [count][components][L][N] -> d_out: [components][L][N].  (shard-local reduce before the all-gather) */
+int dpfhe_reduce_sum(dpfhe_ctx* ctx, uint64_t* d_out, const uint64_t* d_in, size_t count, size_t components, void* stream);
+
+/* -- (e): the one collective - RCCL all-gather of one partial ciphertext per rank over xGMI ----------
+ * One process per GPU.  Rank 0 calls dpfhe_comm_unique_id, ships the 128 bytes to the other ranks by any
+ * means (the host program's own rendezvous), every rank calls dpfhe_comm_create.  d_recv holds
+ * world_size * words_per_rank words; rank r's contribution lands at offset r * words_per_rank. */
+int dpfhe_comm_unique_id(uint8_t out_id[128]);
+int dpfhe_comm_create(dpfhe_comm** out, const uint8_t id[128], int rank, int world_size, int device_id);
+int dpfhe_comm_destroy(dpfhe_comm* comm);
+int dpfhe_comm_allgather(dpfhe_comm* comm, uint64_t* d_recv, const uint64_t* d_send, size_t words_per_rank, void* stream);
+
+const char* dpfhe_strerror(int code);
+/* text of the last HIP/RCCL failure on the calling thread ("" if none) */
+const char* dpfhe_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DPFHE_H */

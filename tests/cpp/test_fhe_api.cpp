@@ -1,0 +1,101 @@
+// GPU test of the C++ facade (deeppowers::fhe) against the C oracle.  Built and run by
+// tests/test_gpu_cpp_api.py (-m gpu).  Exit code 0 = all checks passed.
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+#include "deeppowers/fhe.hpp"
+
+extern "C" {
+struct orc_ctx;
+int orc_ctx_create(orc_ctx** out, uint32_t log2n, uint32_t n_limbs, const uint64_t* moduli, const uint64_t* psi);
+void orc_ctx_destroy(orc_ctx* c);
+void orc_fill_splitmix(const orc_ctx* c, uint64_t* out, size_t n_rns_polys, uint64_t seed);
+void orc_ct_mul(const orc_ctx* c, uint64_t* out3, const uint64_t* a2, const uint64_t* b2, size_t batch, int threads);
+void orc_ntt_fwd(const orc_ctx* c, uint64_t* io, size_t n_rns_polys, int threads);
+void orc_matvec_plain(const orc_ctx* c, uint64_t* y, const uint64_t* W, const uint64_t* x, size_t rows, size_t cols, size_t comps, int threads);
+}
+
+using namespace deeppowers::fhe;
+static int failures = 0;
+#define CHECK(cond)                                                         \
+    do {                                                                    \
+        if (!(cond)) { std::printf("FAIL %s:%d  %s\n", __FILE__, __LINE__, #cond); ++failures; } \
+    } while (0)
+
+static void run(const FheParams& p, size_t batch) {
+    const size_t L = p.n_limbs(), n = p.n();
+    orc_ctx* orc = nullptr;
+    CHECK(orc_ctx_create(&orc, p.log2_n, (uint32_t)L, p.moduli.data(), p.psi.data()) == 0);
+    std::vector<uint64_t> a(batch * 2 * L * n), b(a.size()), want(batch * 3 * L * n), got(want.size());
+    orc_fill_splitmix(orc, a.data(), batch * 2, 1001);
+    orc_fill_splitmix(orc, b.data(), batch * 2, 1002);
+    orc_ct_mul(orc, want.data(), a.data(), b.data(), batch, 0);
+
+    Context ctx(p, 0);
+    Evaluator ev(ctx);
+    Ciphertext A(ctx, 2, batch), B(ctx, 2, batch), C(ctx, 3, batch);
+    A.copy_from_host(a.data());
+    B.copy_from_host(b.data());
+    ev.multiply(A, B, C);
+    ctx.synchronize();
+    C.copy_to_host(got.data());
+    CHECK(std::memcmp(got.data(), want.data(), want.size() * 8) == 0);
+
+    // NTT-domain route: transform, multiply with an NTT-domain output, transform back
+    ev.transform_to_ntt_inplace(A);
+    ev.transform_to_ntt_inplace(B);
+    std::vector<uint64_t> an(a);
+    orc_ntt_fwd(orc, an.data(), batch * 2, 0);
+    std::vector<uint64_t> an_got(a.size());
+    A.copy_to_host(an_got.data());
+    CHECK(an_got == an);
+    Ciphertext Cn(ctx, 3, batch, /*is_ntt=*/true);
+    ev.multiply(A, B, Cn);
+    ev.transform_from_ntt_inplace(Cn);
+    Cn.copy_to_host(got.data());
+    CHECK(std::memcmp(got.data(), want.data(), want.size() * 8) == 0);
+
+    // ct x pt matvec (rows=3, cols=batch) in the NTT domain
+    const size_t rows = 3, cols = batch;
+    std::vector<uint64_t> W(rows * cols * L * n), y_want(rows * 2 * L * n), y_got(y_want.size());
+    orc_fill_splitmix(orc, W.data(), rows * cols, 1003);
+    orc_matvec_plain(orc, y_want.data(), W.data(), an.data(), rows, cols, 2, 0);
+    Plaintext Wd(ctx, rows * cols, true);
+    Wd.copy_from_host(W.data());
+    Ciphertext Y(ctx, 2, rows, true);
+    ev.matvec_plain(Wd, A, Y);
+    Y.copy_to_host(y_got.data());
+    CHECK(y_got == y_want);
+
+    // error behaviour: exceptions with reference error codes
+    try {
+        Ciphertext bad(ctx, 2, batch, true);
+        ev.multiply(bad, Ciphertext(ctx, 2, batch, false), C);
+        CHECK(!"expected INVALID_STATE");
+    } catch (const Exception& e) { CHECK(e.code() == ErrorCode::INVALID_STATE); }
+    try {
+        Ciphertext four(ctx, 4, 1);
+        CHECK(!"expected INVALID_ARGUMENT");
+    } catch (const Exception& e) { CHECK(e.code() == ErrorCode::INVALID_ARGUMENT); }
+    orc_ctx_destroy(orc);
+}
+
+int main() {
+    try {
+        run(FheParams::config1(), 2);
+        run(FheParams::n4096_l4(), 3);
+        run(FheParams::n8192_l6(), 2);
+        try {
+            FheParams p = FheParams::n4096_l4();
+            p.psi[0] = 3;
+            Context bad(p, 0);
+            CHECK(!"expected INVALID_ARGUMENT");
+        } catch (const Exception& e) { CHECK(e.code() == ErrorCode::INVALID_ARGUMENT); }
+    } catch (const std::exception& e) {
+        std::printf("unexpected exception: %s\n", e.what());
+        return 2;
+    }
+    std::printf(failures ? "FAILED (%d)\n" : "OK\n", failures);
+    return failures ? 1 : 0;
+}

@@ -71,6 +71,26 @@ def rns_ct_mul_small():
     return {"log2n": log2n, "moduli": moduli, "psi": psis, "batch": batch, "a": A, "b": B, "c": Cc}
 
 
+def rns_ct_mul_n256():
+    """2 limbs (one fold-eligible 60-bit prime, the 30-bit prime), N=256, batch=3: smallest size the
+    HIP C-ABI dispatches (log2_n >= 8), so the GPU tests can replay a pure big-int vector."""
+    log2n, n = 8, 256
+    moduli = [PRIMES_60[2][0], PRIME_30]
+    psis = [pow(PRIMES_60[2][2], 8192 // n, moduli[0]), pow(PSI_30_N1024, 1024 // n, moduli[1])]
+    g = po.SplitMix64(256)
+    batch = 3
+    A, B, Cc = [], [], []
+    for _ in range(batch):
+        a = [[g.words_mod(n, q) for q in moduli] for _ in range(2)]
+        b = [[g.words_mod(n, q) for q in moduli] for _ in range(2)]
+        c = po.ct_mul_schoolbook(a, b, moduli)
+        A += po.flatten_ct(a); B += po.flatten_ct(b); Cc += po.flatten_ct(c)
+    ntt_a0 = [po.ntt_forward(A[l * n:(l + 1) * n], moduli[l], psis[l]) for l in range(2)]
+    return {"log2n": log2n, "moduli": moduli, "psi": psis, "batch": batch, "a": A, "b": B,
+            "c_sha256": sha(Cc), "c_head": Cc[:8], "c_tail": Cc[-8:], "ntt_a0_limb0_head": ntt_a0[0][:8],
+            "ntt_a0_sha256": sha(ntt_a0[0] + ntt_a0[1])}
+
+
 def identities():
     """Hand-checkable products + NTT(delta_0), NTT(X)."""
     n, q = 8, 17
@@ -104,6 +124,7 @@ if __name__ == "__main__":
         "config1_ct_mul": config1_ct_mul(),
         "rns_ct_mul_small": rns_ct_mul_small(),
         "identities": identities(),
+        "rns_ct_mul_n256": rns_ct_mul_n256(),
         "n4096_ntt_digest": n4096_ntt_digest(),
     }
     for k, v in data.items():

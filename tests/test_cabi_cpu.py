@@ -1,0 +1,73 @@
+"""CPU: the C-ABI library loads, exports every symbol include/dpfhe.h declares, validates its
+arguments, and fails loudly (no compute calls here - there is no GPU in this container)."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+from deeppowers_amd import _cabi
+from deeppowers_amd.params import FheParams, PRIMES_60
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    if not os.path.exists(_cabi.LIB_PATH):
+        import __graft_entry__ as g
+        g.build()
+    return _cabi.load()
+
+
+def test_every_header_symbol_is_exported_and_bound(lib):
+    hdr = open(os.path.join(ROOT, "include", "dpfhe.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(dpfhe_[a-z0-9_]+)\s*\(", hdr))
+    assert declared, "no declarations parsed"
+    assert declared == set(_cabi.SYMBOLS), declared ^ set(_cabi.SYMBOLS)
+    for name in declared:
+        assert getattr(lib, name) is not None
+
+
+def test_strerror_uses_reference_error_codes(lib):
+    # numbers of deeppowers::common::ErrorCode (/root/reference/src/common/error.hpp:10-40)
+    assert lib.dpfhe_strerror(0) == b"success"
+    assert lib.dpfhe_strerror(1001) == b"out of memory"
+    assert lib.dpfhe_strerror(1002) == b"device error"
+    assert lib.dpfhe_strerror(2000) == b"invalid argument"
+    assert lib.dpfhe_strerror(2002) == b"invalid state"
+    assert lib.dpfhe_strerror(3000) == b"runtime error"
+
+
+def _create(lib, log2n, moduli, psi, dev=0):
+    h = C.c_void_p()
+    L = len(moduli)
+    rc = lib.dpfhe_ctx_create(C.byref(h), log2n, L, (C.c_uint64 * L)(*moduli), (C.c_uint64 * L)(*psi), dev)
+    return rc, h
+
+
+def test_ctx_create_rejects_bad_parameters_before_touching_the_device(lib):
+    p = FheParams.n4096_l4()
+    assert _create(lib, 12, p.moduli, p.moduli)[0] == 2000            # psi not a 2N-th root
+    assert _create(lib, 12, [PRIMES_60[0][0] + 2], [3])[0] == 2000    # not 1 mod 2N
+    assert _create(lib, 7, p.moduli, p.psi)[0] == 2000                # log2_n out of range
+    assert _create(lib, 14, p.moduli, p.psi)[0] == 2000
+    assert _create(lib, 12, [(1 << 61) + 1], [3])[0] == 2000          # modulus too wide
+    assert b"psi" in lib.dpfhe_last_error() or b"modulus" in lib.dpfhe_last_error()
+    assert lib.dpfhe_ctx_create(None, 12, 1, None, None, 0) == 2000
+
+
+def test_null_context_and_destroy_are_safe(lib):
+    assert lib.dpfhe_ntt_fwd(None, None, 1, None) == 2000
+    assert lib.dpfhe_ct_mul(None, None, None, None, 1, 0, None) == 2000
+    assert lib.dpfhe_ctx_destroy(None) == 0
+    assert lib.dpfhe_comm_destroy(None) == 0
+    assert lib.dpfhe_ctx_log2n(None) == 0 and lib.dpfhe_ctx_uses_fold(None) == 0
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    monkeypatch.setattr(_cabi, "_lib", None)
+    monkeypatch.setattr(_cabi, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(ImportError, match="no CPU fallback"):
+        _cabi.load()

@@ -1,0 +1,31 @@
+"""-m gpu: builds (g++) and runs the C++ facade test - host code in C++ calling HIP through the C ABI."""
+import os
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def build_cpp_test():
+    exe = os.path.join(ROOT, "tests", "cpp", "test_fhe_api")
+    lib = os.path.join(ROOT, "deeppowers_amd")
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "liboracle.so"])
+    subprocess.check_call([
+        "g++", "-O2", "-std=c++17", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "cpp", "test_fhe_api.cpp"),
+        "-o", exe, "-L" + lib, "-ldpfhe_api", "-ldpfhe_hip", "-L" + os.path.join(ROOT, "oracle"), "-loracle",
+        "-L/opt/rocm/lib", "-lamdhip64", f"-Wl,-rpath,{lib}", f"-Wl,-rpath,{os.path.join(ROOT, 'oracle')}", "-Wl,-rpath,/opt/rocm/lib"])
+    return exe
+
+
+def test_cpp_facade_compiles_and_links():
+    """CPU: the facade header, its library and the test program link (no GPU call)."""
+    assert os.path.exists(build_cpp_test())
+
+
+@pytest.mark.gpu
+def test_cpp_facade_parity_on_gpu():
+    exe = build_cpp_test()
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "OK" in out.stdout

@@ -1,0 +1,343 @@
+"""GPU parity tests (-m gpu): the HIP path through the C ABI vs the CPU oracle and the committed golden
+vectors.  Integer work: every comparison is BIT-EXACT.  Nothing here reads /root/reference."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+from deeppowers_amd import _cabi  # noqa: E402
+from deeppowers_amd.evaluator import Ciphertext, Context, Evaluator, Plaintext, to_device, to_host  # noqa: E402
+from deeppowers_amd.params import PRIMES_60, PRIME_30, PSI_30_N1024, FheParams  # noqa: E402
+from oracle import pyoracle as po  # noqa: E402
+from oracle.cbind import Oracle  # noqa: E402
+
+
+def sha(arr):
+    return hashlib.sha256(np.ascontiguousarray(arr, dtype="<u8").tobytes()).hexdigest()
+
+
+def load(golden_dir, name):
+    with open(os.path.join(golden_dir, name + ".json")) as f:
+        return json.load(f)
+
+
+def generic_prime(bits, two_n):
+    """largest prime < 2^bits that is 1 mod two_n (NOT of the 2^60 - d form: exercises ShoupArith)."""
+    q = (1 << bits) - ((1 << bits) - 1) % two_n
+    while not po.is_prime(q):
+        q -= two_n
+    return q
+
+
+class Rig:
+    def __init__(self, params):
+        self.p = params
+        self.orc = Oracle.from_params(params)
+        self.ctx = Context(params, 0)
+        self.ev = Evaluator(self.ctx)
+
+    def dev(self, a):
+        return to_device(a, self.ctx.device)
+
+
+@pytest.fixture(scope="module")
+def rigs():
+    cache = {}
+
+    def get(name):
+        if name not in cache:
+            if name == "config1":
+                p = FheParams.config1()
+            elif name == "n4096":
+                p = FheParams.n4096_l4()
+            elif name == "n8192":
+                p = FheParams.n8192_l6()
+            elif name.startswith("shoup"):  # generic primes of several widths, 3 limbs
+                log2n = int(name[5:])
+                n = 1 << log2n
+                qs = [generic_prime(59, 2 * n), generic_prime(50, 2 * n), generic_prime(33, 2 * n)]
+                p = FheParams(log2n, tuple(qs), tuple(po.min_primitive_2n_root(n, q) for q in qs))
+            else:  # foldN: pinned 60-bit primes at another N
+                log2n = int(name[4:])
+                n = 1 << log2n
+                qs = [PRIMES_60[i][0] for i in (0, 2, 5)]
+                p = FheParams(log2n, tuple(qs), tuple(pow(PRIMES_60[i][2], 8192 // n, PRIMES_60[i][0]) for i in (0, 2, 5)))
+            cache[name] = Rig(p)
+        return cache[name]
+
+    yield get
+    for r in cache.values():
+        r.ctx.close()
+
+
+ALL = ["config1", "n4096", "n8192", "fold8", "fold9", "fold10", "fold11", "shoup8", "shoup10", "shoup12", "shoup13"]
+
+
+def test_arithmetic_policy_selection(rigs):
+    assert rigs("n4096").ctx.uses_fold and rigs("n8192").ctx.uses_fold
+    assert not rigs("config1").ctx.uses_fold and not rigs("shoup12").ctx.uses_fold
+
+
+# ---- golden vectors -------------------------------------------------------------------------------------
+def test_config1_ct_mul_matches_appendix_b_digest(rigs, golden_dir):
+    d = load(golden_dir, "config1_ct_mul")
+    r = rigs("config1")
+    ab = r.orc.fill(4, 1).reshape(4, 1, 1024)
+    assert ab[0, 0, :4].tolist() == d["a0_head"]
+    a = Ciphertext(r.dev(ab[:2].reshape(1, 2, 1, 1024)))
+    b = Ciphertext(r.dev(ab[2:].reshape(1, 2, 1, 1024)))
+    c = to_host(r.ev.multiply(a, b).data)
+    assert sha(c) == d["sha256"]["c0c1c2"] == "9e97bb5cf219416d6cb3683b99de66ee8aaec17496504a97bf0471fdf43ab66b"
+    assert c[0, 0, 0].tolist() == d["c0"] and c[0, 1, 0].tolist() == d["c1"] and c[0, 2, 0].tolist() == d["c2"]
+
+
+def test_n4096_ntt_golden_digests(rigs, golden_dir):
+    r = rigs("n4096")
+    x = np.zeros((1, 4, 4096), np.uint64)
+    vs = load(golden_dir, "n4096_ntt_digest")
+    for v in vs:
+        x[0, v["limb"]] = po.SplitMix64(v["seed"]).words_mod(4096, v["q"])
+    y = to_host(r.ev.ntt_forward(r.dev(x)))
+    for v in vs:
+        assert y[0, v["limb"], :4].tolist() == v["ntt_head"] and sha(y[0, v["limb"]]) == v["ntt_sha256"]
+
+
+def test_n256_bigint_fixture_mixed_fold_and_30bit_limbs(golden_dir):
+    v = load(golden_dir, "rns_ct_mul_n256")
+    p = FheParams(v["log2n"], tuple(v["moduli"]), tuple(v["psi"]))
+    ctx = Context(p, 0)
+    ev = Evaluator(ctx)
+    assert not ctx.uses_fold  # one limb is the 30-bit prime -> generic path for the whole context
+    shape = (v["batch"], 2, 2, 256)
+    a = np.array(v["a"], np.uint64).reshape(shape)
+    b = np.array(v["b"], np.uint64).reshape(shape)
+    c = to_host(ev.multiply(Ciphertext(to_device(a, ctx.device)), Ciphertext(to_device(b, ctx.device))).data)
+    assert sha(c) == v["c_sha256"] and c.ravel()[:8].tolist() == v["c_head"] and c.ravel()[-8:].tolist() == v["c_tail"]
+    na = to_host(ev.ntt_forward(to_device(a[0, 0], ctx.device)))
+    assert na[0, :8].tolist() == v["ntt_a0_limb0_head"] and sha(na) == v["ntt_a0_sha256"]
+    ctx.close()
+
+
+def test_identities_on_device(rigs):
+    r = rigs("n4096")
+    n, L = 4096, 4
+    delta = np.zeros((1, L, n), np.uint64); delta[:, :, 0] = 1
+    assert np.all(to_host(r.ev.ntt_forward(r.dev(delta))) == 1)
+    X = np.zeros((1, L, n), np.uint64); X[:, :, 1] = 1
+    nx = to_host(r.ev.ntt_forward(r.dev(X)))
+    for l, (q, psi) in enumerate(zip(r.p.moduli, r.p.psi)):
+        for k in (0, 1, 2, 1234, 4095):
+            assert int(nx[0, l, k]) == pow(psi, 2 * po.bit_reverse(k, 12) + 1, q)
+    # (1 + X) * X^(N-1) = X^(N-1) - 1 through the fused multiply (a1 = b1 = 0)
+    a = np.zeros((1, 2, L, n), np.uint64); a[0, 0, :, 0] = 1; a[0, 0, :, 1] = 1
+    b = np.zeros((1, 2, L, n), np.uint64); b[0, 0, :, n - 1] = 1
+    c = to_host(r.ev.multiply(Ciphertext(r.dev(a)), Ciphertext(r.dev(b))).data)
+    for l, q in enumerate(r.p.moduli):
+        want = np.zeros(n, np.uint64); want[0] = q - 1; want[n - 1] = 1
+        assert np.array_equal(c[0, 0, l], want) and not c[0, 1, l].any() and not c[0, 2, l].any()
+
+
+# ---- NTT vs oracle, every geometry and both arithmetic policies ---------------------------------------------
+@pytest.mark.parametrize("name", ALL)
+def test_ntt_forward_inverse_vs_oracle(rigs, name):
+    r = rigs(name)
+    L, n = r.p.n_limbs, r.p.n
+    for npolys, seed in ((1, 3), (5, 4)):
+        x = r.orc.fill(npolys, seed)
+        # extreme residues in the first polynomial
+        x[0, :, : n // 2] = (np.array(r.p.moduli, np.uint64) - np.uint64(1))[:, None]
+        if npolys > 1:
+            x[1] = 0
+            x[2] = (np.array(r.p.moduli, np.uint64) - np.uint64(1))[:, None]
+        want = r.orc.ntt_fwd(x, threads=0)
+        d = r.dev(x)
+        got = to_host(r.ev.ntt_forward(d))
+        assert np.array_equal(got, want)
+        assert np.array_equal(to_host(d), x), "out-of-place transform modified its input"
+        r.ev.ntt_forward_(d)
+        assert np.array_equal(to_host(d), want)
+        assert np.array_equal(to_host(r.ev.ntt_inverse(d)), x)
+        r.ev.ntt_inverse_(d)
+        assert np.array_equal(to_host(d), x)
+        # inverse of arbitrary canonical data (not an NTT image) is the oracle's inverse too
+        assert np.array_equal(to_host(r.ev.ntt_inverse(r.dev(x))), r.orc.ntt_inv(x, threads=0))
+    assert L == r.p.n_limbs
+
+
+@pytest.mark.parametrize("name", ["config1", "n4096", "n8192", "fold8", "shoup10", "shoup13"])
+def test_dyadic_ops_vs_oracle(rigs, name):
+    r = rigs(name)
+    x = r.orc.fill(9, 17)
+    a, b, acc = x[0:3].copy(), x[3:6].copy(), x[6:9].copy()
+    qs = np.array(r.p.moduli, np.uint64)[:, None]
+    a[0, :, :8] = 0; b[0, :, :8] = 0
+    a[1, :, :8] = qs - np.uint64(1); b[1, :, :8] = qs - np.uint64(1); acc[1, :, :8] = qs - np.uint64(1)
+    A, Bd, ACC = r.dev(a), r.dev(b), r.dev(acc)
+    assert np.array_equal(to_host(r.ev.dyadic_mul(A, Bd)), r.orc.dyadic("mul", a, b))
+    assert np.array_equal(to_host(r.ev.add_words(A, Bd)), r.orc.dyadic("add", a, b))
+    assert np.array_equal(to_host(r.ev.sub_words(A, Bd)), r.orc.dyadic("sub", a, b))
+    assert np.array_equal(to_host(r.ev.negate_words(A)), r.orc.dyadic("negate", a))
+    r.ev.dyadic_mul_add_(ACC, A, Bd)
+    assert np.array_equal(to_host(ACC), r.orc.dyadic("mul_add", a, b, acc=acc))
+    out = A.clone()  # out aliases a
+    r.ev.dyadic_mul(out, Bd, out=out)
+    assert np.array_equal(to_host(out), r.orc.dyadic("mul", a, b))
+
+
+# ---- ct x ct (the metric op) ---------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", ALL)
+def test_ct_mul_vs_oracle_all_domains(rigs, name):
+    r = rigs(name)
+    L, n = r.p.n_limbs, r.p.n
+    for batch in (1, 3):
+        a = r.orc.fill(batch * 2, 31).reshape(batch, 2, L, n)
+        b = r.orc.fill(batch * 2, 32).reshape(batch, 2, L, n)
+        qs = np.array(r.p.moduli, np.uint64)[None, :, None]
+        a[0, :, :, : n // 4] = qs - np.uint64(1)  # worst-case magnitudes for the lazy arithmetic
+        b[0, :, :, : n // 4] = qs - np.uint64(1)
+        want = r.orc.ct_mul(np.ascontiguousarray(a), np.ascontiguousarray(b), threads=0)
+        A, Bc = Ciphertext(r.dev(a)), Ciphertext(r.dev(b))
+        c = r.ev.multiply(A, Bc)
+        assert not c.is_ntt and np.array_equal(to_host(c.data), want)
+        want_ntt = r.orc.ntt_fwd(want.reshape(-1, L, n), threads=0).reshape(want.shape)
+        c2 = r.ev.multiply(A, Bc, out_ntt=True)
+        assert c2.is_ntt and np.array_equal(to_host(c2.data), want_ntt)
+        An = Ciphertext(r.ev.ntt_forward(A.data), True)
+        Bn = Ciphertext(r.ev.ntt_forward(Bc.data), True)
+        c3 = r.ev.multiply(An, Bn)
+        assert c3.is_ntt and np.array_equal(to_host(c3.data), want_ntt)
+        c4 = r.ev.multiply(An, Bn, out_ntt=False)
+        assert np.array_equal(to_host(c4.data), want)
+    if n <= 1024:  # and the oracle's NTT path itself equals schoolbook convolution here
+        sb = r.orc.ct_mul(np.ascontiguousarray(a), np.ascontiguousarray(b), threads=0, schoolbook=True)
+        assert np.array_equal(sb, want)
+
+
+def test_ct_mul_empty_batch_and_errors(rigs):
+    r = rigs("n4096")
+    lib = _cabi.load()
+    assert lib.dpfhe_ct_mul(r.ctx.handle, None, None, None, 0, 0, None) == 0  # empty batch is a no-op
+    assert lib.dpfhe_ntt_fwd(r.ctx.handle, None, 0, None) == 0
+    t = r.ctx.empty(1, components=2)
+    assert lib.dpfhe_ntt_fwd(r.ctx.handle, t.data_ptr() + 8, 1, None) == 2000  # misaligned
+    assert lib.dpfhe_ct_mul(r.ctx.handle, t.data_ptr(), t.data_ptr(), t.data_ptr(), 1, 4, None) == 2000  # unknown flag
+    with pytest.raises(_cabi.DpfheError) as e:
+        r.ev.multiply(Ciphertext(t, True), Ciphertext(t, False))
+    assert e.value.code == 2002
+    with pytest.raises(_cabi.DpfheError):
+        r.ev.ntt_forward_(torch.zeros(4, 4095, dtype=torch.int64, device=r.ctx.device))
+    with pytest.raises(_cabi.DpfheError):
+        Context(FheParams.__new__(FheParams), 0) if False else r.ev.multiply(Ciphertext(r.ctx.empty(components=3)), Ciphertext(r.ctx.empty(components=3)))
+
+
+# ---- ct x pt matvec, reduce ------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name,rows,cols", [("n4096", 5, 7), ("fold8", 3, 300), ("shoup10", 4, 130), ("n8192", 2, 3)])
+def test_matvec_plain_vs_oracle(rigs, name, rows, cols):
+    r = rigs(name)
+    L, n = r.p.n_limbs, r.p.n
+    W = r.orc.fill(rows * cols, 41).reshape(rows, cols, L, n)
+    x = r.orc.fill(cols * 2, 42).reshape(cols, 2, L, n)
+    qs = np.array(r.p.moduli, np.uint64)[:, None]
+    W[0, :, :, :16] = qs - np.uint64(1); x[:, :, :, :16] = qs - np.uint64(1)  # max accumulation
+    want = r.orc.matvec_plain(W.ravel(), x.ravel(), rows, cols, threads=0)
+    y = r.ev.matvec_plain(Plaintext(r.dev(W), True), Ciphertext(r.dev(x), True))
+    assert y.is_ntt and np.array_equal(to_host(y.data), want)
+
+
+def test_multiply_plain_and_ct_add_sub_negate(rigs):
+    r = rigs("n4096")
+    L, n = 4, 4096
+    a = r.orc.fill(4, 51).reshape(2, 2, L, n)
+    b = r.orc.fill(4, 52).reshape(2, 2, L, n)
+    pt = r.orc.fill(1, 53).reshape(L, n)
+    A, Bc = Ciphertext(r.dev(a), True), Ciphertext(r.dev(b), True)
+    assert np.array_equal(to_host(r.ev.add(A, Bc).data), r.orc.dyadic("add", a, b))
+    assert np.array_equal(to_host(r.ev.sub(A, Bc).data), r.orc.dyadic("sub", a, b))
+    assert np.array_equal(to_host(r.ev.negate(A).data), r.orc.dyadic("negate", a))
+    got = to_host(r.ev.multiply_plain(A, Plaintext(r.dev(pt), True)).data)
+    want = r.orc.dyadic("mul", a, np.ascontiguousarray(np.broadcast_to(pt, a.shape)))
+    assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("name,count,comps", [("n4096", 37, 3), ("config1", 5, 2), ("shoup13", 1, 3)])
+def test_reduce_sum_vs_oracle(rigs, name, count, comps):
+    r = rigs(name)
+    L, n = r.p.n_limbs, r.p.n
+    x = r.orc.fill(count * comps, 61).reshape(count, comps, L, n)
+    x[:, :, :, :4] = (np.array(r.p.moduli, np.uint64) - np.uint64(1))[None, None, :, None]
+    got = to_host(r.ev.reduce_sum(Ciphertext(r.dev(x))).data)
+    assert np.array_equal(got, r.orc.reduce_sum(x.ravel(), comps))
+
+
+# ---- full BASELINE sizes: size-independent properties + sampled oracle comparison -----------------------------
+def test_config2_full_size_roundtrip_linearity_and_sampled_oracle(rigs):
+    """configs[1]: batch = 1024 RNS polys x 4 limbs, N = 4096 (128 MiB)."""
+    r = rigs("n4096")
+    L, n, batch = 4, 4096, 1024
+    g = torch.Generator(device="cpu").manual_seed(7)
+    q = torch.tensor(r.p.moduli, dtype=torch.int64).view(1, L, 1)
+    x = (torch.randint(0, 2**62, (batch, L, n), generator=g, dtype=torch.int64) % q).to(r.ctx.device)
+    y = (torch.randint(0, 2**62, (batch, L, n), generator=g, dtype=torch.int64) % q).to(r.ctx.device)
+    X = r.ev.ntt_forward(x)
+    assert torch.equal(r.ev.ntt_inverse(X), x)                                   # NTT o INTT = id
+    s = r.ev.add_words(x, y)
+    assert torch.equal(r.ev.ntt_forward(s), r.ev.add_words(X, r.ev.ntt_forward(y)))  # linearity
+    assert int(X.min()) >= 0 and bool((X < q.to(X.device)).all())              # canonical outputs
+    idx = [0, 1, 511, 1023]
+    want = r.orc.ntt_fwd(to_host(x[idx]), threads=0)
+    assert np.array_equal(to_host(X[idx]), want)
+
+
+def test_ct_mul_large_batch_checksum_of_checksums(rigs):
+    """2048 ct-muls at N=4096/L=4: sum of outputs == output of ... (bilinearity): sum_i a_i (x) b == (sum_i a_i) (x) b."""
+    r = rigs("n4096")
+    L, n, batch = 4, 4096, 2048
+    g = torch.Generator(device="cpu").manual_seed(11)
+    q = torch.tensor(r.p.moduli, dtype=torch.int64).view(1, 1, L, 1)
+    a = (torch.randint(0, 2**62, (batch, 2, L, n), generator=g, dtype=torch.int64) % q).to(r.ctx.device)
+    b1 = (torch.randint(0, 2**62, (1, 2, L, n), generator=g, dtype=torch.int64) % q).to(r.ctx.device)
+    b = b1.expand(batch, 2, L, n).contiguous()
+    c = r.ev.multiply(Ciphertext(a), Ciphertext(b))
+    lhs = r.ev.reduce_sum(c)                                       # sum_i (a_i (x) b)
+    asum = r.ev.reduce_sum(Ciphertext(a))                          # sum_i a_i
+    rhs = r.ev.multiply(Ciphertext(asum.data.unsqueeze(0)), Ciphertext(b1))
+    assert torch.equal(lhs.data, rhs.data[0])
+    idx = [0, 777, 2047]
+    want = r.orc.ct_mul(to_host(a[idx]), to_host(b[idx]), threads=0)
+    assert np.array_equal(to_host(c.data[idx]), want)
+
+
+def test_streams_and_concurrent_contexts(rigs):
+    r = rigs("n4096")
+    x = r.orc.fill(8, 71)
+    want = r.orc.ntt_fwd(x, threads=0)
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    d1, d2 = r.dev(x), r.dev(x)
+    torch.cuda.synchronize()
+    with torch.cuda.stream(s1):
+        r.ev.ntt_forward_(d1)
+    r.ev.ntt_forward_(d2, stream=s2)
+    torch.cuda.synchronize()
+    assert np.array_equal(to_host(d1), want) and np.array_equal(to_host(d2), want)
+
+
+def test_rccl_allgather_world_size_one(rigs):
+    import ctypes as C
+    r = rigs("n4096")
+    lib = _cabi.load()
+    uid = (C.c_uint8 * 128)()
+    _cabi.check(lib.dpfhe_comm_unique_id(uid), "unique_id")
+    comm = C.c_void_p()
+    _cabi.check(lib.dpfhe_comm_create(C.byref(comm), uid, 0, 1, 0), "comm_create")
+    send = r.dev(r.orc.fill(3, 81))
+    recv = torch.zeros_like(send)
+    _cabi.check(lib.dpfhe_comm_allgather(comm, recv.data_ptr(), send.data_ptr(), send.numel(), torch.cuda.current_stream().cuda_stream), "allgather")
+    torch.cuda.synchronize()
+    assert torch.equal(send, recv)
+    lib.dpfhe_comm_destroy(comm)
