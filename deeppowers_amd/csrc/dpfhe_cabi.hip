@@ -16,7 +16,8 @@
 #include <vector>
 
 #include "../../include/dpfhe.h"
-#include "kernels.h"
+#include "kernels_misc.h"
+#include "launch.h"
 #include "tables.h"
 
 using namespace dpfhe;
@@ -148,29 +149,6 @@ const DevTables<ShoupArith>& tables_of<ShoupArith>(const dpfhe_ctx* c) { return 
 template <>
 const DevTables<FoldArith>& tables_of<FoldArith>(const dpfhe_ctx* c) { return c->foldt; }
 
-// geometry dispatch: (log2n -> LOGE) pairs proven by tests/test_emulated_kernels.py
-#define DPFHE_GEO_SWITCH(log2n, MACRO)        \
-    switch (log2n) {                          \
-        case 8: MACRO(8, 4); break;           \
-        case 9: MACRO(9, 4); break;           \
-        case 10: MACRO(10, 4); break;         \
-        case 11: MACRO(11, 4); break;         \
-        case 12: MACRO(12, 4); break;         \
-        case 13: MACRO(13, 5); break;         \
-        default: return fail(DPFHE_INVALID_STATE, "geometry", "unsupported log2_n"); \
-    }
-
-template <class Arith>
-static int launch_ntt(dpfhe_ctx* c, bool inverse, u64* out, const u64* in, size_t npolys, hipStream_t s) {
-    const DevTables<Arith>& tb = tables_of<Arith>(c);
-#define NTT_CASE(LN, LE)                                                                                   \
-    if (inverse) hipLaunchKernelGGL((ntt_inv_kernel<Arith, LN, LE>), dim3((unsigned)npolys), dim3(Geo<LN, LE>::T), 0, s, out, in, tb); \
-    else hipLaunchKernelGGL((ntt_fwd_kernel<Arith, LN, LE>), dim3((unsigned)npolys), dim3(Geo<LN, LE>::T), 0, s, out, in, tb)
-    DPFHE_GEO_SWITCH(c->log2n, NTT_CASE)
-#undef NTT_CASE
-    return check_launch("ntt kernel launch");
-}
-
 static int ntt_entry(dpfhe_ctx* c, bool inverse, uint64_t* out, const uint64_t* in, size_t n_rns_polys, void* stream) {
     if (!c) return fail(DPFHE_INVALID_ARGUMENT, "ntt", "null context");
     if (n_rns_polys == 0) return DPFHE_SUCCESS;
@@ -178,7 +156,10 @@ static int ntt_entry(dpfhe_ctx* c, bool inverse, uint64_t* out, const uint64_t* 
     const size_t npolys = n_rns_polys * c->n_limbs;
     if (npolys > kMaxGrid) return fail(DPFHE_INVALID_ARGUMENT, "ntt", "batch too large for one launch");
     hipStream_t s = static_cast<hipStream_t>(stream);
-    return c->fold ? launch_ntt<FoldArith>(c, inverse, out, in, npolys, s) : launch_ntt<ShoupArith>(c, inverse, out, in, npolys, s);
+    const int rc = c->fold ? launch_ntt<FoldArith>((int)c->log2n, inverse, out, in, npolys, c->foldt, s)
+                           : launch_ntt<ShoupArith>((int)c->log2n, inverse, out, in, npolys, c->shoup, s);
+    if (rc) return fail(DPFHE_INVALID_STATE, "ntt", "no kernel geometry for this log2_n");
+    return check_launch("ntt kernel launch");
 }
 
 extern "C" int dpfhe_ntt_fwd(dpfhe_ctx* c, uint64_t* d_io, size_t n, void* s) { return ntt_entry(c, false, d_io, d_io, n, s); }
@@ -222,27 +203,6 @@ extern "C" int dpfhe_sub(dpfhe_ctx* c, uint64_t* o, const uint64_t* a, const uin
 extern "C" int dpfhe_negate(dpfhe_ctx* c, uint64_t* o, const uint64_t* a, size_t n, void* s) { return dyadic_entry(c, DY_NEG, o, a, nullptr, n, s); }
 
 // ------------------------------------------------------------------------------------------------
-template <class Arith, bool IN_NTT, bool OUT_NTT>
-static int launch_ct_mul(dpfhe_ctx* c, u64* out3, const u64* a2, const u64* b2, size_t blocks, hipStream_t s) {
-    const DevTables<Arith>& tb = tables_of<Arith>(c);
-    // the fused kernel keeps four transformed polynomials in registers: always E = 16 words per thread
-#define CT_CASE(LN, LE) \
-    hipLaunchKernelGGL((ct_mul_kernel<Arith, LN, 4, IN_NTT, OUT_NTT>), dim3((unsigned)blocks), dim3(Geo<LN, 4>::T), 0, s, out3, a2, b2, tb)
-    DPFHE_GEO_SWITCH(c->log2n, CT_CASE)
-#undef CT_CASE
-    return check_launch("ct_mul kernel launch");
-}
-
-template <class Arith>
-static int ct_mul_flags(dpfhe_ctx* c, u64* o, const u64* a, const u64* b, size_t blocks, uint32_t flags, hipStream_t s) {
-    switch (flags) {
-        case 0: return launch_ct_mul<Arith, false, false>(c, o, a, b, blocks, s);
-        case DPFHE_IN_NTT: return launch_ct_mul<Arith, true, false>(c, o, a, b, blocks, s);
-        case DPFHE_OUT_NTT: return launch_ct_mul<Arith, false, true>(c, o, a, b, blocks, s);
-        default: return launch_ct_mul<Arith, true, true>(c, o, a, b, blocks, s);
-    }
-}
-
 extern "C" int dpfhe_ct_mul(dpfhe_ctx* c, uint64_t* d_out3, const uint64_t* d_a2, const uint64_t* d_b2, size_t batch,
                             uint32_t flags, void* stream) {
     if (!c) return fail(DPFHE_INVALID_ARGUMENT, "dpfhe_ct_mul", "null context");
@@ -253,8 +213,10 @@ extern "C" int dpfhe_ct_mul(dpfhe_ctx* c, uint64_t* d_out3, const uint64_t* d_a2
     const size_t blocks = batch * c->n_limbs;
     if (blocks > kMaxGrid) return fail(DPFHE_INVALID_ARGUMENT, "dpfhe_ct_mul", "batch too large for one launch");
     hipStream_t s = static_cast<hipStream_t>(stream);
-    return c->fold ? ct_mul_flags<FoldArith>(c, d_out3, d_a2, d_b2, blocks, flags, s)
-                   : ct_mul_flags<ShoupArith>(c, d_out3, d_a2, d_b2, blocks, flags, s);
+    const int rc = c->fold ? launch_ct_mul<FoldArith>((int)c->log2n, flags, d_out3, d_a2, d_b2, blocks, c->foldt, s)
+                           : launch_ct_mul<ShoupArith>((int)c->log2n, flags, d_out3, d_a2, d_b2, blocks, c->shoup, s);
+    if (rc) return fail(DPFHE_INVALID_STATE, "dpfhe_ct_mul", "no kernel geometry for this log2_n");
+    return check_launch("ct_mul kernel launch");
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -282,8 +244,14 @@ extern "C" int dpfhe_reduce_sum(dpfhe_ctx* c, uint64_t* d_out, const uint64_t* d
     if (blocks > kMaxGrid) return fail(DPFHE_INVALID_ARGUMENT, "dpfhe_reduce_sum", "too many components");
     const int n = 1 << c->log2n;
     const LimbConst* lc = c->fold ? c->foldt.lc : c->shoup.lc;
-    hipLaunchKernelGGL(reduce_sum_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), d_out, d_in, lc,
-                       (int)c->n_limbs, n, count, components * c->n_limbs * (size_t)n);
+    const int chunks = (n + 511) / 512;
+    const size_t words_per_item = components * c->n_limbs * (size_t)n;
+    const unsigned splits = (unsigned)(count < (size_t)kReduceSplits ? count : (size_t)kReduceSplits);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    HIP_TRY(hipMemsetAsync(d_out, 0, words_per_item * sizeof(u64), s));
+    hipLaunchKernelGGL(reduce_partial_kernel, dim3((unsigned)(blocks * chunks), splits), dim3(256), 0, s, d_out, d_in, lc, (int)c->n_limbs, n,
+                       chunks, count, words_per_item);
+    hipLaunchKernelGGL(reduce_final_kernel, dim3((unsigned)(blocks * chunks)), dim3(256), 0, s, d_out, lc, (int)c->n_limbs, n, chunks);
     return check_launch("reduce_sum kernel launch");
 }
 

@@ -1,0 +1,169 @@
+// kernels_misc.h - streaming (HBM-bound) kernels: A3 dyadic ops, A7 ct x pt matvec, A8 shard-local reduce.
+// Included by dpfhe_cabi.hip only.  No reference counterpart.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "modarith.h"
+
+namespace dpfhe {
+
+// ------------------------------------------------------------------------------------------------
+// A3: coefficient-wise ops.  One workgroup per residue polynomial (limb constants are scalar loads),
+// 16-byte accesses, every load of an iteration issued before its first use.
+// ------------------------------------------------------------------------------------------------
+enum DyOp { DY_MUL = 0, DY_MUL_ADD = 1, DY_ADD = 2, DY_SUB = 3, DY_NEG = 4 };
+
+struct __attribute__((aligned(16))) U64x2 {
+    u64 a, b;
+};
+
+template <class Arith, int OP>
+__device__ __forceinline__ u64 dy_apply(u64 a, u64 b, u64 acc, const LimbConst& lc) {
+    if (OP == DY_MUL) return Arith::mul_var(a, b, lc);
+    if (OP == DY_MUL_ADD) return add_mod(acc, Arith::mul_var(a, b, lc), lc.q);
+    if (OP == DY_ADD) return add_mod(a, b, lc.q);
+    if (OP == DY_SUB) return sub_mod(a, b, lc.q);
+    return neg_mod(a, lc.q);
+}
+
+template <class Arith, int OP>
+__global__ __launch_bounds__(256) void dyadic_kernel(u64* out, const u64* a, const u64* b, const LimbConst* lcs, int n_limbs, int n) {
+    const size_t p = blockIdx.x;
+    const LimbConst lc = lcs[p % (size_t)n_limbs];
+    const U64x2* pa = reinterpret_cast<const U64x2*>(a + p * n);
+    const U64x2* pb = reinterpret_cast<const U64x2*>(b + p * n);
+    U64x2* po = reinterpret_cast<U64x2*>(out + p * n);
+    const int nv = n >> 1;
+    constexpr int UN = 4;
+    for (int base = threadIdx.x; base < nv; base += 256 * UN) {
+        U64x2 va[UN], vb[UN], vc[UN];
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const int i = base + u * 256;
+            if (i < nv) {
+                va[u] = pa[i];
+                if (OP != DY_NEG) vb[u] = pb[i];
+                if (OP == DY_MUL_ADD) vc[u] = po[i];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const int i = base + u * 256;
+            if (i < nv) {
+                U64x2 r;
+                r.a = dy_apply<Arith, OP>(va[u].a, vb[u].a, vc[u].a, lc);
+                r.b = dy_apply<Arith, OP>(va[u].b, vb[u].b, vc[u].b, lc);
+                po[i] = r;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// A8: out[c][l][:] = sum_i in[i][c][l][:]  (HBM-bound: one read per term).
+// grid (residue-poly chunks, splits): each workgroup reduces its share of the batch to a canonical partial
+// and adds it into `out` (zeroed by the caller on the same stream) with 64-bit atomics - at most 15
+// partials < q < 2^60 per word, so the lazy sum cannot wrap.  reduce_final_kernel then canonicalises.
+// No workspace, no per-call allocation.
+// ------------------------------------------------------------------------------------------------
+constexpr int kReduceSplits = 15;
+
+__global__ __launch_bounds__(256) void reduce_partial_kernel(u64* out, const u64* in, const LimbConst* lcs, int n_limbs, int n, int chunks,
+                                                             size_t count, size_t words_per_item) {
+    const size_t p = blockIdx.x / chunks;  // residue polynomial within one item
+    const int w = (int)(blockIdx.x % chunks) * 512 + threadIdx.x * 2;
+    if (w >= n) return;
+    const u64 q = lcs[p % (size_t)n_limbs].q;
+    const size_t split = blockIdx.y, nsplit = gridDim.y;
+    const size_t lo = count * split / nsplit, hi = count * (split + 1) / nsplit;
+    const u64* src = in + p * n + w;
+    u64 s0 = 0, s1 = 0;
+    size_t it = lo;
+    for (; it + 4 <= hi; it += 4) {
+        U64x2 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const U64x2*>(src + (it + u) * words_per_item);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { s0 = csub(s0 + v[u].a, q); s1 = csub(s1 + v[u].b, q); }
+    }
+    for (; it < hi; ++it) {
+        const U64x2 v = *reinterpret_cast<const U64x2*>(src + it * words_per_item);
+        s0 = csub(s0 + v.a, q); s1 = csub(s1 + v.b, q);
+    }
+    if (hi > lo) {
+        atomicAdd(reinterpret_cast<unsigned long long*>(out + p * n + w), (unsigned long long)s0);
+        atomicAdd(reinterpret_cast<unsigned long long*>(out + p * n + w + 1), (unsigned long long)s1);
+    }
+}
+
+__global__ __launch_bounds__(256) void reduce_final_kernel(u64* out, const LimbConst* lcs, int n_limbs, int n, int chunks) {
+    const size_t p = blockIdx.x / chunks;
+    const int w = (int)(blockIdx.x % chunks) * 512 + threadIdx.x * 2;
+    if (w >= n) return;
+    const u64 q = lcs[p % (size_t)n_limbs].q;
+    U64x2* o = reinterpret_cast<U64x2*>(out + p * n + w);
+    U64x2 v = *o;  // < 15 q
+    v.a = csub(csub(csub(csub(v.a, 8 * q), 4 * q), 2 * q), q);
+    v.b = csub(csub(csub(csub(v.b, 8 * q), 4 * q), 2 * q), q);
+    *o = v;
+}
+
+// ------------------------------------------------------------------------------------------------
+// A7: y[i][c][l][:] = sum_j W[i][j][l][:] (.) x[j][c][l][:],  c in {0,1}.  128-bit lazy accumulation,
+// one reduction at the end.  One workgroup per (row, limb); W is streamed once (the HBM-bound term),
+// x (cols x 2 RNS polys) is re-read by every row through L2 / Infinity Cache.
+// ------------------------------------------------------------------------------------------------
+struct Acc128 {
+    u64 lo, hi;
+};
+__device__ __forceinline__ void acc_mac(Acc128& acc, u64 a, u64 b) {
+    const u64 lo = a * b, hi = mulhi64(a, b);
+    acc.lo += lo;
+    acc.hi += hi + (acc.lo < lo);
+}
+template <class Arith>
+__device__ __forceinline__ u64 acc_reduce(const Acc128& acc, const LimbConst& lc, u64 two64_mod_q) {
+    if (Arith::kFold) {  // hi * 2^64 + lo  =  hi * (2^64 mod q) + lo
+        const u64 h = FoldArith::mul60_full(acc.hi, two64_mod_q, (u32)lc.d);  // < 2q
+        const u64 l = FoldArith::reduce(acc.lo, lc);                      // < 2q
+        return FoldArith::canon(h + l, lc);
+    } else {
+        const u64 h = ShoupArith::mul_var(acc.hi % lc.q, two64_mod_q, lc);
+        return add_mod(h, acc.lo % lc.q, lc.q);
+    }
+}
+
+template <class Arith>
+__global__ __launch_bounds__(256) void matvec_kernel(u64* y, const u64* W, const u64* x, const LimbConst* lcs, int n_limbs, int n,
+                                                     size_t cols) {
+    const size_t L = (size_t)n_limbs;
+    const size_t row = blockIdx.x / L;
+    const int limb = (int)(blockIdx.x % L);
+    const LimbConst lc = lcs[limb];
+    const u64 two64 = lc.two64;
+    const int nv = n >> 1;
+    const size_t wstride = L * n, xstride = 2 * L * n;
+    for (int i = threadIdx.x; i < nv; i += 256) {
+        Acc128 a00{0, 0}, a01{0, 0}, a10{0, 0}, a11{0, 0};  // [component][word]
+        const u64* wp = W + (row * cols * L + limb) * n + 2 * (size_t)i;
+        const u64* xp = x + (size_t)limb * n + 2 * (size_t)i;
+        size_t since = 0;
+        for (size_t j = 0; j < cols; ++j) {
+            const U64x2 w = *reinterpret_cast<const U64x2*>(wp + j * wstride);
+            const U64x2 x0 = *reinterpret_cast<const U64x2*>(xp + j * xstride);
+            const U64x2 x1 = *reinterpret_cast<const U64x2*>(xp + j * xstride + L * n);
+            acc_mac(a00, w.a, x0.a); acc_mac(a01, w.b, x0.b);
+            acc_mac(a10, w.a, x1.a); acc_mac(a11, w.b, x1.b);
+            if (++since == 128) {  // 128 products of < 2^120 stay below 2^128 next to a reduced value
+                a00 = Acc128{acc_reduce<Arith>(a00, lc, two64), 0}; a01 = Acc128{acc_reduce<Arith>(a01, lc, two64), 0};
+                a10 = Acc128{acc_reduce<Arith>(a10, lc, two64), 0}; a11 = Acc128{acc_reduce<Arith>(a11, lc, two64), 0};
+                since = 0;
+            }
+        }
+        u64* yp = y + ((row * 2) * L + limb) * n + 2 * (size_t)i;
+        *reinterpret_cast<U64x2*>(yp) = U64x2{acc_reduce<Arith>(a00, lc, two64), acc_reduce<Arith>(a01, lc, two64)};
+        *reinterpret_cast<U64x2*>(yp + L * n) = U64x2{acc_reduce<Arith>(a10, lc, two64), acc_reduce<Arith>(a11, lc, two64)};
+    }
+}
+
+}  // namespace dpfhe

@@ -1,0 +1,16 @@
+// launch.h - host launchers of the templated kernels; each arithmetic policy is instantiated in its own
+// translation unit (k_ntt_*.hip, k_ctmul_*.hip) so the library builds in parallel.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "devtables.h"
+
+namespace dpfhe {
+
+// return 0, or -1 when log2n has no compiled geometry.  Launch errors are left in hipGetLastError().
+template <class Arith>
+int launch_ntt(int log2n, bool inverse, u64* out, const u64* in, size_t npolys, const DevTables<Arith>& tb, hipStream_t s);
+template <class Arith>
+int launch_ct_mul(int log2n, unsigned flags, u64* out3, const u64* a2, const u64* b2, size_t blocks, const DevTables<Arith>& tb, hipStream_t s);
+
+}  // namespace dpfhe

@@ -1,0 +1,64 @@
+// launch_impl.h - geometry dispatch shared by the per-policy translation units.
+#pragma once
+#include <cstdlib>
+
+#include "kernels.h"
+#include "launch.h"
+
+namespace dpfhe {
+
+// (log2n -> LOGE) pairs proven by tests/test_emulated_kernels.py
+#define DPFHE_GEO_SWITCH(log2n, MACRO) \
+    switch (log2n) {                   \
+        case 8: MACRO(8, 4); break;    \
+        case 9: MACRO(9, 4); break;    \
+        case 10: MACRO(10, 4); break;  \
+        case 11: MACRO(11, 4); break;  \
+        case 12: MACRO(12, 4); break;  \
+        case 13: MACRO(13, 5); break;  \
+        default: return -1;            \
+    }
+
+inline int env_int(const char* name, int dflt) {
+    const char* e = getenv(name);
+    return e ? atoi(e) : dflt;
+}
+
+template <class Arith>
+int launch_ntt(int log2n, bool inverse, u64* out, const u64* in, size_t npolys, const DevTables<Arith>& tb, hipStream_t s) {
+    // MODE 0: twiddles fetched per phase (measured equal or better on MI355X: 84/82 us vs 82/87 us fwd/inv
+    // at BASELINE configs[1]); MODE 1: all per-thread twiddles fetched up front.  DPFHE_NTT_MODE=1 for A/B runs.
+    static const int mode = env_int("DPFHE_NTT_MODE", 0);
+#define NTT_LAUNCH(LN, LE, MODE)                                                                                                           \
+    if (inverse) hipLaunchKernelGGL((ntt_inv_kernel<Arith, LN, LE, MODE>), dim3((unsigned)npolys), dim3(Geo<LN, LE>::T), 0, s, out, in, tb, (unsigned)npolys); \
+    else hipLaunchKernelGGL((ntt_fwd_kernel<Arith, LN, LE, MODE>), dim3((unsigned)npolys), dim3(Geo<LN, LE>::T), 0, s, out, in, tb, (unsigned)npolys)
+#define NTT_CASE(LN, LE)                          \
+    if (mode == 1) { NTT_LAUNCH(LN, LE, 1); }     \
+    else { NTT_LAUNCH(LN, LE, 0); }
+    DPFHE_GEO_SWITCH(log2n, NTT_CASE)
+#undef NTT_CASE
+#undef NTT_LAUNCH
+    return 0;
+}
+
+template <class Arith, bool IN_NTT, bool OUT_NTT>
+static int launch_ct_mul_dom(int log2n, u64* out3, const u64* a2, const u64* b2, size_t blocks, const DevTables<Arith>& tb, hipStream_t s) {
+    // the fused kernel keeps up to four transformed polynomials in registers: always E = 16 words per thread
+#define CT_CASE(LN, LE) \
+    hipLaunchKernelGGL((ct_mul_kernel<Arith, LN, 4, IN_NTT, OUT_NTT>), dim3((unsigned)blocks), dim3(Geo<LN, 4>::T), 0, s, out3, a2, b2, tb)
+    DPFHE_GEO_SWITCH(log2n, CT_CASE)
+#undef CT_CASE
+    return 0;
+}
+
+template <class Arith>
+int launch_ct_mul(int log2n, unsigned flags, u64* out3, const u64* a2, const u64* b2, size_t blocks, const DevTables<Arith>& tb, hipStream_t s) {
+    switch (flags & 3u) {
+        case 0: return launch_ct_mul_dom<Arith, false, false>(log2n, out3, a2, b2, blocks, tb, s);
+        case 1: return launch_ct_mul_dom<Arith, true, false>(log2n, out3, a2, b2, blocks, tb, s);
+        case 2: return launch_ct_mul_dom<Arith, false, true>(log2n, out3, a2, b2, blocks, tb, s);
+        default: return launch_ct_mul_dom<Arith, true, true>(log2n, out3, a2, b2, blocks, tb, s);
+    }
+}
+
+}  // namespace dpfhe

@@ -27,6 +27,14 @@ namespace dpfhe {
 typedef uint64_t u64;
 typedef uint32_t u32;
 
+// tools/emulate.cpp defines DPFHE_EMU_CHECK: host-only counters of broken lazy-arithmetic preconditions
+#if defined(DPFHE_EMU_CHECK) && !defined(__HIPCC__)
+extern long g_emu_overflows;
+#define DPFHE_EMU_ASSERT(cond) do { if (!(cond)) ++g_emu_overflows; } while (0)
+#else
+#define DPFHE_EMU_ASSERT(cond) do { } while (0)
+#endif
+
 struct LimbConst {  // one per RNS limb, read through scalar loads (limb index is workgroup-uniform)
     u64 q;
     u64 d;          // 2^60 - q (FoldArith only; 0 when not applicable)
@@ -90,20 +98,37 @@ struct ShoupArith {
 struct FoldArith {
     typedef TwFold Tw;
     static constexpr bool kFold = true;
-    // y*w mod q for y < 2^64, w < 2^60; result < 2^60 + 2^53 (< 2q), typically < q + 2^45
-    static DPF_HD u64 mul60(u64 y, u64 w, u32 d) {
-        const u32 y0 = (u32)y, y1 = (u32)(y >> 32), w0 = (u32)w, w1 = (u32)(w >> 32);
-        u64 p = mad32(y0, w0, 0);
-        u64 m = mad32(y0, w1, p >> 32);
-        u64 n = mad32(y1, w0, (u32)m);
-        u64 r = mad32(y1, w1, (n >> 32) + (m >> 32));  // P = [p.lo, n.lo, r.lo, r.hi] < 2^124
-        u64 xl = (u64)(u32)p | ((u64)((u32)n & 0x0fffffffu) << 32);
-        u64 xh = (r << 4) | ((u32)n >> 28);            // P >> 60
+    // fold of the 124-bit product P = [p0, n0, r0, r1] (little-endian 32-bit words, r = P >> 64 < 2^60):
+    // P = xl + xh 2^60  ==  xl + xh d (mod q), twice.  Result < 2^60 + 2^53 (< 2q), typically < q + 2^45.
+    static DPF_HD u64 fold124(u32 p0, u32 n0, u64 r, u32 d) {
+        u64 xl = (u64)p0 | ((u64)(n0 & 0x0fffffffu) << 32);
+        u64 xh = (r << 4) | (n0 >> 28);                // P >> 60
         u64 A = mad32((u32)xh, d, xl);
         u64 B = mad32((u32)(xh >> 32), d, A >> 32);    // R = xl + xh*d = [A.lo, B.lo, B.hi] < 2^89
         u32 yh = (u32)(B >> 28);                       // R >> 60
         u64 yl = (u64)(u32)A | ((u64)((u32)B & 0x0fffffffu) << 32);
         return mad32(yh, d, yl);
+    }
+    // y*w mod q for y < 15 * 2^60 (every lazily reduced word, see kLimit in ntt_core.h) and w < 2^60.
+    // The middle column y0 w1 + y1 w0 + carry stays below 2^64 under that bound, so the four partial
+    // products chain through the 64-bit addend of v_mad_u64_u32 with no carry fix-up.
+    static DPF_HD u64 mul60(u64 y, u64 w, u32 d) {
+        DPFHE_EMU_ASSERT(y < (15ull << 60) && w < (1ull << 60));
+        const u32 y0 = (u32)y, y1 = (u32)(y >> 32), w0 = (u32)w, w1 = (u32)(w >> 32);
+        u64 p = mad32(y0, w0, 0);
+        u64 m = mad32(y0, w1, p >> 32);
+        u64 n = mad32(y1, w0, m);
+        u64 r = mad32(y1, w1, n >> 32);
+        return fold124((u32)p, (u32)n, r, d);
+    }
+    // same for ANY y < 2^64 (one extra carry add)
+    static DPF_HD u64 mul60_full(u64 y, u64 w, u32 d) {
+        const u32 y0 = (u32)y, y1 = (u32)(y >> 32), w0 = (u32)w, w1 = (u32)(w >> 32);
+        u64 p = mad32(y0, w0, 0);
+        u64 m = mad32(y0, w1, p >> 32);
+        u64 n = mad32(y1, w0, (u32)m);
+        u64 r = mad32(y1, w1, (n >> 32) + (m >> 32));
+        return fold124((u32)p, (u32)n, r, d);
     }
     static DPF_HD u64 mul_tw(u64 y, const Tw& t, const LimbConst& c) { return mul60(y, t.w, (u32)c.d); }
     // any x < 2^64  ->  x mod q representative < 2^60 + 16 d

@@ -20,7 +20,6 @@ namespace dpfhe {
 
 // tools/emulate.cpp defines DPFHE_EMU_CHECK to count 64-bit wrap-arounds in the lazy arithmetic
 #if defined(DPFHE_EMU_CHECK) && !defined(__HIPCC__)
-extern long g_emu_overflows;
 inline u64 chk_add(u64 a, u64 b) { if ((unsigned __int128)a + b >> 64) ++g_emu_overflows; return a + b; }
 inline u64 chk_sub_add(u64 a, u64 b, u64 off) {  // a - b + off must stay in [0, 2^64)
     __int128 v = (__int128)a - (__int128)b + (__int128)off;
@@ -105,12 +104,12 @@ DPF_HD int tid_high(int c, int tid) { return (c + G::LOGE >= G::LOGN) ? 0 : (tid
 
 // ------------------------------------------------------------------------------------------------
 // static bound plans (FoldArith).  Bounds are in units of q/1024.  A value with bound B is < B q/1024.
-// All data words stay below 2^64 > 16 q.
+// All data words stay below 15 q (kLimit).
 // ------------------------------------------------------------------------------------------------
 constexpr int kUnit = 1024;
 constexpr int kMulB = kUnit + 9;    // mul60 output  < q + 2^53           (q > 2^59.99)
 constexpr int kRedB = kUnit + 1;    // reduce output < 2^60 + 16d
-constexpr int kLimit = 16 * kUnit;  // 16 q < 2^64
+constexpr int kLimit = 15 * kUnit;  // every word < 15 q < 15 * 2^60: the precondition of FoldArith::mul60
 
 template <int LOGE>
 struct GsPlan {  // one Gentleman-Sande phase on E local elements, up to LOGE stages
@@ -235,12 +234,29 @@ struct NttBody {
     }
 
     // ---------------- forward (Cooley-Tukey) phase ----------------
+    // Per-thread twiddles of one phase, fetched ahead of use: twr[u][i] is the i-th distinct twiddle of
+    // in-phase stage u (2^(LOGE-1-lb) of them).  Only the entries a phase touches are ever live.
+    typedef Tw TwRegs[LOGE][E / 2];
+
+    template <int P, bool FWD>
+    static DPF_HD void load_tw(int tid, const Tw* tw, TwRegs& twr) {
+        constexpr Phase ph = G::phase(P);
+        const int th = tid_high<G>(ph.c, tid);
+#pragma unroll
+        for (int u = 0; u < ph.r; ++u) {
+            const int pos = FWD ? (ph.b + ph.r - 1 - u) : (ph.b + u);
+            const int lb = pos - ph.c;
+#pragma unroll
+            for (int i = 0; i < E / 2; ++i)  // constant trip count (the bound below folds after unrolling u)
+                if (i < (1 << (LOGE - 1 - lb))) twr[u][i] = tw[tw_index<G>(ph.c, th, i << (lb + 1), pos)];
+        }
+    }
+
     template <int P>
-    static DPF_HD void fwd_phase(int tid, u64 (&x)[E], const Tw* tw, const LimbConst& lc) {
+    static DPF_HD void fwd_phase_r(u64 (&x)[E], const TwRegs& twr, const LimbConst& lc) {
         constexpr Phase ph = G::phase(P);
         constexpr CtPlan kCt = make_ct_plan(LOGN, kUnit);  // canonical input
         const u64 two_q = 2 * lc.q;
-        const int th = tid_high<G>(ph.c, tid);
 #pragma unroll
         for (int u = 0; u < ph.r; ++u) {
             const int pos = ph.b + ph.r - 1 - u;        // bit position = distance exponent
@@ -254,7 +270,7 @@ struct NttBody {
 #pragma unroll
             for (int k = 0; k < E; ++k) {
                 if (k & (1 << lb)) continue;
-                const Tw w = tw[tw_index<G>(ph.c, th, k, pos)];
+                const Tw w = twr[u][k >> (lb + 1)];
                 u64 a = x[k];
                 if (!Arith::kFold) a = csub(a, two_q);  // Harvey: [0,4q) -> [0,2q)
                 const u64 t = Arith::mul_tw(x[k | (1 << lb)], w, lc);
@@ -262,6 +278,12 @@ struct NttBody {
                 x[k | (1 << lb)] = chk_sub_add(a, t, two_q);
             }
         }
+    }
+    template <int P>
+    static DPF_HD void fwd_phase(int tid, u64 (&x)[E], const Tw* tw, const LimbConst& lc) {
+        TwRegs twr;
+        load_tw<P, true>(tid, tw, twr);
+        fwd_phase_r<P>(x, twr, lc);
     }
     // forward output -> canonical residues
     static DPF_HD void fwd_canon(u64 (&x)[E], const LimbConst& lc) {
@@ -282,17 +304,16 @@ struct NttBody {
     }
 
     template <int P, int IN>
-    static DPF_HD void inv_phase(int tid, u64 (&x)[E], const Tw* tw, const Tw& w_last, const Tw& w_ninv, const LimbConst& lc) {
+    static DPF_HD void inv_phase_r(u64 (&x)[E], const TwRegs& twr, const Tw& w_last, const Tw& w_ninv, const LimbConst& lc) {
         constexpr Phase ph = G::phase(P);
         constexpr GsPlan<LOGE> plan = gs_plan<P, IN>();
         const u64 q = lc.q, two_q = 2 * lc.q;
-        const int th = tid_high<G>(ph.c, tid);
-#pragma unroll
+#pragma clang loop unroll(full)
         for (int u = 0; u < ph.r; ++u) {
             const int pos = ph.b + u;
             const int lb = pos - ph.c;
             const bool last = (pos == LOGN - 1);
-#pragma unroll
+#pragma clang loop unroll(full)
             for (int k = 0; k < E; ++k) {
                 if (k & (1 << lb)) continue;
                 const int kk = k | (1 << lb);
@@ -312,15 +333,21 @@ struct NttBody {
                     x[kk] = Arith::mul_tw(dlt, w_last, lc);
                 } else {
                     x[k] = s;
-                    x[kk] = Arith::mul_tw(dlt, tw[tw_index<G>(ph.c, th, k, pos)], lc);
+                    x[kk] = Arith::mul_tw(dlt, twr[u][k >> (lb + 1)], lc);
                 }
             }
         }
         if (Arith::kFold) {
-#pragma unroll
+#pragma clang loop unroll(full)
             for (int k = 0; k < E; ++k)
                 if (plan.red_end[k]) x[k] = FoldArith::reduce(x[k], lc);
         }
+    }
+    template <int P, int IN>
+    static DPF_HD void inv_phase(int tid, u64 (&x)[E], const Tw* tw, const Tw& w_last, const Tw& w_ninv, const LimbConst& lc) {
+        TwRegs twr;
+        load_tw<P, false>(tid, tw, twr);
+        inv_phase_r<P, IN>(x, twr, w_last, w_ninv, lc);
     }
     // inverse output (all words are outputs of the last-stage multiplies, < 2q) -> canonical
     static DPF_HD void inv_canon(u64 (&x)[E], const LimbConst& lc) {

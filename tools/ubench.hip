@@ -24,10 +24,10 @@ using namespace dpfhe;
 // 1. instruction issue rates.  8 independent chains per wave, ITER iterations, asm so nothing is folded.
 // ---------------------------------------------------------------------------------------------------
 enum Op { ADD_U32, MAD_U64_U32, MUL_LO_U32, MUL_HI_U32, MUL_U32_U24, MAD_U32_U24, MUL_HI_U32_U24, LSHL_ADD_U64, ADDC_PAIR, ALIGNBIT, MOV_B32,
-          MOV_B64, FMA_F64, MAD_U32_U16, DOT4_U32_U8, CNDMASK, CMP_GE_U64, AND_B32, ADD3_U32, FMA_F32, PK_FMA_F32, MAD_I64_I32, NOPS };
+          MOV_B64, FMA_F64, MAD_U32_U16, DOT4_U32_U8, CNDMASK, CMP_GE_U64, AND_B32, ADD3_U32, FMA_F32, PK_FMA_F32, MAD_I64_I32, LSHR_B64, LSHL_B64, PK_MOV_B32, BFI_B32, PERM_B32, LSHL_OR_B32, NOT_B32, SUB_U32, NOPS };
 static const char* kOpName[] = {"v_add_u32", "v_mad_u64_u32", "v_mul_lo_u32", "v_mul_hi_u32", "v_mul_u32_u24", "v_mad_u32_u24", "v_mul_hi_u32_u24",
                                 "v_lshl_add_u64", "v_add_co+v_addc (pair)", "v_alignbit_b32", "v_mov_b32", "v_mov_b64", "v_fma_f64", "v_mad_u32_u16",
-                                "v_dot4_u32_u8", "v_cndmask_b32", "v_cmp_ge_u64", "v_and_b32", "v_add3_u32", "v_fma_f32", "v_pk_fma_f32", "v_mad_i64_i32"};
+                                "v_dot4_u32_u8", "v_cndmask_b32", "v_cmp_ge_u64", "v_and_b32", "v_add3_u32", "v_fma_f32", "v_pk_fma_f32", "v_mad_i64_i32", "v_lshrrev_b64", "v_lshlrev_b64", "v_pk_mov_b32", "v_bfi_b32", "v_perm_b32", "v_lshl_or_b32", "v_not_b32", "v_sub_u32"};
 
 template <int OP>
 __global__ __launch_bounds__(256) void rate_kernel(unsigned long long* out, unsigned long long* cycles, int iters, unsigned seed) {
@@ -62,6 +62,14 @@ __global__ __launch_bounds__(256) void rate_kernel(unsigned long long* out, unsi
             if (OP == ADD3_U32) { asm volatile("v_add3_u32 %0, %0, %1, %2" : "+v"(lo) : "v"(b), "v"(c)); asm volatile("v_add3_u32 %0, %0, %1, %2" : "+v"(hi) : "v"(c), "v"(b)); }
             if (OP == FMA_F32) { asm volatile("v_fma_f32 %0, %0, %1, %1" : "+v"(lo) : "v"(1.0001f)); asm volatile("v_fma_f32 %0, %0, %1, %1" : "+v"(hi) : "v"(1.0001f)); }
             if (OP == PK_FMA_F32) { unsigned long long k = 0x3f8000013f800001ull; asm volatile("v_pk_fma_f32 %0, %0, %1, %1" : "+v"(a[i]) : "v"(k)); asm volatile("v_pk_fma_f32 %0, %0, %1, %1" : "+v"(a[i]) : "v"(k)); continue; }
+            if (OP == LSHR_B64) { asm volatile("v_lshrrev_b64 %0, 3, %0" : "+v"(a[i])); asm volatile("v_lshrrev_b64 %0, 32, %0" : "+v"(a[i])); continue; }
+            if (OP == LSHL_B64) { asm volatile("v_lshlrev_b64 %0, 4, %0" : "+v"(a[i])); asm volatile("v_lshlrev_b64 %0, 1, %0" : "+v"(a[i])); continue; }
+            if (OP == PK_MOV_B32) { unsigned long long k = ((unsigned long long)b << 32) | c; asm volatile("v_pk_mov_b32 %0, %0, %1 op_sel:[1,0]" : "+v"(a[i]) : "v"(k)); asm volatile("v_pk_mov_b32 %0, %1, %0 op_sel:[0,1]" : "+v"(a[i]) : "v"(k)); continue; }
+            if (OP == BFI_B32) { asm volatile("v_bfi_b32 %0, %0, %1, %2" : "+v"(lo) : "v"(b), "v"(c)); asm volatile("v_bfi_b32 %0, %0, %1, %2" : "+v"(hi) : "v"(c), "v"(b)); }
+            if (OP == PERM_B32) { asm volatile("v_perm_b32 %0, %0, %1, %2" : "+v"(lo) : "v"(b), "v"(c)); asm volatile("v_perm_b32 %0, %0, %1, %2" : "+v"(hi) : "v"(c), "v"(b)); }
+            if (OP == LSHL_OR_B32) { asm volatile("v_lshl_or_b32 %0, %0, 4, %1" : "+v"(lo) : "v"(b)); asm volatile("v_lshl_or_b32 %0, %0, 4, %1" : "+v"(hi) : "v"(c)); }
+            if (OP == NOT_B32) { asm volatile("v_not_b32 %0, %0" : "+v"(lo)); asm volatile("v_not_b32 %0, %0" : "+v"(hi)); }
+            if (OP == SUB_U32) { asm volatile("v_sub_u32 %0, %0, %1" : "+v"(lo) : "v"(b)); asm volatile("v_sub_u32 %0, %0, %1" : "+v"(hi) : "v"(c)); }
             a[i] = ((unsigned long long)hi << 32) | lo;
         }
     }
@@ -230,6 +238,8 @@ int main() {
     run_rate<MAD_U32_U16>(n_cu, ghz); run_rate<DOT4_U32_U8>(n_cu, ghz); run_rate<LSHL_ADD_U64>(n_cu, ghz); run_rate<ADDC_PAIR>(n_cu, ghz); run_rate<ALIGNBIT>(n_cu, ghz);
     run_rate<MOV_B32>(n_cu, ghz); run_rate<MOV_B64>(n_cu, ghz); run_rate<AND_B32>(n_cu, ghz); run_rate<ADD3_U32>(n_cu, ghz); run_rate<CNDMASK>(n_cu, ghz);
     run_rate<CMP_GE_U64>(n_cu, ghz); run_rate<FMA_F64>(n_cu, ghz);
+    run_rate<LSHR_B64>(n_cu, ghz); run_rate<LSHL_B64>(n_cu, ghz); run_rate<PK_MOV_B32>(n_cu, ghz); run_rate<BFI_B32>(n_cu, ghz); run_rate<PERM_B32>(n_cu, ghz);
+    run_rate<LSHL_OR_B32>(n_cu, ghz); run_rate<NOT_B32>(n_cu, ghz); run_rate<SUB_U32>(n_cu, ghz);
     std::printf("--- register-only butterflies ---\n");
     run_bfly<FoldArith>("fold", n_cu, 4); run_bfly<FoldArith>("fold", n_cu, 8); run_bfly<ShoupArith>("shoup", n_cu, 4); run_bfly<ShoupArith>("shoup", n_cu, 8);
     std::printf("--- HBM copy ---\n");
