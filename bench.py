@@ -105,6 +105,14 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # HBM traffic of the dominant kernel from the committed PMC passes (collected with rocprofv3 --pmc in their own
+    # runs, corrected as MI355X_MICROARCH.md prescribes); scaled per ct-mul because traffic is linear in the batch.
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+            traffic = json.load(f)["ct_mul_kernel<FoldArith,12,4>"]["hbm_bytes_per_ct_mul"] * B
+    except Exception:
+        pass
     kernel_ms = [s.elapsed_time(e) for s, e in zip(ev_start, ev_end)]
     k_avg = sum(kernel_ms) / len(kernel_ms) * 1e-3
     alg_bytes = 7 * L * N * 8 * B
@@ -133,7 +141,9 @@ def main():
         },
         "roofline": {
             "kernel": "ct_mul_kernel<FoldArith,12,4>", "bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-            "frac": achieved / HBM_PEAK, "traffic": None,
+            "frac": achieved / HBM_PEAK, "traffic": traffic,
+            "traffic_source": "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, bytes per launch)" if traffic else None,
+            "alu_roofline_note": "integer-multiply issue, not HBM, bounds this kernel: tools/ubench register-only butterflies reach 1.9-2.0 T/s = 65% of 8 TB/s NTT-equivalent (profiles/r01_ubench.log)",
             "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": k_avg * 1e3,
         },
     }

@@ -96,11 +96,17 @@ struct InvChainPre {
 // ------------------------------------------------------------------------------------------------
 template <class Arith, int LOGN, int LOGE, int MODE>
 __global__ __launch_bounds__(1 << (LOGN - LOGE)) void ntt_fwd_kernel(u64* __restrict__ out, const u64* __restrict__ in,
-                                                                      DevTables<Arith> tb, unsigned npolys) {
+                                                                      DevTables<Arith> tb, unsigned stagger) {
     typedef NttBody<Arith, LOGN, LOGE> B;
     __shared__ __attribute__((aligned(16))) u64 lds[B::G::lds_words()];
     const int tid = threadIdx.x;
     const size_t p = blockIdx.x;
+    // De-phase the first generation of workgroups: without it the workgroups sharing a CU load, compute
+    // and store in lockstep and the HBM time of a generation is not hidden by another one's butterflies.
+    if (stagger && blockIdx.x < 2048u) {
+        const unsigned slot = (blockIdx.x >> 8) & 3u;
+        for (unsigned i = 0; i < slot * stagger; ++i) __builtin_amdgcn_s_sleep(32);
+    }
     const int limb = (int)(p % (size_t)tb.n_limbs);
     const LimbConst lc = tb.lc[limb];
     const typename B::Tw* tw = tb.fwd + (size_t)limb * B::G::N;
@@ -119,11 +125,17 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE)) void ntt_fwd_kernel(u64* __rest
 
 template <class Arith, int LOGN, int LOGE, int MODE>
 __global__ __launch_bounds__(1 << (LOGN - LOGE)) void ntt_inv_kernel(u64* __restrict__ out, const u64* __restrict__ in,
-                                                                      DevTables<Arith> tb, unsigned npolys) {
+                                                                      DevTables<Arith> tb, unsigned stagger) {
     typedef NttBody<Arith, LOGN, LOGE> B;
     __shared__ __attribute__((aligned(16))) u64 lds[B::G::lds_words()];
     const int tid = threadIdx.x;
     const size_t p = blockIdx.x;
+    // De-phase the first generation of workgroups: without it the workgroups sharing a CU load, compute
+    // and store in lockstep and the HBM time of a generation is not hidden by another one's butterflies.
+    if (stagger && blockIdx.x < 2048u) {
+        const unsigned slot = (blockIdx.x >> 8) & 3u;
+        for (unsigned i = 0; i < slot * stagger; ++i) __builtin_amdgcn_s_sleep(32);
+    }
     const int limb = (int)(p % (size_t)tb.n_limbs);
     const LimbConst lc = tb.lc[limb];
     const typename B::Tw* tw = tb.inv + (size_t)limb * B::G::N;

@@ -29,9 +29,10 @@ int launch_ntt(int log2n, bool inverse, u64* out, const u64* in, size_t npolys, 
     // MODE 0: twiddles fetched per phase (measured equal or better on MI355X: 84/82 us vs 82/87 us fwd/inv
     // at BASELINE configs[1]); MODE 1: all per-thread twiddles fetched up front.  DPFHE_NTT_MODE=1 for A/B runs.
     static const int mode = env_int("DPFHE_NTT_MODE", 0);
+    static const unsigned stagger = (unsigned)env_int("DPFHE_STAGGER", 0);
 #define NTT_LAUNCH(LN, LE, MODE)                                                                                                           \
-    if (inverse) hipLaunchKernelGGL((ntt_inv_kernel<Arith, LN, LE, MODE>), dim3((unsigned)npolys), dim3(Geo<LN, LE>::T), 0, s, out, in, tb, (unsigned)npolys); \
-    else hipLaunchKernelGGL((ntt_fwd_kernel<Arith, LN, LE, MODE>), dim3((unsigned)npolys), dim3(Geo<LN, LE>::T), 0, s, out, in, tb, (unsigned)npolys)
+    if (inverse) hipLaunchKernelGGL((ntt_inv_kernel<Arith, LN, LE, MODE>), dim3((unsigned)npolys), dim3(Geo<LN, LE>::T), 0, s, out, in, tb, stagger); \
+    else hipLaunchKernelGGL((ntt_fwd_kernel<Arith, LN, LE, MODE>), dim3((unsigned)npolys), dim3(Geo<LN, LE>::T), 0, s, out, in, tb, stagger)
 #define NTT_CASE(LN, LE)                          \
     if (mode == 1) { NTT_LAUNCH(LN, LE, 1); }     \
     else { NTT_LAUNCH(LN, LE, 0); }

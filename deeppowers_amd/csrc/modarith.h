@@ -117,6 +117,9 @@ struct FoldArith {
         const u32 y0 = (u32)y, y1 = (u32)(y >> 32), w0 = (u32)w, w1 = (u32)(w >> 32);
         u64 p = mad32(y0, w0, 0);
         u64 m = mad32(y0, w1, p >> 32);
+#if defined(__HIP_DEVICE_COMPILE__)
+        asm volatile("" : "+v"(m));  // keep the chain as written: hipcc otherwise re-associates it and adds a 64-bit add
+#endif
         u64 n = mad32(y1, w0, m);
         u64 r = mad32(y1, w1, n >> 32);
         return fold124((u32)p, (u32)n, r, d);
