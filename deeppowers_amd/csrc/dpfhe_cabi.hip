@@ -227,12 +227,14 @@ extern "C" int dpfhe_matvec_plain(dpfhe_ctx* c, uint64_t* d_y, const uint64_t* d
     if (cols == 0) return fail(DPFHE_INVALID_ARGUMENT, "dpfhe_matvec_plain", "cols must be > 0");
     if (!d_y || !d_W || !d_x || misaligned(d_y) || misaligned(d_W) || misaligned(d_x))
         return fail(DPFHE_INVALID_ARGUMENT, "dpfhe_matvec_plain", "null or misaligned buffer");
-    const size_t blocks = rows * c->n_limbs;
+    const int n = 1 << c->log2n;
+    const int chunks = (n + 511) / 512;
+    constexpr int RT = 4;
+    const size_t blocks = ((rows + RT - 1) / RT) * c->n_limbs * (size_t)chunks;
     if (blocks > kMaxGrid) return fail(DPFHE_INVALID_ARGUMENT, "dpfhe_matvec_plain", "too many rows for one launch");
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const int n = 1 << c->log2n;
-    if (c->fold) hipLaunchKernelGGL((matvec_kernel<FoldArith>), dim3((unsigned)blocks), dim3(256), 0, s, d_y, d_W, d_x, c->foldt.lc, (int)c->n_limbs, n, cols);
-    else hipLaunchKernelGGL((matvec_kernel<ShoupArith>), dim3((unsigned)blocks), dim3(256), 0, s, d_y, d_W, d_x, c->shoup.lc, (int)c->n_limbs, n, cols);
+    if (c->fold) hipLaunchKernelGGL((matvec_kernel<FoldArith, RT>), dim3((unsigned)blocks), dim3(256), 0, s, d_y, d_W, d_x, c->foldt.lc, (int)c->n_limbs, n, chunks, rows, cols);
+    else hipLaunchKernelGGL((matvec_kernel<ShoupArith, RT>), dim3((unsigned)blocks), dim3(256), 0, s, d_y, d_W, d_x, c->shoup.lc, (int)c->n_limbs, n, chunks, rows, cols);
     return check_launch("matvec kernel launch");
 }
 

@@ -133,36 +133,57 @@ __device__ __forceinline__ u64 acc_reduce(const Acc128& acc, const LimbConst& lc
     }
 }
 
-template <class Arith>
+// RT rows per workgroup: x_j is loaded once per column and re-used from registers for RT rows, so the
+// L2/Infinity-Cache traffic for x drops RT-fold and the W stream (read exactly once) owns the HBM pipe.
+// grid = (row tiles * L * chunks); every thread owns 2 consecutive words of RT x 2 output polynomials.
+template <class Arith, int RT>
 __global__ __launch_bounds__(256) void matvec_kernel(u64* y, const u64* W, const u64* x, const LimbConst* lcs, int n_limbs, int n,
-                                                     size_t cols) {
+                                                     int chunks, size_t rows, size_t cols) {
     const size_t L = (size_t)n_limbs;
-    const size_t row = blockIdx.x / L;
-    const int limb = (int)(blockIdx.x % L);
+    const int chunk = (int)(blockIdx.x % chunks);
+    const int limb = (int)((blockIdx.x / chunks) % L);
+    const size_t row0 = (blockIdx.x / chunks / L) * RT;
+    const int w0 = chunk * 512 + threadIdx.x * 2;
+    if (w0 >= n) return;
     const LimbConst lc = lcs[limb];
     const u64 two64 = lc.two64;
-    const int nv = n >> 1;
-    const size_t wstride = L * n, xstride = 2 * L * n;
-    for (int i = threadIdx.x; i < nv; i += 256) {
-        Acc128 a00{0, 0}, a01{0, 0}, a10{0, 0}, a11{0, 0};  // [component][word]
-        const u64* wp = W + (row * cols * L + limb) * n + 2 * (size_t)i;
-        const u64* xp = x + (size_t)limb * n + 2 * (size_t)i;
-        size_t since = 0;
-        for (size_t j = 0; j < cols; ++j) {
-            const U64x2 w = *reinterpret_cast<const U64x2*>(wp + j * wstride);
-            const U64x2 x0 = *reinterpret_cast<const U64x2*>(xp + j * xstride);
-            const U64x2 x1 = *reinterpret_cast<const U64x2*>(xp + j * xstride + L * n);
-            acc_mac(a00, w.a, x0.a); acc_mac(a01, w.b, x0.b);
-            acc_mac(a10, w.a, x1.a); acc_mac(a11, w.b, x1.b);
-            if (++since == 128) {  // 128 products of < 2^120 stay below 2^128 next to a reduced value
-                a00 = Acc128{acc_reduce<Arith>(a00, lc, two64), 0}; a01 = Acc128{acc_reduce<Arith>(a01, lc, two64), 0};
-                a10 = Acc128{acc_reduce<Arith>(a10, lc, two64), 0}; a11 = Acc128{acc_reduce<Arith>(a11, lc, two64), 0};
-                since = 0;
-            }
+    const size_t wstride = L * n, xstride = 2 * L * n, rstride = cols * L * n;
+    Acc128 acc[RT][2][2];
+#pragma unroll
+    for (int r = 0; r < RT; ++r)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) acc[r][c][0] = acc[r][c][1] = Acc128{0, 0};
+    const u64* wp = W + (row0 * cols * L + limb) * n + w0;
+    const u64* xp = x + (size_t)limb * n + w0;
+    size_t since = 0;
+    for (size_t j = 0; j < cols; ++j) {
+        const U64x2 x0 = *reinterpret_cast<const U64x2*>(xp + j * xstride);
+        const U64x2 x1 = *reinterpret_cast<const U64x2*>(xp + j * xstride + L * n);
+        U64x2 w[RT];
+#pragma unroll
+        for (int r = 0; r < RT; ++r)
+            w[r] = (row0 + r < rows) ? *reinterpret_cast<const U64x2*>(wp + r * rstride + j * wstride) : U64x2{0, 0};
+#pragma unroll
+        for (int r = 0; r < RT; ++r) {
+            acc_mac(acc[r][0][0], w[r].a, x0.a); acc_mac(acc[r][0][1], w[r].b, x0.b);
+            acc_mac(acc[r][1][0], w[r].a, x1.a); acc_mac(acc[r][1][1], w[r].b, x1.b);
         }
-        u64* yp = y + ((row * 2) * L + limb) * n + 2 * (size_t)i;
-        *reinterpret_cast<U64x2*>(yp) = U64x2{acc_reduce<Arith>(a00, lc, two64), acc_reduce<Arith>(a01, lc, two64)};
-        *reinterpret_cast<U64x2*>(yp + L * n) = U64x2{acc_reduce<Arith>(a10, lc, two64), acc_reduce<Arith>(a11, lc, two64)};
+        if (++since == 128) {  // 128 products of < 2^120 stay below 2^128 next to a reduced value
+#pragma unroll
+            for (int r = 0; r < RT; ++r)
+#pragma unroll
+                for (int c = 0; c < 2; ++c)
+#pragma unroll
+                    for (int k = 0; k < 2; ++k) acc[r][c][k] = Acc128{acc_reduce<Arith>(acc[r][c][k], lc, two64), 0};
+            since = 0;
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < RT; ++r) {
+        if (row0 + r >= rows) break;
+        u64* yp = y + (((row0 + r) * 2) * L + limb) * n + w0;
+        *reinterpret_cast<U64x2*>(yp) = U64x2{acc_reduce<Arith>(acc[r][0][0], lc, two64), acc_reduce<Arith>(acc[r][0][1], lc, two64)};
+        *reinterpret_cast<U64x2*>(yp + L * n) = U64x2{acc_reduce<Arith>(acc[r][1][0], lc, two64), acc_reduce<Arith>(acc[r][1][1], lc, two64)};
     }
 }
 

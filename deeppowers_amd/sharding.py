@@ -27,9 +27,9 @@ def shard_bounds(total: int, world: int, rank: int) -> tuple[int, int]:
 
 def allgather_partials(partial: torch.Tensor, group=None) -> torch.Tensor:
     """[...] -> [world, ...]; rank r's partial lands at index r on every rank."""
-    world = dist.get_world_size(group) if dist.is_initialized() else 1
-    if world == 1:
+    if not dist.is_initialized():
         return partial.unsqueeze(0)
+    world = dist.get_world_size(group)
     flat = partial.contiguous().view(-1)  # flat concatenation: the one layout every backend accepts
     out = torch.empty(world * flat.numel(), dtype=partial.dtype, device=partial.device)
     dist.all_gather_into_tensor(out, flat, group=group)

@@ -341,3 +341,21 @@ def test_rccl_allgather_world_size_one(rigs):
     torch.cuda.synchronize()
     assert torch.equal(send, recv)
     lib.dpfhe_comm_destroy(comm)
+
+
+def test_bench_distributed_path_world_size_one():
+    """bench.py launched the way the driver launches N>1 (torch.distributed.run, RCCL process group, barrier,
+    all-gather on the side stream) - at world size 1 because the test box has one GPU."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, DPFHE_FORCE_DIST="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", "29533", os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1",
+           "--batch-per-gpu", "64", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 1 and d["bit_exact_sample"] is True and d["value"] > 0 and d["unit"] == "ct-mul/s"
+    assert set(("roofline", "config", "metric", "ms_per_step", "scaling", "dtype", "data")) <= set(d)
