@@ -101,6 +101,13 @@ def main():
         red_done[k].record(side)
         return k
 
+    # one-off initialisation that is not part of any step: RCCL communicator creation and code-object loading
+    if dist.is_initialized():
+        allgather_partials(partials[0])
+        dist.barrier()
+    ev.reduce_sum(ev.multiply(Ciphertext(a.data[:1]), Ciphertext(b.data[:1])))
+    torch.cuda.synchronize()
+
     for _ in range(args.warmup):
         step()
 

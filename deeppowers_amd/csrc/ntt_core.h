@@ -177,27 +177,29 @@ struct NttBody {
 
     // ---------------- global <-> registers ----------------
     // window-top mapping (forward input / inverse output): word j = k*T + tid, 8 B per lane, coalesced
+    // (unsigned index on a workgroup-uniform base: hipcc then uses the SGPR-base + 32-bit VGPR offset form and
+    //  spends no VALU on 64-bit address arithmetic)
     static DPF_HD void load_top(int tid, u64 (&x)[E], const u64* g) {
-#pragma unroll
-        for (int k = 0; k < E; ++k) x[k] = g[k * T + tid];
+#pragma clang loop unroll(full)
+        for (int k = 0; k < E; ++k) x[k] = g[(unsigned)(k * T) + (unsigned)tid];
     }
     static DPF_HD void store_top(int tid, const u64 (&x)[E], u64* g) {
-#pragma unroll
-        for (int k = 0; k < E; ++k) g[k * T + tid] = x[k];
+#pragma clang loop unroll(full)
+        for (int k = 0; k < E; ++k) g[(unsigned)(k * T) + (unsigned)tid] = x[k];
     }
     // window-0 mapping (forward output / inverse input): thread owns words [tid*E, tid*E + E)
     struct alignas(16) V2 {
         u64 a, b;
     };
     static DPF_HD void load_bot(int tid, u64 (&x)[E], const u64* g) {
-        const V2* p = reinterpret_cast<const V2*>(g + tid * E);
-#pragma unroll
-        for (int k = 0; k < E / 2; ++k) { V2 v = p[k]; x[2 * k] = v.a; x[2 * k + 1] = v.b; }
+        const V2* p = reinterpret_cast<const V2*>(g);
+#pragma clang loop unroll(full)
+        for (int k = 0; k < E / 2; ++k) { V2 v = p[(unsigned)tid * (E / 2) + k]; x[2 * k] = v.a; x[2 * k + 1] = v.b; }
     }
     static DPF_HD void store_bot(int tid, const u64 (&x)[E], u64* g) {
-        V2* p = reinterpret_cast<V2*>(g + tid * E);
-#pragma unroll
-        for (int k = 0; k < E / 2; ++k) p[k] = V2{x[2 * k], x[2 * k + 1]};
+        V2* p = reinterpret_cast<V2*>(g);
+#pragma clang loop unroll(full)
+        for (int k = 0; k < E / 2; ++k) p[(unsigned)tid * (E / 2) + k] = V2{x[2 * k], x[2 * k + 1]};
     }
 
     // ---------------- LDS exchange between forward phases P and P+1 ----------------
@@ -213,10 +215,10 @@ struct NttBody {
         constexpr int c = G::phase(SIDE).c;
         if (c == 0) {
             V2* p = reinterpret_cast<V2*>(lds + xaddr<P, SIDE, FWD>(tid, 0));
-#pragma unroll
+#pragma clang loop unroll(full)
             for (int k = 0; k < E / 2; ++k) p[k] = V2{x[2 * k], x[2 * k + 1]};
         } else {
-#pragma unroll
+#pragma clang loop unroll(full)
             for (int k = 0; k < E; ++k) lds[xaddr<P, SIDE, FWD>(tid, k)] = x[k];
         }
     }
@@ -225,10 +227,10 @@ struct NttBody {
         constexpr int c = G::phase(SIDE).c;
         if (c == 0) {
             const V2* p = reinterpret_cast<const V2*>(lds + xaddr<P, SIDE, FWD>(tid, 0));
-#pragma unroll
+#pragma clang loop unroll(full)
             for (int k = 0; k < E / 2; ++k) { V2 v = p[k]; x[2 * k] = v.a; x[2 * k + 1] = v.b; }
         } else {
-#pragma unroll
+#pragma clang loop unroll(full)
             for (int k = 0; k < E; ++k) x[k] = lds[xaddr<P, SIDE, FWD>(tid, k)];
         }
     }
@@ -242,11 +244,11 @@ struct NttBody {
     static DPF_HD void load_tw(int tid, const Tw* tw, TwRegs& twr) {
         constexpr Phase ph = G::phase(P);
         const int th = tid_high<G>(ph.c, tid);
-#pragma unroll
+#pragma clang loop unroll(full)
         for (int u = 0; u < ph.r; ++u) {
             const int pos = FWD ? (ph.b + ph.r - 1 - u) : (ph.b + u);
             const int lb = pos - ph.c;
-#pragma unroll
+#pragma clang loop unroll(full)
             for (int i = 0; i < E / 2; ++i)  // constant trip count (the bound below folds after unrolling u)
                 if (i < (1 << (LOGE - 1 - lb))) twr[u][i] = tw[tw_index<G>(ph.c, th, i << (lb + 1), pos)];
         }
@@ -257,17 +259,17 @@ struct NttBody {
         constexpr Phase ph = G::phase(P);
         constexpr CtPlan kCt = make_ct_plan(LOGN, kUnit);  // canonical input
         const u64 two_q = 2 * lc.q;
-#pragma unroll
+#pragma clang loop unroll(full)
         for (int u = 0; u < ph.r; ++u) {
             const int pos = ph.b + ph.r - 1 - u;        // bit position = distance exponent
             const int sigma = LOGN - 1 - pos;           // global stage number
             const int lb = pos - ph.c;
             if (Arith::kFold && kCt.red[sigma]) {
-#pragma unroll
+#pragma clang loop unroll(full)
                 for (int k = 0; k < E; ++k)
                     if (!(k & (1 << lb))) x[k] = FoldArith::reduce(x[k], lc);
             }
-#pragma unroll
+#pragma clang loop unroll(full)
             for (int k = 0; k < E; ++k) {
                 if (k & (1 << lb)) continue;
                 const Tw w = twr[u][k >> (lb + 1)];
@@ -287,7 +289,7 @@ struct NttBody {
     }
     // forward output -> canonical residues
     static DPF_HD void fwd_canon(u64 (&x)[E], const LimbConst& lc) {
-#pragma unroll
+#pragma clang loop unroll(full)
         for (int k = 0; k < E; ++k) {
             if (Arith::kFold) x[k] = FoldArith::canon(x[k], lc);
             else x[k] = csub(csub(x[k], 2 * lc.q), lc.q);
@@ -351,7 +353,7 @@ struct NttBody {
     }
     // inverse output (all words are outputs of the last-stage multiplies, < 2q) -> canonical
     static DPF_HD void inv_canon(u64 (&x)[E], const LimbConst& lc) {
-#pragma unroll
+#pragma clang loop unroll(full)
         for (int k = 0; k < E; ++k) x[k] = csub(x[k], lc.q);
     }
 };
