@@ -219,6 +219,20 @@ extern "C" int dpfhe_ct_mul(dpfhe_ctx* c, uint64_t* d_out3, const uint64_t* d_a2
     return check_launch("ct_mul kernel launch");
 }
 
+extern "C" int dpfhe_relinearize(dpfhe_ctx* c, uint64_t* d_out2, const uint64_t* d_in3, const uint64_t* d_evk, size_t batch, void* stream) {
+    if (!c) return fail(DPFHE_INVALID_ARGUMENT, "dpfhe_relinearize", "null context");
+    if (batch == 0) return DPFHE_SUCCESS;
+    if (!d_out2 || !d_in3 || !d_evk || misaligned(d_out2) || misaligned(d_in3) || misaligned(d_evk))
+        return fail(DPFHE_INVALID_ARGUMENT, "dpfhe_relinearize", "null or misaligned buffer");
+    const size_t blocks = batch * c->n_limbs;
+    if (blocks > kMaxGrid) return fail(DPFHE_INVALID_ARGUMENT, "dpfhe_relinearize", "batch too large for one launch");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int rc = c->fold ? launch_relin<FoldArith>((int)c->log2n, d_out2, d_in3, d_evk, blocks, c->foldt, s)
+                           : launch_relin<ShoupArith>((int)c->log2n, d_out2, d_in3, d_evk, blocks, c->shoup, s);
+    if (rc) return fail(DPFHE_INVALID_STATE, "dpfhe_relinearize", "no kernel geometry for this log2_n");
+    return check_launch("relin kernel launch");
+}
+
 // ------------------------------------------------------------------------------------------------
 extern "C" int dpfhe_matvec_plain(dpfhe_ctx* c, uint64_t* d_y, const uint64_t* d_W, const uint64_t* d_x, size_t rows, size_t cols,
                                   void* stream) {

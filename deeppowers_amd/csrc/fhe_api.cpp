@@ -112,6 +112,8 @@ Ciphertext::Ciphertext(const Context& ctx, size_t size, size_t batch, bool is_nt
     if (size != 2 && size != 3) throw Exception(ErrorCode::INVALID_ARGUMENT, "Ciphertext: size must be 2 or 3");
 }
 
+RelinKeys::RelinKeys(const Context& ctx) : PolyBuffer(ctx, ctx.params().n_limbs(), 2, /*is_ntt=*/true) {}
+
 // ---- Evaluator --------------------------------------------------------------------------------------------
 class Evaluator::Impl {
 public:
@@ -171,6 +173,13 @@ void Evaluator::multiply(const Ciphertext& a, const Ciphertext& b, Ciphertext& o
     if (out.size() != 3 || out.batch() != a.batch()) throw Exception(ErrorCode::INVALID_ARGUMENT, "multiply: output must be a 3-component ciphertext of the same batch");
     const uint32_t flags = (a.is_ntt() ? DPFHE_IN_NTT : 0u) | (out.is_ntt() ? DPFHE_OUT_NTT : 0u);
     check(dpfhe_ct_mul(impl_->h(), out.data(), a.data(), b.data(), a.batch(), flags, s), "dpfhe_ct_mul");
+}
+void Evaluator::relinearize(const Ciphertext& in3, const RelinKeys& keys, Ciphertext& out2, Stream* s) const {
+    if (in3.is_ntt()) throw Exception(ErrorCode::INVALID_STATE, "relinearize: input must be in the coefficient domain");
+    if (in3.size() != 3 || out2.size() != 2 || out2.batch() != in3.batch())
+        throw Exception(ErrorCode::INVALID_ARGUMENT, "relinearize: 3-component input, 2-component output of the same batch");
+    check(dpfhe_relinearize(impl_->h(), out2.data(), in3.data(), keys.data(), in3.batch(), s), "dpfhe_relinearize");
+    out2.set_ntt(false);
 }
 void Evaluator::multiply_plain(const Ciphertext& a, const Plaintext& p, Ciphertext& out, Stream* s) const {
     if (!a.is_ntt() || !p.is_ntt()) throw Exception(ErrorCode::INVALID_STATE, "multiply_plain: operands must be in the NTT domain");

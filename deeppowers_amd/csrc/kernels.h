@@ -245,4 +245,91 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE), 2) void ct_mul_kernel(u64* __re
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// N1: relinearisation with RNS-digit evaluation keys (no special prime).
+//   c2 = sum_j d_j g_j (mod Q) with d_j = [c2]_{q_j} (digit j = limb j of c2, coefficient domain) and g_j the CRT basis
+//   element of limb j, so   (c0', c1') = (c0, c1) + sum_j d_j (.) evk_j,   evk_j = (-(a_j s) + e_j + g_j s^2, a_j).
+// One workgroup per (ciphertext, limb i): for every digit j: load d_j, reduce it mod q_i, forward NTT in registers,
+// multiply-accumulate with the two key polynomials (NTT domain, L2-resident: 2 L^2 N words in total); then two inverse
+// NTTs, add c0_i / c1_i, store.  L + 2 transforms per workgroup; HBM: L + 2 reads and 2 writes of a residue polynomial.
+// ------------------------------------------------------------------------------------------------
+template <class Arith>
+__device__ __forceinline__ u64 canon_any(u64 v, const LimbConst& lc) {  // any v < 2^64 -> [0, q)
+    if (Arith::kFold) return FoldArith::canon(v, lc);
+    else return ShoupArith::mul_var(v, 1, lc);
+}
+
+template <class Arith, int LOGN, int LOGE>
+__global__ __launch_bounds__(1 << (LOGN - LOGE), (Arith::kFold ? 2 : 1)) void relin_kernel(u64* __restrict__ out2, const u64* __restrict__ in3,
+                                                                       const u64* __restrict__ evk, DevTables<Arith> tb) {
+    typedef NttBody<Arith, LOGN, LOGE> B;
+    constexpr int E = B::E, N = B::G::N;
+    __shared__ __attribute__((aligned(16))) u64 lds[B::G::lds_words()];
+    int tid = threadIdx.x;
+    const int L = tb.n_limbs;
+    const size_t bi = blockIdx.x / (unsigned)L;
+    const int limb = (int)(blockIdx.x % (unsigned)L);
+    const LimbConst lc = tb.lc[limb];
+    const InvLast<typename B::Tw> last = tb.last[limb];
+    const u64* c2 = in3 + ((bi * 3 + 2) * L) * N;           // digit j at + j*N
+    u64 acc0[E], acc1[E];
+#pragma unroll
+    for (int k = 0; k < E; ++k) acc0[k] = acc1[k] = 0;
+    int lazy_terms = 0;
+#pragma unroll 1
+    for (int j = 0; j < L; ++j) {
+        asm volatile("" : "+v"(tid));
+        u64 x[E];
+        B::load_top(tid, x, c2 + (size_t)j * N);
+#pragma unroll
+        for (int k = 0; k < E; ++k) x[k] = canon_any<Arith>(x[k], lc);   // [c2]_{q_j} mod q_i
+        if (j > 0) __syncthreads();
+        FwdChain<B, 0>::run(tid, x, lds, tb.fwd + (size_t)limb * N, lc);
+        const u64* k0 = evk + (((size_t)j * 2 + 0) * L + limb) * N;      // key polynomials, NTT domain (window-0 mapping)
+        const u64* k1 = evk + (((size_t)j * 2 + 1) * L + limb) * N;
+        if (Arith::kFold) {
+            if (lazy_terms == 13) {  // 13 products + one reduced word stay below 15 q
+#pragma unroll
+                for (int k = 0; k < E; ++k) { acc0[k] = FoldArith::reduce(acc0[k], lc); acc1[k] = FoldArith::reduce(acc1[k], lc); }
+                lazy_terms = 1;
+            }
+            ++lazy_terms;
+        } else {
+            B::fwd_canon(x, lc);
+        }
+        {   // one key polynomial at a time keeps the live set at x + acc0 + acc1 + one key (no spills at 2 waves/SIMD)
+            u64 e[E];
+            B::load_bot(tid, e, k0);
+#pragma unroll
+            for (int k = 0; k < E; ++k)
+                acc0[k] = Arith::kFold ? acc0[k] + FoldArith::mul60(x[k], e[k], (u32)lc.d) : add_mod(acc0[k], ShoupArith::mul_var(x[k], e[k], lc), lc.q);
+            asm volatile("" ::: "memory");
+            B::load_bot(tid, e, k1);
+#pragma unroll
+            for (int k = 0; k < E; ++k)
+                acc1[k] = Arith::kFold ? acc1[k] + FoldArith::mul60(x[k], e[k], (u32)lc.d) : add_mod(acc1[k], ShoupArith::mul_var(x[k], e[k], lc), lc.q);
+        }
+    }
+    if (Arith::kFold) {
+#pragma unroll
+        for (int k = 0; k < E; ++k) { acc0[k] = FoldArith::reduce(acc0[k], lc); acc1[k] = FoldArith::reduce(acc1[k], lc); }
+    }
+    constexpr int kInvIn = Arith::kFold ? 2 * kMulB : kUnit;
+#pragma unroll 1
+    for (int c = 0; c < 2; ++c) {
+        asm volatile("" : "+v"(tid));
+        u64 x[E];
+#pragma unroll
+        for (int k = 0; k < E; ++k) x[k] = c == 0 ? acc0[k] : acc1[k];
+        u64 orig[E];
+        B::load_top(tid, orig, in3 + ((bi * 3 + c) * L + limb) * N);
+        __syncthreads();
+        InvChain<B, B::NPH - 1, kInvIn>::run(tid, x, lds, tb.inv + (size_t)limb * N, last, lc);
+        B::inv_canon(x, lc);
+#pragma unroll
+        for (int k = 0; k < E; ++k) x[k] = add_mod(x[k], orig[k], lc.q);
+        B::store_top(tid, x, out2 + ((bi * 2 + c) * L + limb) * N);
+    }
+}
+
 }  // namespace dpfhe

@@ -226,6 +226,22 @@ class Evaluator:
         _cabi.check(self._lib.dpfhe_ct_mul(self.ctx.handle, out.data_ptr(), a.data.data_ptr(), b.data.data_ptr(), a.batch, flags, _stream_ptr(stream)), "dpfhe_ct_mul")
         return Ciphertext(out, out_ntt)
 
+    # ---- N1: relinearisation ---------------------------------------------------------------
+    def relinearize(self, ct3: Ciphertext, evk: torch.Tensor, out: torch.Tensor | None = None, stream=None) -> Ciphertext:
+        """3 -> 2 components.  evk: [L digits][2][L][N], NTT domain (see include/dpfhe.h); ct3 coefficient domain."""
+        if ct3.size != 3 or ct3.is_ntt:
+            raise _cabi.DpfheError(2002 if ct3.is_ntt else 2000, "relinearize expects a 3-component coefficient-domain ciphertext")
+        p = self.ctx.params
+        self._chk(ct3.data, evk)
+        if tuple(evk.shape) != (p.n_limbs, 2, p.n_limbs, p.n):
+            raise _cabi.DpfheError(2000, "evk must be [L][2][L][N]")
+        lead = ct3.data.shape[:-3]
+        if out is None:
+            out = self.ctx.empty(*lead, components=2)
+        self._chk(out)
+        _cabi.check(self._lib.dpfhe_relinearize(self.ctx.handle, out.data_ptr(), ct3.data.data_ptr(), evk.data_ptr(), ct3.batch, _stream_ptr(stream)), "dpfhe_relinearize")
+        return Ciphertext(out, False)
+
     # ---- A7 -------------------------------------------------------------------------------------------
     def multiply_plain(self, a: Ciphertext, p: Plaintext, stream=None) -> Ciphertext:
         """ct (.) pt, both in the NTT domain: every component times the plaintext polynomial."""

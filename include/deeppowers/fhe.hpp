@@ -102,6 +102,13 @@ public:
     explicit Ciphertext(const Context& ctx, size_t size = 2, size_t batch = 1, bool is_ntt = false);
 };
 
+// N1: evaluation keys for relinearisation: L digits x 2 polynomials, NTT domain
+// (evk_j = (-(a_j s) + e_j + g_j s^2, a_j), g_j = CRT basis element of limb j; layout [L][2][L][N]).
+class RelinKeys : public PolyBuffer {
+public:
+    explicit RelinKeys(const Context& ctx);
+};
+
 class Evaluator {
 public:
     explicit Evaluator(const Context& ctx);
@@ -120,6 +127,8 @@ public:
     void dyadic_multiply_add(const PolyBuffer& a, const PolyBuffer& b, PolyBuffer& acc, Stream* stream = nullptr) const;
     // A6: the metric op.  out must be a 3-component ciphertext of the same batch; its domain flag selects OUT_NTT.
     void multiply(const Ciphertext& a, const Ciphertext& b, Ciphertext& out, Stream* stream = nullptr) const;
+    // N1: 3 -> 2 components, coefficient domain in and out
+    void relinearize(const Ciphertext& in3, const RelinKeys& keys, Ciphertext& out2, Stream* stream = nullptr) const;
     // A7: ct (.) pt per component (NTT domain) and the matrix-vector product y_i = sum_j W_ij (.) x_j
     void multiply_plain(const Ciphertext& a, const Plaintext& p, Ciphertext& out, Stream* stream = nullptr) const;
     void matvec_plain(const Plaintext& W /* batch = rows*cols */, const Ciphertext& x /* batch = cols */, Ciphertext& y /* batch = rows */,

@@ -56,7 +56,7 @@ enum {
 enum { DPFHE_IN_NTT = 1u, DPFHE_OUT_NTT = 2u };
 
 /* -- A0: context ----------------------------------------------------------------------------------
- * log2_n in [8, 14]; n_limbs >= 1; moduli[i] prime < 2^60 with q = 1 (mod 2N); psi[i] a primitive
+ * log2_n in [8, 13]; n_limbs >= 1; moduli[i] prime < 2^60 with q = 1 (mod 2N); psi[i] a primitive
  * 2N-th root of unity mod q_i (psi^N = -1).  Builds twiddle / Shoup / Barrett tables on device_id. */
 int dpfhe_ctx_create(dpfhe_ctx** out, uint32_t log2_n, uint32_t n_limbs, const uint64_t* moduli,
                      const uint64_t* psi, int device_id);
@@ -85,6 +85,12 @@ int dpfhe_negate(dpfhe_ctx* ctx, uint64_t* d_out, const uint64_t* d_a, size_t n_
  * fused kernel: 7 residue polynomials of HBM traffic per limb). */
 int dpfhe_ct_mul(dpfhe_ctx* ctx, uint64_t* d_out3, const uint64_t* d_a2, const uint64_t* d_b2, size_t batch,
                  uint32_t flags, void* stream);
+
+/* -- N1 (first "next" row): relinearisation 3 -> 2 components with RNS-digit evaluation keys ----
+ * d_in3: [batch][3][L][N], d_out2: [batch][2][L][N], both coefficient domain.
+ * d_evk: [L digits][2][L][N] in the NTT domain: evk_j = (-(a_j s) + e_j + g_j s^2, a_j) with g_j the CRT basis
+ * element of limb j (1 mod q_j, 0 mod the others).  (c0', c1') = (c0, c1) + sum_j [c2]_{q_j} (.) evk_j. */
+int dpfhe_relinearize(dpfhe_ctx* ctx, uint64_t* d_out2, const uint64_t* d_in3, const uint64_t* d_evk, size_t batch, void* stream);
 
 /* -- A7: ciphertext x plaintext matrix-vector product, everything in the NTT domain ------------------
  * d_W: [rows][cols][L][N] plaintext polys; d_x: [cols][2][L][N]; d_y: [rows][2][L][N],

@@ -35,11 +35,12 @@ def _load():
     lib.orc_dyadic.argtypes = [C.c_void_p, C.c_int, _U64P, _U64P, _U64P, C.c_size_t, C.c_int]
     lib.orc_ct_mul.argtypes = [C.c_void_p, _U64P, _U64P, _U64P, C.c_size_t, C.c_int]
     lib.orc_ct_mul_schoolbook.argtypes = [C.c_void_p, _U64P, _U64P, _U64P, C.c_size_t, C.c_int]
+    lib.orc_relinearize.argtypes = [C.c_void_p, _U64P, _U64P, _U64P, C.c_size_t, C.c_int]
     lib.orc_matvec_plain.argtypes = [C.c_void_p, _U64P, _U64P, _U64P, C.c_size_t, C.c_size_t, C.c_size_t, C.c_int]
     lib.orc_reduce_sum.argtypes = [C.c_void_p, _U64P, _U64P, C.c_size_t, C.c_size_t]
     lib.orc_fill_splitmix.argtypes = [C.c_void_p, _U64P, C.c_size_t, C.c_uint64]
     for f in ("orc_ctx_destroy", "orc_get_root_powers", "orc_schoolbook_negacyclic", "orc_ntt_fwd", "orc_ntt_inv",
-              "orc_dyadic", "orc_ct_mul", "orc_ct_mul_schoolbook", "orc_matvec_plain", "orc_reduce_sum", "orc_fill_splitmix"):
+              "orc_dyadic", "orc_ct_mul", "orc_ct_mul_schoolbook", "orc_relinearize", "orc_matvec_plain", "orc_reduce_sum", "orc_fill_splitmix"):
         getattr(lib, f).restype = None
     return lib
 
@@ -122,6 +123,12 @@ class Oracle:
         f = lib().orc_ct_mul_schoolbook if schoolbook else lib().orc_ct_mul
         f(self._h, _p(out), _p(a2), _p(b2), batch, threads)
         return out.reshape(batch, 3, self.L, self.n)
+
+    def relinearize(self, ct3, evk, threads=1):
+        batch = ct3.size // (3 * self.L * self.n)
+        out = np.empty(batch * 2 * self.L * self.n, np.uint64)
+        lib().orc_relinearize(self._h, _p(out), _p(np.ascontiguousarray(ct3)), _p(np.ascontiguousarray(evk)), batch, threads)
+        return out.reshape(batch, 2, self.L, self.n)
 
     def matvec_plain(self, W, x, rows, cols, comps=2, threads=1):
         y = np.empty(rows * comps * self.L * self.n, np.uint64)

@@ -330,6 +330,47 @@ void orc_ct_mul_schoolbook(const orc_ctx* c, uint64_t* out3, const uint64_t* a2,
     }
 }
 
+/* N1 relinearisation with RNS-digit keys (published algorithm: Bajard-Eynard-Hasan-Zucca RNS
+ * decomposition / "BV" key switching without special prime):  (c0',c1') = (c0,c1) + sum_j [c2]_{q_j} (.) evk_j.
+ * in3 [batch][3][L][N], out2 [batch][2][L][N] coefficient domain; evk [L][2][L][N] NTT domain. */
+void orc_relinearize(const orc_ctx* c, uint64_t* out2, const uint64_t* in3, const uint64_t* evk, size_t batch, int threads) {
+    const size_t n = 1ull << c->log2n, L = c->n_limbs;
+    threads = clamp_threads(threads);
+#pragma omp parallel num_threads(threads)
+    {
+        uint64_t* w = malloc(3 * n * sizeof(uint64_t));
+#pragma omp for schedule(static)
+        for (long long it = 0; it < (long long)(batch * L); ++it) {
+            const size_t bi = (size_t)it / L, i = (size_t)it % L;
+            const orc_limb* T = &c->limb[i];
+            const uint64_t q = T->q;
+            uint64_t *d = w, *acc0 = w + n, *acc1 = w + 2 * n;
+            memset(acc0, 0, 2 * n * sizeof(uint64_t));
+            for (size_t j = 0; j < L; ++j) {
+                const uint64_t* c2j = in3 + ((bi * 3 + 2) * L + j) * n;
+                for (size_t k = 0; k < n; ++k) d[k] = c2j[k] % q;
+                ntt_fwd_poly(T, d);
+                const uint64_t* k0 = evk + ((j * 2 + 0) * L + i) * n;
+                const uint64_t* k1 = evk + ((j * 2 + 1) * L + i) * n;
+                for (size_t k = 0; k < n; ++k) {
+                    uint64_t s0 = acc0[k] + mulmod_barrett(d[k], k0[k], T); acc0[k] = s0 - ((s0 >= q) ? q : 0);
+                    uint64_t s1 = acc1[k] + mulmod_barrett(d[k], k1[k], T); acc1[k] = s1 - ((s1 >= q) ? q : 0);
+                }
+            }
+            ntt_inv_poly(T, acc0); ntt_inv_poly(T, acc1);
+            const uint64_t* c0 = in3 + ((bi * 3 + 0) * L + i) * n;
+            const uint64_t* c1 = in3 + ((bi * 3 + 1) * L + i) * n;
+            uint64_t* o0 = out2 + ((bi * 2 + 0) * L + i) * n;
+            uint64_t* o1 = out2 + ((bi * 2 + 1) * L + i) * n;
+            for (size_t k = 0; k < n; ++k) {
+                uint64_t s0 = acc0[k] + c0[k]; o0[k] = s0 - ((s0 >= q) ? q : 0);
+                uint64_t s1 = acc1[k] + c1[k]; o1[k] = s1 - ((s1 >= q) ? q : 0);
+            }
+        }
+        free(w);
+    }
+}
+
 /* y[rows][comps][L][N] = sum_j W[rows][cols][L][N] (.) x[cols][comps][L][N]   (all NTT domain) */
 void orc_matvec_plain(const orc_ctx* c, uint64_t* y, const uint64_t* W, const uint64_t* x, size_t rows, size_t cols, size_t comps, int threads) {
     const size_t n = 1ull << c->log2n, L = c->n_limbs;

@@ -13,6 +13,7 @@ void orc_ctx_destroy(orc_ctx* c);
 void orc_fill_splitmix(const orc_ctx* c, uint64_t* out, size_t n_rns_polys, uint64_t seed);
 void orc_ct_mul(const orc_ctx* c, uint64_t* out3, const uint64_t* a2, const uint64_t* b2, size_t batch, int threads);
 void orc_ntt_fwd(const orc_ctx* c, uint64_t* io, size_t n_rns_polys, int threads);
+void orc_relinearize(const orc_ctx* c, uint64_t* out2, const uint64_t* in3, const uint64_t* evk, size_t batch, int threads);
 void orc_matvec_plain(const orc_ctx* c, uint64_t* y, const uint64_t* W, const uint64_t* x, size_t rows, size_t cols, size_t comps, int threads);
 }
 
@@ -67,6 +68,19 @@ static void run(const FheParams& p, size_t batch) {
     ev.matvec_plain(Wd, A, Y);
     Y.copy_to_host(y_got.data());
     CHECK(y_got == y_want);
+
+    // relinearisation of the product with random (canonical) key words: bit-exact vs the oracle
+    {
+        std::vector<uint64_t> evk(L * 2 * L * n), r_want(batch * 2 * L * n), r_got(r_want.size());
+        orc_fill_splitmix(orc, evk.data(), L * 2, 1004);
+        orc_relinearize(orc, r_want.data(), want.data(), evk.data(), batch, 0);
+        RelinKeys K(ctx);
+        K.copy_from_host(evk.data());
+        Ciphertext R(ctx, 2, batch);
+        ev.relinearize(C, K, R);
+        R.copy_to_host(r_got.data());
+        CHECK(r_got == r_want);
+    }
 
     // error behaviour: exceptions with reference error codes
     try {

@@ -104,3 +104,102 @@ def test_tensor_product_is_multiplicative_under_decryption_hip():
         ctx.close()
         return out
     run_semantic(mul)
+
+
+# ---- N1: relinearisation ------------------------------------------------------------------------------------------
+def keygen_relin(rng, p, s):
+    """evk[j] = (-(a_j s) + e_j + g_j s^2, a_j) in the NTT domain; g_j s^2 is s^2 in limb j and 0 elsewhere (CRT basis)."""
+    n, L = p.n, p.n_limbs
+    orc = Oracle.from_params(p)
+    evk = np.zeros((L, 2, L, n), np.uint64)
+    errs = []
+    for j in range(L):
+        e = rng.integers(-8, 9, n)
+        errs.append([int(v) for v in e])
+        for i, q in enumerate(p.moduli):
+            sq = [int(v) % q for v in s]
+            a = [int(rng.integers(0, 2**62)) % q for _ in range(n)]
+            a_s = po.negacyclic_schoolbook(a, sq, q)
+            s2 = po.negacyclic_schoolbook(sq, sq, q) if i == j else [0] * n
+            evk[j, 0, i] = [(-a_s[k] + int(e[k]) + s2[k]) % q for k in range(n)]
+            evk[j, 1, i] = a
+    evk_ntt = orc.ntt_fwd(evk.reshape(-1, L, n)).reshape(evk.shape)
+    return evk_ntt, errs
+
+
+def run_relin_semantic(multiply, relin):
+    p = small_params()
+    rng = np.random.default_rng(77)
+    s = rng.integers(-1, 2, p.n)
+    m1, m2 = rng.integers(0, 1000, p.n), rng.integers(0, 1000, p.n)
+    ct1, _ = encrypt(rng, p, s, m1, 1 << 40)
+    ct2, _ = encrypt(rng, p, s, m2, 1 << 40)
+    ct3 = multiply(p, ct1, ct2)
+    evk, errs = keygen_relin(rng, p, s)
+    ct2r = relin(p, ct3, evk)
+    assert ct2r.shape == (2, p.n_limbs, p.n)
+    ph3, Q = phase(p, ct3, s)
+    phr, _ = phase(p, ct2r, s)
+    # exact noise introduced by key switching: sum_j [c2]_{q_j} * e_j  (integer negacyclic products)
+    noise = [0] * p.n
+    for j in range(p.n_limbs):
+        dj = [int(v) for v in ct3[2, j]]
+        term = negacyclic_int(dj, errs[j], Q)
+        noise = [(a + b) % Q for a, b in zip(noise, term)]
+    assert phr == [(a + b) % Q for a, b in zip(ph3, noise)]   # phase(relin(ct)) = phase(ct) + sum_j d_j e_j  exactly
+    small = max(min(v, Q - v) for v in noise)
+    assert small < (1 << 75) < Q >> 64                         # and that noise is tiny next to Q
+
+
+def _oracle_mul(p, a, b):
+    return Oracle.from_params(p).ct_mul(np.ascontiguousarray(a), np.ascontiguousarray(b))[0]
+
+
+def test_relinearisation_preserves_the_phase_oracle():
+    run_relin_semantic(_oracle_mul, lambda p, ct3, evk: Oracle.from_params(p).relinearize(ct3[None], evk)[0])
+
+
+@pytest.mark.gpu
+def test_relinearisation_preserves_the_phase_hip():
+    from deeppowers_amd.evaluator import Ciphertext, Context, Evaluator, to_device, to_host
+
+    def relin(p, ct3, evk):
+        ctx = Context(p, 0)
+        ev = Evaluator(ctx)
+        out = to_host(ev.relinearize(Ciphertext(to_device(ct3[None], ctx.device)), to_device(evk, ctx.device)).data)[0]
+        ctx.close()
+        return out
+    run_relin_semantic(_oracle_mul, relin)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["config1", "n4096", "n8192", "shoup10"])
+def test_relinearize_bit_exact_vs_oracle(name):
+    from deeppowers_amd.evaluator import Ciphertext, Context, Evaluator, to_device, to_host
+    if name == "config1":
+        p = FheParams.config1()
+    elif name == "n4096":
+        p = FheParams.n4096_l4()
+    elif name == "n8192":
+        p = FheParams.n8192_l6()
+    else:
+        n = 1024
+        def gp(bits):
+            q = (1 << bits) - ((1 << bits) - 1) % (2 * n)
+            while not po.is_prime(q):
+                q -= 2 * n
+            return q
+        qs = (gp(59), gp(50), gp(33))
+        p = FheParams(10, qs, tuple(po.min_primitive_2n_root(n, q) for q in qs))
+    orc = Oracle.from_params(p)
+    L, n, batch = p.n_limbs, p.n, 3
+    ct3 = orc.fill(batch * 3, 91).reshape(batch, 3, L, n)
+    ct3[0, 2] = (np.array(p.moduli, np.uint64) - np.uint64(1))[:, None]   # worst-case digits
+    evk = orc.fill(L * 2, 92).reshape(L, 2, L, n)
+    evk[0, 0] = (np.array(p.moduli, np.uint64) - np.uint64(1))[:, None]
+    want = orc.relinearize(ct3, evk, threads=0)
+    ctx = Context(p, 0)
+    ev = Evaluator(ctx)
+    got = to_host(ev.relinearize(Ciphertext(to_device(ct3, ctx.device)), to_device(evk, ctx.device)).data)
+    ctx.close()
+    assert np.array_equal(got, want)

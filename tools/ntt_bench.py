@@ -45,6 +45,12 @@ def main():
         med, mn = timeit(lambda: ev.multiply(a, c, out=out), reps=15, warm=3)
         alg = 7 * L * N * 8 * bb
         print(f"{tag} {name} ct_mul x{bb}: median {med:8.1f} us  -> {bb / med:7.3f} M ct-mul/s   {alg / med / 1e6:7.1f} GB/s = {alg / med / 8e6 * 100:5.1f}% of 8 TB/s")
+        evk = torch.randint(0, 2**62, (L, 2, L, N), dtype=torch.int64, device=ctx.device) % q.view(1, 1, L, 1)
+        c3 = Ciphertext(out)
+        out2 = ctx.empty(bb, components=2)
+        med, mn = timeit(lambda: ev.relinearize(c3, evk, out=out2), reps=10, warm=2)
+        alg = (L + 4) * L * N * 8 * bb   # per (ct, limb): L digit reads + c0, c1 reads + 2 writes
+        print(f"{tag} {name} relinearize x{bb}: median {med:8.1f} us  -> {bb / med:7.3f} M relin/s   {alg / med / 1e6:7.1f} GB/s")
         ctx.close()
 
 
