@@ -27,6 +27,7 @@ SYMBOLS = {
     "dpfhe_ct_mul": ([C.c_void_p, _U64P, _U64P, _U64P, C.c_size_t, C.c_uint32, C.c_void_p], C.c_int),
     "dpfhe_relinearize": ([C.c_void_p, _U64P, _U64P, _U64P, C.c_size_t, C.c_void_p], C.c_int),
     "dpfhe_matvec_plain": ([C.c_void_p, _U64P, _U64P, _U64P, C.c_size_t, C.c_size_t, C.c_void_p], C.c_int),
+    "dpfhe_matvec_scalar": ([C.c_void_p, _U64P, _U64P, _U64P, C.c_size_t, C.c_size_t, C.c_void_p], C.c_int),
     "dpfhe_reduce_sum": ([C.c_void_p, _U64P, _U64P, C.c_size_t, C.c_size_t, C.c_void_p], C.c_int),
     "dpfhe_comm_unique_id": ([C.POINTER(C.c_uint8)], C.c_int),
     "dpfhe_comm_create": ([C.POINTER(C.c_void_p), C.POINTER(C.c_uint8), C.c_int, C.c_int, C.c_int], C.c_int),

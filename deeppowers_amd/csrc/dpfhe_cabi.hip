@@ -252,6 +252,24 @@ extern "C" int dpfhe_matvec_plain(dpfhe_ctx* c, uint64_t* d_y, const uint64_t* d
     return check_launch("matvec kernel launch");
 }
 
+extern "C" int dpfhe_matvec_scalar(dpfhe_ctx* c, uint64_t* d_y, const uint64_t* d_w, const uint64_t* d_x, size_t rows, size_t cols,
+                                   void* stream) {
+    if (!c) return fail(DPFHE_INVALID_ARGUMENT, "dpfhe_matvec_scalar", "null context");
+    if (rows == 0) return DPFHE_SUCCESS;
+    if (cols == 0) return fail(DPFHE_INVALID_ARGUMENT, "dpfhe_matvec_scalar", "cols must be > 0");
+    if (!d_y || !d_w || !d_x || misaligned(d_y) || misaligned(d_x) || (reinterpret_cast<uintptr_t>(d_w) & 7))
+        return fail(DPFHE_INVALID_ARGUMENT, "dpfhe_matvec_scalar", "null or misaligned buffer");
+    const int n = 1 << c->log2n;
+    const int chunks = (n + 511) / 512;
+    constexpr int RT = 8;
+    const size_t blocks = ((rows + RT - 1) / RT) * c->n_limbs * (size_t)chunks;
+    if (blocks > kMaxGrid) return fail(DPFHE_INVALID_ARGUMENT, "dpfhe_matvec_scalar", "too many rows for one launch");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (c->fold) hipLaunchKernelGGL((matvec_scalar_kernel<FoldArith, RT>), dim3((unsigned)blocks), dim3(256), 0, s, d_y, d_w, d_x, c->foldt.lc, (int)c->n_limbs, n, chunks, rows, cols);
+    else hipLaunchKernelGGL((matvec_scalar_kernel<ShoupArith, RT>), dim3((unsigned)blocks), dim3(256), 0, s, d_y, d_w, d_x, c->shoup.lc, (int)c->n_limbs, n, chunks, rows, cols);
+    return check_launch("matvec_scalar kernel launch");
+}
+
 extern "C" int dpfhe_reduce_sum(dpfhe_ctx* c, uint64_t* d_out, const uint64_t* d_in, size_t count, size_t components, void* stream) {
     if (!c) return fail(DPFHE_INVALID_ARGUMENT, "dpfhe_reduce_sum", "null context");
     if (components == 0 || count == 0) return fail(DPFHE_INVALID_ARGUMENT, "dpfhe_reduce_sum", "count and components must be > 0");

@@ -187,4 +187,56 @@ __global__ __launch_bounds__(256) void matvec_kernel(u64* y, const u64* W, const
     }
 }
 
+// A7, scalar weights (SURVEY.md section 8a A7 "cheap special case"): W_ij are residues in Z_q (one word per limb),
+// y_i = sum_j w_ij * x_j.  The weights of a row tile are workgroup-uniform (scalar loads -> SGPR multiplier operands),
+// x_j is loaded once per column and used for RT rows: RT*4 multiply-accumulates per 32 bytes loaded - ALU-bound.
+// d_w: [rows][cols][L];  x: [cols][2][L][N];  y: [rows][2][L][N].
+template <class Arith, int RT>
+__global__ __launch_bounds__(256) void matvec_scalar_kernel(u64* y, const u64* w, const u64* x, const LimbConst* lcs, int n_limbs, int n,
+                                                            int chunks, size_t rows, size_t cols) {
+    const size_t L = (size_t)n_limbs;
+    const int chunk = (int)(blockIdx.x % chunks);
+    const int limb = (int)((blockIdx.x / chunks) % L);
+    const size_t row0 = (blockIdx.x / chunks / L) * RT;
+    const int w0 = chunk * 512 + threadIdx.x * 2;
+    if (w0 >= n) return;
+    const LimbConst lc = lcs[limb];
+    const u64 two64 = lc.two64;
+    const size_t xstride = 2 * L * n;
+    Acc128 acc[RT][2][2];
+#pragma unroll
+    for (int r = 0; r < RT; ++r)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) acc[r][c][0] = acc[r][c][1] = Acc128{0, 0};
+    const u64* xp = x + (size_t)limb * n + w0;
+    size_t since = 0;
+    for (size_t j = 0; j < cols; ++j) {
+        const U64x2 x0 = *reinterpret_cast<const U64x2*>(xp + j * xstride);
+        const U64x2 x1 = *reinterpret_cast<const U64x2*>(xp + j * xstride + L * n);
+#pragma unroll
+        for (int r = 0; r < RT; ++r) {
+            const size_t row = row0 + r < rows ? row0 + r : rows - 1;   // clamp: out-of-range rows are computed, not stored
+            const u64 wr = w[(row * cols + j) * L + limb];              // uniform -> scalar load
+            acc_mac(acc[r][0][0], wr, x0.a); acc_mac(acc[r][0][1], wr, x0.b);
+            acc_mac(acc[r][1][0], wr, x1.a); acc_mac(acc[r][1][1], wr, x1.b);
+        }
+        if (++since == 128) {
+#pragma unroll
+            for (int r = 0; r < RT; ++r)
+#pragma unroll
+                for (int c = 0; c < 2; ++c)
+#pragma unroll
+                    for (int k = 0; k < 2; ++k) acc[r][c][k] = Acc128{acc_reduce<Arith>(acc[r][c][k], lc, two64), 0};
+            since = 0;
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < RT; ++r) {
+        if (row0 + r >= rows) break;
+        u64* yp = y + (((row0 + r) * 2) * L + limb) * n + w0;
+        *reinterpret_cast<U64x2*>(yp) = U64x2{acc_reduce<Arith>(acc[r][0][0], lc, two64), acc_reduce<Arith>(acc[r][0][1], lc, two64)};
+        *reinterpret_cast<U64x2*>(yp + L * n) = U64x2{acc_reduce<Arith>(acc[r][1][0], lc, two64), acc_reduce<Arith>(acc[r][1][1], lc, two64)};
+    }
+}
+
 }  // namespace dpfhe

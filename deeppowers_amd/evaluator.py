@@ -226,6 +226,20 @@ class Evaluator:
         _cabi.check(self._lib.dpfhe_ct_mul(self.ctx.handle, out.data_ptr(), a.data.data_ptr(), b.data.data_ptr(), a.batch, flags, _stream_ptr(stream)), "dpfhe_ct_mul")
         return Ciphertext(out, out_ntt)
 
+    def matvec_scalar(self, w: torch.Tensor, x: Ciphertext, out: torch.Tensor | None = None, stream=None) -> Ciphertext:
+        """y_i = sum_j w_ij * x_j with scalar weights w: [rows][cols][L] residues (either domain)."""
+        p = self.ctx.params
+        self._chk(x.data)
+        if (w.dtype != torch.int64 or not w.is_cuda or not w.is_contiguous() or w.dim() != 3 or w.shape[2] != p.n_limbs
+                or x.data.dim() != 4 or x.size != 2 or w.shape[1] != x.data.shape[0]):
+            raise _cabi.DpfheError(2000, "matvec_scalar: w [rows][cols][L] int64 cuda, x [cols][2][L][N]")
+        rows, cols = w.shape[0], w.shape[1]
+        if out is None:
+            out = self.ctx.empty(rows, components=2)
+        self._chk(out)
+        _cabi.check(self._lib.dpfhe_matvec_scalar(self.ctx.handle, out.data_ptr(), w.data_ptr(), x.data.data_ptr(), rows, cols, _stream_ptr(stream)), "dpfhe_matvec_scalar")
+        return Ciphertext(out, x.is_ntt)
+
     # ---- N1 (SURVEY.md 8f): relinearisation ---------------------------------------------------------------
     def relinearize(self, ct3: Ciphertext, evk: torch.Tensor, out: torch.Tensor | None = None, stream=None) -> Ciphertext:
         """3 -> 2 components.  evk: [L digits][2][L][N], NTT domain (see include/dpfhe.h); ct3 coefficient domain."""

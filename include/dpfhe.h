@@ -98,6 +98,11 @@ int dpfhe_relinearize(dpfhe_ctx* ctx, uint64_t* d_out2, const uint64_t* d_in3, c
 int dpfhe_matvec_plain(dpfhe_ctx* ctx, uint64_t* d_y, const uint64_t* d_W, const uint64_t* d_x, size_t rows,
                        size_t cols, void* stream);
 
+/* scalar-weight variant (the realistic plaintext linear layer: W_ij in Z_q, given as one residue per limb):
+ * d_w: [rows][cols][L] words;  y_i = sum_j w_ij * x_j.  Works in either domain (scalars commute with the NTT). */
+int dpfhe_matvec_scalar(dpfhe_ctx* ctx, uint64_t* d_y, const uint64_t* d_w, const uint64_t* d_x, size_t rows,
+                        size_t cols, void* stream);
+
 /* -- A8: modular sum of `count` ciphertexts of `components` RNS polys each into one ------------------
  * d_in: [count][components][L][N] -> d_out: [components][L][N].  (shard-local reduce before the all-gather) */
 int dpfhe_reduce_sum(dpfhe_ctx* ctx, uint64_t* d_out, const uint64_t* d_in, size_t count, size_t components, void* stream);

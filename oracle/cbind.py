@@ -37,10 +37,11 @@ def _load():
     lib.orc_ct_mul_schoolbook.argtypes = [C.c_void_p, _U64P, _U64P, _U64P, C.c_size_t, C.c_int]
     lib.orc_relinearize.argtypes = [C.c_void_p, _U64P, _U64P, _U64P, C.c_size_t, C.c_int]
     lib.orc_matvec_plain.argtypes = [C.c_void_p, _U64P, _U64P, _U64P, C.c_size_t, C.c_size_t, C.c_size_t, C.c_int]
+    lib.orc_matvec_scalar.argtypes = [C.c_void_p, _U64P, _U64P, _U64P, C.c_size_t, C.c_size_t, C.c_size_t, C.c_int]
     lib.orc_reduce_sum.argtypes = [C.c_void_p, _U64P, _U64P, C.c_size_t, C.c_size_t]
     lib.orc_fill_splitmix.argtypes = [C.c_void_p, _U64P, C.c_size_t, C.c_uint64]
     for f in ("orc_ctx_destroy", "orc_get_root_powers", "orc_schoolbook_negacyclic", "orc_ntt_fwd", "orc_ntt_inv",
-              "orc_dyadic", "orc_ct_mul", "orc_ct_mul_schoolbook", "orc_relinearize", "orc_matvec_plain", "orc_reduce_sum", "orc_fill_splitmix"):
+              "orc_dyadic", "orc_ct_mul", "orc_ct_mul_schoolbook", "orc_relinearize", "orc_matvec_scalar", "orc_matvec_plain", "orc_reduce_sum", "orc_fill_splitmix"):
         getattr(lib, f).restype = None
     return lib
 
@@ -133,6 +134,11 @@ class Oracle:
     def matvec_plain(self, W, x, rows, cols, comps=2, threads=1):
         y = np.empty(rows * comps * self.L * self.n, np.uint64)
         lib().orc_matvec_plain(self._h, _p(y), _p(W), _p(x), rows, cols, comps, threads)
+        return y.reshape(rows, comps, self.L, self.n)
+
+    def matvec_scalar(self, w, x, rows, cols, comps=2, threads=1):
+        y = np.empty(rows * comps * self.L * self.n, np.uint64)
+        lib().orc_matvec_scalar(self._h, _p(y), _p(np.ascontiguousarray(w)), _p(np.ascontiguousarray(x)), rows, cols, comps, threads)
         return y.reshape(rows, comps, self.L, self.n)
 
     def reduce_sum(self, cts, comps):

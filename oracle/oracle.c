@@ -391,6 +391,26 @@ void orc_matvec_plain(const orc_ctx* c, uint64_t* y, const uint64_t* W, const ui
     }
 }
 
+/* scalar-weight matvec: y[rows][comps][L][N] = sum_j w[rows][cols][L] * x[cols][comps][L][N] */
+void orc_matvec_scalar(const orc_ctx* c, uint64_t* y, const uint64_t* w, const uint64_t* x, size_t rows, size_t cols, size_t comps, int threads) {
+    const size_t n = 1ull << c->log2n, L = c->n_limbs;
+    threads = clamp_threads(threads);
+#pragma omp parallel for num_threads(threads) schedule(static)
+    for (long long it = 0; it < (long long)(rows * comps * L); ++it) {
+        const size_t i = (size_t)it / (comps * L), cc = ((size_t)it / L) % comps, l = (size_t)it % L;
+        const orc_limb* T = &c->limb[l];
+        uint64_t* yo = y + ((i * comps + cc) * L + l) * n;
+        for (size_t k = 0; k < n; ++k) {
+            uint64_t acc = 0;
+            for (size_t j = 0; j < cols; ++j) {
+                uint64_t p = mulmod_barrett(w[(i * cols + j) * L + l] % T->q, x[((j * comps + cc) * L + l) * n + k], T);
+                acc += p; acc -= (acc >= T->q) ? T->q : 0;
+            }
+            yo[k] = acc;
+        }
+    }
+}
+
 /* sum of `count` ciphertexts of `comps` components into one (A8 local_reduce) */
 void orc_reduce_sum(const orc_ctx* c, uint64_t* out, const uint64_t* in, size_t count, size_t comps) {
     const size_t n = 1ull << c->log2n, L = c->n_limbs, words = comps * L * n;

@@ -250,6 +250,21 @@ def test_matvec_plain_vs_oracle(rigs, name, rows, cols):
     assert y.is_ntt and np.array_equal(to_host(y.data), want)
 
 
+@pytest.mark.parametrize("name,rows,cols", [("n4096", 13, 9), ("fold8", 3, 300), ("shoup10", 9, 130), ("config1", 8, 5)])
+def test_matvec_scalar_vs_oracle(rigs, name, rows, cols):
+    r = rigs(name)
+    L, n = r.p.n_limbs, r.p.n
+    rng = np.random.default_rng(5)
+    qs = np.array(r.p.moduli, np.uint64)
+    w = (rng.integers(0, 2**62, (rows, cols, L), dtype=np.uint64) % qs[None, None, :]).astype(np.uint64)
+    w[0, :, :] = qs - np.uint64(1)
+    x = r.orc.fill(cols * 2, 43).reshape(cols, 2, L, n)
+    x[:, :, :, :16] = (qs - np.uint64(1))[None, None, :, None]
+    want = r.orc.matvec_scalar(w, x, rows, cols, threads=0)
+    y = r.ev.matvec_scalar(r.dev(w), Ciphertext(r.dev(x), True))
+    assert y.is_ntt and np.array_equal(to_host(y.data), want)
+
+
 def test_multiply_plain_and_ct_add_sub_negate(rigs):
     r = rigs("n4096")
     L, n = 4, 4096

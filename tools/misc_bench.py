@@ -32,3 +32,7 @@ y = ctx.empty(rows, components=2)
 med, mn = timeit(lambda: ev.matvec_plain(W, x, out=y), reps=8, warm=2)
 byts = (rows * cols + cols * 2 + rows * 2) * L * N * 8
 print(f"matvec_plain rows={rows} cols={cols} (W {rows*cols*L*N*8/2**30:.1f} GiB): median {med:9.1f} us  {byts / med / 1e6:7.1f} GB/s = {byts / med / 8e6 * 100:5.1f}% of 8 TB/s; {rows*cols*2*L*N/med/1e3:.2f} G mod-FMA/s")
+
+w = torch.randint(0, 2**62, (rows, cols, L), dtype=torch.int64, device=ctx.device) % q.view(1, 1, L)
+med, mn = timeit(lambda: ev.matvec_scalar(w, x, out=y), reps=8, warm=2)
+print(f"matvec_scalar rows={rows} cols={cols}: median {med:9.1f} us  {rows*cols*2*L*N/med/1e3:.2f} G mod-FMA/s")
