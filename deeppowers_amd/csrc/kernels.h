@@ -44,111 +44,41 @@ struct InvChain {
 };
 
 // ------------------------------------------------------------------------------------------------
-// Same chains with the per-thread twiddles of phases >= 1 already in registers (fetched before phase 0
-// started, so their L2 latency hides under the first butterflies instead of stalling every phase).
+// A1 / A2: batched NTT, one workgroup per residue polynomial (4 resident per CU at N=4096; the hardware
+// dispatcher keeps the generations de-phased - persistent workgroups with prefetch, up-front twiddle fetch and
+// staggered starts were all measured slower).
 // ------------------------------------------------------------------------------------------------
-template <class B, bool FWD, int P = 1>
-struct PreloadTw {
-    static __device__ __forceinline__ void run(int tid, const typename B::Tw* tw, typename B::TwRegs (&twr)[B::NPH]) {
-        if constexpr (P < B::NPH) {
-            B::template load_tw<P, FWD>(tid, tw, twr[P]);
-            PreloadTw<B, FWD, P + 1>::run(tid, tw, twr);
-        }
-    }
-};
-
-template <class B, int P>
-struct FwdChainPre {
-    static __device__ __forceinline__ void run(int tid, u64 (&x)[B::E], u64* lds, const typename B::Tw* tw,
-                                               const typename B::TwRegs (&twr)[B::NPH], const LimbConst& lc) {
-        if constexpr (P == 0) B::template fwd_phase<0>(tid, x, tw, lc);  // workgroup-uniform twiddles: scalar loads
-        else B::template fwd_phase_r<P>(x, twr[P], lc);
-        if constexpr (P + 1 < B::NPH) {
-            if (P > 0) __syncthreads();
-            B::template lds_write<P, P, true>(tid, x, lds);
-            __syncthreads();
-            B::template lds_read<P, P + 1, true>(tid, x, lds);
-            FwdChainPre<B, P + 1>::run(tid, x, lds, tw, twr, lc);
-        }
-    }
-};
-
-template <class B, int P, int IN>
-struct InvChainPre {
-    static __device__ __forceinline__ void run(int tid, u64 (&x)[B::E], u64* lds, const typename B::Tw* tw,
-                                               const typename B::TwRegs (&twr)[B::NPH], const InvLast<typename B::Tw>& last,
-                                               const LimbConst& lc) {
-        if constexpr (P == 0) B::template inv_phase<0, IN>(tid, x, tw, last.w_last, last.w_ninv, lc);
-        else B::template inv_phase_r<P, IN>(x, twr[P], last.w_last, last.w_ninv, lc);
-        if constexpr (P > 0) {
-            if (P < B::NPH - 1) __syncthreads();
-            B::template lds_write<P - 1, P, false>(tid, x, lds);
-            __syncthreads();
-            B::template lds_read<P - 1, P - 1, false>(tid, x, lds);
-            InvChainPre<B, P - 1, IN>::run(tid, x, lds, tw, twr, last, lc);
-        }
-    }
-};
-
-// ------------------------------------------------------------------------------------------------
-// A1 / A2: batched NTT, one workgroup per residue polynomial.  MODE 0: twiddles fetched per phase;
-// MODE 1: all per-thread twiddles fetched together with the coefficients, before the first butterfly.
-// ------------------------------------------------------------------------------------------------
-template <class Arith, int LOGN, int LOGE, int MODE>
+template <class Arith, int LOGN, int LOGE>
 __global__ __launch_bounds__(1 << (LOGN - LOGE)) void ntt_fwd_kernel(u64* __restrict__ out, const u64* __restrict__ in,
-                                                                      DevTables<Arith> tb, unsigned stagger) {
+                                                                      DevTables<Arith> tb) {
     typedef NttBody<Arith, LOGN, LOGE> B;
     __shared__ __attribute__((aligned(16))) u64 lds[B::G::lds_words()];
     const int tid = threadIdx.x;
     const size_t p = blockIdx.x;
-    // De-phase the first generation of workgroups: without it the workgroups sharing a CU load, compute
-    // and store in lockstep and the HBM time of a generation is not hidden by another one's butterflies.
-    if (stagger && blockIdx.x < 2048u) {
-        const unsigned slot = (blockIdx.x >> 8) & 3u;
-        for (unsigned i = 0; i < slot * stagger; ++i) __builtin_amdgcn_s_sleep(32);
-    }
     const int limb = (int)(p % (size_t)tb.n_limbs);
     const LimbConst lc = tb.lc[limb];
     const typename B::Tw* tw = tb.fwd + (size_t)limb * B::G::N;
     u64 x[B::E];
     B::load_top(tid, x, in + p * B::G::N);
-    if (MODE == 1) {
-        typename B::TwRegs twr[B::NPH];
-        PreloadTw<B, true>::run(tid, tw, twr);
-        FwdChainPre<B, 0>::run(tid, x, lds, tw, twr, lc);
-    } else {
-        FwdChain<B, 0>::run(tid, x, lds, tw, lc);
-    }
+    FwdChain<B, 0>::run(tid, x, lds, tw, lc);
     B::fwd_canon(x, lc);
     B::store_bot(tid, x, out + p * B::G::N);
 }
 
-template <class Arith, int LOGN, int LOGE, int MODE>
+template <class Arith, int LOGN, int LOGE>
 __global__ __launch_bounds__(1 << (LOGN - LOGE)) void ntt_inv_kernel(u64* __restrict__ out, const u64* __restrict__ in,
-                                                                      DevTables<Arith> tb, unsigned stagger) {
+                                                                      DevTables<Arith> tb) {
     typedef NttBody<Arith, LOGN, LOGE> B;
     __shared__ __attribute__((aligned(16))) u64 lds[B::G::lds_words()];
     const int tid = threadIdx.x;
     const size_t p = blockIdx.x;
-    // De-phase the first generation of workgroups: without it the workgroups sharing a CU load, compute
-    // and store in lockstep and the HBM time of a generation is not hidden by another one's butterflies.
-    if (stagger && blockIdx.x < 2048u) {
-        const unsigned slot = (blockIdx.x >> 8) & 3u;
-        for (unsigned i = 0; i < slot * stagger; ++i) __builtin_amdgcn_s_sleep(32);
-    }
     const int limb = (int)(p % (size_t)tb.n_limbs);
     const LimbConst lc = tb.lc[limb];
     const typename B::Tw* tw = tb.inv + (size_t)limb * B::G::N;
     const InvLast<typename B::Tw> last = tb.last[limb];
     u64 x[B::E];
     B::load_bot(tid, x, in + p * B::G::N);
-    if (MODE == 1) {
-        typename B::TwRegs twr[B::NPH];
-        PreloadTw<B, false>::run(tid, tw, twr);
-        InvChainPre<B, B::NPH - 1, kUnit>::run(tid, x, lds, tw, twr, last, lc);
-    } else {
-        InvChain<B, B::NPH - 1, kUnit>::run(tid, x, lds, tw, last, lc);
-    }
+    InvChain<B, B::NPH - 1, kUnit>::run(tid, x, lds, tw, last, lc);
     B::inv_canon(x, lc);
     B::store_top(tid, x, out + p * B::G::N);
 }

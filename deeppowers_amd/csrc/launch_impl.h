@@ -1,7 +1,5 @@
 // launch_impl.h - geometry dispatch shared by the per-policy translation units.
 #pragma once
-#include <cstdlib>
-
 #include "kernels.h"
 #include "launch.h"
 
@@ -19,26 +17,13 @@ namespace dpfhe {
         default: return -1;            \
     }
 
-inline int env_int(const char* name, int dflt) {
-    const char* e = getenv(name);
-    return e ? atoi(e) : dflt;
-}
-
 template <class Arith>
 int launch_ntt(int log2n, bool inverse, u64* out, const u64* in, size_t npolys, const DevTables<Arith>& tb, hipStream_t s) {
-    // MODE 0: twiddles fetched per phase (measured equal or better on MI355X: 84/82 us vs 82/87 us fwd/inv
-    // at BASELINE configs[1]); MODE 1: all per-thread twiddles fetched up front.  DPFHE_NTT_MODE=1 for A/B runs.
-    static const int mode = env_int("DPFHE_NTT_MODE", 0);
-    static const unsigned stagger = (unsigned)env_int("DPFHE_STAGGER", 0);
-#define NTT_LAUNCH(LN, LE, MODE)                                                                                                           \
-    if (inverse) hipLaunchKernelGGL((ntt_inv_kernel<Arith, LN, LE, MODE>), dim3((unsigned)npolys), dim3(Geo<LN, LE>::T), 0, s, out, in, tb, stagger); \
-    else hipLaunchKernelGGL((ntt_fwd_kernel<Arith, LN, LE, MODE>), dim3((unsigned)npolys), dim3(Geo<LN, LE>::T), 0, s, out, in, tb, stagger)
-#define NTT_CASE(LN, LE)                          \
-    if (mode == 1) { NTT_LAUNCH(LN, LE, 1); }     \
-    else { NTT_LAUNCH(LN, LE, 0); }
+#define NTT_CASE(LN, LE)                                                                                                              \
+    if (inverse) hipLaunchKernelGGL((ntt_inv_kernel<Arith, LN, LE>), dim3((unsigned)npolys), dim3(Geo<LN, LE>::T), 0, s, out, in, tb); \
+    else hipLaunchKernelGGL((ntt_fwd_kernel<Arith, LN, LE>), dim3((unsigned)npolys), dim3(Geo<LN, LE>::T), 0, s, out, in, tb)
     DPFHE_GEO_SWITCH(log2n, NTT_CASE)
 #undef NTT_CASE
-#undef NTT_LAUNCH
     return 0;
 }
 
