@@ -195,12 +195,13 @@ def main():
         for name, fn in (("fwd", ev.ntt_forward), ("inv", ev.ntt_inverse)):
             for _ in range(5):
                 fn(x, out=y)
-            ts = []
-            for _ in range(30):
-                s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                s.record(); fn(x, out=y); e.record()
-                e.synchronize()
-                ts.append(s.elapsed_time(e) * 1e-3)
+            # 30 launches enqueued back to back, each bracketed by its own pair of HIP events; one host sync at the end
+            # (a host sync after every launch lets the clocks ramp down and reads 10-15 % slower)
+            evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(30)]
+            for s_, e_ in evs:
+                s_.record(); fn(x, out=y); e_.record()
+            torch.cuda.synchronize()
+            ts = [s_.elapsed_time(e_) * 1e-3 for s_, e_ in evs]
             ts.sort()
             med = ts[len(ts) // 2]
             nbytes = 2 * N * 8 * nb * L
