@@ -23,6 +23,7 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: required by RCCL across processes on this driver
 
 HBM_PEAK = 8.0e12  # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
 
