@@ -202,5 +202,274 @@ void Evaluator::reduce_sum(const PolyBuffer& in, PolyBuffer& out, Stream* s) con
     out.set_ntt(in.is_ntt());
 }
 
+// =====================================================================================================================
+// N2: keys, encryption, decryption (host side)
+// =====================================================================================================================
+namespace {
+typedef unsigned __int128 u128;
+
+struct SplitMix {  // deterministic host RNG (same generator as the synthetic-data spec)
+    uint64_t s;
+    explicit SplitMix(uint64_t seed) : s(seed) {}
+    uint64_t next() {
+        s += 0x9E3779B97F4A7C15ull;
+        uint64_t z = s;
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        return z ^ (z >> 31);
+    }
+    uint64_t below(uint64_t bound) { return (uint64_t)(((u128)next() * bound) >> 64); }  // unbiased enough for tests/examples
+};
+
+uint64_t lift_signed(int64_t v, uint64_t q) { return v >= 0 ? (uint64_t)v % q : q - ((uint64_t)(-v) % q == 0 ? q : (uint64_t)(-v) % q); }
+uint64_t powmod(uint64_t b, uint64_t e, uint64_t q) {
+    uint64_t r = 1;
+    for (b %= q; e; e >>= 1) { if (e & 1) r = (uint64_t)((u128)r * b % q); b = (uint64_t)((u128)b * b % q); }
+    return r;
+}
+
+// little-endian multiword unsigned integers, just enough for CRT composition of <= 1024 limbs
+typedef std::vector<uint64_t> Big;
+void big_mul_small(Big& a, uint64_t m) {
+    u128 carry = 0;
+    for (auto& w : a) { u128 t = (u128)w * m + carry; w = (uint64_t)t; carry = t >> 64; }
+    if (carry) a.push_back((uint64_t)carry);
+}
+void big_add(Big& a, const Big& b) {
+    if (a.size() < b.size()) a.resize(b.size(), 0);
+    u128 carry = 0;
+    for (size_t i = 0; i < a.size(); ++i) { u128 t = (u128)a[i] + (i < b.size() ? b[i] : 0) + carry; a[i] = (uint64_t)t; carry = t >> 64; }
+    if (carry) a.push_back((uint64_t)carry);
+}
+int big_cmp(const Big& a, const Big& b) {
+    size_t n = a.size() > b.size() ? a.size() : b.size();
+    for (size_t i = n; i-- > 0;) {
+        uint64_t x = i < a.size() ? a[i] : 0, y = i < b.size() ? b[i] : 0;
+        if (x != y) return x < y ? -1 : 1;
+    }
+    return 0;
+}
+Big big_sub(const Big& a, const Big& b) {  // a >= b
+    Big r(a.size(), 0);
+    uint64_t borrow = 0;
+    for (size_t i = 0; i < a.size(); ++i) {
+        u128 t = (u128)a[i] - (i < b.size() ? b[i] : 0) - borrow;
+        r[i] = (uint64_t)t; borrow = (uint64_t)(t >> 64) & 1;
+    }
+    return r;
+}
+void big_shr_round(Big& a, unsigned sh) {  // a = floor((a + 2^(sh-1)) / 2^sh)
+    if (sh) {
+        Big half((sh - 1) / 64 + 1, 0);
+        half[(sh - 1) / 64] = 1ull << ((sh - 1) % 64);
+        big_add(a, half);
+    }
+    const size_t ws = sh / 64, bs = sh % 64;
+    Big r(a.size() > ws ? a.size() - ws : 1, 0);
+    for (size_t i = 0; i + ws < a.size(); ++i) {
+        r[i] = a[i + ws] >> bs;
+        if (bs && i + ws + 1 < a.size()) r[i] |= a[i + ws + 1] << (64 - bs);
+    }
+    a = r;
+}
+}  // namespace
+
+// ---- SecretKey ----------------------------------------------------------------------------------------------------------
+class SecretKey::Impl {
+public:
+    const Context* ctx = nullptr;
+    std::vector<int8_t> s;
+    std::unique_ptr<PolyBuffer> s_hat, s2_hat;
+};
+
+SecretKey::SecretKey(const Context& ctx, uint64_t seed) : impl_(new Impl) {
+    impl_->ctx = &ctx;
+    const FheParams& p = ctx.params();
+    const size_t n = p.n(), L = p.n_limbs();
+    SplitMix rng(seed);
+    impl_->s.resize(n);
+    for (auto& v : impl_->s) v = (int8_t)((int)rng.below(3) - 1);
+    std::vector<uint64_t> host(L * n);
+    for (size_t l = 0; l < L; ++l)
+        for (size_t k = 0; k < n; ++k) host[l * n + k] = lift_signed(impl_->s[k], p.moduli[l]);
+    impl_->s_hat.reset(new PolyBuffer(ctx, 1, 1, false));
+    impl_->s2_hat.reset(new PolyBuffer(ctx, 1, 1, true));
+    impl_->s_hat->copy_from_host(host.data());
+    Evaluator ev(ctx);
+    ev.transform_to_ntt_inplace(*impl_->s_hat);
+    ev.dyadic_multiply(*impl_->s_hat, *impl_->s_hat, *impl_->s2_hat);
+    ctx.synchronize();
+}
+SecretKey::~SecretKey() = default;
+const std::vector<int8_t>& SecretKey::coefficients() const { return impl_->s; }
+const uint64_t* SecretKey::ntt() const { return impl_->s_hat->data(); }
+const uint64_t* SecretKey::ntt_squared() const { return impl_->s2_hat->data(); }
+
+// ---- KeyGenerator ----------------------------------------------------------------------------------------------------------
+class KeyGenerator::Impl {
+public:
+    const Context* ctx = nullptr;
+    std::unique_ptr<SecretKey> sk;
+    SplitMix rng{0};
+};
+
+KeyGenerator::KeyGenerator(const Context& ctx, uint64_t seed) : impl_(new Impl) {
+    impl_->ctx = &ctx;
+    impl_->sk.reset(new SecretKey(ctx, seed));
+    impl_->rng = SplitMix(seed ^ 0xD1B54A32D192ED03ull);
+}
+KeyGenerator::~KeyGenerator() = default;
+const SecretKey& KeyGenerator::secret_key() const { return *impl_->sk; }
+
+void KeyGenerator::create_relin_keys(RelinKeys& out) {
+    const Context& ctx = *impl_->ctx;
+    const FheParams& p = ctx.params();
+    const size_t n = p.n(), L = p.n_limbs(), poly = L * n;
+    dpfhe_ctx* h = static_cast<dpfhe_ctx*>(ctx.handle());
+    PolyBuffer a(ctx, 1, 1, true), e(ctx, 1, 1, false), t(ctx, 1, 1, true);
+    std::vector<uint64_t> ha(poly), he(poly);
+    for (size_t j = 0; j < L; ++j) {
+        for (size_t l = 0; l < L; ++l)
+            for (size_t k = 0; k < n; ++k) ha[l * n + k] = impl_->rng.below(p.moduli[l]);      // uniform: any domain
+        for (size_t k = 0; k < n; ++k) {
+            const int64_t ev = (int64_t)impl_->rng.below(17) - 8;
+            for (size_t l = 0; l < L; ++l) he[l * n + k] = lift_signed(ev, p.moduli[l]);
+        }
+        a.copy_from_host(ha.data());
+        e.copy_from_host(he.data());
+        e.set_ntt(false);
+        uint64_t* b = out.data() + (j * 2 + 0) * poly;   // evk_j[0]
+        uint64_t* a_out = out.data() + (j * 2 + 1) * poly;  // evk_j[1] = a_j
+        check(dpfhe_ntt_fwd(h, e.data(), 1, nullptr), "dpfhe_ntt_fwd");                                   // NTT(e_j)
+        check(dpfhe_dyadic_mul(h, t.data(), a.data(), impl_->sk->ntt(), 1, nullptr), "dpfhe_dyadic_mul");  // a_j s
+        check(dpfhe_sub(h, b, e.data(), t.data(), 1, nullptr), "dpfhe_sub");                               // e_j - a_j s
+        // + g_j s^2 : s^2 in limb j only (g_j = 1 mod q_j, 0 mod the other primes)
+        check(dpfhe_add(h, t.data(), b, impl_->sk->ntt_squared(), 1, nullptr), "dpfhe_add");
+        hip_check(hipMemcpyAsync(b + j * n, t.data() + j * n, n * sizeof(uint64_t), hipMemcpyDeviceToDevice, nullptr), "hipMemcpyAsync");
+        hip_check(hipMemcpyAsync(a_out, a.data(), poly * sizeof(uint64_t), hipMemcpyDeviceToDevice, nullptr), "hipMemcpyAsync");
+        ctx.synchronize();
+    }
+    out.set_ntt(true);
+}
+
+// ---- Encryptor --------------------------------------------------------------------------------------------------------------
+class Encryptor::Impl {
+public:
+    const Context* ctx = nullptr;
+    const SecretKey* sk = nullptr;
+    SplitMix rng{0};
+};
+Encryptor::Encryptor(const Context& ctx, const SecretKey& sk, uint64_t seed) : impl_(new Impl) {
+    impl_->ctx = &ctx; impl_->sk = &sk; impl_->rng = SplitMix(seed);
+}
+Encryptor::~Encryptor() = default;
+
+void Encryptor::encrypt(const int64_t* messages, unsigned log2_scale, Ciphertext& out) {
+    if (!messages) throw Exception(ErrorCode::INVALID_ARGUMENT, "encrypt: null messages");
+    if (out.size() != 2) throw Exception(ErrorCode::INVALID_ARGUMENT, "encrypt: output must be a 2-component ciphertext");
+    if (log2_scale > 200) throw Exception(ErrorCode::INVALID_ARGUMENT, "encrypt: log2_scale too large");
+    const Context& ctx = *impl_->ctx;
+    const FheParams& p = ctx.params();
+    const size_t n = p.n(), L = p.n_limbs(), poly = L * n;
+    dpfhe_ctx* h = static_cast<dpfhe_ctx*>(ctx.handle());
+    PolyBuffer a(ctx, 1, 1, false), t(ctx, 1, 1, false);
+    std::vector<uint64_t> ha(poly), hm(poly);
+    for (size_t item = 0; item < out.batch(); ++item) {
+        for (size_t l = 0; l < L; ++l) {
+            const uint64_t q = p.moduli[l];
+            const uint64_t scale = powmod(2, log2_scale, q);
+            for (size_t k = 0; k < n; ++k) ha[l * n + k] = impl_->rng.below(q);
+            for (size_t k = 0; k < n; ++k) hm[l * n + k] = (uint64_t)((u128)lift_signed(messages[item * n + k], q) * scale % q);
+        }
+        for (size_t k = 0; k < n; ++k) {   // + e, the same small integer in every limb
+            const int64_t ev = (int64_t)impl_->rng.below(17) - 8;
+            for (size_t l = 0; l < L; ++l) { const uint64_t q = p.moduli[l]; uint64_t v = hm[l * n + k] + lift_signed(ev, q); hm[l * n + k] = v >= q ? v - q : v; }
+        }
+        uint64_t* c0 = out.data() + (item * 2 + 0) * poly;
+        uint64_t* c1 = out.data() + (item * 2 + 1) * poly;
+        a.copy_from_host(ha.data());                       // c1 = a (coefficient domain)
+        hip_check(hipMemcpy(c1, a.data(), poly * sizeof(uint64_t), hipMemcpyDeviceToDevice), "hipMemcpy D2D");
+        t.copy_from_host(hm.data());                       // e + 2^scale m
+        check(dpfhe_ntt_fwd(h, a.data(), 1, nullptr), "dpfhe_ntt_fwd");
+        check(dpfhe_dyadic_mul(h, a.data(), a.data(), impl_->sk->ntt(), 1, nullptr), "dpfhe_dyadic_mul");
+        check(dpfhe_ntt_inv(h, a.data(), 1, nullptr), "dpfhe_ntt_inv");          // a s
+        check(dpfhe_sub(h, c0, t.data(), a.data(), 1, nullptr), "dpfhe_sub");     // c0 = e + 2^scale m - a s
+        ctx.synchronize();
+    }
+    out.set_ntt(false);
+}
+
+// ---- Decryptor --------------------------------------------------------------------------------------------------------------
+class Decryptor::Impl {
+public:
+    const Context* ctx = nullptr;
+    const SecretKey* sk = nullptr;
+    std::vector<uint64_t> garner_inv;  // [i][j<i]: (q_j)^-1 mod q_i  (mixed-radix conversion)
+    Big Q, halfQ;
+};
+Decryptor::Decryptor(const Context& ctx, const SecretKey& sk) : impl_(new Impl) {
+    impl_->ctx = &ctx; impl_->sk = &sk;
+    const FheParams& p = ctx.params();
+    const size_t L = p.n_limbs();
+    impl_->garner_inv.assign(L * L, 0);
+    for (size_t i = 0; i < L; ++i)
+        for (size_t j = 0; j < i; ++j) impl_->garner_inv[i * L + j] = powmod(p.moduli[j] % p.moduli[i], p.moduli[i] - 2, p.moduli[i]);
+    impl_->Q = Big{1};
+    for (size_t i = 0; i < L; ++i) big_mul_small(impl_->Q, p.moduli[i]);
+    impl_->halfQ = impl_->Q;
+    for (size_t i = 0; i < impl_->halfQ.size(); ++i) {  // >> 1
+        impl_->halfQ[i] >>= 1;
+        if (i + 1 < impl_->halfQ.size()) impl_->halfQ[i] |= impl_->Q[i + 1] << 63;
+    }
+}
+Decryptor::~Decryptor() = default;
+
+void Decryptor::decrypt(const Ciphertext& ct, unsigned log2_scale, int64_t* out) {
+    if (!out) throw Exception(ErrorCode::INVALID_ARGUMENT, "decrypt: null output");
+    if (ct.is_ntt()) throw Exception(ErrorCode::INVALID_STATE, "decrypt: ciphertext must be in the coefficient domain");
+    const Context& ctx = *impl_->ctx;
+    const FheParams& p = ctx.params();
+    const size_t n = p.n(), L = p.n_limbs(), poly = L * n;
+    dpfhe_ctx* h = static_cast<dpfhe_ctx*>(ctx.handle());
+    PolyBuffer acc(ctx, 1, 1, true), t(ctx, 1, 1, true);
+    std::vector<uint64_t> ph(poly), digit(L);
+    for (size_t item = 0; item < ct.batch(); ++item) {
+        const uint64_t* c = ct.data() + item * ct.size() * poly;
+        // phase = c0 + c1 s (+ c2 s^2), evaluated in the NTT domain
+        check(dpfhe_ntt_fwd_oop(h, t.data(), c + poly, 1, nullptr), "dpfhe_ntt_fwd_oop");
+        check(dpfhe_dyadic_mul(h, acc.data(), t.data(), impl_->sk->ntt(), 1, nullptr), "dpfhe_dyadic_mul");
+        if (ct.size() == 3) {
+            check(dpfhe_ntt_fwd_oop(h, t.data(), c + 2 * poly, 1, nullptr), "dpfhe_ntt_fwd_oop");
+            check(dpfhe_dyadic_mul_add(h, acc.data(), t.data(), impl_->sk->ntt_squared(), 1, nullptr), "dpfhe_dyadic_mul_add");
+        }
+        check(dpfhe_ntt_inv(h, acc.data(), 1, nullptr), "dpfhe_ntt_inv");
+        check(dpfhe_add(h, acc.data(), acc.data(), c, 1, nullptr), "dpfhe_add");
+        ctx.synchronize();
+        hip_check(hipMemcpy(ph.data(), acc.data(), poly * sizeof(uint64_t), hipMemcpyDeviceToHost), "hipMemcpy D2H");
+        for (size_t k = 0; k < n; ++k) {
+            // Garner mixed radix: x = v0 + v1 q0 + v2 q0 q1 + ...
+            for (size_t i = 0; i < L; ++i) {
+                const uint64_t qi = p.moduli[i];
+                uint64_t v = ph[i * n + k] % qi;
+                for (size_t j = 0; j < i; ++j) {
+                    const uint64_t dj = digit[j] % qi;
+                    v = v >= dj ? v - dj : v + qi - dj;
+                    v = (uint64_t)((u128)v * impl_->garner_inv[i * L + j] % qi);
+                }
+                digit[i] = v;
+            }
+            Big x{0};
+            for (size_t i = L; i-- > 0;) { big_mul_small(x, p.moduli[i]); big_add(x, Big{digit[i]}); }
+            const bool neg = big_cmp(x, impl_->halfQ) > 0;
+            if (neg) x = big_sub(impl_->Q, x);
+            big_shr_round(x, log2_scale);
+            for (size_t i = 1; i < x.size(); ++i)
+                if (x[i]) throw Exception(ErrorCode::RUNTIME_ERROR, "decrypt: value does not fit 62 bits (scale or noise overflow)");
+            if (x[0] >> 62) throw Exception(ErrorCode::RUNTIME_ERROR, "decrypt: value does not fit 62 bits (scale or noise overflow)");
+            out[item * n + k] = neg ? -(int64_t)x[0] : (int64_t)x[0];
+        }
+    }
+}
+
 }  // namespace fhe
 }  // namespace deeppowers

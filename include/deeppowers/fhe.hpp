@@ -141,5 +141,69 @@ private:
     std::unique_ptr<Impl> impl_;
 };
 
+// ---- N2: secret key, encryption, decryption, key generation -------------------------------
+// Host-side (client-side in the reference's story, /root/reference/README.md:57-60): sampling and CRT decoding run on
+// the CPU, polynomial arithmetic goes through the same C ABI as everything else.  Symmetric RLWE:
+//   ct = (c0, c1) = (-(a s) + e + 2^log2_scale * m,  a),   s ternary, e uniform in [-8, 8].
+// Messages are integer polynomials (N signed coefficients per item); decryption returns round(phase / 2^log2_scale),
+// where phase = c0 + c1 s (+ c2 s^2) is CRT-composed over all limbs and centred mod Q = prod q_i.
+class SecretKey {
+public:
+    SecretKey(const Context& ctx, uint64_t seed);
+    ~SecretKey();
+    SecretKey(const SecretKey&) = delete;
+    SecretKey& operator=(const SecretKey&) = delete;
+    const std::vector<int8_t>& coefficients() const;  // ternary s
+    const uint64_t* ntt() const;                        // device, [L][N]: NTT(s)
+    const uint64_t* ntt_squared() const;                // device, [L][N]: NTT(s)^2 = NTT(s^2)
+
+private:
+    class Impl;
+    std::unique_ptr<Impl> impl_;
+};
+
+class KeyGenerator {
+public:
+    explicit KeyGenerator(const Context& ctx, uint64_t seed = 1);
+    ~KeyGenerator();
+    KeyGenerator(const KeyGenerator&) = delete;
+    KeyGenerator& operator=(const KeyGenerator&) = delete;
+    const SecretKey& secret_key() const;
+    void create_relin_keys(RelinKeys& out);  // evk_j = (-(a_j s) + e_j + g_j s^2, a_j), NTT domain
+
+private:
+    class Impl;
+    std::unique_ptr<Impl> impl_;
+};
+
+class Encryptor {
+public:
+    Encryptor(const Context& ctx, const SecretKey& sk, uint64_t seed = 2);
+    ~Encryptor();
+    Encryptor(const Encryptor&) = delete;
+    Encryptor& operator=(const Encryptor&) = delete;
+    // messages: out.batch() * N signed coefficients; out: 2-component ciphertext(s), coefficient domain
+    void encrypt(const int64_t* messages, unsigned log2_scale, Ciphertext& out);
+
+private:
+    class Impl;
+    std::unique_ptr<Impl> impl_;
+};
+
+class Decryptor {
+public:
+    Decryptor(const Context& ctx, const SecretKey& sk);
+    ~Decryptor();
+    Decryptor(const Decryptor&) = delete;
+    Decryptor& operator=(const Decryptor&) = delete;
+    // ct: 2 or 3 components, coefficient domain.  messages_out: ct.batch() * N values round(phase / 2^log2_scale);
+    // throws RUNTIME_ERROR if a value does not fit 62 bits (wrong scale or noise overflow).
+    void decrypt(const Ciphertext& ct, unsigned log2_scale, int64_t* messages_out);
+
+private:
+    class Impl;
+    std::unique_ptr<Impl> impl_;
+};
+
 }  // namespace fhe
 }  // namespace deeppowers

@@ -95,8 +95,45 @@ static void run(const FheParams& p, size_t batch) {
     orc_ctx_destroy(orc);
 }
 
+// N2 + N1 end to end: encrypt -> multiply -> (relinearize) -> decrypt == negacyclic product of the messages
+static void end_to_end(const FheParams& p, size_t batch) {
+    const size_t n = p.n();
+    Context ctx(p, 0);
+    Evaluator ev(ctx);
+    KeyGenerator kg(ctx, /*seed=*/11);
+    Encryptor enc(ctx, kg.secret_key(), /*seed=*/12);
+    Decryptor dec(ctx, kg.secret_key());
+    RelinKeys rk(ctx);
+    kg.create_relin_keys(rk);
+    std::vector<int64_t> m1(batch * n), m2(batch * n), out(batch * n), want(batch * n, 0);
+    uint64_t s = 99;
+    auto rnd = [&]() { s = s * 6364136223846793005ull + 1442695040888963407ull; return (int64_t)((s >> 33) % 201) - 100; };
+    for (auto& v : m1) v = rnd();
+    for (auto& v : m2) v = rnd();
+    for (size_t b = 0; b < batch; ++b)
+        for (size_t i = 0; i < n; ++i)
+            for (size_t j = 0; j < n; ++j) {
+                const int64_t pr = m1[b * n + i] * m2[b * n + j];
+                if (i + j < n) want[b * n + i + j] += pr; else want[b * n + i + j - n] -= pr;
+            }
+    const unsigned scale = 45;
+    Ciphertext c1(ctx, 2, batch), c2(ctx, 2, batch), c3(ctx, 3, batch), cr(ctx, 2, batch);
+    enc.encrypt(m1.data(), scale, c1);
+    enc.encrypt(m2.data(), scale, c2);
+    dec.decrypt(c1, scale, out.data());
+    CHECK(out == m1);                                   // fresh ciphertext decrypts to its message
+    ev.multiply(c1, c2, c3);
+    dec.decrypt(c3, 2 * scale, out.data());
+    CHECK(out == want);                                 // 3-component product decrypts to m1 * m2 in Z[X]/(X^N+1)
+    ev.relinearize(c3, rk, cr);
+    dec.decrypt(cr, 2 * scale, out.data());
+    CHECK(out == want);                                 // and so does its relinearisation
+    try { dec.decrypt(c3, 0, out.data()); CHECK(!"expected RUNTIME_ERROR"); } catch (const Exception& e) { CHECK(e.code() == ErrorCode::RUNTIME_ERROR); }
+}
+
 int main() {
     try {
+        end_to_end(FheParams::n4096_l4(), 2);
         run(FheParams::config1(), 2);
         run(FheParams::n4096_l4(), 3);
         run(FheParams::n8192_l6(), 2);

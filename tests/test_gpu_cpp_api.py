@@ -23,6 +23,25 @@ def test_cpp_facade_compiles_and_links():
     assert os.path.exists(build_cpp_test())
 
 
+def build_example():
+    exe = os.path.join(ROOT, "examples", "encrypted_multiply")
+    lib = os.path.join(ROOT, "deeppowers_amd")
+    subprocess.check_call([
+        "g++", "-O2", "-std=c++17", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "encrypted_multiply.cpp"),
+        "-o", exe, "-L" + lib, "-ldpfhe_api", "-ldpfhe_hip", "-L/opt/rocm/lib", "-lamdhip64", f"-Wl,-rpath,{lib}", "-Wl,-rpath,/opt/rocm/lib"])
+    return exe
+
+
+def test_example_compiles():
+    assert os.path.exists(build_example())
+
+
+@pytest.mark.gpu
+def test_example_encrypt_multiply_relinearize_decrypt():
+    out = subprocess.run([build_example()], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "OK" in out.stdout, out.stdout + out.stderr
+
+
 @pytest.mark.gpu
 def test_cpp_facade_parity_on_gpu():
     exe = build_cpp_test()
