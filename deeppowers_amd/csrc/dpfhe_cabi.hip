@@ -227,10 +227,42 @@ extern "C" int dpfhe_relinearize(dpfhe_ctx* c, uint64_t* d_out2, const uint64_t*
     const size_t blocks = batch * c->n_limbs;
     if (blocks > kMaxGrid) return fail(DPFHE_INVALID_ARGUMENT, "dpfhe_relinearize", "batch too large for one launch");
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const int rc = c->fold ? launch_relin<FoldArith>((int)c->log2n, d_out2, d_in3, d_evk, blocks, c->foldt, s)
-                           : launch_relin<ShoupArith>((int)c->log2n, d_out2, d_in3, d_evk, blocks, c->shoup, s);
+    const int rc = c->fold ? launch_relin<FoldArith>((int)c->log2n, 0, d_out2, d_in3, d_evk, blocks, c->foldt, s)
+                           : launch_relin<ShoupArith>((int)c->log2n, 0, d_out2, d_in3, d_evk, blocks, c->shoup, s);
     if (rc) return fail(DPFHE_INVALID_STATE, "dpfhe_relinearize", "no kernel geometry for this log2_n");
     return check_launch("relin kernel launch");
+}
+
+extern "C" int dpfhe_switch_key(dpfhe_ctx* c, uint64_t* d_out2, const uint64_t* d_in2, const uint64_t* d_key, size_t batch, void* stream) {
+    if (!c) return fail(DPFHE_INVALID_ARGUMENT, "dpfhe_switch_key", "null context");
+    if (batch == 0) return DPFHE_SUCCESS;
+    if (!d_out2 || !d_in2 || !d_key || misaligned(d_out2) || misaligned(d_in2) || misaligned(d_key) || d_out2 == d_in2)
+        return fail(DPFHE_INVALID_ARGUMENT, "dpfhe_switch_key", "null, misaligned or aliased buffer");
+    const size_t blocks = batch * c->n_limbs;
+    if (blocks > kMaxGrid) return fail(DPFHE_INVALID_ARGUMENT, "dpfhe_switch_key", "batch too large for one launch");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int rc = c->fold ? launch_relin<FoldArith>((int)c->log2n, 1, d_out2, d_in2, d_key, blocks, c->foldt, s)
+                           : launch_relin<ShoupArith>((int)c->log2n, 1, d_out2, d_in2, d_key, blocks, c->shoup, s);
+    if (rc) return fail(DPFHE_INVALID_STATE, "dpfhe_switch_key", "no kernel geometry for this log2_n");
+    return check_launch("switch_key kernel launch");
+}
+
+extern "C" int dpfhe_apply_galois(dpfhe_ctx* c, uint64_t* d_out, const uint64_t* d_in, size_t n_rns_polys, uint32_t galois_elt, void* stream) {
+    if (!c) return fail(DPFHE_INVALID_ARGUMENT, "dpfhe_apply_galois", "null context");
+    const unsigned two_n = 2u << c->log2n;
+    if (!(galois_elt & 1u) || galois_elt >= two_n) return fail(DPFHE_INVALID_ARGUMENT, "dpfhe_apply_galois", "galois_elt must be odd and < 2N");
+    if (n_rns_polys == 0) return DPFHE_SUCCESS;
+    if (!d_out || !d_in || d_out == d_in || misaligned(d_out) || misaligned(d_in))
+        return fail(DPFHE_INVALID_ARGUMENT, "dpfhe_apply_galois", "null, misaligned or aliased buffer");
+    const size_t npolys = n_rns_polys * c->n_limbs;
+    if (npolys > kMaxGrid) return fail(DPFHE_INVALID_ARGUMENT, "dpfhe_apply_galois", "batch too large for one launch");
+    unsigned inv = 1;  // g^-1 mod 2N by Newton iteration (g odd): x <- x (2 - g x)
+    for (int i = 0; i < 5; ++i) inv *= 2u - galois_elt * inv;
+    inv &= two_n - 1u;
+    const LimbConst* lc = c->fold ? c->foldt.lc : c->shoup.lc;
+    hipLaunchKernelGGL(galois_kernel, dim3((unsigned)npolys), dim3(256), 0, static_cast<hipStream_t>(stream), d_out, d_in, lc, (int)c->n_limbs,
+                       1 << c->log2n, inv);
+    return check_launch("galois kernel launch");
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -113,6 +113,9 @@ Ciphertext::Ciphertext(const Context& ctx, size_t size, size_t batch, bool is_nt
 }
 
 RelinKeys::RelinKeys(const Context& ctx) : PolyBuffer(ctx, ctx.params().n_limbs(), 2, /*is_ntt=*/true) {}
+GaloisKeys::GaloisKeys(const Context& ctx, uint32_t galois_elt) : PolyBuffer(ctx, ctx.params().n_limbs(), 2, /*is_ntt=*/true), galois_elt_(galois_elt) {
+    if (!(galois_elt & 1u) || galois_elt >= 2 * ctx.params().n()) throw Exception(ErrorCode::INVALID_ARGUMENT, "GaloisKeys: galois_elt must be odd and < 2N");
+}
 
 // ---- Evaluator --------------------------------------------------------------------------------------------
 class Evaluator::Impl {
@@ -179,6 +182,16 @@ void Evaluator::relinearize(const Ciphertext& in3, const RelinKeys& keys, Cipher
     if (in3.size() != 3 || out2.size() != 2 || out2.batch() != in3.batch())
         throw Exception(ErrorCode::INVALID_ARGUMENT, "relinearize: 3-component input, 2-component output of the same batch");
     check(dpfhe_relinearize(impl_->h(), out2.data(), in3.data(), keys.data(), in3.batch(), s), "dpfhe_relinearize");
+    out2.set_ntt(false);
+}
+void Evaluator::apply_galois(const Ciphertext& in2, const GaloisKeys& keys, Ciphertext& out2, Stream* s) const {
+    if (in2.is_ntt()) throw Exception(ErrorCode::INVALID_STATE, "apply_galois: input must be in the coefficient domain");
+    if (in2.size() != 2 || out2.size() != 2 || out2.batch() != in2.batch())
+        throw Exception(ErrorCode::INVALID_ARGUMENT, "apply_galois: 2-component input and output of the same batch");
+    Ciphertext rotated(*impl_->ctx, 2, in2.batch());
+    check(dpfhe_apply_galois(impl_->h(), rotated.data(), in2.data(), in2.batch() * 2, keys.galois_elt(), s), "dpfhe_apply_galois");
+    check(dpfhe_switch_key(impl_->h(), out2.data(), rotated.data(), keys.data(), in2.batch(), s), "dpfhe_switch_key");
+    hip_check(hipStreamSynchronize(static_cast<hipStream_t>(s)), "hipStreamSynchronize");  // `rotated` is freed on return
     out2.set_ntt(false);
 }
 void Evaluator::multiply_plain(const Ciphertext& a, const Plaintext& p, Ciphertext& out, Stream* s) const {
@@ -321,8 +334,40 @@ KeyGenerator::KeyGenerator(const Context& ctx, uint64_t seed) : impl_(new Impl) 
 KeyGenerator::~KeyGenerator() = default;
 const SecretKey& KeyGenerator::secret_key() const { return *impl_->sk; }
 
-void KeyGenerator::create_relin_keys(RelinKeys& out) {
+namespace {
+// shared by relinearisation and Galois keys: key_j = (-(a_j s) + e_j + g_j * target, a_j), everything in the NTT domain
+template <class Rng>
+void make_switch_key(const Context& ctx, const SecretKey& sk, Rng& rng, const uint64_t* d_target_ntt, PolyBuffer& out);
+}  // namespace
+
+void KeyGenerator::create_galois_keys(GaloisKeys& out) {
     const Context& ctx = *impl_->ctx;
+    const FheParams& p = ctx.params();
+    const size_t n = p.n(), L = p.n_limbs();
+    const std::vector<int8_t>& s = impl_->sk->coefficients();
+    std::vector<int64_t> sg(n, 0);
+    for (size_t i = 0; i < n; ++i) {   // sigma_g(s): coefficient i -> index i g mod 2N, negated past N
+        const size_t idx = (i * (size_t)out.galois_elt()) & (2 * n - 1);
+        if (idx < n) sg[idx] = s[i]; else sg[idx - n] = -s[i];
+    }
+    std::vector<uint64_t> host(L * n);
+    for (size_t l = 0; l < L; ++l)
+        for (size_t k = 0; k < n; ++k) host[l * n + k] = lift_signed(sg[k], p.moduli[l]);
+    PolyBuffer target(ctx, 1, 1, false);
+    target.copy_from_host(host.data());
+    Evaluator ev(ctx);
+    ev.transform_to_ntt_inplace(target);
+    ctx.synchronize();
+    make_switch_key(ctx, *impl_->sk, impl_->rng, target.data(), out);
+}
+
+void KeyGenerator::create_relin_keys(RelinKeys& out) { make_switch_key(*impl_->ctx, *impl_->sk, impl_->rng, impl_->sk->ntt_squared(), out); }
+
+namespace {
+template <class Rng>
+void make_switch_key(const Context& ctx, const SecretKey& sk_ref, Rng& rng_ref, const uint64_t* d_target_ntt, PolyBuffer& out) {
+    struct { const SecretKey* sk; Rng* rng; } impl_s{&sk_ref, &rng_ref};
+    auto* impl_ = &impl_s;
     const FheParams& p = ctx.params();
     const size_t n = p.n(), L = p.n_limbs(), poly = L * n;
     dpfhe_ctx* h = static_cast<dpfhe_ctx*>(ctx.handle());
@@ -330,9 +375,9 @@ void KeyGenerator::create_relin_keys(RelinKeys& out) {
     std::vector<uint64_t> ha(poly), he(poly);
     for (size_t j = 0; j < L; ++j) {
         for (size_t l = 0; l < L; ++l)
-            for (size_t k = 0; k < n; ++k) ha[l * n + k] = impl_->rng.below(p.moduli[l]);      // uniform: any domain
+            for (size_t k = 0; k < n; ++k) ha[l * n + k] = impl_->rng->below(p.moduli[l]);      // uniform: any domain
         for (size_t k = 0; k < n; ++k) {
-            const int64_t ev = (int64_t)impl_->rng.below(17) - 8;
+            const int64_t ev = (int64_t)impl_->rng->below(17) - 8;
             for (size_t l = 0; l < L; ++l) he[l * n + k] = lift_signed(ev, p.moduli[l]);
         }
         a.copy_from_host(ha.data());
@@ -343,14 +388,15 @@ void KeyGenerator::create_relin_keys(RelinKeys& out) {
         check(dpfhe_ntt_fwd(h, e.data(), 1, nullptr), "dpfhe_ntt_fwd");                                   // NTT(e_j)
         check(dpfhe_dyadic_mul(h, t.data(), a.data(), impl_->sk->ntt(), 1, nullptr), "dpfhe_dyadic_mul");  // a_j s
         check(dpfhe_sub(h, b, e.data(), t.data(), 1, nullptr), "dpfhe_sub");                               // e_j - a_j s
-        // + g_j s^2 : s^2 in limb j only (g_j = 1 mod q_j, 0 mod the other primes)
-        check(dpfhe_add(h, t.data(), b, impl_->sk->ntt_squared(), 1, nullptr), "dpfhe_add");
+        // + g_j * target : the target polynomial in limb j only (g_j = 1 mod q_j, 0 mod the other primes)
+        check(dpfhe_add(h, t.data(), b, d_target_ntt, 1, nullptr), "dpfhe_add");
         hip_check(hipMemcpyAsync(b + j * n, t.data() + j * n, n * sizeof(uint64_t), hipMemcpyDeviceToDevice, nullptr), "hipMemcpyAsync");
         hip_check(hipMemcpyAsync(a_out, a.data(), poly * sizeof(uint64_t), hipMemcpyDeviceToDevice, nullptr), "hipMemcpyAsync");
         ctx.synchronize();
     }
     out.set_ntt(true);
 }
+}  // namespace
 
 // ---- Encryptor --------------------------------------------------------------------------------------------------------------
 class Encryptor::Impl {

@@ -189,7 +189,10 @@ __device__ __forceinline__ u64 canon_any(u64 v, const LimbConst& lc) {  // any v
     else return ShoupArith::mul_var(v, 1, lc);
 }
 
-template <class Arith, int LOGN, int LOGE>
+// MODE 0: relinearisation - input has 3 components, digits come from c2, both c0 and c1 are added back.
+// MODE 1: key switch after a Galois automorphism (N3) - input has 2 components, digits come from c1, only c0 is added:
+//         (c0', c1') = (c0 + sum_j d_j b_j, sum_j d_j a_j).
+template <class Arith, int LOGN, int LOGE, int MODE>
 __global__ __launch_bounds__(1 << (LOGN - LOGE), (Arith::kFold ? 2 : 1)) void relin_kernel(u64* __restrict__ out2, const u64* __restrict__ in3,
                                                                        const u64* __restrict__ evk, DevTables<Arith> tb) {
     typedef NttBody<Arith, LOGN, LOGE> B;
@@ -201,7 +204,8 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE), (Arith::kFold ? 2 : 1)) void re
     const int limb = (int)(blockIdx.x % (unsigned)L);
     const LimbConst lc = tb.lc[limb];
     const InvLast<typename B::Tw> last = tb.last[limb];
-    const u64* c2 = in3 + ((bi * 3 + 2) * L) * N;           // digit j at + j*N
+    constexpr int kInComps = MODE == 0 ? 3 : 2;
+    const u64* c2 = in3 + ((bi * kInComps + (kInComps - 1)) * L) * N;   // digit j at + j*N
     u64 acc0[E], acc1[E];
 #pragma unroll
     for (int k = 0; k < E; ++k) acc0[k] = acc1[k] = 0;
@@ -251,13 +255,16 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE), (Arith::kFold ? 2 : 1)) void re
         u64 x[E];
 #pragma unroll
         for (int k = 0; k < E; ++k) x[k] = c == 0 ? acc0[k] : acc1[k];
+        const bool add_back = (MODE == 0) || (c == 0);
         u64 orig[E];
-        B::load_top(tid, orig, in3 + ((bi * 3 + c) * L + limb) * N);
+        if (add_back) B::load_top(tid, orig, in3 + ((bi * kInComps + c) * L + limb) * N);
         __syncthreads();
         InvChain<B, B::NPH - 1, kInvIn>::run(tid, x, lds, tb.inv + (size_t)limb * N, last, lc);
         B::inv_canon(x, lc);
+        if (add_back) {
 #pragma unroll
-        for (int k = 0; k < E; ++k) x[k] = add_mod(x[k], orig[k], lc.q);
+            for (int k = 0; k < E; ++k) x[k] = add_mod(x[k], orig[k], lc.q);
+        }
         B::store_top(tid, x, out2 + ((bi * 2 + c) * L + limb) * N);
     }
 }

@@ -239,4 +239,17 @@ __global__ __launch_bounds__(256) void matvec_scalar_kernel(u64* y, const u64* w
     }
 }
 
+// N3: Galois automorphism a(X) -> a(X^g), g odd, coefficient domain (a signed permutation; HBM-bound).
+// Gather form: out[k] = +in[j] if j = k g^-1 mod 2N < N, else -in[j - N]  (coalesced writes, scattered 8-byte reads).
+__global__ __launch_bounds__(256) void galois_kernel(u64* out, const u64* in, const LimbConst* lcs, int n_limbs, int n, unsigned g_inv) {
+    const size_t p = blockIdx.x;
+    const u64 q = lcs[p % (size_t)n_limbs].q;
+    const unsigned mask2n = 2u * (unsigned)n - 1u;
+    for (int k = threadIdx.x; k < n; k += 256) {
+        const unsigned j = ((unsigned)k * g_inv) & mask2n;
+        const u64 v = in[p * n + (j & ((unsigned)n - 1u))];
+        out[p * n + k] = (j < (unsigned)n) ? v : neg_mod(v, q);
+    }
+}
+
 }  // namespace dpfhe

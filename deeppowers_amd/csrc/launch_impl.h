@@ -48,9 +48,10 @@ int launch_ct_mul(int log2n, unsigned flags, u64* out3, const u64* a2, const u64
 }
 
 template <class Arith>
-int launch_relin(int log2n, u64* out2, const u64* in3, const u64* evk, size_t blocks, const DevTables<Arith>& tb, hipStream_t s) {
-#define RL_CASE(LN, LE) \
-    hipLaunchKernelGGL((relin_kernel<Arith, LN, 4>), dim3((unsigned)blocks), dim3(Geo<LN, 4>::T), 0, s, out2, in3, evk, tb)
+int launch_relin(int log2n, int mode, u64* out2, const u64* in3, const u64* evk, size_t blocks, const DevTables<Arith>& tb, hipStream_t s) {
+#define RL_CASE(LN, LE)                                                                                                                  \
+    if (mode == 0) hipLaunchKernelGGL((relin_kernel<Arith, LN, 4, 0>), dim3((unsigned)blocks), dim3(Geo<LN, 4>::T), 0, s, out2, in3, evk, tb); \
+    else hipLaunchKernelGGL((relin_kernel<Arith, LN, 4, 1>), dim3((unsigned)blocks), dim3(Geo<LN, 4>::T), 0, s, out2, in3, evk, tb)
     DPFHE_GEO_SWITCH(log2n, RL_CASE)
 #undef RL_CASE
     return 0;

@@ -256,6 +256,28 @@ class Evaluator:
         _cabi.check(self._lib.dpfhe_relinearize(self.ctx.handle, out.data_ptr(), ct3.data.data_ptr(), evk.data_ptr(), ct3.batch, _stream_ptr(stream)), "dpfhe_relinearize")
         return Ciphertext(out, False)
 
+    # ---- N3: Galois automorphism + key switch ----------------------------------------------------
+    def apply_galois_words(self, t: torch.Tensor, galois_elt: int, out: torch.Tensor | None = None, stream=None) -> torch.Tensor:
+        """a(X) -> a(X^galois_elt) on every RNS polynomial of t (coefficient domain, out of place)."""
+        out = torch.empty_like(t) if out is None else out
+        self._chk(t, out)
+        _cabi.check(self._lib.dpfhe_apply_galois(self.ctx.handle, out.data_ptr(), t.data_ptr(), self._npolys(t), int(galois_elt), _stream_ptr(stream)), "dpfhe_apply_galois")
+        return out
+
+    def apply_galois(self, ct: Ciphertext, galois_elt: int, key: torch.Tensor, stream=None) -> Ciphertext:
+        """ct (2 components, coefficient domain) encrypting m(X) under s  ->  ciphertext of m(X^g) under s.
+        key: [L][2][L][N] NTT-domain switching key from sigma_g(s) to s."""
+        if ct.size != 2 or ct.is_ntt:
+            raise _cabi.DpfheError(2002 if ct.is_ntt else 2000, "apply_galois expects a 2-component coefficient-domain ciphertext")
+        p = self.ctx.params
+        self._chk(key)
+        if tuple(key.shape) != (p.n_limbs, 2, p.n_limbs, p.n):
+            raise _cabi.DpfheError(2000, "key must be [L][2][L][N]")
+        rotated = self.apply_galois_words(ct.data, galois_elt, stream=stream)
+        out = torch.empty_like(rotated)
+        _cabi.check(self._lib.dpfhe_switch_key(self.ctx.handle, out.data_ptr(), rotated.data_ptr(), key.data_ptr(), ct.batch, _stream_ptr(stream)), "dpfhe_switch_key")
+        return Ciphertext(out, False)
+
     # ---- A7 -------------------------------------------------------------------------------------------
     def multiply_plain(self, a: Ciphertext, p: Plaintext, stream=None) -> Ciphertext:
         """ct (.) pt, both in the NTT domain: every component times the plaintext polynomial."""

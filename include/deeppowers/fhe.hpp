@@ -109,6 +109,16 @@ public:
     explicit RelinKeys(const Context& ctx);
 };
 
+// N3: switching key from sigma_g(s) to s for one Galois element g (odd, < 2N); same layout as RelinKeys.
+class GaloisKeys : public PolyBuffer {
+public:
+    GaloisKeys(const Context& ctx, uint32_t galois_elt);
+    uint32_t galois_elt() const { return galois_elt_; }
+
+private:
+    uint32_t galois_elt_;
+};
+
 class Evaluator {
 public:
     explicit Evaluator(const Context& ctx);
@@ -129,6 +139,8 @@ public:
     void multiply(const Ciphertext& a, const Ciphertext& b, Ciphertext& out, Stream* stream = nullptr) const;
     // N1: 3 -> 2 components, coefficient domain in and out
     void relinearize(const Ciphertext& in3, const RelinKeys& keys, Ciphertext& out2, Stream* stream = nullptr) const;
+    // N3: ciphertext of m(X) -> ciphertext of m(X^g) under the same key (automorphism + key switch), coefficient domain
+    void apply_galois(const Ciphertext& in2, const GaloisKeys& keys, Ciphertext& out2, Stream* stream = nullptr) const;
     // A7: ct (.) pt per component (NTT domain) and the matrix-vector product y_i = sum_j W_ij (.) x_j
     void multiply_plain(const Ciphertext& a, const Plaintext& p, Ciphertext& out, Stream* stream = nullptr) const;
     void matvec_plain(const Plaintext& W /* batch = rows*cols */, const Ciphertext& x /* batch = cols */, Ciphertext& y /* batch = rows */,
@@ -170,6 +182,7 @@ public:
     KeyGenerator& operator=(const KeyGenerator&) = delete;
     const SecretKey& secret_key() const;
     void create_relin_keys(RelinKeys& out);  // evk_j = (-(a_j s) + e_j + g_j s^2, a_j), NTT domain
+    void create_galois_keys(GaloisKeys& out);  // key_j = (-(a_j s) + e_j + g_j sigma_g(s), a_j) for out.galois_elt()
 
 private:
     class Impl;

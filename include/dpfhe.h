@@ -92,6 +92,12 @@ int dpfhe_ct_mul(dpfhe_ctx* ctx, uint64_t* d_out3, const uint64_t* d_a2, const u
  * element of limb j (1 mod q_j, 0 mod the others).  (c0', c1') = (c0, c1) + sum_j [c2]_{q_j} (.) evk_j. */
 int dpfhe_relinearize(dpfhe_ctx* ctx, uint64_t* d_out2, const uint64_t* d_in3, const uint64_t* d_evk, size_t batch, void* stream);
 
+/* -- N3: Galois automorphism a(X) -> a(X^galois_elt) (galois_elt odd, < 2N), coefficient domain, d_out != d_in;
+ *        and the key switch that follows it:  (c0', c1') = (c0 + sum_j [c1]_{q_j} (.) key_j[0], sum_j [c1]_{q_j} (.) key_j[1]),
+ *        key_j = (-(a_j s) + e_j + g_j sigma(s), a_j) in the NTT domain, layout [L][2][L][N] like the relinearisation keys. */
+int dpfhe_apply_galois(dpfhe_ctx* ctx, uint64_t* d_out, const uint64_t* d_in, size_t n_rns_polys, uint32_t galois_elt, void* stream);
+int dpfhe_switch_key(dpfhe_ctx* ctx, uint64_t* d_out2, const uint64_t* d_in2, const uint64_t* d_key, size_t batch, void* stream);
+
 /* -- A7: ciphertext x plaintext matrix-vector product, everything in the NTT domain ------------------
  * d_W: [rows][cols][L][N] plaintext polys; d_x: [cols][2][L][N]; d_y: [rows][2][L][N],
  * y_i = sum_j W_ij (.) x_j  with 128-bit lazy accumulation and one reduction at the end. */

@@ -371,6 +371,59 @@ void orc_relinearize(const orc_ctx* c, uint64_t* out2, const uint64_t* in3, cons
     }
 }
 
+/* N3: Galois automorphism a(X) -> a(X^g) on n_rns_polys RNS polynomials (coefficient domain), scatter form:
+ * coefficient i goes to index i*g mod 2N, negated when that index is >= N (X^N = -1). */
+void orc_apply_galois(const orc_ctx* c, uint64_t* out, const uint64_t* in, size_t n_rns_polys, uint32_t g) {
+    const size_t n = 1ull << c->log2n, L = c->n_limbs;
+    for (size_t p = 0; p < n_rns_polys * L; ++p) {
+        const uint64_t q = c->limb[p % L].q;
+        for (size_t i = 0; i < n; ++i) {
+            const size_t idx = (i * (size_t)g) & (2 * n - 1);
+            const uint64_t v = in[p * n + i];
+            if (idx < n) out[p * n + idx] = v;
+            else out[p * n + idx - n] = v ? q - v : 0;
+        }
+    }
+}
+
+/* key switch after an automorphism: (c0 + sum_j [c1]_{q_j} (.) key_j[0], sum_j [c1]_{q_j} (.) key_j[1]); in2,out2 [batch][2][L][N] */
+void orc_switch_key(const orc_ctx* c, uint64_t* out2, const uint64_t* in2, const uint64_t* key, size_t batch, int threads) {
+    const size_t n = 1ull << c->log2n, L = c->n_limbs;
+    threads = clamp_threads(threads);
+#pragma omp parallel num_threads(threads)
+    {
+        uint64_t* w = malloc(3 * n * sizeof(uint64_t));
+#pragma omp for schedule(static)
+        for (long long it = 0; it < (long long)(batch * L); ++it) {
+            const size_t bi = (size_t)it / L, i = (size_t)it % L;
+            const orc_limb* T = &c->limb[i];
+            const uint64_t q = T->q;
+            uint64_t *d = w, *acc0 = w + n, *acc1 = w + 2 * n;
+            memset(acc0, 0, 2 * n * sizeof(uint64_t));
+            for (size_t j = 0; j < L; ++j) {
+                const uint64_t* c1j = in2 + ((bi * 2 + 1) * L + j) * n;
+                for (size_t k = 0; k < n; ++k) d[k] = c1j[k] % q;
+                ntt_fwd_poly(T, d);
+                const uint64_t* k0 = key + ((j * 2 + 0) * L + i) * n;
+                const uint64_t* k1 = key + ((j * 2 + 1) * L + i) * n;
+                for (size_t k = 0; k < n; ++k) {
+                    uint64_t s0 = acc0[k] + mulmod_barrett(d[k], k0[k], T); acc0[k] = s0 - ((s0 >= q) ? q : 0);
+                    uint64_t s1 = acc1[k] + mulmod_barrett(d[k], k1[k], T); acc1[k] = s1 - ((s1 >= q) ? q : 0);
+                }
+            }
+            ntt_inv_poly(T, acc0); ntt_inv_poly(T, acc1);
+            const uint64_t* c0 = in2 + ((bi * 2 + 0) * L + i) * n;
+            uint64_t* o0 = out2 + ((bi * 2 + 0) * L + i) * n;
+            uint64_t* o1 = out2 + ((bi * 2 + 1) * L + i) * n;
+            for (size_t k = 0; k < n; ++k) {
+                uint64_t s0 = acc0[k] + c0[k]; o0[k] = s0 - ((s0 >= q) ? q : 0);
+                o1[k] = acc1[k];
+            }
+        }
+        free(w);
+    }
+}
+
 /* y[rows][comps][L][N] = sum_j W[rows][cols][L][N] (.) x[cols][comps][L][N]   (all NTT domain) */
 void orc_matvec_plain(const orc_ctx* c, uint64_t* y, const uint64_t* W, const uint64_t* x, size_t rows, size_t cols, size_t comps, int threads) {
     const size_t n = 1ull << c->log2n, L = c->n_limbs;

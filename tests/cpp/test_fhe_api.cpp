@@ -128,6 +128,25 @@ static void end_to_end(const FheParams& p, size_t batch) {
     ev.relinearize(c3, rk, cr);
     dec.decrypt(cr, 2 * scale, out.data());
     CHECK(out == want);                                 // and so does its relinearisation
+    // N3: m(X) -> m(X^g) under encryption.  RNS-digit key switching adds ~ L N q sigma ~ 2^77 of noise, so the
+    // rotated message needs a scale well above that (the product above sits at 2^90 already).
+    const unsigned gscale = 100;
+    Ciphertext cg(ctx, 2, batch);
+    enc.encrypt(m1.data(), gscale, cg);
+    for (uint32_t g : {3u, (uint32_t)(2 * n - 1), 25u}) {
+        GaloisKeys gk(ctx, g);
+        kg.create_galois_keys(gk);
+        Ciphertext rot(ctx, 2, batch);
+        ev.apply_galois(cg, gk, rot);
+        dec.decrypt(rot, gscale, out.data());
+        std::vector<int64_t> wantg(batch * n, 0);
+        for (size_t b = 0; b < batch; ++b)
+            for (size_t i = 0; i < n; ++i) {
+                const size_t idx = (i * (size_t)g) & (2 * n - 1);
+                if (idx < n) wantg[b * n + idx] = m1[b * n + i]; else wantg[b * n + idx - n] = -m1[b * n + i];
+            }
+        CHECK(out == wantg);
+    }
     try { dec.decrypt(c3, 0, out.data()); CHECK(!"expected RUNTIME_ERROR"); } catch (const Exception& e) { CHECK(e.code() == ErrorCode::RUNTIME_ERROR); }
 }
 

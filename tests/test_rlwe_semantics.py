@@ -203,3 +203,100 @@ def test_relinearize_bit_exact_vs_oracle(name):
     got = to_host(ev.relinearize(Ciphertext(to_device(ct3, ctx.device)), to_device(evk, ctx.device)).data)
     ctx.close()
     assert np.array_equal(got, want)
+
+
+# ---- N3: Galois automorphism + key switch ---------------------------------------------------------------------------
+def galois_int(a, g, mod=None):
+    """a(X) -> a(X^g) on an integer coefficient list (signed permutation); optional reduction mod `mod`."""
+    n = len(a)
+    out = [0] * n
+    for i, v in enumerate(a):
+        idx = (i * g) % (2 * n)
+        if idx < n:
+            out[idx] = v
+        else:
+            out[idx - n] = -v
+    return [x % mod for x in out] if mod else out
+
+
+def keygen_galois(rng, p, s, g):
+    """key_j = (-(a_j s) + e_j + g_j sigma_g(s), a_j), NTT domain."""
+    n, L = p.n, p.n_limbs
+    orc = Oracle.from_params(p)
+    key = np.zeros((L, 2, L, n), np.uint64)
+    errs = []
+    sg = galois_int([int(v) for v in s], g)
+    for j in range(L):
+        e = rng.integers(-8, 9, n)
+        errs.append([int(v) for v in e])
+        for i, q in enumerate(p.moduli):
+            sq = [int(v) % q for v in s]
+            a = [int(rng.integers(0, 2**62)) % q for _ in range(n)]
+            a_s = po.negacyclic_schoolbook(a, sq, q)
+            extra = [v % q for v in sg] if i == j else [0] * n
+            key[j, 0, i] = [(-a_s[k] + int(e[k]) + extra[k]) % q for k in range(n)]
+            key[j, 1, i] = a
+    return orc.ntt_fwd(key.reshape(-1, L, n)).reshape(key.shape), errs
+
+
+def run_galois_semantic(apply):
+    p = small_params()
+    rng = np.random.default_rng(123)
+    s = rng.integers(-1, 2, p.n)
+    m = rng.integers(0, 1000, p.n)
+    delta = 1 << 40
+    ct, ph = encrypt(rng, p, s, m, delta)
+    for g in (3, 5, 2 * p.n - 1, 25):
+        key, errs = keygen_galois(rng, p, s, g)
+        out = apply(p, ct, g, key)
+        got, Q = phase(p, out, s)
+        # rotated ciphertext (sigma(c0), sigma(c1)); key-switch noise = sum_j [sigma(c1)]_{q_j} * e_j
+        sc1 = [galois_int([int(v) for v in ct[1, l]], g, q) for l, q in enumerate(p.moduli)]
+        noise = [0] * p.n
+        for j in range(p.n_limbs):
+            term = negacyclic_int(sc1[j], errs[j], Q)
+            noise = [(a + b) % Q for a, b in zip(noise, term)]
+        want = [(a + b) % Q for a, b in zip(galois_int(ph, g, Q), noise)]
+        assert got == want, f"galois element {g}"
+
+
+def test_galois_automorphism_and_key_switch_oracle():
+    def apply(p, ct, g, key):
+        orc = Oracle.from_params(p)
+        return orc.switch_key(orc.apply_galois(ct, g)[None], key)[0]
+    run_galois_semantic(apply)
+
+
+@pytest.mark.gpu
+def test_galois_automorphism_and_key_switch_hip():
+    from deeppowers_amd.evaluator import Ciphertext, Context, Evaluator, to_device, to_host
+
+    def apply(p, ct, g, key):
+        ctx = Context(p, 0)
+        ev = Evaluator(ctx)
+        out = to_host(ev.apply_galois(Ciphertext(to_device(ct[None], ctx.device)), g, to_device(key, ctx.device)).data)[0]
+        ctx.close()
+        return out
+    run_galois_semantic(apply)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["config1", "n4096", "n8192"])
+def test_apply_galois_and_switch_key_bit_exact_vs_oracle(name):
+    from deeppowers_amd.evaluator import Ciphertext, Context, Evaluator, to_device, to_host
+    p = {"config1": FheParams.config1, "n4096": FheParams.n4096_l4, "n8192": FheParams.n8192_l6}[name]()
+    orc = Oracle.from_params(p)
+    L, n, batch = p.n_limbs, p.n, 3
+    ct = orc.fill(batch * 2, 301).reshape(batch, 2, L, n)
+    ct[0, :, :, :5] = 0
+    key = orc.fill(L * 2, 302).reshape(L, 2, L, n)
+    ctx = Context(p, 0)
+    ev = Evaluator(ctx)
+    for g in (3, 2 * n - 1, 5 ** 7 % (2 * n)):
+        rot = orc.apply_galois(ct, g)
+        got_rot = to_host(ev.apply_galois_words(to_device(ct, ctx.device), g))
+        assert np.array_equal(got_rot, rot), g
+        want = orc.switch_key(rot, key, threads=0)
+        got = to_host(ev.apply_galois(Ciphertext(to_device(ct, ctx.device)), g, to_device(key, ctx.device)).data)
+        assert np.array_equal(got, want), g
+    ctx.close()
