@@ -173,19 +173,11 @@ def main():
         },
     }
 
-    if rank == 0:
-        # correctness of the timed output on a sample (bit-exact vs the oracle)
-        from oracle.cbind import Oracle
-        orc = Oracle.from_params(params)
-        idx = [0, B // 2, B - 1]
-        want = orc.ct_mul(to_host(a.data[idx]), to_host(b.data[idx]), threads=0)
-        ok = bool(np.array_equal(to_host(out[idx]), want))
-        # and the reduced result of the last step equals the oracle's sum over a sample-sized re-computation path:
-        # totals == reduce_sum(outs) recomputed on the main stream
+    if world == 1:
+        # the reduced result of the last step equals a recomputation of the reduction on the main stream
         chk = ev.reduce_sum(Ciphertext(out), stream=main)
         torch.cuda.synchronize()
-        ok = ok and bool(torch.equal(chk.data, totals[last])) if world == 1 else ok
-        result["bit_exact_sample"] = ok
+        result["reduce_consistent"] = bool(torch.equal(chk.data, totals[last]))
 
     if world == 1:
         # BASELINE configs[1]: NTT / INTT HBM-roofline run, batch 1024 RNS polys x 4 limbs
@@ -220,7 +212,9 @@ def main():
             t1 = time.perf_counter(); orc.ct_mul(ah, bh, threads=cores); t_probe = time.perf_counter() - t1
             n_s = int(min(B, max(probe, probe * args.cpu_seconds / max(t_probe, 1e-6))))
             ah, bh = to_host(a.data[:n_s]), to_host(b.data[:n_s])
-            t1 = time.perf_counter(); orc.ct_mul(ah, bh, threads=cores); t_all = time.perf_counter() - t1
+            t1 = time.perf_counter(); cpu_out = orc.ct_mul(ah, bh, threads=cores); t_all = time.perf_counter() - t1
+            # the CPU baseline leg doubles as the checker of the timed GPU output: every word of the sample must match
+            result["bit_exact_sample"] = bool(np.array_equal(to_host(out[:n_s]), cpu_out))
             n_1 = max(1, n_s // cores)
             t1 = time.perf_counter(); orc.ct_mul(ah[:n_1], bh[:n_1], threads=1); t_one = time.perf_counter() - t1
             result["cpu_baseline"] = {

@@ -372,5 +372,5 @@ def test_bench_distributed_path_world_size_one():
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
     d = json.loads(line)
-    assert d["n_gpus"] == 1 and d["bit_exact_sample"] is True and d["value"] > 0 and d["unit"] == "ct-mul/s"
+    assert d["n_gpus"] == 1 and d["reduce_consistent"] is True and d["value"] > 0 and d["unit"] == "ct-mul/s"
     assert set(("roofline", "config", "metric", "ms_per_step", "scaling", "dtype", "data")) <= set(d)
