@@ -16,4 +16,4 @@ for set in "GRBM_GUI_ACTIVE FETCH_SIZE" "GRBM_GUI_ACTIVE WRITE_SIZE" "SQ_WAVE_CY
   [ -n "$f" ] && python tools/pmc_summary.py $f "ntt_|ct_mul|reduce_" > $OUT/pmc$i.txt 2>&1
   echo "pmc pass $i rc=$? ($set)"; head -12 $OUT/pmc$i.txt
 done
-find $OUT -name "*.db" -size +16M -delete
+find $OUT -name "*.db" -delete   # summaries are kept; raw databases exceed the 64 MiB copy-back limit

@@ -23,4 +23,4 @@ timeout 900 rocprofv3 --kernel-trace --stats -d $OUT/prof -o bench -- python ben
 ls -R $OUT/prof | head -20
 find $OUT/prof -name "*kernel_stats*" | head -1 | xargs -r head -20
 # keep the merged-back payload small: drop the raw trace, keep stats
-find $OUT/prof -name "*kernel_trace*" -size +8M -delete
+find $OUT -name "*.db" -delete

@@ -14,4 +14,4 @@ for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE
   f=$(find $OUT/p$i -name "*.db" | head -1)
   [ -n "$f" ] && python tools/pmc_summary.py $f "ntt_|ct_mul" > $OUT/p$i.txt 2>&1 && cat $OUT/p$i.txt | head -60
 done
-find $OUT -name "*.db" -size +20M -delete
+find $OUT -name "*.db" -delete
