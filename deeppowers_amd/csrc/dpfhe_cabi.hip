@@ -39,7 +39,8 @@ struct dpfhe_ctx {
     uint32_t log2n = 0, n_limbs = 0;
     int device = 0;
     bool fold = false;
-    void* d_blob = nullptr;  // one allocation: LimbConst[L] | fwd | inv | last  (both arithmetic layouts share it)
+    void* d_blob = nullptr;  // one allocation: LimbConst[L] | fwd | inv | last | RescaleConst[L]  (both arithmetic layouts share it)
+    const RescaleConst* d_rescale = nullptr;
     DevTables<ShoupArith> shoup{};
     DevTables<FoldArith> foldt{};
 };
@@ -73,7 +74,7 @@ extern "C" int dpfhe_ctx_create(dpfhe_ctx** out, uint32_t log2_n, uint32_t n_lim
     auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
     const size_t tw_sz = fold ? sizeof(TwFold) : sizeof(TwShoup);
     const size_t o_lc = 0, o_fwd = up(o_lc + L * sizeof(LimbConst)), o_inv = up(o_fwd + L * n * tw_sz),
-                 o_last = up(o_inv + L * n * tw_sz), total = up(o_last + L * 2 * tw_sz);
+                 o_last = up(o_inv + L * n * tw_sz), o_resc = up(o_last + L * 2 * tw_sz), total = up(o_resc + L * sizeof(RescaleConst));
     std::vector<unsigned char> blob(total, 0);
     for (size_t l = 0; l < L; ++l) {
         std::memcpy(&blob[o_lc + l * sizeof(LimbConst)], &ht[l].lc, sizeof(LimbConst));
@@ -95,6 +96,14 @@ extern "C" int dpfhe_ctx_create(dpfhe_ctx** out, uint32_t log2_n, uint32_t n_lim
             s->w_ninv.w = ht[l].lc.ninv; s->w_ninv.wsh = ht[l].lc.ninv_sh;
         }
     }
+    {   // rescale constants relative to the LAST prime (used only when L >= 2)
+        const u64 ql = moduli[L - 1], hh = ql / 2;
+        RescaleConst* r = reinterpret_cast<RescaleConst*>(&blob[o_resc]);
+        for (size_t l = 0; l + 1 < L; ++l) {
+            const u64 q = moduli[l];
+            r[l].h_mod = hh % q; r[l].inv = h_powmod(ql % q, q - 2, q); r[l].q_last = ql; r[l].h = hh;
+        }
+    }
     hipError_t e = hipMalloc(&c->d_blob, total);
     if (e == hipSuccess) e = hipMemcpy(c->d_blob, blob.data(), total, hipMemcpyHostToDevice);
     if (e != hipSuccess) {
@@ -104,6 +113,7 @@ extern "C" int dpfhe_ctx_create(dpfhe_ctx** out, uint32_t log2_n, uint32_t n_lim
         return fail(e == hipErrorOutOfMemory ? DPFHE_OUT_OF_MEMORY : DPFHE_DEVICE_ERROR, "dpfhe_ctx_create: table upload", hipGetErrorString(e));
     }
     unsigned char* d = static_cast<unsigned char*>(c->d_blob);
+    c->d_rescale = reinterpret_cast<const RescaleConst*>(d + o_resc);
     if (fold) {
         c->foldt.lc = reinterpret_cast<const LimbConst*>(d + o_lc);
         c->foldt.fwd = reinterpret_cast<const TwFold*>(d + o_fwd);
@@ -245,6 +255,21 @@ extern "C" int dpfhe_switch_key(dpfhe_ctx* c, uint64_t* d_out2, const uint64_t* 
                            : launch_relin<ShoupArith>((int)c->log2n, 1, d_out2, d_in2, d_key, blocks, c->shoup, s);
     if (rc) return fail(DPFHE_INVALID_STATE, "dpfhe_switch_key", "no kernel geometry for this log2_n");
     return check_launch("switch_key kernel launch");
+}
+
+extern "C" int dpfhe_rescale(dpfhe_ctx* c, uint64_t* d_out, const uint64_t* d_in, size_t n_rns_polys, void* stream) {
+    if (!c) return fail(DPFHE_INVALID_ARGUMENT, "dpfhe_rescale", "null context");
+    if (c->n_limbs < 2) return fail(DPFHE_INVALID_STATE, "dpfhe_rescale", "no limb left to drop");
+    if (n_rns_polys == 0) return DPFHE_SUCCESS;
+    if (!d_out || !d_in || misaligned(d_out) || misaligned(d_in)) return fail(DPFHE_INVALID_ARGUMENT, "dpfhe_rescale", "null or misaligned buffer");
+    const int n = 1 << c->log2n;
+    const int chunks = (n + 511) / 512;
+    const size_t blocks = n_rns_polys * (c->n_limbs - 1) * (size_t)chunks;
+    if (blocks > kMaxGrid) return fail(DPFHE_INVALID_ARGUMENT, "dpfhe_rescale", "batch too large for one launch");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (c->fold) hipLaunchKernelGGL((rescale_kernel<FoldArith>), dim3((unsigned)blocks), dim3(256), 0, s, d_out, d_in, c->foldt.lc, c->d_rescale, (int)c->n_limbs, n, chunks);
+    else hipLaunchKernelGGL((rescale_kernel<ShoupArith>), dim3((unsigned)blocks), dim3(256), 0, s, d_out, d_in, c->shoup.lc, c->d_rescale, (int)c->n_limbs, n, chunks);
+    return check_launch("rescale kernel launch");
 }
 
 extern "C" int dpfhe_apply_galois(dpfhe_ctx* c, uint64_t* d_out, const uint64_t* d_in, size_t n_rns_polys, uint32_t galois_elt, void* stream) {

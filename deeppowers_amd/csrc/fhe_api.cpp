@@ -29,6 +29,12 @@ const uint64_t kPrimes60[6][3] = {
     {1152921504606584833ull, 317490233586139ull, 23981819781494ull},  {1152921504606109697ull, 279138086580908ull, 253932030982881ull}};
 }  // namespace
 
+FheParams FheParams::drop_last_limb() const {
+    if (moduli.size() < 2) throw Exception(ErrorCode::INVALID_STATE, "drop_last_limb: no limb left to drop");
+    FheParams p{log2_n, moduli, psi};
+    p.moduli.pop_back(); p.psi.pop_back();
+    return p;
+}
 FheParams FheParams::config1() { return FheParams{10, {1073707009ull}, {169871ull}}; }
 FheParams FheParams::n4096_l4() {
     FheParams p{12, {}, {}};
@@ -183,6 +189,15 @@ void Evaluator::relinearize(const Ciphertext& in3, const RelinKeys& keys, Cipher
         throw Exception(ErrorCode::INVALID_ARGUMENT, "relinearize: 3-component input, 2-component output of the same batch");
     check(dpfhe_relinearize(impl_->h(), out2.data(), in3.data(), keys.data(), in3.batch(), s), "dpfhe_relinearize");
     out2.set_ntt(false);
+}
+void Evaluator::rescale(const Ciphertext& in, Ciphertext& out, Stream* s) const {
+    if (in.is_ntt()) throw Exception(ErrorCode::INVALID_STATE, "rescale: input must be in the coefficient domain");
+    const size_t L = impl_->ctx->params().n_limbs(), n = impl_->ctx->params().n();
+    if (L < 2) throw Exception(ErrorCode::INVALID_STATE, "rescale: no limb left to drop");
+    if (out.size() != in.size() || out.batch() != in.batch() || out.words() != in.batch() * in.size() * (L - 1) * n)
+        throw Exception(ErrorCode::INVALID_ARGUMENT, "rescale: output must live on the next-level context (L-1 limbs), same size and batch");
+    check(dpfhe_rescale(impl_->h(), out.data(), in.data(), in.batch() * in.size(), s), "dpfhe_rescale");
+    out.set_ntt(false);
 }
 void Evaluator::apply_galois(const Ciphertext& in2, const GaloisKeys& keys, Ciphertext& out2, Stream* s) const {
     if (in2.is_ntt()) throw Exception(ErrorCode::INVALID_STATE, "apply_galois: input must be in the coefficient domain");

@@ -239,6 +239,45 @@ __global__ __launch_bounds__(256) void matvec_scalar_kernel(u64* y, const u64* w
     }
 }
 
+// N1 (second half): rescale / modulus switch to the next level, coefficient domain.
+//   out_i = ((in_i + h) - ((in_last + h) mod q_last)) * q_last^-1   (mod q_i),  h = floor(q_last / 2),  i < L-1
+// i.e. round(x / q_last) of the CRT-composed value, limb by limb (no big integers).  HBM-bound.
+struct RescaleConst {
+    u64 h_mod;     // floor(q_last / 2) mod q_i
+    u64 inv;       // q_last^-1 mod q_i
+    u64 q_last;
+    u64 h;         // floor(q_last / 2)
+};
+
+template <class Arith>
+__global__ __launch_bounds__(256) void rescale_kernel(u64* out, const u64* in, const LimbConst* lcs, const RescaleConst* rcs, int n_limbs, int n,
+                                                      int chunks) {
+    const int Lo = n_limbs - 1;
+    const int chunk = (int)(blockIdx.x % chunks);
+    const int limb = (int)((blockIdx.x / chunks) % Lo);
+    const size_t poly = blockIdx.x / chunks / Lo;
+    const int w0 = chunk * 512 + threadIdx.x * 2;
+    if (w0 >= n) return;
+    const LimbConst lc = lcs[limb];
+    const RescaleConst rc = rcs[limb];
+    const U64x2 x = *reinterpret_cast<const U64x2*>(in + (poly * n_limbs + limb) * n + w0);
+    const U64x2 last = *reinterpret_cast<const U64x2*>(in + (poly * n_limbs + Lo) * n + w0);
+    U64x2 r;
+    {
+        const u64 t = csub(last.a + rc.h, rc.q_last);             // (in_last + h) mod q_last
+        const u64 tm = Arith::kFold ? FoldArith::canon(t, lc) : ShoupArith::mul_var(t, 1, lc);   // ... mod q_i
+        const u64 d = sub_mod(add_mod(x.a, rc.h_mod, lc.q), tm, lc.q);
+        r.a = Arith::mul_var(d, rc.inv, lc);
+    }
+    {
+        const u64 t = csub(last.b + rc.h, rc.q_last);
+        const u64 tm = Arith::kFold ? FoldArith::canon(t, lc) : ShoupArith::mul_var(t, 1, lc);
+        const u64 d = sub_mod(add_mod(x.b, rc.h_mod, lc.q), tm, lc.q);
+        r.b = Arith::mul_var(d, rc.inv, lc);
+    }
+    *reinterpret_cast<U64x2*>(out + (poly * Lo + limb) * n + w0) = r;
+}
+
 // N3: Galois automorphism a(X) -> a(X^g), g odd, coefficient domain (a signed permutation; HBM-bound).
 // Gather form: out[k] = +in[j] if j = k g^-1 mod 2N < N, else -in[j - N]  (coalesced writes, scattered 8-byte reads).
 __global__ __launch_bounds__(256) void galois_kernel(u64* out, const u64* in, const LimbConst* lcs, int n_limbs, int n, unsigned g_inv) {

@@ -256,6 +256,15 @@ class Evaluator:
         _cabi.check(self._lib.dpfhe_relinearize(self.ctx.handle, out.data_ptr(), ct3.data.data_ptr(), evk.data_ptr(), ct3.batch, _stream_ptr(stream)), "dpfhe_relinearize")
         return Ciphertext(out, False)
 
+    def rescale_words(self, t: torch.Tensor, stream=None) -> torch.Tensor:
+        """[..., L, N] -> [..., L-1, N]: round(x / q_last) limb by limb (coefficient domain).  The result belongs to the
+        context of the first L-1 moduli."""
+        self._chk(t)
+        p = self.ctx.params
+        out = torch.empty(t.shape[:-2] + (p.n_limbs - 1, p.n), dtype=torch.int64, device=t.device)
+        _cabi.check(self._lib.dpfhe_rescale(self.ctx.handle, out.data_ptr(), t.data_ptr(), self._npolys(t), _stream_ptr(stream)), "dpfhe_rescale")
+        return out
+
     # ---- N3 (SURVEY.md 8f): Galois automorphism + key switch ----------------------------------------------------
     def apply_galois_words(self, t: torch.Tensor, galois_elt: int, out: torch.Tensor | None = None, stream=None) -> torch.Tensor:
         """a(X) -> a(X^galois_elt) on every RNS polynomial of t (coefficient domain, out of place)."""

@@ -66,6 +66,10 @@ class FheParams:
     def words_per_ct(self, components: int = 2) -> int:
         return components * self.n_limbs * self.n
 
+    def drop_last_limb(self) -> "FheParams":
+        """the next level after a rescale"""
+        return FheParams(self.log2_n, tuple(self.moduli[:-1]), tuple(self.psi[:-1]))
+
     # ---- the BASELINE.json parameter sets -----------------------------------------------------
     @staticmethod
     def config1() -> "FheParams":

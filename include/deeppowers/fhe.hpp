@@ -44,6 +44,7 @@ struct FheParams {
     std::vector<uint64_t> psi;     // primitive 2N-th roots of unity
     size_t n() const { return size_t(1) << log2_n; }
     size_t n_limbs() const { return moduli.size(); }
+    FheParams drop_last_limb() const;  // the level after a rescale
     static FheParams config1();     // N=1024, one 30-bit limb       (BASELINE.json configs[0])
     static FheParams n4096_l4();    // N=4096, 4 x 60-bit limbs      (configs[1..3], the metric)
     static FheParams n8192_l6();    // N=8192, 6 x 60-bit limbs      (configs[4] sizes)
@@ -139,6 +140,9 @@ public:
     void multiply(const Ciphertext& a, const Ciphertext& b, Ciphertext& out, Stream* stream = nullptr) const;
     // N1: 3 -> 2 components, coefficient domain in and out
     void relinearize(const Ciphertext& in3, const RelinKeys& keys, Ciphertext& out2, Stream* stream = nullptr) const;
+    // N1, second half: out = round(in / q_last) at the next level; `out` must have been created on a Context of
+    // params().drop_last_limb() with the same size and batch (coefficient domain)
+    void rescale(const Ciphertext& in, Ciphertext& out_next_level, Stream* stream = nullptr) const;
     // N3: ciphertext of m(X) -> ciphertext of m(X^g) under the same key (automorphism + key switch), coefficient domain
     void apply_galois(const Ciphertext& in2, const GaloisKeys& keys, Ciphertext& out2, Stream* stream = nullptr) const;
     // A7: ct (.) pt per component (NTT domain) and the matrix-vector product y_i = sum_j W_ij (.) x_j

@@ -92,6 +92,11 @@ int dpfhe_ct_mul(dpfhe_ctx* ctx, uint64_t* d_out3, const uint64_t* d_a2, const u
  * element of limb j (1 mod q_j, 0 mod the others).  (c0', c1') = (c0, c1) + sum_j [c2]_{q_j} (.) evk_j. */
 int dpfhe_relinearize(dpfhe_ctx* ctx, uint64_t* d_out2, const uint64_t* d_in3, const uint64_t* d_evk, size_t batch, void* stream);
 
+/* -- N1, second half: rescale (exact RNS "divide by the last prime and round"), coefficient domain.
+ * d_in: [n_rns_polys][L][N]  ->  d_out: [n_rns_polys][L-1][N] = round(x / q_{L-1}) limb by limb; requires L >= 2.
+ * The result lives at the next level: use a context created with the first L-1 moduli for further work on it. */
+int dpfhe_rescale(dpfhe_ctx* ctx, uint64_t* d_out, const uint64_t* d_in, size_t n_rns_polys, void* stream);
+
 /* -- N3: Galois automorphism a(X) -> a(X^galois_elt) (galois_elt odd, < 2N), coefficient domain, d_out != d_in;
  *        and the key switch that follows it:  (c0', c1') = (c0 + sum_j [c1]_{q_j} (.) key_j[0], sum_j [c1]_{q_j} (.) key_j[1]),
  *        key_j = (-(a_j s) + e_j + g_j sigma(s), a_j) in the NTT domain, layout [L][2][L][N] like the relinearisation keys. */

@@ -371,6 +371,24 @@ void orc_relinearize(const orc_ctx* c, uint64_t* out2, const uint64_t* in3, cons
     }
 }
 
+/* N1 second half: rescale = exact RNS divide-by-q_last-and-round (Cheon-Han-Kim-Kim-Song full-RNS CKKS; SEAL's
+ * divide_and_round_q_last):  out_i = ((x_i + h) - ((x_last + h) mod q_last)) * q_last^-1 mod q_i,  h = floor(q_last/2). */
+void orc_rescale(const orc_ctx* c, uint64_t* out, const uint64_t* in, size_t n_rns_polys) {
+    const size_t n = 1ull << c->log2n, L = c->n_limbs;
+    const uint64_t ql = c->limb[L - 1].q, h = ql / 2;
+    for (size_t p = 0; p < n_rns_polys; ++p)
+        for (size_t i = 0; i + 1 < L; ++i) {
+            const uint64_t q = c->limb[i].q;
+            const uint64_t inv = powmod(ql % q, q - 2, q);
+            for (size_t k = 0; k < n; ++k) {
+                const uint64_t t = (in[(p * L + L - 1) * n + k] + h) % ql;
+                const uint64_t a = (uint64_t)(((u128)in[(p * L + i) * n + k] + h % q) % q);
+                const uint64_t d = (a + q - t % q) % q;
+                out[(p * (L - 1) + i) * n + k] = mulmod_slow(d, inv, q);
+            }
+        }
+}
+
 /* N3: Galois automorphism a(X) -> a(X^g) on n_rns_polys RNS polynomials (coefficient domain), scatter form:
  * coefficient i goes to index i*g mod 2N, negated when that index is >= N (X^N = -1). */
 void orc_apply_galois(const orc_ctx* c, uint64_t* out, const uint64_t* in, size_t n_rns_polys, uint32_t g) {

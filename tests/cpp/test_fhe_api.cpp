@@ -1,5 +1,6 @@
 // GPU test of the C++ facade (deeppowers::fhe) against the C oracle.  Built and run by
 // tests/test_gpu_cpp_api.py (-m gpu).  Exit code 0 = all checks passed.
+#include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <vector>
@@ -146,6 +147,26 @@ static void end_to_end(const FheParams& p, size_t batch) {
                 if (idx < n) wantg[b * n + idx] = m1[b * n + i]; else wantg[b * n + idx - n] = -m1[b * n + i];
             }
         CHECK(out == wantg);
+    }
+    // N1 second half: rescale the relinearised product to the next level; the same secret (same seed) decrypts it there
+    {
+        const FheParams p2 = p.drop_last_limb();
+        Context ctx2(p2, 0);
+        KeyGenerator kg2(ctx2, /*seed=*/11);             // same seed -> same ternary secret
+        Decryptor dec2(ctx2, kg2.secret_key());
+        Ciphertext low(ctx2, 2, batch);
+        ev.rescale(cr, low);
+        ctx.synchronize();
+        // scale 2^90 / q_last: decrypt at the largest power of two below it and compare after the same division
+        const double ql = (double)p.moduli.back();
+        std::vector<int64_t> got(batch * n);
+        dec2.decrypt(low, 30, got.data());               // 2^90 / q_last ~ 2^30 (q_last ~ 2^60)
+        bool ok = true;
+        for (size_t i = 0; i < got.size(); ++i) {
+            const double expect = (double)want[i] * (1152921504606846976.0 / ql);   // * 2^60 / q_last
+            if (std::fabs((double)got[i] - expect) > 2.0) ok = false;
+        }
+        CHECK(ok);
     }
     try { dec.decrypt(c3, 0, out.data()); CHECK(!"expected RUNTIME_ERROR"); } catch (const Exception& e) { CHECK(e.code() == ErrorCode::RUNTIME_ERROR); }
 }

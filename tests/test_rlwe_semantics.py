@@ -300,3 +300,64 @@ def test_apply_galois_and_switch_key_bit_exact_vs_oracle(name):
         got = to_host(ev.apply_galois(Ciphertext(to_device(ct, ctx.device)), g, to_device(key, ctx.device)).data)
         assert np.array_equal(got, want), g
     ctx.close()
+
+
+# ---- N1 second half: rescale ---------------------------------------------------------------------------------------------
+def run_rescale_semantic(rescale):
+    p = small_params()
+    rng = np.random.default_rng(9)
+    s = rng.integers(-1, 2, p.n)
+    m = rng.integers(0, 1000, p.n)
+    ct, ph = encrypt(rng, p, s, m, 1 << 90)                 # scale well above q_last ~ 2^60
+    out = rescale(p, ct)                                    # [2][L-1][N]
+    p2 = p.drop_last_limb()
+    got, Q2 = phase(p2, out, s)
+    ql = p.moduli[-1]
+    centre = lambda v, Q: v - Q if v > Q // 2 else v
+    worst = 0
+    for k in range(p.n):
+        want = ph[k] / ql                                   # exact phase is an integer well inside Q
+        err = abs(centre(got[k], Q2) - (ph[k] // ql))
+        worst = max(worst, err)
+    assert worst <= p.n + 2                                 # rounding error (1 + |s|_1) / 2 at most
+
+
+def test_rescale_divides_the_phase_oracle():
+    run_rescale_semantic(lambda p, ct: Oracle.from_params(p).rescale(ct))
+
+
+@pytest.mark.gpu
+def test_rescale_divides_the_phase_hip():
+    from deeppowers_amd.evaluator import Context, Evaluator, to_device, to_host
+
+    def rescale(p, ct):
+        ctx = Context(p, 0)
+        out = to_host(Evaluator(ctx).rescale_words(to_device(ct, ctx.device)))
+        ctx.close()
+        return out
+    run_rescale_semantic(rescale)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["n4096", "n8192", "mixed"])
+def test_rescale_bit_exact_vs_oracle(name):
+    from deeppowers_amd.evaluator import Context, Evaluator, to_device, to_host
+    if name == "mixed":   # generic (Shoup/Barrett) path: 59/50/33-bit primes
+        n = 1024
+        def gp(bits):
+            q = (1 << bits) - ((1 << bits) - 1) % (2 * n)
+            while not po.is_prime(q):
+                q -= 2 * n
+            return q
+        qs = (gp(59), gp(50), gp(33))
+        p = FheParams(10, qs, tuple(po.min_primitive_2n_root(n, q) for q in qs))
+    else:
+        p = FheParams.n4096_l4() if name == "n4096" else FheParams.n8192_l6()
+    orc = Oracle.from_params(p)
+    x = orc.fill(6, 401).reshape(3, 2, p.n_limbs, p.n)
+    x[0, 0, :, :8] = 0
+    x[0, 1, :, :8] = (np.array(p.moduli, np.uint64) - np.uint64(1))[:, None]
+    ctx = Context(p, 0)
+    got = to_host(Evaluator(ctx).rescale_words(to_device(x, ctx.device)))
+    ctx.close()
+    assert got.shape == (3, 2, p.n_limbs - 1, p.n) and np.array_equal(got, orc.rescale(x))
