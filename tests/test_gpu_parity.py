@@ -374,3 +374,29 @@ def test_bench_distributed_path_world_size_one():
     d = json.loads(line)
     assert d["n_gpus"] == 1 and d["reduce_consistent"] is True and d["value"] > 0 and d["unit"] == "ct-mul/s"
     assert set(("roofline", "config", "metric", "ms_per_step", "scaling", "dtype", "data")) <= set(d)
+
+
+def test_config3_full_size_matvec_linearity_and_sampled_rows(rigs):
+    """BASELINE configs[2]: hidden = 768 rows, 64 input ciphertexts, N=4096, L=4 (6 GiB of plaintext weights)."""
+    r = rigs("n4096")
+    L, n, rows, cols = 4, 4096, 768, 64
+    g = torch.Generator(device="cpu").manual_seed(21)
+    q = torch.tensor(r.p.moduli, dtype=torch.int64, device=r.ctx.device).view(1, 1, L, 1)
+    dg = torch.Generator(device=r.ctx.device).manual_seed(22)
+    W = torch.randint(0, 2**62, (rows, cols, L, n), generator=dg, dtype=torch.int64, device=r.ctx.device) % q
+    x1 = torch.randint(0, 2**62, (cols, 2, L, n), generator=dg, dtype=torch.int64, device=r.ctx.device) % q
+    x2 = torch.randint(0, 2**62, (cols, 2, L, n), generator=dg, dtype=torch.int64, device=r.ctx.device) % q
+    Wp = Plaintext(W, True)
+    y1 = r.ev.matvec_plain(Wp, Ciphertext(x1, True))
+    y2 = r.ev.matvec_plain(Wp, Ciphertext(x2, True))
+    y12 = r.ev.matvec_plain(Wp, Ciphertext(r.ev.add_words(x1, x2), True))
+    assert torch.equal(y12.data, r.ev.add_words(y1.data, y2.data))                    # linearity in x at full size
+    idx = [0, 383, 767]
+    want = r.orc.matvec_plain(to_host(W[idx]).ravel(), to_host(x1).ravel(), len(idx), cols, threads=0)
+    assert np.array_equal(to_host(y1.data[idx]), want)                                # sampled rows vs the oracle
+    # scalar-weight variant on the same shape: equals the polynomial variant with constant polynomials' NTT = constants
+    w = torch.randint(0, 2**62, (rows, cols, L), generator=dg, dtype=torch.int64, device=r.ctx.device) % q.view(1, 1, L)
+    ys = r.ev.matvec_scalar(w, Ciphertext(x1, True))
+    want_s = r.orc.matvec_scalar(to_host(w[idx]), to_host(x1), len(idx), cols, threads=0)
+    assert np.array_equal(to_host(ys.data[idx]), want_s)
+    del W
