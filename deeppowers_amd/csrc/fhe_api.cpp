@@ -4,6 +4,10 @@
 #define __HIP_PLATFORM_AMD__ 1
 #include <hip/hip_runtime_api.h>
 
+#include <cstring>
+#include <istream>
+#include <ostream>
+
 #include "deeppowers/fhe.hpp"
 #include "dpfhe.h"
 
@@ -77,6 +81,7 @@ void Context::synchronize() const {
 // ---- PolyBuffer -----------------------------------------------------------------------------------------
 class PolyBuffer::Impl {
 public:
+    const Context* ctx = nullptr;
     uint64_t* d = nullptr;
     size_t batch = 0, comps = 0, words = 0;
     bool ntt = false;
@@ -88,6 +93,7 @@ public:
 
 PolyBuffer::PolyBuffer(const Context& ctx, size_t batch, size_t components, bool is_ntt) : impl_(new Impl) {
     if (batch == 0 || components == 0) throw Exception(ErrorCode::INVALID_ARGUMENT, "PolyBuffer: batch and components must be > 0");
+    impl_->ctx = &ctx;
     impl_->batch = batch; impl_->comps = components; impl_->ntt = is_ntt; impl_->device_id = ctx.device_id();
     impl_->words = batch * components * ctx.params().n_limbs() * ctx.params().n();
     hip_check(hipSetDevice(impl_->device_id), "hipSetDevice");
@@ -112,6 +118,50 @@ void PolyBuffer::copy_from_host(const uint64_t* src) {
 void PolyBuffer::copy_to_host(uint64_t* dst) const {
     if (!dst) throw Exception(ErrorCode::INVALID_ARGUMENT, "copy_to_host: null destination");
     hip_check(hipMemcpy(dst, impl_->d, impl_->words * sizeof(uint64_t), hipMemcpyDeviceToHost), "hipMemcpy D2H");
+}
+
+namespace {
+const char kMagic[8] = {'D', 'P', 'F', 'H', 'E', 'v', '1', 0};
+struct WireHeader {   // all little-endian; x86-64 / gfx950 hosts are little-endian
+    char magic[8];
+    uint32_t log2_n, n_limbs;
+    uint64_t batch, components;
+    uint32_t is_ntt, reserved;
+};
+}  // namespace
+
+void PolyBuffer::save(std::ostream& os) const {
+    const FheParams& p = impl_->ctx->params();
+    WireHeader h{};
+    std::memcpy(h.magic, kMagic, 8);
+    h.log2_n = p.log2_n; h.n_limbs = (uint32_t)p.n_limbs(); h.batch = impl_->batch; h.components = impl_->comps;
+    h.is_ntt = impl_->ntt ? 1u : 0u; h.reserved = 0;
+    std::vector<uint64_t> host(impl_->words);
+    copy_to_host(host.data());
+    os.write(reinterpret_cast<const char*>(&h), sizeof h);
+    os.write(reinterpret_cast<const char*>(p.moduli.data()), (std::streamsize)(p.n_limbs() * sizeof(uint64_t)));
+    os.write(reinterpret_cast<const char*>(host.data()), (std::streamsize)(host.size() * sizeof(uint64_t)));
+    if (!os) throw Exception(ErrorCode::RUNTIME_ERROR, "save: stream write failed");
+}
+
+void PolyBuffer::load(std::istream& is) {
+    const FheParams& p = impl_->ctx->params();
+    WireHeader h{};
+    is.read(reinterpret_cast<char*>(&h), sizeof h);
+    if (!is || std::memcmp(h.magic, kMagic, 8) != 0) throw Exception(ErrorCode::INVALID_ARGUMENT, "load: not a DPFHEv1 stream");
+    if (h.log2_n != p.log2_n || h.n_limbs != p.n_limbs() || h.batch != impl_->batch || h.components != impl_->comps)
+        throw Exception(ErrorCode::INVALID_ARGUMENT, "load: header does not match this buffer (log2_n / limbs / batch / components)");
+    std::vector<uint64_t> moduli(h.n_limbs);
+    is.read(reinterpret_cast<char*>(moduli.data()), (std::streamsize)(moduli.size() * sizeof(uint64_t)));
+    if (!is || moduli != p.moduli) throw Exception(ErrorCode::INVALID_ARGUMENT, "load: moduli differ from this context");
+    std::vector<uint64_t> host(impl_->words);
+    is.read(reinterpret_cast<char*>(host.data()), (std::streamsize)(host.size() * sizeof(uint64_t)));
+    if (!is) throw Exception(ErrorCode::INVALID_ARGUMENT, "load: truncated stream");
+    const size_t n = p.n(), L = p.n_limbs();
+    for (size_t i = 0; i < host.size(); ++i)
+        if (host[i] >= p.moduli[(i / n) % L]) throw Exception(ErrorCode::INVALID_ARGUMENT, "load: non-canonical residue in the payload");
+    copy_from_host(host.data());
+    impl_->ntt = h.is_ntt != 0;
 }
 
 Ciphertext::Ciphertext(const Context& ctx, size_t size, size_t batch, bool is_ntt) : PolyBuffer(ctx, batch, size, is_ntt) {

@@ -16,6 +16,7 @@
 
 #include <cstddef>
 #include <cstdint>
+#include <iosfwd>
 #include <memory>
 #include <stdexcept>
 #include <string>
@@ -87,6 +88,11 @@ public:
     void set_ntt(bool v);
     void copy_from_host(const uint64_t* src);  // words() canonical residues
     void copy_to_host(uint64_t* dst) const;
+    // N4: wire format.  Little-endian: "DPFHEv1\0", u32 log2_n, u32 n_limbs, u64 batch, u64 components,
+    // u32 is_ntt, u32 reserved, u64 moduli[n_limbs], then batch*components*n_limbs*N u64 words.  load() checks that the
+    // header matches this buffer's context and shape (throws INVALID_ARGUMENT otherwise) and sets the domain flag.
+    void save(std::ostream& os) const;
+    void load(std::istream& is);
 
 private:
     class Impl;

@@ -1,6 +1,7 @@
 // GPU test of the C++ facade (deeppowers::fhe) against the C oracle.  Built and run by
 // tests/test_gpu_cpp_api.py (-m gpu).  Exit code 0 = all checks passed.
 #include <cmath>
+#include <sstream>
 #include <cstdio>
 #include <cstring>
 #include <vector>
@@ -81,6 +82,21 @@ static void run(const FheParams& p, size_t batch) {
         ev.relinearize(C, K, R);
         R.copy_to_host(r_got.data());
         CHECK(r_got == r_want);
+    }
+
+    // N4: wire format round trip (header + payload) and rejection of a stream from another shape
+    {
+        std::stringstream ss;
+        C.save(ss);
+        const std::string blob = ss.str();
+        CHECK(blob.size() == 40 + 8 * L + want.size() * 8 && blob.compare(0, 7, "DPFHEv1") == 0);
+        Ciphertext D(ctx, 3, batch, /*is_ntt=*/true);
+        D.load(ss);
+        std::vector<uint64_t> back(want.size());
+        D.copy_to_host(back.data());
+        CHECK(back == want && !D.is_ntt());
+        std::stringstream ss2(blob);
+        try { Ciphertext E(ctx, 2, batch); E.load(ss2); CHECK(!"expected INVALID_ARGUMENT"); } catch (const Exception& e) { CHECK(e.code() == ErrorCode::INVALID_ARGUMENT); }
     }
 
     // error behaviour: exceptions with reference error codes
