@@ -134,7 +134,43 @@ def main():
         return ntt
 
 
+    def measure_other_configs():
+        """BASELINE configs[2] (ct x pt matvec, hidden=768, 64 input ciphertexts) and the N1 relinearisation, kernel-only."""
+        from deeppowers_amd.evaluator import Plaintext
+        other = {}
+
+        def timed(fn, reps):
+            fn(); fn()
+            evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+            for s_, e_ in evs:
+                s_.record(); fn(); e_.record()
+            torch.cuda.synchronize()
+            ts = sorted(s_.elapsed_time(e_) * 1e-3 for s_, e_ in evs)
+            return ts[len(ts) // 2]
+
+        rows, cols = 768, 64
+        W = Plaintext(torch.randint(0, 2**62, (rows, cols, L, N), generator=g, dtype=torch.int64, device=dev) % q, True)
+        xs = Ciphertext(torch.randint(0, 2**62, (cols, 2, L, N), generator=g, dtype=torch.int64, device=dev) % q, True)
+        y = ctx.empty(rows, components=2)
+        t = timed(lambda: ev.matvec_plain(W, xs, out=y), 6)
+        nbytes = (rows * cols + cols * 2 + rows * 2) * L * N * 8
+        other["matvec_plain"] = {"workload": "BASELINE configs[2]: 768 rows x 64 input ciphertexts, polynomial weights (6 GiB), N=4096, L=4",
+                                 "median_us": t * 1e6, "GBps": nbytes / t / 1e9, "frac_of_hbm_peak": nbytes / t / HBM_PEAK,
+                                 "mod_fma_per_s": rows * cols * 2 * L * N / t}
+        del W
+        w = torch.randint(0, 2**62, (rows, cols, L), generator=g, dtype=torch.int64, device=dev) % q.view(1, 1, L)
+        t = timed(lambda: ev.matvec_scalar(w, xs, out=y), 6)
+        other["matvec_scalar"] = {"workload": "same shape, scalar weights in Z_q", "median_us": t * 1e6, "mod_fma_per_s": rows * cols * 2 * L * N / t}
+        nb = 2048
+        c3 = Ciphertext(torch.randint(0, 2**62, (nb, 3, L, N), generator=g, dtype=torch.int64, device=dev) % q)
+        evk = torch.randint(0, 2**62, (L, 2, L, N), generator=g, dtype=torch.int64, device=dev) % q
+        o2 = ctx.empty(nb, components=2)
+        t = timed(lambda: ev.relinearize(c3, evk, out=o2), 6)
+        other["relinearize"] = {"workload": f"{nb} three-component ciphertexts, RNS-digit keys, N=4096, L=4", "median_us": t * 1e6, "per_s": nb / t}
+        return other
+
     ntt_result = measure_ntt() if world == 1 else None   # before the long multiply loop heats the chip into lower clocks
+    other_result = measure_other_configs() if world == 1 else None
 
     for _ in range(args.warmup):
         step()
@@ -202,6 +238,7 @@ def main():
 
     if ntt_result is not None:
         result["ntt"] = ntt_result
+        result["other_configs"] = other_result
     if world == 1:
         # the reduced result of the last step equals a recomputation of the reduction on the main stream
         chk = ev.reduce_sum(Ciphertext(out), stream=main)
