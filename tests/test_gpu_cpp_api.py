@@ -23,17 +23,26 @@ def test_cpp_facade_compiles_and_links():
     assert os.path.exists(build_cpp_test())
 
 
-def build_example():
-    exe = os.path.join(ROOT, "examples", "encrypted_multiply")
+def build_example(name="encrypted_multiply"):
+    exe = os.path.join(ROOT, "examples", name)
     lib = os.path.join(ROOT, "deeppowers_amd")
     subprocess.check_call([
-        "g++", "-O2", "-std=c++17", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "encrypted_multiply.cpp"),
+        "g++", "-O2", "-std=c++17", "-I" + os.path.join(ROOT, "include"), "-I/opt/rocm/include", os.path.join(ROOT, "examples", name + ".cpp"),
         "-o", exe, "-L" + lib, "-ldpfhe_api", "-ldpfhe_hip", "-L/opt/rocm/lib", "-lamdhip64", f"-Wl,-rpath,{lib}", "-Wl,-rpath,/opt/rocm/lib"])
     return exe
 
 
 def test_example_compiles():
-    assert os.path.exists(build_example())
+    assert os.path.exists(build_example()) and os.path.exists(build_example("bench_ct_mul"))
+
+
+@pytest.mark.gpu
+def test_cpp_bench_runs():
+    import json
+    out = subprocess.run([build_example("bench_ct_mul"), "256", "3"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    d = json.loads(out.stdout.strip().splitlines()[-1])
+    assert d["host"] == "c++" and d["value"] > 1e4
 
 
 @pytest.mark.gpu
