@@ -168,6 +168,42 @@ Ciphertext::Ciphertext(const Context& ctx, size_t size, size_t batch, bool is_nt
     if (size != 2 && size != 3) throw Exception(ErrorCode::INVALID_ARGUMENT, "Ciphertext: size must be 2 or 3");
 }
 
+// ---- ScalarMatrix -----------------------------------------------------------------------------------------------------------
+class ScalarMatrix::Impl {
+public:
+    const Context* ctx = nullptr;
+    size_t rows = 0, cols = 0;
+    uint64_t* d = nullptr;
+    ~Impl() {
+        if (d) (void)hipFree(d);
+    }
+};
+ScalarMatrix::ScalarMatrix(const Context& ctx, size_t rows, size_t cols) : impl_(new Impl) {
+    if (rows == 0 || cols == 0) throw Exception(ErrorCode::INVALID_ARGUMENT, "ScalarMatrix: rows and cols must be > 0");
+    impl_->ctx = &ctx; impl_->rows = rows; impl_->cols = cols;
+    hip_check(hipSetDevice(ctx.device_id()), "hipSetDevice");
+    void* p = nullptr;
+    hip_check(hipMalloc(&p, rows * cols * ctx.params().n_limbs() * sizeof(uint64_t)), "hipMalloc");
+    impl_->d = static_cast<uint64_t*>(p);
+}
+ScalarMatrix::~ScalarMatrix() = default;
+size_t ScalarMatrix::rows() const { return impl_->rows; }
+size_t ScalarMatrix::cols() const { return impl_->cols; }
+const uint64_t* ScalarMatrix::data() const { return impl_->d; }
+void ScalarMatrix::set(const int64_t* w) {
+    if (!w) throw Exception(ErrorCode::INVALID_ARGUMENT, "ScalarMatrix::set: null weights");
+    const FheParams& p = impl_->ctx->params();
+    const size_t L = p.n_limbs(), count = impl_->rows * impl_->cols;
+    std::vector<uint64_t> host(count * L);
+    for (size_t i = 0; i < count; ++i)
+        for (size_t l = 0; l < L; ++l) {
+            const uint64_t q = p.moduli[l];
+            const uint64_t m = (uint64_t)(w[i] < 0 ? -(w[i] + 1) : w[i]) % q;            // |w| (two's-complement safe), mod q
+            host[i * L + l] = w[i] >= 0 ? m : (q - 1 - m);                                 // -(m+1) = q - 1 - m
+        }
+    hip_check(hipMemcpy(impl_->d, host.data(), host.size() * sizeof(uint64_t), hipMemcpyHostToDevice), "hipMemcpy H2D");
+}
+
 RelinKeys::RelinKeys(const Context& ctx) : PolyBuffer(ctx, ctx.params().n_limbs(), 2, /*is_ntt=*/true) {}
 GaloisKeys::GaloisKeys(const Context& ctx, uint32_t galois_elt) : PolyBuffer(ctx, ctx.params().n_limbs(), 2, /*is_ntt=*/true), galois_elt_(galois_elt) {
     if (!(galois_elt & 1u) || galois_elt >= 2 * ctx.params().n()) throw Exception(ErrorCode::INVALID_ARGUMENT, "GaloisKeys: galois_elt must be odd and < 2N");
@@ -273,6 +309,12 @@ void Evaluator::matvec_plain(const Plaintext& W, const Ciphertext& x, Ciphertext
     if (x.size() != 2 || y.size() != 2 || cols == 0 || W.batch() != rows * cols) throw Exception(ErrorCode::INVALID_ARGUMENT, "matvec_plain: W batch must be rows*cols, x/y 2-component");
     check(dpfhe_matvec_plain(impl_->h(), y.data(), W.data(), x.data(), rows, cols, s), "dpfhe_matvec_plain");
     y.set_ntt(true);
+}
+void Evaluator::matvec_scalar(const ScalarMatrix& W, const Ciphertext& x, Ciphertext& y, Stream* s) const {
+    if (x.size() != 2 || y.size() != 2 || x.batch() != W.cols() || y.batch() != W.rows())
+        throw Exception(ErrorCode::INVALID_ARGUMENT, "matvec_scalar: x batch = cols, y batch = rows, 2-component ciphertexts");
+    check(dpfhe_matvec_scalar(impl_->h(), y.data(), W.data(), x.data(), W.rows(), W.cols(), s), "dpfhe_matvec_scalar");
+    y.set_ntt(x.is_ntt());
 }
 void Evaluator::reduce_sum(const PolyBuffer& in, PolyBuffer& out, Stream* s) const {
     if (out.batch() != 1 || out.size() != in.size()) throw Exception(ErrorCode::INVALID_ARGUMENT, "reduce_sum: output must be one item of the same size");

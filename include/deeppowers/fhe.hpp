@@ -109,6 +109,23 @@ public:
     explicit Ciphertext(const Context& ctx, size_t size = 2, size_t batch = 1, bool is_ntt = false);
 };
 
+// Plaintext scalar weights of a linear layer: rows x cols integers, stored as one residue per limb ([rows][cols][L]).
+class ScalarMatrix {
+public:
+    ScalarMatrix(const Context& ctx, size_t rows, size_t cols);
+    ~ScalarMatrix();
+    ScalarMatrix(const ScalarMatrix&) = delete;
+    ScalarMatrix& operator=(const ScalarMatrix&) = delete;
+    void set(const int64_t* weights);  // rows*cols signed integers, row-major
+    size_t rows() const;
+    size_t cols() const;
+    const uint64_t* data() const;      // device
+
+private:
+    class Impl;
+    std::unique_ptr<Impl> impl_;
+};
+
 // N1: evaluation keys for relinearisation: L digits x 2 polynomials, NTT domain
 // (evk_j = (-(a_j s) + e_j + g_j s^2, a_j), g_j = CRT basis element of limb j; layout [L][2][L][N]).
 class RelinKeys : public PolyBuffer {
@@ -155,6 +172,10 @@ public:
     void multiply_plain(const Ciphertext& a, const Plaintext& p, Ciphertext& out, Stream* stream = nullptr) const;
     void matvec_plain(const Plaintext& W /* batch = rows*cols */, const Ciphertext& x /* batch = cols */, Ciphertext& y /* batch = rows */,
                       Stream* stream = nullptr) const;
+    // A7, scalar weights: y_i = sum_j w_ij * x_j (either domain; y takes x's domain).  x: batch = cols, y: batch = rows.
+    // With one ciphertext per input feature and one sample per coefficient this IS the encrypted linear layer that
+    // replaces the plaintext matvec sites of the reference (gpt_model.cpp:793,848,883).
+    void matvec_scalar(const ScalarMatrix& W, const Ciphertext& x, Ciphertext& y, Stream* stream = nullptr) const;
     // A8: modular sum over the batch -> one item
     void reduce_sum(const PolyBuffer& in, PolyBuffer& out, Stream* stream = nullptr) const;
 

@@ -33,7 +33,13 @@ def build_example(name="encrypted_multiply"):
 
 
 def test_example_compiles():
-    assert os.path.exists(build_example()) and os.path.exists(build_example("bench_ct_mul"))
+    assert all(os.path.exists(build_example(e)) for e in ("encrypted_multiply", "bench_ct_mul", "encrypted_linear"))
+
+
+@pytest.mark.gpu
+def test_example_encrypted_linear_layer():
+    out = subprocess.run([build_example("encrypted_linear")], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "OK" in out.stdout, out.stdout + out.stderr
 
 
 @pytest.mark.gpu
