@@ -267,9 +267,47 @@ extern "C" int dpfhe_rescale(dpfhe_ctx* c, uint64_t* d_out, const uint64_t* d_in
     const size_t blocks = n_rns_polys * (c->n_limbs - 1) * (size_t)chunks;
     if (blocks > kMaxGrid) return fail(DPFHE_INVALID_ARGUMENT, "dpfhe_rescale", "batch too large for one launch");
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (c->fold) hipLaunchKernelGGL((rescale_kernel<FoldArith>), dim3((unsigned)blocks), dim3(256), 0, s, d_out, d_in, c->foldt.lc, c->d_rescale, (int)c->n_limbs, n, chunks);
-    else hipLaunchKernelGGL((rescale_kernel<ShoupArith>), dim3((unsigned)blocks), dim3(256), 0, s, d_out, d_in, c->shoup.lc, c->d_rescale, (int)c->n_limbs, n, chunks);
+    if (c->fold) hipLaunchKernelGGL((rescale_kernel<FoldArith>), dim3((unsigned)blocks), dim3(256), 0, s, d_out, d_in, (const u64*)nullptr, 0, 0, c->foldt.lc, c->d_rescale, (int)c->n_limbs, n, chunks);
+    else hipLaunchKernelGGL((rescale_kernel<ShoupArith>), dim3((unsigned)blocks), dim3(256), 0, s, d_out, d_in, (const u64*)nullptr, 0, 0, c->shoup.lc, c->d_rescale, (int)c->n_limbs, n, chunks);
     return check_launch("rescale kernel launch");
+}
+
+// hybrid key switching = inner product over all L limbs (relin_kernel MODE 2/3) + divide by the special prime and add (c0, c1)
+static int hybrid_entry(dpfhe_ctx* c, const char* what, int in_comps, uint64_t* d_out2, const uint64_t* d_in, const uint64_t* d_key,
+                        uint64_t* d_work, size_t batch, void* stream) {
+    if (!c) return fail(DPFHE_INVALID_ARGUMENT, what, "null context");
+    if (c->n_limbs < 2) return fail(DPFHE_INVALID_STATE, what, "the extended context needs at least one data limb and the special prime");
+    if (batch == 0) return DPFHE_SUCCESS;
+    if (!d_out2 || !d_in || !d_key || !d_work || misaligned(d_out2) || misaligned(d_in) || misaligned(d_key) || misaligned(d_work))
+        return fail(DPFHE_INVALID_ARGUMENT, what, "null or misaligned buffer");
+    const size_t L = c->n_limbs, Ld = L - 1;
+    const int n = 1 << c->log2n;
+    const size_t blocks = batch * L;
+    if (blocks > kMaxGrid) return fail(DPFHE_INVALID_ARGUMENT, what, "batch too large for one launch");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int mode = in_comps == 3 ? 2 : 3;
+    const int rc = c->fold ? launch_relin<FoldArith>((int)c->log2n, mode, d_work, d_in, d_key, blocks, c->foldt, s)
+                           : launch_relin<ShoupArith>((int)c->log2n, mode, d_work, d_in, d_key, blocks, c->shoup, s);
+    if (rc) return fail(DPFHE_INVALID_STATE, what, "no kernel geometry for this log2_n");
+    int e = check_launch("hybrid key-switch kernel launch");
+    if (e) return e;
+    // divide by P with rounding and add c0 (and c1 for relinearisation): one pass over the 2*batch polynomials of `work`
+    const int chunks = (n + 511) / 512;
+    const size_t rblocks = batch * 2 * Ld * (size_t)chunks;
+    if (rblocks > kMaxGrid) return fail(DPFHE_INVALID_ARGUMENT, what, "batch too large for one launch");
+    const int add_mask = in_comps == 3 ? 3 : 1;
+    if (c->fold) hipLaunchKernelGGL((rescale_kernel<FoldArith>), dim3((unsigned)rblocks), dim3(256), 0, s, d_out2, d_work, d_in, in_comps, add_mask, c->foldt.lc, c->d_rescale, (int)L, n, chunks);
+    else hipLaunchKernelGGL((rescale_kernel<ShoupArith>), dim3((unsigned)rblocks), dim3(256), 0, s, d_out2, d_work, d_in, in_comps, add_mask, c->shoup.lc, c->d_rescale, (int)L, n, chunks);
+    return check_launch("hybrid rescale launch");
+}
+
+extern "C" int dpfhe_relinearize_hybrid(dpfhe_ctx* c, uint64_t* d_out2, const uint64_t* d_in3, const uint64_t* d_key, uint64_t* d_work, size_t batch,
+                                        void* stream) {
+    return hybrid_entry(c, "dpfhe_relinearize_hybrid", 3, d_out2, d_in3, d_key, d_work, batch, stream);
+}
+extern "C" int dpfhe_switch_key_hybrid(dpfhe_ctx* c, uint64_t* d_out2, const uint64_t* d_in2, const uint64_t* d_key, uint64_t* d_work, size_t batch,
+                                       void* stream) {
+    return hybrid_entry(c, "dpfhe_switch_key_hybrid", 2, d_out2, d_in2, d_key, d_work, batch, stream);
 }
 
 extern "C" int dpfhe_apply_galois(dpfhe_ctx* c, uint64_t* d_out, const uint64_t* d_in, size_t n_rns_polys, uint32_t galois_elt, void* stream) {

@@ -402,13 +402,25 @@ public:
     std::unique_ptr<PolyBuffer> s_hat, s2_hat;
 };
 
-SecretKey::SecretKey(const Context& ctx, uint64_t seed) : impl_(new Impl) {
+namespace {
+std::vector<int8_t> sample_ternary(size_t n, uint64_t seed) {
+    SplitMix rng(seed);
+    std::vector<int8_t> s(n);
+    for (auto& v : s) v = (int8_t)((int)rng.below(3) - 1);
+    return s;
+}
+}  // namespace
+
+SecretKey::SecretKey(const Context& ctx, uint64_t seed) : SecretKey(ctx, sample_ternary(ctx.params().n(), seed)) {}
+
+SecretKey::SecretKey(const Context& ctx, const std::vector<int8_t>& coeffs) : impl_(new Impl) {
     impl_->ctx = &ctx;
     const FheParams& p = ctx.params();
     const size_t n = p.n(), L = p.n_limbs();
-    SplitMix rng(seed);
-    impl_->s.resize(n);
-    for (auto& v : impl_->s) v = (int8_t)((int)rng.below(3) - 1);
+    if (coeffs.size() != n) throw Exception(ErrorCode::INVALID_ARGUMENT, "SecretKey: need N ternary coefficients");
+    for (int8_t v : coeffs)
+        if (v < -1 || v > 1) throw Exception(ErrorCode::INVALID_ARGUMENT, "SecretKey: coefficients must be in {-1, 0, 1}");
+    impl_->s = coeffs;
     std::vector<uint64_t> host(L * n);
     for (size_t l = 0; l < L; ++l)
         for (size_t k = 0; k < n; ++k) host[l * n + k] = lift_signed(impl_->s[k], p.moduli[l]);
@@ -444,7 +456,8 @@ const SecretKey& KeyGenerator::secret_key() const { return *impl_->sk; }
 namespace {
 // shared by relinearisation and Galois keys: key_j = (-(a_j s) + e_j + g_j * target, a_j), everything in the NTT domain
 template <class Rng>
-void make_switch_key(const Context& ctx, const SecretKey& sk, Rng& rng, const uint64_t* d_target_ntt, PolyBuffer& out);
+void make_switch_key(const Context& ctx, const SecretKey& sk, Rng& rng, const uint64_t* d_target_ntt, PolyBuffer& out,
+                     size_t n_digits = 0 /* 0 = all limbs */, const uint64_t* d_target_scaled_ntt = nullptr);
 }  // namespace
 
 void KeyGenerator::create_galois_keys(GaloisKeys& out) {
@@ -471,8 +484,10 @@ void KeyGenerator::create_galois_keys(GaloisKeys& out) {
 void KeyGenerator::create_relin_keys(RelinKeys& out) { make_switch_key(*impl_->ctx, *impl_->sk, impl_->rng, impl_->sk->ntt_squared(), out); }
 
 namespace {
+// n_digits < L (hybrid): only the data limbs are digits and d_target_ntt must already carry the factor P.
 template <class Rng>
-void make_switch_key(const Context& ctx, const SecretKey& sk_ref, Rng& rng_ref, const uint64_t* d_target_ntt, PolyBuffer& out) {
+void make_switch_key(const Context& ctx, const SecretKey& sk_ref, Rng& rng_ref, const uint64_t* d_target_ntt, PolyBuffer& out, size_t n_digits,
+                     const uint64_t*) {
     struct { const SecretKey* sk; Rng* rng; } impl_s{&sk_ref, &rng_ref};
     auto* impl_ = &impl_s;
     const FheParams& p = ctx.params();
@@ -480,7 +495,8 @@ void make_switch_key(const Context& ctx, const SecretKey& sk_ref, Rng& rng_ref, 
     dpfhe_ctx* h = static_cast<dpfhe_ctx*>(ctx.handle());
     PolyBuffer a(ctx, 1, 1, true), e(ctx, 1, 1, false), t(ctx, 1, 1, true);
     std::vector<uint64_t> ha(poly), he(poly);
-    for (size_t j = 0; j < L; ++j) {
+    const size_t digits = n_digits ? n_digits : L;
+    for (size_t j = 0; j < digits; ++j) {
         for (size_t l = 0; l < L; ++l)
             for (size_t k = 0; k < n; ++k) ha[l * n + k] = impl_->rng->below(p.moduli[l]);      // uniform: any domain
         for (size_t k = 0; k < n; ++k) {
@@ -622,6 +638,95 @@ void Decryptor::decrypt(const Ciphertext& ct, unsigned log2_scale, int64_t* out)
             out[item * n + k] = neg ? -(int64_t)x[0] : (int64_t)x[0];
         }
     }
+}
+
+// ---- HybridKeySwitcher ---------------------------------------------------------------------------------------------------
+class HybridKeySwitcher::Impl {
+public:
+    const Context* data_ctx = nullptr;
+    std::unique_ptr<Context> ext;
+    std::unique_ptr<SecretKey> sk_ext;
+    std::unique_ptr<PolyBuffer> relin;                       // [Ld][2][L][N]
+    std::vector<std::pair<uint32_t, std::unique_ptr<PolyBuffer>>> galois;
+    SplitMix rng{0};
+    uint64_t p_special = 0;
+
+    // target (NTT domain on ext, all limbs) scaled by P limb-wise: P mod q_i for data limbs, 0 for the P limb
+    void make_key(const uint64_t* d_target_ntt_ext, PolyBuffer& out) {
+        const FheParams& pe = ext->params();
+        const size_t n = pe.n(), L = pe.n_limbs();
+        std::vector<uint64_t> host(L * n);
+        hip_check(hipMemcpy(host.data(), d_target_ntt_ext, L * n * sizeof(uint64_t), hipMemcpyDeviceToHost), "hipMemcpy D2H");
+        for (size_t l = 0; l < L; ++l) {
+            const uint64_t q = pe.moduli[l], f = p_special % q;   // 0 on the special limb itself
+            for (size_t k = 0; k < n; ++k) host[l * n + k] = (uint64_t)((u128)host[l * n + k] * f % q);
+        }
+        PolyBuffer scaled(*ext, 1, 1, true);
+        scaled.copy_from_host(host.data());
+        make_switch_key(*ext, *sk_ext, rng, scaled.data(), out, L - 1, nullptr);
+    }
+};
+
+HybridKeySwitcher::HybridKeySwitcher(const Context& data_ctx, const SecretKey& sk, uint64_t special_prime, uint64_t special_psi, uint64_t seed)
+    : impl_(new Impl) {
+    impl_->data_ctx = &data_ctx;
+    FheParams pe = data_ctx.params();
+    pe.moduli.push_back(special_prime);
+    pe.psi.push_back(special_psi);
+    impl_->ext.reset(new Context(pe, data_ctx.device_id()));
+    impl_->sk_ext.reset(new SecretKey(*impl_->ext, sk.coefficients()));
+    impl_->rng = SplitMix(seed);
+    impl_->p_special = special_prime;
+    impl_->relin.reset(new PolyBuffer(*impl_->ext, pe.n_limbs() - 1, 2, true));
+    impl_->make_key(impl_->sk_ext->ntt_squared(), *impl_->relin);
+}
+HybridKeySwitcher::~HybridKeySwitcher() = default;
+
+void HybridKeySwitcher::add_galois_element(uint32_t g) {
+    const FheParams& pe = impl_->ext->params();
+    const size_t n = pe.n(), L = pe.n_limbs();
+    if (!(g & 1u) || g >= 2 * n) throw Exception(ErrorCode::INVALID_ARGUMENT, "add_galois_element: element must be odd and < 2N");
+    for (auto& kv : impl_->galois) if (kv.first == g) return;
+    const std::vector<int8_t>& s = impl_->sk_ext->coefficients();
+    std::vector<uint64_t> host(L * n, 0);
+    for (size_t i = 0; i < n; ++i) {
+        const size_t idx = (i * (size_t)g) & (2 * n - 1);
+        const int64_t v = idx < n ? s[i] : -s[i];
+        for (size_t l = 0; l < L; ++l) host[l * n + (idx & (n - 1))] = lift_signed(v, pe.moduli[l]);
+    }
+    PolyBuffer target(*impl_->ext, 1, 1, false);
+    target.copy_from_host(host.data());
+    Evaluator ev(*impl_->ext);
+    ev.transform_to_ntt_inplace(target);
+    impl_->ext->synchronize();
+    std::unique_ptr<PolyBuffer> key(new PolyBuffer(*impl_->ext, L - 1, 2, true));
+    impl_->make_key(target.data(), *key);
+    impl_->galois.emplace_back(g, std::move(key));
+}
+
+void HybridKeySwitcher::relinearize(const Ciphertext& in3, Ciphertext& out2, Stream* s) const {
+    if (in3.is_ntt() || in3.size() != 3 || out2.size() != 2 || out2.batch() != in3.batch())
+        throw Exception(ErrorCode::INVALID_ARGUMENT, "HybridKeySwitcher::relinearize: 3-component coefficient-domain input, 2-component output");
+    PolyBuffer work(*impl_->ext, in3.batch(), 2, false);
+    check(dpfhe_relinearize_hybrid(static_cast<dpfhe_ctx*>(impl_->ext->handle()), out2.data(), in3.data(), impl_->relin->data(), work.data(), in3.batch(), s),
+          "dpfhe_relinearize_hybrid");
+    hip_check(hipStreamSynchronize(static_cast<hipStream_t>(s)), "hipStreamSynchronize");   // `work` is freed on return
+    out2.set_ntt(false);
+}
+
+void HybridKeySwitcher::apply_galois(const Ciphertext& in2, uint32_t g, Ciphertext& out2, Stream* s) const {
+    if (in2.is_ntt() || in2.size() != 2 || out2.size() != 2 || out2.batch() != in2.batch())
+        throw Exception(ErrorCode::INVALID_ARGUMENT, "HybridKeySwitcher::apply_galois: 2-component coefficient-domain input and output");
+    const PolyBuffer* key = nullptr;
+    for (auto& kv : impl_->galois) if (kv.first == g) key = kv.second.get();
+    if (!key) throw Exception(ErrorCode::INVALID_STATE, "HybridKeySwitcher::apply_galois: no key for this element (add_galois_element first)");
+    Ciphertext rotated(*impl_->data_ctx, 2, in2.batch());
+    PolyBuffer work(*impl_->ext, in2.batch(), 2, false);
+    check(dpfhe_apply_galois(static_cast<dpfhe_ctx*>(impl_->data_ctx->handle()), rotated.data(), in2.data(), in2.batch() * 2, g, s), "dpfhe_apply_galois");
+    check(dpfhe_switch_key_hybrid(static_cast<dpfhe_ctx*>(impl_->ext->handle()), out2.data(), rotated.data(), key->data(), work.data(), in2.batch(), s),
+          "dpfhe_switch_key_hybrid");
+    hip_check(hipStreamSynchronize(static_cast<hipStream_t>(s)), "hipStreamSynchronize");
+    out2.set_ntt(false);
 }
 
 }  // namespace fhe

@@ -192,6 +192,10 @@ __device__ __forceinline__ u64 canon_any(u64 v, const LimbConst& lc) {  // any v
 // MODE 0: relinearisation - input has 3 components, digits come from c2, both c0 and c1 are added back.
 // MODE 1: key switch after a Galois automorphism (N3) - input has 2 components, digits come from c1, only c0 is added:
 //         (c0', c1') = (c0 + sum_j d_j b_j, sum_j d_j a_j).
+// MODE 2 / 3: the inner product of HYBRID key switching (one special prime P = the context's LAST limb).  The data
+//         lives on the first Ld = L - 1 limbs; the kernel runs for all L limbs (including P), takes the Ld digits from
+//         c2 (MODE 2, 3-component input) or c1 (MODE 3, 2-component input) and writes t = sum_j d_j (.) key_j to a work
+//         buffer [batch][2][L][N] with nothing added back; dpfhe's rescale-add pass then divides by P and adds (c0, c1).
 template <class Arith, int LOGN, int LOGE, int MODE>
 __global__ __launch_bounds__(1 << (LOGN - LOGE), (Arith::kFold ? 2 : 1)) void relin_kernel(u64* __restrict__ out2, const u64* __restrict__ in3,
                                                                        const u64* __restrict__ evk, DevTables<Arith> tb) {
@@ -204,14 +208,16 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE), (Arith::kFold ? 2 : 1)) void re
     const int limb = (int)(blockIdx.x % (unsigned)L);
     const LimbConst lc = tb.lc[limb];
     const InvLast<typename B::Tw> last = tb.last[limb];
-    constexpr int kInComps = MODE == 0 ? 3 : 2;
-    const u64* c2 = in3 + ((bi * kInComps + (kInComps - 1)) * L) * N;   // digit j at + j*N
+    constexpr int kInComps = (MODE == 0 || MODE == 2) ? 3 : 2;
+    constexpr bool kHybrid = MODE >= 2;
+    const int Ld = kHybrid ? L - 1 : L;                                   // limbs of the data (= number of digits)
+    const u64* c2 = in3 + ((bi * kInComps + (kInComps - 1)) * Ld) * N;  // digit j at + j*N
     u64 acc0[E], acc1[E];
 #pragma unroll
     for (int k = 0; k < E; ++k) acc0[k] = acc1[k] = 0;
     int lazy_terms = 0;
 #pragma unroll 1
-    for (int j = 0; j < L; ++j) {
+    for (int j = 0; j < Ld; ++j) {
         asm volatile("" : "+v"(tid));
         u64 x[E];
         B::load_top(tid, x, c2 + (size_t)j * N);
@@ -255,7 +261,7 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE), (Arith::kFold ? 2 : 1)) void re
         u64 x[E];
 #pragma unroll
         for (int k = 0; k < E; ++k) x[k] = c == 0 ? acc0[k] : acc1[k];
-        const bool add_back = (MODE == 0) || (c == 0);
+        const bool add_back = (MODE == 0) || (MODE == 1 && c == 0);
         u64 orig[E];
         if (add_back) B::load_top(tid, orig, in3 + ((bi * kInComps + c) * L + limb) * N);
         __syncthreads();

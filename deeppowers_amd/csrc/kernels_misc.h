@@ -249,9 +249,11 @@ struct RescaleConst {
     u64 h;         // floor(q_last / 2)
 };
 
+// `addend` (optional) is the last step of hybrid key switching: polynomial p = 2*b + comp of the rescaled pair gets
+// component comp of ciphertext b of `addend` ([batch][add_in_comps][L-1][N]) added when bit comp of add_mask is set.
 template <class Arith>
-__global__ __launch_bounds__(256) void rescale_kernel(u64* out, const u64* in, const LimbConst* lcs, const RescaleConst* rcs, int n_limbs, int n,
-                                                      int chunks) {
+__global__ __launch_bounds__(256) void rescale_kernel(u64* out, const u64* in, const u64* addend, int add_in_comps, int add_mask,
+                                                      const LimbConst* lcs, const RescaleConst* rcs, int n_limbs, int n, int chunks) {
     const int Lo = n_limbs - 1;
     const int chunk = (int)(blockIdx.x % chunks);
     const int limb = (int)((blockIdx.x / chunks) % Lo);
@@ -274,6 +276,12 @@ __global__ __launch_bounds__(256) void rescale_kernel(u64* out, const u64* in, c
         const u64 tm = Arith::kFold ? FoldArith::canon(t, lc) : ShoupArith::mul_var(t, 1, lc);
         const u64 d = sub_mod(add_mod(x.b, rc.h_mod, lc.q), tm, lc.q);
         r.b = Arith::mul_var(d, rc.inv, lc);
+    }
+    if (addend && ((add_mask >> (poly & 1)) & 1)) {
+        const size_t ap = (poly >> 1) * (size_t)add_in_comps + (poly & 1);
+        const U64x2 ad = *reinterpret_cast<const U64x2*>(addend + (ap * Lo + limb) * n + w0);
+        r.a = add_mod(r.a, ad.a, lc.q);
+        r.b = add_mod(r.b, ad.b, lc.q);
     }
     *reinterpret_cast<U64x2*>(out + (poly * Lo + limb) * n + w0) = r;
 }

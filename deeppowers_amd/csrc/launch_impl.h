@@ -49,11 +49,15 @@ int launch_ct_mul(int log2n, unsigned flags, u64* out3, const u64* a2, const u64
 
 template <class Arith>
 int launch_relin(int log2n, int mode, u64* out2, const u64* in3, const u64* evk, size_t blocks, const DevTables<Arith>& tb, hipStream_t s) {
-#define RL_CASE(LN, LE)                                                                                                                  \
-    if (mode == 0) hipLaunchKernelGGL((relin_kernel<Arith, LN, 4, 0>), dim3((unsigned)blocks), dim3(Geo<LN, 4>::T), 0, s, out2, in3, evk, tb); \
-    else hipLaunchKernelGGL((relin_kernel<Arith, LN, 4, 1>), dim3((unsigned)blocks), dim3(Geo<LN, 4>::T), 0, s, out2, in3, evk, tb)
+#define RL_ONE(LN, M) hipLaunchKernelGGL((relin_kernel<Arith, LN, 4, M>), dim3((unsigned)blocks), dim3(Geo<LN, 4>::T), 0, s, out2, in3, evk, tb)
+#define RL_CASE(LN, LE)                \
+    if (mode == 0) RL_ONE(LN, 0);      \
+    else if (mode == 1) RL_ONE(LN, 1); \
+    else if (mode == 2) RL_ONE(LN, 2); \
+    else RL_ONE(LN, 3)
     DPFHE_GEO_SWITCH(log2n, RL_CASE)
 #undef RL_CASE
+#undef RL_ONE
     return 0;
 }
 

@@ -256,6 +256,24 @@ class Evaluator:
         _cabi.check(self._lib.dpfhe_relinearize(self.ctx.handle, out.data_ptr(), ct3.data.data_ptr(), evk.data_ptr(), ct3.batch, _stream_ptr(stream)), "dpfhe_relinearize")
         return Ciphertext(out, False)
 
+    def keyswitch_hybrid(self, ct: Ciphertext, key: torch.Tensor, stream=None) -> Ciphertext:
+        """Hybrid key switching; THIS evaluator's context is the extended one (last limb = special prime P) while `ct`
+        lives on the first L-1 limbs.  3 components: relinearisation; 2 components: key switch after an automorphism.
+        key: [L-1][2][L][N] NTT domain, key_j = (-(a_j s) + e_j + P g_j T, a_j)."""
+        p = self.ctx.params
+        L, Ld, n = p.n_limbs, p.n_limbs - 1, p.n
+        d = ct.data
+        if ct.is_ntt or ct.size not in (2, 3) or d.dim() != 4 or d.shape[-2] != Ld or d.shape[-1] != n or d.dtype != torch.int64 or not d.is_contiguous():
+            raise _cabi.DpfheError(2000, "keyswitch_hybrid: coefficient-domain [batch][2|3][L-1][N] ciphertexts on the extended context")
+        if tuple(key.shape) != (Ld, 2, L, n):
+            raise _cabi.DpfheError(2000, "key must be [L-1][2][L][N]")
+        batch = d.shape[0]
+        out = torch.empty(batch, 2, Ld, n, dtype=torch.int64, device=d.device)
+        work = torch.empty(batch, 2, L, n, dtype=torch.int64, device=d.device)
+        fn = self._lib.dpfhe_relinearize_hybrid if ct.size == 3 else self._lib.dpfhe_switch_key_hybrid
+        _cabi.check(fn(self.ctx.handle, out.data_ptr(), d.data_ptr(), key.data_ptr(), work.data_ptr(), batch, _stream_ptr(stream)), "dpfhe_*_hybrid")
+        return Ciphertext(out, False)
+
     def rescale_words(self, t: torch.Tensor, stream=None) -> torch.Tensor:
         """[..., L, N] -> [..., L-1, N]: round(x / q_last) limb by limb (coefficient domain).  The result belongs to the
         context of the first L-1 moduli."""

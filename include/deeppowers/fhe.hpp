@@ -193,6 +193,7 @@ private:
 class SecretKey {
 public:
     SecretKey(const Context& ctx, uint64_t seed);
+    SecretKey(const Context& ctx, const std::vector<int8_t>& ternary_coefficients);  // the same secret on another context
     ~SecretKey();
     SecretKey(const SecretKey&) = delete;
     SecretKey& operator=(const SecretKey&) = delete;
@@ -243,6 +244,26 @@ public:
     // ct: 2 or 3 components, coefficient domain.  messages_out: ct.batch() * N values round(phase / 2^log2_scale);
     // throws RUNTIME_ERROR if a value does not fit 62 bits (wrong scale or noise overflow).
     void decrypt(const Ciphertext& ct, unsigned log2_scale, int64_t* messages_out);
+
+private:
+    class Impl;
+    std::unique_ptr<Impl> impl_;
+};
+
+// Hybrid key switching with one special prime P (SURVEY.md 8f N1 "base extension"): keys live on the extended
+// context (data moduli + P) and the switching noise drops from ~ L N q sigma to ~ L N q sigma / P.
+class HybridKeySwitcher {
+public:
+    // data_ctx: the level the ciphertexts live on; (special_prime, special_psi): one more NTT prime and its 2N-th root
+    HybridKeySwitcher(const Context& data_ctx, const SecretKey& sk, uint64_t special_prime, uint64_t special_psi, uint64_t seed = 3);
+    ~HybridKeySwitcher();
+    HybridKeySwitcher(const HybridKeySwitcher&) = delete;
+    HybridKeySwitcher& operator=(const HybridKeySwitcher&) = delete;
+    void add_galois_element(uint32_t galois_elt);  // generates and keeps the key for sigma_g
+    // 3 -> 2 components, coefficient domain, on data_ctx
+    void relinearize(const Ciphertext& in3, Ciphertext& out2, Stream* stream = nullptr) const;
+    // ciphertext of m(X) -> ciphertext of m(X^g); the element must have been added
+    void apply_galois(const Ciphertext& in2, uint32_t galois_elt, Ciphertext& out2, Stream* stream = nullptr) const;
 
 private:
     class Impl;

@@ -97,6 +97,18 @@ int dpfhe_relinearize(dpfhe_ctx* ctx, uint64_t* d_out2, const uint64_t* d_in3, c
  * The result lives at the next level: use a context created with the first L-1 moduli for further work on it. */
 int dpfhe_rescale(dpfhe_ctx* ctx, uint64_t* d_out, const uint64_t* d_in, size_t n_rns_polys, void* stream);
 
+/* -- N1, hybrid key switching with ONE special prime P: ctx is the EXTENDED context whose last limb is P (L = Ld + 1
+ * limbs); ciphertext data live on the first Ld limbs.  Keys: [Ld digits][2][L][N], NTT domain,
+ *   key_j = (-(a_j s) + e_j + P g_j T, a_j)  over all L limbs (T = s^2 for relinearisation, sigma_g(s) for rotations).
+ * d_work: caller-provided scratch of batch * 2 * L * N words.  Result (coefficient domain, Ld limbs):
+ *   relinearize_hybrid : d_in3 [batch][3][Ld][N] -> d_out2 [batch][2][Ld][N] = (c0, c1) + round(sum_j [c2]_{q_j} key_j / P)
+ *   switch_key_hybrid  : d_in2 [batch][2][Ld][N] -> d_out2 = (c0, 0) + round(sum_j [c1]_{q_j} key_j / P)
+ * The noise added is ~ Ld N q sigma / P instead of ~ Ld N q sigma. */
+int dpfhe_relinearize_hybrid(dpfhe_ctx* ctx_ext, uint64_t* d_out2, const uint64_t* d_in3, const uint64_t* d_key, uint64_t* d_work,
+                             size_t batch, void* stream);
+int dpfhe_switch_key_hybrid(dpfhe_ctx* ctx_ext, uint64_t* d_out2, const uint64_t* d_in2, const uint64_t* d_key, uint64_t* d_work,
+                            size_t batch, void* stream);
+
 /* -- N3: Galois automorphism a(X) -> a(X^galois_elt) (galois_elt odd, < 2N), coefficient domain, d_out != d_in;
  *        and the key switch that follows it:  (c0', c1') = (c0 + sum_j [c1]_{q_j} (.) key_j[0], sum_j [c1]_{q_j} (.) key_j[1]),
  *        key_j = (-(a_j s) + e_j + g_j sigma(s), a_j) in the NTT domain, layout [L][2][L][N] like the relinearisation keys. */

@@ -36,6 +36,7 @@ def _load():
     lib.orc_ct_mul.argtypes = [C.c_void_p, _U64P, _U64P, _U64P, C.c_size_t, C.c_int]
     lib.orc_ct_mul_schoolbook.argtypes = [C.c_void_p, _U64P, _U64P, _U64P, C.c_size_t, C.c_int]
     lib.orc_relinearize.argtypes = [C.c_void_p, _U64P, _U64P, _U64P, C.c_size_t, C.c_int]
+    lib.orc_keyswitch_hybrid.argtypes = [C.c_void_p, _U64P, _U64P, _U64P, C.c_size_t, C.c_int, C.c_int]
     lib.orc_rescale.argtypes = [C.c_void_p, _U64P, _U64P, C.c_size_t]
     lib.orc_apply_galois.argtypes = [C.c_void_p, _U64P, _U64P, C.c_size_t, C.c_uint32]
     lib.orc_switch_key.argtypes = [C.c_void_p, _U64P, _U64P, _U64P, C.c_size_t, C.c_int]
@@ -44,7 +45,7 @@ def _load():
     lib.orc_reduce_sum.argtypes = [C.c_void_p, _U64P, _U64P, C.c_size_t, C.c_size_t]
     lib.orc_fill_splitmix.argtypes = [C.c_void_p, _U64P, C.c_size_t, C.c_uint64]
     for f in ("orc_ctx_destroy", "orc_get_root_powers", "orc_schoolbook_negacyclic", "orc_ntt_fwd", "orc_ntt_inv",
-              "orc_dyadic", "orc_ct_mul", "orc_ct_mul_schoolbook", "orc_relinearize", "orc_matvec_scalar", "orc_apply_galois", "orc_switch_key", "orc_rescale", "orc_matvec_plain", "orc_reduce_sum", "orc_fill_splitmix"):
+              "orc_dyadic", "orc_ct_mul", "orc_ct_mul_schoolbook", "orc_relinearize", "orc_matvec_scalar", "orc_apply_galois", "orc_switch_key", "orc_rescale", "orc_keyswitch_hybrid", "orc_matvec_plain", "orc_reduce_sum", "orc_fill_splitmix"):
         getattr(lib, f).restype = None
     return lib
 
@@ -133,6 +134,14 @@ class Oracle:
         out = np.empty(batch * 2 * self.L * self.n, np.uint64)
         lib().orc_relinearize(self._h, _p(out), _p(np.ascontiguousarray(ct3)), _p(np.ascontiguousarray(evk)), batch, threads)
         return out.reshape(batch, 2, self.L, self.n)
+
+    def keyswitch_hybrid(self, ct, key, in_comps, threads=1):
+        """self is the EXTENDED context (last limb = special prime); ct: [batch][in_comps][L-1][N]."""
+        ct = np.ascontiguousarray(ct)
+        batch = ct.size // (in_comps * (self.L - 1) * self.n)
+        out = np.empty(batch * 2 * (self.L - 1) * self.n, np.uint64)
+        lib().orc_keyswitch_hybrid(self._h, _p(out), _p(ct), _p(np.ascontiguousarray(key)), batch, in_comps, threads)
+        return out.reshape(batch, 2, self.L - 1, self.n)
 
     def rescale(self, x):
         x = np.ascontiguousarray(x)

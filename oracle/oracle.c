@@ -389,6 +389,56 @@ void orc_rescale(const orc_ctx* c, uint64_t* out, const uint64_t* in, size_t n_r
         }
 }
 
+/* Hybrid key switching with one special prime P = last limb of the (extended) context c; data on the first Ld = L-1 limbs.
+ * t = sum_{j<Ld} [digit_j] (.) key_j over all L limbs, then out = round(t / P) (+ c0, and + c1 when in_comps == 3).
+ * in: [batch][in_comps][Ld][N], key: [Ld][2][L][N] (NTT domain), out2: [batch][2][Ld][N].  (GHS / hybrid key switching,
+ * Gentry-Halevi-Smart 2012; RNS form as in Han-Ki 2020 with dnum = Ld.) */
+void orc_keyswitch_hybrid(const orc_ctx* c, uint64_t* out2, const uint64_t* in, const uint64_t* key, size_t batch, int in_comps, int threads) {
+    const size_t n = 1ull << c->log2n, L = c->n_limbs, Ld = L - 1;
+    const uint64_t P = c->limb[Ld].q, h = P / 2;
+    threads = clamp_threads(threads);
+#pragma omp parallel num_threads(threads)
+    {
+        uint64_t* t = malloc((2 * L + 1) * n * sizeof(uint64_t));   /* t[c][i][k] and a digit buffer */
+        uint64_t* d = t + 2 * L * n;
+#pragma omp for schedule(static)
+        for (long long bi = 0; bi < (long long)batch; ++bi) {
+            const uint64_t* digits = in + (((size_t)bi * in_comps + (in_comps - 1)) * Ld) * n;
+            for (size_t i = 0; i < L; ++i) {
+                const orc_limb* T = &c->limb[i];
+                const uint64_t q = T->q;
+                uint64_t *acc0 = t + (0 * L + i) * n, *acc1 = t + (1 * L + i) * n;
+                memset(acc0, 0, n * sizeof(uint64_t)); memset(acc1, 0, n * sizeof(uint64_t));
+                for (size_t j = 0; j < Ld; ++j) {
+                    for (size_t k = 0; k < n; ++k) d[k] = digits[j * n + k] % q;
+                    ntt_fwd_poly(T, d);
+                    const uint64_t* k0 = key + ((j * 2 + 0) * L + i) * n;
+                    const uint64_t* k1 = key + ((j * 2 + 1) * L + i) * n;
+                    for (size_t k = 0; k < n; ++k) {
+                        uint64_t s0 = acc0[k] + mulmod_barrett(d[k], k0[k], T); acc0[k] = s0 - ((s0 >= q) ? q : 0);
+                        uint64_t s1 = acc1[k] + mulmod_barrett(d[k], k1[k], T); acc1[k] = s1 - ((s1 >= q) ? q : 0);
+                    }
+                }
+                ntt_inv_poly(T, acc0); ntt_inv_poly(T, acc1);
+            }
+            for (int comp = 0; comp < 2; ++comp)
+                for (size_t i = 0; i < Ld; ++i) {
+                    const uint64_t q = c->limb[i].q;
+                    const uint64_t inv = powmod(P % q, q - 2, q);
+                    const int add = (in_comps == 3) || (comp == 0);
+                    for (size_t k = 0; k < n; ++k) {
+                        const uint64_t tl = (t[(comp * L + Ld) * n + k] + h) % P;
+                        const uint64_t a = (uint64_t)(((u128)t[(comp * L + i) * n + k] + h % q) % q);
+                        uint64_t r = mulmod_slow((a + q - tl % q) % q, inv, q);
+                        if (add) { r += in[(((size_t)bi * in_comps + comp) * Ld + i) * n + k]; r -= (r >= q) ? q : 0; }
+                        out2[(((size_t)bi * 2 + comp) * Ld + i) * n + k] = r;
+                    }
+                }
+        }
+        free(t);
+    }
+}
+
 /* N3: Galois automorphism a(X) -> a(X^g) on n_rns_polys RNS polynomials (coefficient domain), scatter form:
  * coefficient i goes to index i*g mod 2N, negated when that index is >= N (X^N = -1). */
 void orc_apply_galois(const orc_ctx* c, uint64_t* out, const uint64_t* in, size_t n_rns_polys, uint32_t g) {

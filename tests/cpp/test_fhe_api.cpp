@@ -164,6 +164,29 @@ static void end_to_end(const FheParams& p, size_t batch) {
             }
         CHECK(out == wantg);
     }
+    // hybrid key switching (special prime = the 6th pinned prime): the product decrypts at scale 2^60 already,
+    // a rotation of a FRESH ciphertext at scale 2^30 - impossible with the plain RNS-digit keys above (noise ~2^77)
+    {
+        HybridKeySwitcher hks(ctx, kg.secret_key(), 1152921504606109697ull, /*psi for N=4096:*/ 279138086580908ull);
+        Ciphertext lo1(ctx, 2, batch), lo2(ctx, 2, batch), lo3(ctx, 3, batch), lor(ctx, 2, batch), rot(ctx, 2, batch);
+        enc.encrypt(m1.data(), 30, lo1);
+        enc.encrypt(m2.data(), 30, lo2);
+        ev.multiply(lo1, lo2, lo3);
+        hks.relinearize(lo3, lor);
+        dec.decrypt(lor, 60, out.data());
+        CHECK(out == want);
+        hks.add_galois_element(5);
+        hks.apply_galois(lo1, 5, rot);
+        dec.decrypt(rot, 30, out.data());
+        std::vector<int64_t> wantg(batch * n, 0);
+        for (size_t b = 0; b < batch; ++b)
+            for (size_t i = 0; i < n; ++i) {
+                const size_t idx = (i * 5) & (2 * n - 1);
+                if (idx < n) wantg[b * n + idx] = m1[b * n + i]; else wantg[b * n + idx - n] = -m1[b * n + i];
+            }
+        CHECK(out == wantg);
+    }
+
     // N1 second half: rescale the relinearised product to the next level; the same secret (same seed) decrypts it there
     {
         const FheParams p2 = p.drop_last_limb();

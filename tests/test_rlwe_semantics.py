@@ -361,3 +361,105 @@ def test_rescale_bit_exact_vs_oracle(name):
     got = to_host(Evaluator(ctx).rescale_words(to_device(x, ctx.device)))
     ctx.close()
     assert got.shape == (3, 2, p.n_limbs - 1, p.n) and np.array_equal(got, orc.rescale(x))
+
+
+# ---- N1 hybrid key switching (one special prime) -------------------------------------------------------------------------
+def ext_params(p, special_idx=5):
+    n = p.n
+    P = PRIMES_60[special_idx][0]
+    return FheParams(p.log2_n, p.moduli + (P,), p.psi + (pow(PRIMES_60[special_idx][2], 8192 // n, P),))
+
+
+def keygen_hybrid(rng, p, pe, s, target):
+    """key_j = (-(a_j s) + e_j + P g_j target, a_j) over the limbs of the extended parameter set pe; NTT domain."""
+    n, Ld, L = p.n, p.n_limbs, pe.n_limbs
+    P = pe.moduli[-1]
+    orc = Oracle.from_params(pe)
+    key = np.zeros((Ld, 2, L, n), np.uint64)
+    for j in range(Ld):
+        e = rng.integers(-8, 9, n)
+        for i, q in enumerate(pe.moduli):
+            sq = [int(v) % q for v in s]
+            a = [int(rng.integers(0, 2**62)) % q for _ in range(n)]
+            a_s = po.negacyclic_schoolbook(a, sq, q)
+            extra = [(P % q) * (int(v) % q) % q for v in target] if i == j else [0] * n
+            key[j, 0, i] = [(-a_s[k] + int(e[k]) + extra[k]) % q for k in range(n)]
+            key[j, 1, i] = a
+    return orc.ntt_fwd(key.reshape(-1, L, n)).reshape(key.shape)
+
+
+def run_hybrid_semantic(keyswitch):
+    p = small_params()
+    pe = ext_params(p)
+    rng = np.random.default_rng(31)
+    s = rng.integers(-1, 2, p.n)
+    m1, m2 = rng.integers(0, 1000, p.n), rng.integers(0, 1000, p.n)
+    ct1, _ = encrypt(rng, p, s, m1, 1 << 30)
+    ct2, _ = encrypt(rng, p, s, m2, 1 << 30)
+    ct3 = _oracle_mul(p, ct1, ct2)
+    s2 = negacyclic_int([int(v) for v in s], [int(v) for v in s], 1 << 200)
+    s2 = [v - (1 << 200) if v > (1 << 199) else v for v in s2]
+    key = keygen_hybrid(rng, p, pe, s, s2)
+    out = keyswitch(pe, ct3, key)
+    ph3, Q = phase(p, ct3, s)
+    phr, _ = phase(p, out, s)
+    centre = lambda v: v - Q if v > Q // 2 else v
+    worst = max(abs(centre((a - b) % Q)) for a, b in zip(phr, ph3))
+    assert worst < (1 << 24), worst          # ~ Ld N q sigma / P plus rounding, instead of ~2^77 without the special prime
+    # rotation: key switch from sigma_g(s) to s with the same machinery
+    g = 5
+    key_g = keygen_hybrid(rng, p, pe, s, galois_int([int(v) for v in s], g))
+    rot = Oracle.from_params(p).apply_galois(ct1, g)
+    out_g = keyswitch(pe, rot, key_g)
+    ph1, _ = phase(p, ct1, s)
+    want = galois_int(ph1, g, Q)
+    got, _ = phase(p, out_g, s)
+    assert max(abs(centre((a - b) % Q)) for a, b in zip(got, want)) < (1 << 24)
+
+
+def test_hybrid_key_switching_oracle():
+    run_hybrid_semantic(lambda pe, ct, key: Oracle.from_params(pe).keyswitch_hybrid(ct[None], key, ct.shape[0])[0])
+
+
+@pytest.mark.gpu
+def test_hybrid_key_switching_hip():
+    from deeppowers_amd.evaluator import Ciphertext, Context, Evaluator, to_device, to_host
+
+    def ks(pe, ct, key):
+        ctx = Context(pe, 0)
+        out = to_host(Evaluator(ctx).keyswitch_hybrid(Ciphertext(to_device(ct[None], ctx.device)), to_device(key, ctx.device)).data)[0]
+        ctx.close()
+        return out
+    run_hybrid_semantic(ks)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["n4096", "n8192", "mixed"])
+def test_hybrid_key_switching_bit_exact_vs_oracle(name):
+    from deeppowers_amd.evaluator import Ciphertext, Context, Evaluator, to_device, to_host
+    if name == "mixed":
+        n = 1024
+        def gp(bits):
+            q = (1 << bits) - ((1 << bits) - 1) % (2 * n)
+            while not po.is_prime(q):
+                q -= 2 * n
+            return q
+        qs = (gp(59), gp(50), gp(33), gp(58))
+        pe = FheParams(10, qs, tuple(po.min_primitive_2n_root(n, q) for q in qs))
+    elif name == "n4096":
+        pe = FheParams(12, tuple(x[0] for x in PRIMES_60[:5]), tuple(x[1] for x in PRIMES_60[:5]))   # 4 data limbs + P
+    else:
+        pe = FheParams.n8192_l6()                                                                      # 5 data limbs + P
+    orc = Oracle.from_params(pe)
+    L, Ld, n, batch = pe.n_limbs, pe.n_limbs - 1, pe.n, 3
+    data = Oracle(pe.log2_n, pe.moduli[:-1], pe.psi[:-1])
+    key = orc.fill(Ld * 2, 502).reshape(Ld, 2, L, n)
+    ctx = Context(pe, 0)
+    ev = Evaluator(ctx)
+    for comps in (3, 2):
+        ct = data.fill(batch * comps, 501 + comps).reshape(batch, comps, Ld, n)
+        ct[0, comps - 1] = (np.array(pe.moduli[:-1], np.uint64) - np.uint64(1))[:, None]
+        want = orc.keyswitch_hybrid(ct, key, comps, threads=0)
+        got = to_host(ev.keyswitch_hybrid(Ciphertext(to_device(ct, ctx.device)), to_device(key, ctx.device)).data)
+        assert np.array_equal(got, want), comps
+    ctx.close()
