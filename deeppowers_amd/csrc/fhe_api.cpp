@@ -266,7 +266,7 @@ void Evaluator::multiply(const Ciphertext& a, const Ciphertext& b, Ciphertext& o
     Impl::same(a, b, "multiply");
     if (a.size() != 2) throw Exception(ErrorCode::INVALID_ARGUMENT, "multiply: inputs must be 2-component ciphertexts");
     if (out.size() != 3 || out.batch() != a.batch()) throw Exception(ErrorCode::INVALID_ARGUMENT, "multiply: output must be a 3-component ciphertext of the same batch");
-    const uint32_t flags = (a.is_ntt() ? DPFHE_IN_NTT : 0u) | (out.is_ntt() ? DPFHE_OUT_NTT : 0u);
+    const uint32_t flags = (a.is_ntt() ? (uint32_t)DPFHE_IN_NTT : 0u) | (out.is_ntt() ? (uint32_t)DPFHE_OUT_NTT : 0u);
     check(dpfhe_ct_mul(impl_->h(), out.data(), a.data(), b.data(), a.batch(), flags, s), "dpfhe_ct_mul");
 }
 void Evaluator::relinearize(const Ciphertext& in3, const RelinKeys& keys, Ciphertext& out2, Stream* s) const {
