@@ -81,9 +81,9 @@ extern "C" int dpfhe_ctx_create(dpfhe_ctx** out, uint32_t log2_n, uint32_t n_lim
         if (fold) {
             TwFold* f = reinterpret_cast<TwFold*>(&blob[o_fwd]) + l * n;
             TwFold* v = reinterpret_cast<TwFold*>(&blob[o_inv]) + l * n;
-            for (size_t i = 0; i < n; ++i) { f[i].w = ht[l].rp[i]; v[i].w = ht[l].irp[i]; }
+            for (size_t i = 0; i < n; ++i) { f[i] = h_tw_fold(ht[l].rp[i], moduli[l]); v[i] = h_tw_fold(ht[l].irp[i], moduli[l]); }
             InvLast<TwFold>* s = reinterpret_cast<InvLast<TwFold>*>(&blob[o_last]) + l;
-            s->w_last.w = ht[l].w_last; s->w_ninv.w = ht[l].lc.ninv;
+            s->w_last = h_tw_fold(ht[l].w_last, moduli[l]); s->w_ninv = h_tw_fold(ht[l].lc.ninv, moduli[l]);
         } else {
             TwShoup* f = reinterpret_cast<TwShoup*>(&blob[o_fwd]) + l * n;
             TwShoup* v = reinterpret_cast<TwShoup*>(&blob[o_inv]) + l * n;

@@ -6,10 +6,12 @@
 //   ShoupArith - any prime q < 2^60.  Harvey lazy butterflies with Shoup companions
 //                (w' = floor(w 2^64 / q)):  10 32x32 multiplies per butterfly.
 //   FoldArith  - primes just below 2^60, q = 2^60 - d with d < 2^24 (every prime of SURVEY.md
-//                Appendix A has d < 2^20).  2^60 = d (mod q), so a 124-bit product is folded with
-//                three small multiplies instead of a quotient estimate:  7 multiplies per
-//                butterfly, no companion table, and a 3-instruction partial reduction that lets
-//                butterflies run without per-stage corrections (static bound plans in ntt_core.h).
+//                Appendix A has d < 2^20).  2^60 = d (mod q), so products are folded with small
+//                multiplies instead of a quotient estimate, and a 3-instruction partial reduction
+//                lets butterflies run without per-stage corrections (static bound plans in
+//                ntt_core.h).  Twiddle multiplies use a split companion table (w and w 2^32 mod q in
+//                30-bit halves): 7 v_mad_u64_u32 + 2 cheap ops, every addend a natural 64-bit
+//                register pair.  Variable x variable products (dyadic) use mul60: 7 + 8 ops.
 //
 // Everything is written on 32-bit halves through mad32(a,b,c) = a*b + c, which is exactly one
 // v_mad_u64_u32 on gfx950 (there is no 64x64 vector multiply on CDNA4).
@@ -66,8 +68,10 @@ DPF_HD u64 csub(u64 x, u64 m) {
 struct alignas(16) TwShoup {
     u64 w, wsh;
 };
-struct TwFold {
-    u64 w;
+// FoldArith twiddle.  With w = a + b 2^30 and w 2^32 mod q = a' + b' 2^30 (all four < 2^30):
+//   w  = a  | b  << 32,   ws = a' | b' << 32      (tables.h: h_tw_fold)
+struct alignas(16) TwFold {
+    u64 w, ws;
 };
 
 struct ShoupArith {
@@ -109,7 +113,7 @@ struct FoldArith {
         u64 yl = (u64)(u32)A | ((u64)((u32)B & 0x0fffffffu) << 32);
         return mad32(yh, d, yl);
     }
-    // y*w mod q for y < 15 * 2^60 (every lazily reduced word, see kLimit in ntt_core.h) and w < 2^60.
+    // y*w mod q for y < 15 * 2^60 (kLimit in ntt_core.h: what a transform may hand to a dyadic product) and w < 2^60.
     // The middle column y0 w1 + y1 w0 + carry stays below 2^64 under that bound, so the four partial
     // products chain through the 64-bit addend of v_mad_u64_u32 with no carry fix-up.
     static DPF_HD u64 mul60(u64 y, u64 w, u32 d) {
@@ -133,10 +137,27 @@ struct FoldArith {
         u64 r = mad32(y1, w1, (n >> 32) + (m >> 32));
         return fold124((u32)p, (u32)n, r, d);
     }
-    static DPF_HD u64 mul_tw(u64 y, const Tw& t, const LimbConst& c) { return mul60(y, t.w, (u32)c.d); }
     // any x < 2^64  ->  x mod q representative < 2^60 + 16 d
     static DPF_HD u64 reduce(u64 x, const LimbConst& c) {
         return mad32((u32)(x >> 60), (u32)c.d, x & 0x0fffffffffffffffull);
+    }
+    // y*w mod q for ANY 64-bit y; result < 2^60 + 13 d.
+    //   y w  ==  y0 w + y1 (w 2^32 mod q)  =  L + H 2^30     with  L = y0 a + y1 a',  H = y0 b + y1 b'  (< 2^63)
+    //        ==  L + H.lo 2^30 + H.hi 4d                      (2^62 == 4d)            (< 3 2^62 + 2^57 < 2^64)
+    // Seven chained multiply-adds whose addends are all whole 64-bit results (no {hi,0} pair to build, no
+    // shifts), then the 3-instruction reduce.  mul60 below needs 8 more ALU ops for the same job.
+    static DPF_HD u64 mul_tw(u64 y, const Tw& t, const LimbConst& c) {
+        const u32 y0 = (u32)y, y1 = (u32)(y >> 32);
+        const u32 a = (u32)t.w, b = (u32)(t.w >> 32), as = (u32)t.ws, bs = (u32)(t.ws >> 32);
+        DPFHE_EMU_ASSERT(((a | b | as | bs) >> 30) == 0);
+        const u64 H = mad32(y1, bs, mad32(y0, b, 0));
+        u32 two30 = 1u << 30;
+#if defined(__HIP_DEVICE_COMPILE__)
+        asm("s_mov_b32 %0, 0x40000000" : "=s"(two30));  // opaque: hipcc would turn H.lo * 2^30 into shift + zero-extend + add
+#endif
+        const u64 L = mad32(y1, as, mad32(y0, a, mad32((u32)H, two30, 0)));
+        const u64 R = mad32((u32)(H >> 32), 4 * (u32)c.d, L);
+        return reduce(R, c);
     }
     static DPF_HD u64 canon(u64 x, const LimbConst& c) { return csub(reduce(x, c), c.q); }
     // a*b mod q, canonical; a < 2^64, b < 2^60

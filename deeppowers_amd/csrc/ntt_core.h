@@ -104,12 +104,15 @@ DPF_HD int tid_high(int c, int tid) { return (c + G::LOGE >= G::LOGN) ? 0 : (tid
 
 // ------------------------------------------------------------------------------------------------
 // static bound plans (FoldArith).  Bounds are in units of q/1024.  A value with bound B is < B q/1024.
-// All data words stay below 15 q (kLimit).
+// FoldArith::mul_tw takes any 64-bit word, so inside a transform a word only has to fit (kWord); words that
+// leave a transform unreduced feed FoldArith::mul60 and stay below 15 q (kLimit).
 // ------------------------------------------------------------------------------------------------
 constexpr int kUnit = 1024;
 constexpr int kMulB = kUnit + 9;    // mul60 output  < q + 2^53           (q > 2^59.99)
 constexpr int kRedB = kUnit + 1;    // reduce output < 2^60 + 16d
-constexpr int kLimit = 15 * kUnit;  // every word < 15 q < 15 * 2^60: the precondition of FoldArith::mul60
+constexpr int kTwB = kRedB;         // mul_tw output < 2^60 + 13d
+constexpr int kWord = 16 * kUnit;   // 16 q < 2^64: a lazy sum must not wrap
+constexpr int kLimit = 15 * kUnit;  // < 15 q < 15 * 2^60: the precondition of FoldArith::mul60's first operand
 
 template <int LOGE>
 struct GsPlan {  // one Gentleman-Sande phase on E local elements, up to LOGE stages
@@ -132,15 +135,15 @@ constexpr GsPlan<LOGE> make_gs_plan(int lb0, int r, int in_bound, int out_bound,
             if (k & bit) continue;
             int bx = bnd[k], by = bnd[k | bit];
             int offq = (by + kUnit - 1) / kUnit;
-            if (bx + by > kLimit || bx + offq * kUnit > kLimit) {
+            if (bx + by > kWord || bx + offq * kUnit > kWord) {
                 if (bx > kRedB) { p.red[u][k] = true; bx = kRedB; }
                 if (by > kRedB) { p.red[u][k | bit] = true; by = kRedB; }
                 offq = (by + kUnit - 1) / kUnit;
             }
             p.off[u][k] = offq;
             const bool final_stage = last_all_mul && (u == r - 1);
-            bnd[k] = final_stage ? kMulB : bx + by;   // last inverse stage multiplies x' by N^-1 too
-            bnd[k | bit] = kMulB;
+            bnd[k] = final_stage ? kTwB : bx + by;   // last inverse stage multiplies x' by N^-1 too
+            bnd[k | bit] = kTwB;
         }
     }
     for (int k = 0; k < E; ++k) {
@@ -159,7 +162,7 @@ constexpr CtPlan make_ct_plan(int logn, int in_bound) {
     CtPlan p{};
     int b = in_bound;
     for (int s = 0; s < logn; ++s) {
-        if (b + 2 * kUnit > kLimit) { p.red[s] = true; b = kRedB; }
+        if (b + 2 * kUnit > kWord) { p.red[s] = true; b = kRedB; }
         b += 2 * kUnit;   // x' = x + t, y' = x - t + 2q with t < 2q
     }
     p.out_bound = b;

@@ -26,6 +26,12 @@ inline u32 h_brv(u32 x, int bits) {
     return r;
 }
 
+// FoldArith twiddle of w: w and w 2^32 mod q, each split into 30-bit halves (modarith.h TwFold)
+inline TwFold h_tw_fold(u64 w, u64 q) {
+    const u64 ws = (u64)(((u128)w << 32) % q), m30 = (1ull << 30) - 1;
+    return TwFold{(w & m30) | ((w >> 30) << 32), (ws & m30) | ((ws >> 30) << 32)};
+}
+
 // q = 2^60 - d with d < 2^24: eligible for FoldArith
 inline bool fold_eligible(u64 q) { return q < (1ull << 60) && ((1ull << 60) - q) < (1ull << 24); }
 

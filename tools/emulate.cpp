@@ -17,20 +17,20 @@ extern "C" long emu_overflows() { return g_emu_overflows; }
 
 template <class Arith> struct TwTab;
 template <> struct TwTab<ShoupArith> {
-    static std::vector<TwShoup> make(const std::vector<u64>& w, const std::vector<u64>& sh) {
+    static std::vector<TwShoup> make(const std::vector<u64>& w, const std::vector<u64>& sh, u64) {
         std::vector<TwShoup> v(w.size());
         for (size_t i = 0; i < w.size(); ++i) v[i] = TwShoup{w[i], sh[i]};
         return v;
     }
-    static TwShoup one(u64 w, u64 sh) { return TwShoup{w, sh}; }
+    static TwShoup one(u64 w, u64 sh, u64) { return TwShoup{w, sh}; }
 };
 template <> struct TwTab<FoldArith> {
-    static std::vector<TwFold> make(const std::vector<u64>& w, const std::vector<u64>&) {
+    static std::vector<TwFold> make(const std::vector<u64>& w, const std::vector<u64>&, u64 q) {
         std::vector<TwFold> v(w.size());
-        for (size_t i = 0; i < w.size(); ++i) v[i] = TwFold{w[i]};
+        for (size_t i = 0; i < w.size(); ++i) v[i] = h_tw_fold(w[i], q);
         return v;
     }
-    static TwFold one(u64 w, u64) { return TwFold{w}; }
+    static TwFold one(u64 w, u64, u64 q) { return h_tw_fold(w, q); }
 };
 
 template <class B, int P>
@@ -73,13 +73,13 @@ static int emu(int inverse, u64 q, u64 psi, const u64* in, u64* out) {
     std::vector<u64> regs((size_t)T * E), lds(B::G::lds_words(), 0xDEADBEEFDEADBEEFull);
     auto X = [&](int tid) -> u64(&)[E] { return *reinterpret_cast<u64(*)[E]>(&regs[(size_t)tid * E]); };
     if (!inverse) {
-        auto tw = TwTab<Arith>::make(t.rp, t.rp_sh);
+        auto tw = TwTab<Arith>::make(t.rp, t.rp_sh, q);
         for (int tid = 0; tid < T; ++tid) B::load_top(tid, X(tid), in);
         FwdSteps<B, 0>::run(regs, lds, tw.data(), t.lc);
         for (int tid = 0; tid < T; ++tid) { B::fwd_canon(X(tid), t.lc); B::store_bot(tid, X(tid), out); }
     } else {
-        auto tw = TwTab<Arith>::make(t.irp, t.irp_sh);
-        auto wl = TwTab<Arith>::one(t.w_last, t.w_last_sh), wn = TwTab<Arith>::one(t.lc.ninv, t.lc.ninv_sh);
+        auto tw = TwTab<Arith>::make(t.irp, t.irp_sh, q);
+        auto wl = TwTab<Arith>::one(t.w_last, t.w_last_sh, q), wn = TwTab<Arith>::one(t.lc.ninv, t.lc.ninv_sh, q);
         for (int tid = 0; tid < T; ++tid) B::load_bot(tid, X(tid), in);
         InvSteps<B, B::NPH - 1, kUnit>::run(regs, lds, tw.data(), wl, wn, t.lc);
         for (int tid = 0; tid < T; ++tid) { B::inv_canon(X(tid), t.lc); B::store_top(tid, X(tid), out); }

@@ -6,6 +6,10 @@ import sys
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import deeppowers_amd._cabi as _cabi  # noqa: E402
+
+if os.environ.get("DPFHE_AB_LIB"):  # A/B experiments: time another build of the library (tool only)
+    _cabi.LIB_PATH = os.path.abspath(os.environ["DPFHE_AB_LIB"])
 from deeppowers_amd.evaluator import Ciphertext, Context, Evaluator  # noqa: E402
 from deeppowers_amd.params import FheParams  # noqa: E402
 

@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "../deeppowers_amd/csrc/modarith.h"
+#include "../deeppowers_amd/csrc/tables.h"
 
 using namespace dpfhe;
 
@@ -117,6 +118,14 @@ static void run_rate(int n_cu, double clk_ghz_nominal) {
 // ---------------------------------------------------------------------------------------------------
 // 2. register-only butterfly throughput: radix-16 network (32 butterflies) on 16 words, repeated
 // ---------------------------------------------------------------------------------------------------
+// the twiddle multiply FoldArith used before the split-twiddle form (kept as the comparison point): mul60 on a plain
+// 60-bit twiddle, 7 v_mad_u64_u32 + 3 v_mov + 3 v_alignbit + 2 v_and per product
+struct Mul60Arith {
+    struct Tw { u64 w; };
+    static constexpr bool kFold = true;
+    static DPF_HD u64 mul_tw(u64 y, const Tw& t, const LimbConst& c) { return FoldArith::mul60(y, t.w, (u32)c.d); }
+};
+
 template <class Arith>
 __global__ __launch_bounds__(256) void bfly_kernel(u64* out, const typename Arith::Tw* tw, LimbConst lc, int iters) {
     u64 x[16];
@@ -160,6 +169,10 @@ static void run_bfly(const char* name, int n_cu, int blocks_per_cu) {
         std::memset(&tw[i], 0, sizeof(tw[i]));
         tw[i].w = w;
         if (!Arith::kFold) reinterpret_cast<u64*>(&tw[i])[1] = (u64)(((unsigned __int128)w << 64) / lc.q);
+        if (sizeof(tw[i]) == 16 && Arith::kFold) {
+            const TwFold t = h_tw_fold(w, lc.q);
+            std::memcpy(&tw[i], &t, 16);
+        }
     }
     HIPCHECK(hipMalloc(&d_tw, tw.size() * sizeof(tw[0])));
     HIPCHECK(hipMemcpy(d_tw, tw.data(), tw.size() * sizeof(tw[0]), hipMemcpyHostToDevice));
@@ -226,7 +239,32 @@ static void run_copy(const char* name) {
     HIPCHECK(hipFree(d_in)); HIPCHECK(hipFree(d_out));
 }
 
-int main() {
+static int selftest_mul_tw() {  // host check of FoldArith::mul_tw against __int128 (any 64-bit y)
+    LimbConst lc{};
+    lc.q = 1152921504606830593ull; lc.d = (1ull << 60) - lc.q;
+    u64 s = 12345; int bad = 0;
+    auto next = [&]() { s += 0x9E3779B97F4A7C15ull; u64 z = s; z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; return z ^ (z >> 31); };
+    for (int i = 0; i < 2000000; ++i) {
+        u64 y = next(), w = next() % lc.q;
+        if (i % 7 == 0) y = ~0ull - (i & 15);
+        if (i % 11 == 0) w = lc.q - 1 - (i & 3);
+        const u64 r = FoldArith::mul_tw(y, h_tw_fold(w, lc.q), lc);
+        const u64 ref = (u64)(((unsigned __int128)y * w) % lc.q);
+        if (r % lc.q != ref || r >= (1ull << 60) + 16 * lc.d) ++bad;
+    }
+    std::printf("FoldArith::mul_tw host selftest: %d mismatches / 2000000\n", bad);
+    return bad;
+}
+
+int main(int argc, char** argv) {
+    if (selftest_mul_tw()) return 1;
+    if (argc > 1 && !std::strcmp(argv[1], "bfly")) {
+        hipDeviceProp_t pp;
+        HIPCHECK(hipGetDeviceProperties(&pp, 0));
+        const int n = pp.multiProcessorCount;
+        run_bfly<FoldArith>("fold", n, 4); run_bfly<FoldArith>("fold", n, 8); run_bfly<Mul60Arith>("mul60", n, 4); run_bfly<Mul60Arith>("mul60", n, 8);
+        return 0;
+    }
     hipDeviceProp_t p;
     HIPCHECK(hipGetDeviceProperties(&p, 0));
     const double ghz = p.clockRate / 1e6;
@@ -241,7 +279,7 @@ int main() {
     run_rate<LSHR_B64>(n_cu, ghz); run_rate<LSHL_B64>(n_cu, ghz); run_rate<PK_MOV_B32>(n_cu, ghz); run_rate<BFI_B32>(n_cu, ghz); run_rate<PERM_B32>(n_cu, ghz);
     run_rate<LSHL_OR_B32>(n_cu, ghz); run_rate<NOT_B32>(n_cu, ghz); run_rate<SUB_U32>(n_cu, ghz);
     std::printf("--- register-only butterflies ---\n");
-    run_bfly<FoldArith>("fold", n_cu, 4); run_bfly<FoldArith>("fold", n_cu, 8); run_bfly<ShoupArith>("shoup", n_cu, 4); run_bfly<ShoupArith>("shoup", n_cu, 8);
+    run_bfly<FoldArith>("fold", n_cu, 4); run_bfly<FoldArith>("fold", n_cu, 8); run_bfly<Mul60Arith>("mul60", n_cu, 4); run_bfly<Mul60Arith>("mul60", n_cu, 8); run_bfly<ShoupArith>("shoup", n_cu, 4); run_bfly<ShoupArith>("shoup", n_cu, 8);
     std::printf("--- HBM copy ---\n");
     run_copy<0>("8B col loads + 16B row stores"); run_copy<1>("16B coalesced");
     return 0;
