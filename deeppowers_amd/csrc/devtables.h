@@ -10,10 +10,15 @@ struct InvLast {  // per limb: last inverse stage twiddles with N^-1 folded in
     Tw w_ninv;    // N^-1
 };
 
+// Twiddle tables are stored in the layout of the kernel geometry that reads them (tables.h permute_window0):
+// fwd/inv for the batched NTT kernels (launch.h ntt_loge), fwd4/inv4 for the fused kernels, which always run 16
+// words per thread.  The two coincide unless the NTT geometry is not LOGE = 4 (N = 8192).
 template <class Arith>
 struct DevTables {
     const typename Arith::Tw* fwd;          // [L][N]  psi^brv(i)
     const typename Arith::Tw* inv;          // [L][N]  psi^-brv(i)
+    const typename Arith::Tw* fwd4;
+    const typename Arith::Tw* inv4;
     const InvLast<typename Arith::Tw>* last;  // [L]
     const LimbConst* lc;                    // [L]
     int n_limbs;

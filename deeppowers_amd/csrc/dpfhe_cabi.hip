@@ -18,6 +18,7 @@
 #include "../../include/dpfhe.h"
 #include "kernels_misc.h"
 #include "launch.h"
+#include "ntt_core.h"
 #include "tables.h"
 
 using namespace dpfhe;
@@ -70,27 +71,40 @@ extern "C" int dpfhe_ctx_create(dpfhe_ctx** out, uint32_t log2_n, uint32_t n_lim
     if (!c) return fail(DPFHE_OUT_OF_MEMORY, "dpfhe_ctx_create", "host allocation");
     c->log2n = log2_n; c->n_limbs = n_limbs; c->device = device_id; c->fold = fold;
 
-    // blob layout (all 256-byte aligned sections)
+    // blob layout (all 256-byte aligned sections).  One twiddle table pair per kernel geometry in use: slot 0 = the
+    // fused kernels' LOGE 4 layout, slot 1 = the batched NTT kernels' layout when that differs (N = 8192).
     auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
     const size_t tw_sz = fold ? sizeof(TwFold) : sizeof(TwShoup);
-    const size_t o_lc = 0, o_fwd = up(o_lc + L * sizeof(LimbConst)), o_inv = up(o_fwd + L * n * tw_sz),
-                 o_last = up(o_inv + L * n * tw_sz), o_resc = up(o_last + L * 2 * tw_sz), total = up(o_resc + L * sizeof(RescaleConst));
+    const int loge_ntt = ntt_loge((int)log2_n);
+    const bool two_geo = loge_ntt != kFusedLoge;
+    const size_t tab = L * n * tw_sz;
+    const size_t o_lc = 0, o_fwd4 = up(o_lc + L * sizeof(LimbConst)), o_inv4 = up(o_fwd4 + tab),
+                 o_fwd = two_geo ? up(o_inv4 + tab) : o_fwd4, o_inv = two_geo ? up(o_fwd + tab) : o_inv4,
+                 o_last = up(o_inv + tab), o_resc = up(o_last + L * 2 * tw_sz), total = up(o_resc + L * sizeof(RescaleConst));
     std::vector<unsigned char> blob(total, 0);
+    auto put = [&](size_t off, size_t l, const auto& v) { std::memcpy(&blob[off + l * n * tw_sz], v.data(), n * tw_sz); };
     for (size_t l = 0; l < L; ++l) {
         std::memcpy(&blob[o_lc + l * sizeof(LimbConst)], &ht[l].lc, sizeof(LimbConst));
-        if (fold) {
-            TwFold* f = reinterpret_cast<TwFold*>(&blob[o_fwd]) + l * n;
-            TwFold* v = reinterpret_cast<TwFold*>(&blob[o_inv]) + l * n;
-            for (size_t i = 0; i < n; ++i) { f[i] = h_tw_fold(ht[l].rp[i], moduli[l]); v[i] = h_tw_fold(ht[l].irp[i], moduli[l]); }
-            InvLast<TwFold>* s = reinterpret_cast<InvLast<TwFold>*>(&blob[o_last]) + l;
-            s->w_last = h_tw_fold(ht[l].w_last, moduli[l]); s->w_ninv = h_tw_fold(ht[l].lc.ninv, moduli[l]);
-        } else {
-            TwShoup* f = reinterpret_cast<TwShoup*>(&blob[o_fwd]) + l * n;
-            TwShoup* v = reinterpret_cast<TwShoup*>(&blob[o_inv]) + l * n;
-            for (size_t i = 0; i < n; ++i) {
-                f[i].w = ht[l].rp[i]; f[i].wsh = ht[l].rp_sh[i];
-                v[i].w = ht[l].irp[i]; v[i].wsh = ht[l].irp_sh[i];
+        const u64 q = moduli[l];
+        for (int geo = 0; geo < (two_geo ? 2 : 1); ++geo) {
+            const int loge = geo ? loge_ntt : kFusedLoge, perm = geo_perm_stages((int)log2_n, loge);
+            const size_t of = geo ? o_fwd : o_fwd4, ov = geo ? o_inv : o_inv4;
+            if (fold) {
+                std::vector<TwFold> f(n), v(n);
+                for (size_t i = 0; i < n; ++i) { f[i] = h_tw_fold(ht[l].rp[i], q); v[i] = h_tw_fold(ht[l].irp[i], q); }
+                permute_window0(f, (int)log2_n, loge, perm); permute_window0(v, (int)log2_n, loge, perm);
+                put(of, l, f); put(ov, l, v);
+            } else {
+                std::vector<TwShoup> f(n), v(n);
+                for (size_t i = 0; i < n; ++i) { f[i] = TwShoup{ht[l].rp[i], ht[l].rp_sh[i]}; v[i] = TwShoup{ht[l].irp[i], ht[l].irp_sh[i]}; }
+                permute_window0(f, (int)log2_n, loge, perm); permute_window0(v, (int)log2_n, loge, perm);
+                put(of, l, f); put(ov, l, v);
             }
+        }
+        if (fold) {
+            InvLast<TwFold>* s = reinterpret_cast<InvLast<TwFold>*>(&blob[o_last]) + l;
+            s->w_last = h_tw_fold(ht[l].w_last, q); s->w_ninv = h_tw_fold(ht[l].lc.ninv, q);
+        } else {
             InvLast<TwShoup>* s = reinterpret_cast<InvLast<TwShoup>*>(&blob[o_last]) + l;
             s->w_last.w = ht[l].w_last; s->w_last.wsh = ht[l].w_last_sh;
             s->w_ninv.w = ht[l].lc.ninv; s->w_ninv.wsh = ht[l].lc.ninv_sh;
@@ -118,12 +132,16 @@ extern "C" int dpfhe_ctx_create(dpfhe_ctx** out, uint32_t log2_n, uint32_t n_lim
         c->foldt.lc = reinterpret_cast<const LimbConst*>(d + o_lc);
         c->foldt.fwd = reinterpret_cast<const TwFold*>(d + o_fwd);
         c->foldt.inv = reinterpret_cast<const TwFold*>(d + o_inv);
+        c->foldt.fwd4 = reinterpret_cast<const TwFold*>(d + o_fwd4);
+        c->foldt.inv4 = reinterpret_cast<const TwFold*>(d + o_inv4);
         c->foldt.last = reinterpret_cast<const InvLast<TwFold>*>(d + o_last);
         c->foldt.n_limbs = (int)n_limbs;
     } else {
         c->shoup.lc = reinterpret_cast<const LimbConst*>(d + o_lc);
         c->shoup.fwd = reinterpret_cast<const TwShoup*>(d + o_fwd);
         c->shoup.inv = reinterpret_cast<const TwShoup*>(d + o_inv);
+        c->shoup.fwd4 = reinterpret_cast<const TwShoup*>(d + o_fwd4);
+        c->shoup.inv4 = reinterpret_cast<const TwShoup*>(d + o_inv4);
         c->shoup.last = reinterpret_cast<const InvLast<TwShoup>*>(d + o_last);
         c->shoup.n_limbs = (int)n_limbs;
     }

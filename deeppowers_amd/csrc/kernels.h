@@ -117,6 +117,7 @@ template <class Arith, int LOGN, int LOGE, bool IN_NTT, bool OUT_NTT>
 __global__ __launch_bounds__(1 << (LOGN - LOGE), 2) void ct_mul_kernel(u64* __restrict__ out3, const u64* __restrict__ a2,
                                                                         const u64* __restrict__ b2, DevTables<Arith> tb) {
     typedef NttBody<Arith, LOGN, LOGE> B;
+    static_assert(LOGE == 4, "the fused kernels read the LOGE = 4 twiddle layout (DevTables::fwd4 / inv4)");
     constexpr int E = B::E, N = B::G::N;
     __shared__ __attribute__((aligned(16))) u64 lds[(IN_NTT && OUT_NTT) ? 16 : B::G::lds_words()];
     int tid = threadIdx.x;
@@ -149,7 +150,7 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE), 2) void ct_mul_kernel(u64* __re
             } else {
                 B::load_top(tid, x, src);
                 if (step > 0) lds_barrier();  // the previous transform's last exchange is fully read
-                FwdChain<B, 0>::run(tid, x, lds, tb.fwd + (size_t)limb * N, lc);
+                FwdChain<B, 0>::run(tid, x, lds, tb.fwd4 + (size_t)limb * N, lc);
                 if (step == 1 || step == 3 || !Arith::kFold) B::fwd_canon(x, lc);  // b-side operands < 2^60 for mul60
             }
             if (step == 0) {
@@ -192,7 +193,7 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE), 2) void ct_mul_kernel(u64* __re
                 B::store_bot(tid, x, d);
             } else {
                 if (!IN_NTT || step > 2) lds_barrier();
-                InvChain<B, B::NPH - 1, kInvIn>::run(tid, x, lds, tb.inv + (size_t)limb * N, last, lc);
+                InvChain<B, B::NPH - 1, kInvIn>::run(tid, x, lds, tb.inv4 + (size_t)limb * N, last, lc);
                 B::inv_canon(x, lc);
                 B::store_top(tid, x, d);
             }
@@ -225,6 +226,7 @@ template <class Arith, int LOGN, int LOGE, int MODE>
 __global__ __launch_bounds__(1 << (LOGN - LOGE), (Arith::kFold ? 2 : 1)) void relin_kernel(u64* __restrict__ out2, const u64* __restrict__ in3,
                                                                        const u64* __restrict__ evk, DevTables<Arith> tb) {
     typedef NttBody<Arith, LOGN, LOGE> B;
+    static_assert(LOGE == 4, "the fused kernels read the LOGE = 4 twiddle layout (DevTables::fwd4 / inv4)");
     constexpr int E = B::E, N = B::G::N;
     __shared__ __attribute__((aligned(16))) u64 lds[B::G::lds_words()];
     int tid = threadIdx.x;
@@ -249,7 +251,7 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE), (Arith::kFold ? 2 : 1)) void re
 #pragma unroll
         for (int k = 0; k < E; ++k) x[k] = canon_any<Arith>(x[k], lc);   // [c2]_{q_j} mod q_i
         if (j > 0) lds_barrier();
-        FwdChain<B, 0>::run(tid, x, lds, tb.fwd + (size_t)limb * N, lc);
+        FwdChain<B, 0>::run(tid, x, lds, tb.fwd4 + (size_t)limb * N, lc);
         const u64* k0 = evk + (((size_t)j * 2 + 0) * L + limb) * N;      // key polynomials, NTT domain (window-0 mapping)
         const u64* k1 = evk + (((size_t)j * 2 + 1) * L + limb) * N;
         if (Arith::kFold) {
@@ -293,7 +295,7 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE), (Arith::kFold ? 2 : 1)) void re
         u64 orig[E];
         if (add_back && kPrefetch) B::load_top(tid, orig, in3 + ((bi * kInComps + c) * L + limb) * N);
         lds_barrier();
-        InvChain<B, B::NPH - 1, kInvIn>::run(tid, x, lds, tb.inv + (size_t)limb * N, last, lc);
+        InvChain<B, B::NPH - 1, kInvIn>::run(tid, x, lds, tb.inv4 + (size_t)limb * N, last, lc);
         if (add_back && !kPrefetch) B::load_top(tid, orig, in3 + ((bi * kInComps + c) * L + limb) * N);
         B::inv_canon(x, lc);
         if (add_back) {

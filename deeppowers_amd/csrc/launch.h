@@ -7,6 +7,10 @@
 
 namespace dpfhe {
 
+// words-per-thread exponent of the batched NTT kernels (launch_impl.h DPFHE_GEO_SWITCH); the fused kernels use 4
+constexpr int ntt_loge(int log2n) { return log2n == 13 ? 5 : 4; }
+constexpr int kFusedLoge = 4;
+
 // return 0, or -1 when log2n has no compiled geometry.  Launch errors are left in hipGetLastError().
 template <class Arith>
 int launch_ntt(int log2n, bool inverse, u64* out, const u64* in, size_t npolys, const DevTables<Arith>& tb, hipStream_t s);

@@ -40,26 +40,34 @@ struct Phase {
     int r;   // number of radix-2 stages
 };
 
+// forward phase p of geometry (logn, loge) handles bits [b, b+r) going DOWN from the top; balanced split of logn
+constexpr int geo_nph(int logn, int loge) { return (logn + loge - 1) / loge; }
+constexpr Phase geo_phase(int logn, int loge, int p) {
+    int rem = logn, top = logn, r = 0;
+    for (int i = 0; i <= p; ++i) {
+        int left = geo_nph(logn, loge) - i;
+        r = (rem + left - 1) / left;
+        top = rem;
+        rem -= r;
+    }
+    int b = top - r;
+    int c = b < (logn - loge) ? b : (logn - loge);
+    return Phase{c, b, r};
+}
+// stages (bit positions [0, n)) of the window-0 phase whose twiddle-table section is stored transposed (tw_index)
+constexpr int geo_perm_stages(int logn, int loge) {
+    return geo_nph(logn, loge) >= 2 ? geo_phase(logn, loge, geo_nph(logn, loge) - 1).r : 0;
+}
+
 template <int LOGN_, int LOGE_>
 struct Geo {
     static constexpr int LOGN = LOGN_, LOGE = LOGE_;
     static constexpr int N = 1 << LOGN, E = 1 << LOGE, T = N / E;
-    static constexpr int NPH = (LOGN + LOGE - 1) / LOGE;
+    static constexpr int NPH = geo_nph(LOGN, LOGE);
     static_assert(LOGN >= LOGE && LOGE >= 1, "bad geometry");
 
-    // forward phase p handles bits [b, b+r) going DOWN from the top; balanced split of LOGN
-    static constexpr Phase phase(int p) {
-        int rem = LOGN, top = LOGN, r = 0;
-        for (int i = 0; i <= p; ++i) {
-            int left = NPH - i;
-            r = (rem + left - 1) / left;
-            top = rem;
-            rem -= r;
-        }
-        int b = top - r;
-        int c = b < (LOGN - LOGE) ? b : (LOGN - LOGE);
-        return Phase{c, b, r};
-    }
+    static constexpr Phase phase(int p) { return geo_phase(LOGN, LOGE, p); }
+    static constexpr int kPermStages = geo_perm_stages(LOGN, LOGE);
     // coefficient index of local element k of thread tid in a phase with window start c
     static DPF_HD int index(int c, int tid, int k) {
         return ((tid >> c) << (c + LOGE)) | (k << c) | (tid & ((1 << c) - 1));
@@ -92,11 +100,25 @@ struct Geo {
 
 // twiddle table index of the butterfly whose lower element is local k, at global bit position `pos`
 // (distance 2^pos): table[(N >> (pos+1)) + (j >> (pos+1))], split into thread part + constant part.
+// In the window-0 phase a thread needs 2^(LOGE-1-pos) consecutive entries per stage, so one wave-wide fetch would
+// touch up to 64 different 128-byte lines; the device tables are therefore stored with those stages transposed
+// ([entry-of-thread][thread], tables.h permute_window0) and every fetch is lane-contiguous.
+// The index is split into a workgroup-uniform part and a per-thread part so that the fetch uses the scalar-base +
+// 32-bit-lane-offset addressing form (no per-entry 64-bit address arithmetic, no extra address registers).
 template <class G>
-DPF_HD int tw_index(int c, int th /* = tid >> c */, int k, int pos) {
+DPF_HD int tw_index_uniform(int c, int k, int pos) {
     const int lb = pos - c;
-    return (1 << (G::LOGN - 1 - pos)) + (th << (G::LOGE - 1 - lb)) + (k >> (lb + 1));
+    if (G::kPermStages > 0 && c == 0) return (1 << (G::LOGN - 1 - pos)) + (k >> (lb + 1)) * G::T;
+    return (1 << (G::LOGN - 1 - pos)) + (k >> (lb + 1));
 }
+template <class G>
+DPF_HD unsigned tw_index_thread(int c, int th /* = tid >> c */, int pos) {
+    const int lb = pos - c;
+    if (G::kPermStages > 0 && c == 0) return (unsigned)th;
+    return (unsigned)th << (G::LOGE - 1 - lb);
+}
+template <class G>
+DPF_HD int tw_index(int c, int th, int k, int pos) { return tw_index_uniform<G>(c, k, pos) + (int)tw_index_thread<G>(c, th, pos); }
 // tid >> c, forced to the constant 0 for the top window (all its twiddles are workgroup-uniform and
 // are fetched with scalar loads)
 template <class G>
@@ -194,13 +216,78 @@ struct NttBody {
     struct alignas(16) V2 {
         u64 a, b;
     };
+#if defined(__HIP_DEVICE_COMPILE__)
+    // Device path: a thread's E words are 8E contiguous bytes, so plain 16-byte accesses put the 64 lanes of one
+    // instruction on 64 different 128-byte lines.  The wave instead moves 1 KiB-contiguous slices (lane L, slice r:
+    // piece L >> kLow of thread (r << kLow) | (L & (2^kLow - 1)), a piece = 16 bytes) and transposes pieces <-> lanes
+    // in registers: one swap stage per piece-index bit (v_permlane32_swap, v_permlane16_swap, row DPP), an involution.
+    static constexpr int PC = E / 2, LP = LOGE - 1, kLow = 6 - LP;   // pieces per thread; lane bits [kLow, 6) <-> piece index
+    static constexpr bool kWaveIO = (T % 64 == 0) && LP >= 1 && LP <= 4;
+    template <int LANEBIT>
+    static __device__ __forceinline__ void lane_swap(u32& a, u32& b) {  // lanes with LANEBIT clear: b <- partner's a; set: a <- partner's b
+        if constexpr (LANEBIT == 5) { auto v = __builtin_amdgcn_permlane32_swap(a, b, false, false); a = v[0]; b = v[1]; }
+        else if constexpr (LANEBIT == 4) { auto v = __builtin_amdgcn_permlane16_swap(a, b, false, false); a = v[0]; b = v[1]; }
+        else if constexpr (LANEBIT == 3) {
+            const u32 na = __builtin_amdgcn_update_dpp(a, b, 0x118 /*row_shr:8*/, 0xf, 0xc, false);
+            const u32 nb = __builtin_amdgcn_update_dpp(b, a, 0x108 /*row_shl:8*/, 0xf, 0x3, false);
+            a = na; b = nb;
+        } else {
+            static_assert(LANEBIT == 2, "piece transposition uses lane bits 2..5");
+            const u32 na = __builtin_amdgcn_update_dpp(a, b, 0x114 /*row_shr:4*/, 0xf, 0xa, false);
+            const u32 nb = __builtin_amdgcn_update_dpp(b, a, 0x104 /*row_shl:4*/, 0xf, 0x5, false);
+            a = na; b = nb;
+        }
+    }
+    template <int S>
+    static __device__ __forceinline__ void transpose_stage(u64 (&x)[E]) {  // piece-index bit LP-1-S <-> lane bit 5-S
+        constexpr int rb = 1 << (LP - 1 - S);
+#pragma clang loop unroll(full)
+        for (int r = 0; r < PC; ++r) {
+            if (r & rb) continue;
+#pragma clang loop unroll(full)
+            for (int e = 0; e < 2; ++e) {
+                u32 alo = (u32)x[2 * r + e], ahi = (u32)(x[2 * r + e] >> 32);
+                u32 blo = (u32)x[2 * (r | rb) + e], bhi = (u32)(x[2 * (r | rb) + e] >> 32);
+                lane_swap<5 - S>(alo, blo);
+                lane_swap<5 - S>(ahi, bhi);
+                x[2 * r + e] = (u64)alo | ((u64)ahi << 32);
+                x[2 * (r | rb) + e] = (u64)blo | ((u64)bhi << 32);
+            }
+        }
+        if constexpr (S + 1 < LP) transpose_stage<S + 1>(x);
+    }
+    static __device__ __forceinline__ unsigned slice_piece(int tid, int r) {  // 16-byte piece index of slice r for this lane
+        const unsigned lane = (unsigned)tid & 63u, wave_thread0 = (unsigned)tid & ~63u;
+        const unsigned t = wave_thread0 + (((unsigned)r << kLow) | (lane & ((1u << kLow) - 1u)));
+        return t * PC + (lane >> kLow);
+    }
+#endif
     static DPF_HD void load_bot(int tid, u64 (&x)[E], const u64* g) {
         const V2* p = reinterpret_cast<const V2*>(g);
+#if defined(__HIP_DEVICE_COMPILE__)
+        if constexpr (kWaveIO) {
+#pragma clang loop unroll(full)
+            for (int r = 0; r < PC; ++r) { V2 v = p[slice_piece(tid, r)]; x[2 * r] = v.a; x[2 * r + 1] = v.b; }
+            transpose_stage<0>(x);
+            return;
+        }
+#endif
 #pragma clang loop unroll(full)
         for (int k = 0; k < E / 2; ++k) { V2 v = p[(unsigned)tid * (E / 2) + k]; x[2 * k] = v.a; x[2 * k + 1] = v.b; }
     }
     static DPF_HD void store_bot(int tid, const u64 (&x)[E], u64* g) {
         V2* p = reinterpret_cast<V2*>(g);
+#if defined(__HIP_DEVICE_COMPILE__)
+        if constexpr (kWaveIO) {
+            u64 y[E];
+#pragma clang loop unroll(full)
+            for (int k = 0; k < E; ++k) y[k] = x[k];
+            transpose_stage<0>(y);
+#pragma clang loop unroll(full)
+            for (int r = 0; r < PC; ++r) p[slice_piece(tid, r)] = V2{y[2 * r], y[2 * r + 1]};
+            return;
+        }
+#endif
 #pragma clang loop unroll(full)
         for (int k = 0; k < E / 2; ++k) p[(unsigned)tid * (E / 2) + k] = V2{x[2 * k], x[2 * k + 1]};
     }
@@ -253,7 +340,7 @@ struct NttBody {
             const int lb = pos - ph.c;
 #pragma clang loop unroll(full)
             for (int i = 0; i < E / 2; ++i)  // constant trip count (the bound below folds after unrolling u)
-                if (i < (1 << (LOGE - 1 - lb))) twr[u][i] = tw[tw_index<G>(ph.c, th, i << (lb + 1), pos)];
+                if (i < (1 << (LOGE - 1 - lb))) twr[u][i] = (tw + tw_index_uniform<G>(ph.c, i << (lb + 1), pos))[tw_index_thread<G>(ph.c, th, pos)];
         }
     }
 

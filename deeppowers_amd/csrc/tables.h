@@ -35,6 +35,20 @@ inline TwFold h_tw_fold(u64 w, u64 q) {
 // q = 2^60 - d with d < 2^24: eligible for FoldArith
 inline bool fold_eligible(u64 q) { return q < (1ull << 60) && ((1ull << 60) - q) < (1ull << 24); }
 
+// Device layout of a twiddle table for kernel geometry (log2n, loge): the sections of the window-0 stages
+// (bit positions < perm_stages = Geo::kPermStages) are transposed from [thread][entry] to [entry][thread] so that a
+// wave fetches lane-contiguous entries (ntt_core.h tw_index).  T = N >> loge threads.
+template <class Tw>
+inline void permute_window0(std::vector<Tw>& t, int log2n, int loge, int perm_stages) {
+    const size_t n = (size_t)1 << log2n, T = n >> loge;
+    std::vector<Tw> src(t);
+    for (int pos = 0; pos < perm_stages && pos < loge - 1; ++pos) {
+        const size_t m = n >> (pos + 1), cnt = m / T;   // cnt = 2^(loge-1-pos) entries per thread
+        for (size_t tid = 0; tid < T; ++tid)
+            for (size_t i = 0; i < cnt; ++i) t[m + i * T + tid] = src[m + tid * cnt + i];
+    }
+}
+
 struct HostLimbTables {
     LimbConst lc;
     std::vector<u64> rp, irp;        // psi^brv(i), psi^-brv(i)           (index m + i of a CT/GS walk)

@@ -74,11 +74,13 @@ static int emu(int inverse, u64 q, u64 psi, const u64* in, u64* out) {
     auto X = [&](int tid) -> u64(&)[E] { return *reinterpret_cast<u64(*)[E]>(&regs[(size_t)tid * E]); };
     if (!inverse) {
         auto tw = TwTab<Arith>::make(t.rp, t.rp_sh, q);
+        permute_window0(tw, LOGN, LOGE, B::G::kPermStages);
         for (int tid = 0; tid < T; ++tid) B::load_top(tid, X(tid), in);
         FwdSteps<B, 0>::run(regs, lds, tw.data(), t.lc);
         for (int tid = 0; tid < T; ++tid) { B::fwd_canon(X(tid), t.lc); B::store_bot(tid, X(tid), out); }
     } else {
         auto tw = TwTab<Arith>::make(t.irp, t.irp_sh, q);
+        permute_window0(tw, LOGN, LOGE, B::G::kPermStages);
         auto wl = TwTab<Arith>::one(t.w_last, t.w_last_sh, q), wn = TwTab<Arith>::one(t.lc.ninv, t.lc.ninv_sh, q);
         for (int tid = 0; tid < T; ++tid) B::load_bot(tid, X(tid), in);
         InvSteps<B, B::NPH - 1, kUnit>::run(regs, lds, tw.data(), wl, wn, t.lc);
