@@ -24,10 +24,27 @@ __device__ __forceinline__ void lds_barrier() { __syncthreads(); }
 template <class B, int P>
 struct FwdChain {
     typedef typename B::TwRegs TwRegs;
+    // entry point (P = 0): the top window's twiddles are workgroup-uniform scalars, so the per-thread twiddles of phase 1
+    // are requested right away, together with the caller's data loads, a whole phase ahead of their first use
+    // (EARLY = false where the extra 4 (E-1) live registers during phase 0 would spill: the fused kernels)
+    template <bool EARLY = true>
     static __device__ __forceinline__ void run(int tid, u64 (&x)[B::E], u64* lds, const typename B::Tw* tw, const LimbConst& lc) {
         TwRegs twr;
         B::template load_tw<P, true>(tid, tw, twr);
-        run_with(tid, x, lds, tw, lc, twr);
+        if constexpr (!EARLY) {
+            run_with(tid, x, lds, tw, lc, twr);
+        } else if constexpr (P + 1 < B::NPH) {
+            TwRegs nxt;
+            B::template load_tw<P + 1, true>(tid, tw, nxt);
+            B::template fwd_phase_r<P>(x, twr, lc);
+            if (P > 0) lds_barrier();
+            B::template lds_write<P, P, true>(tid, x, lds);
+            lds_barrier();
+            B::template lds_read<P, P + 1, true>(tid, x, lds);
+            FwdChain<B, P + 1>::run_with(tid, x, lds, tw, lc, nxt);
+        } else {
+            B::template fwd_phase_r<P>(x, twr, lc);
+        }
     }
     static __device__ __forceinline__ void run_with(int tid, u64 (&x)[B::E], u64* lds, const typename B::Tw* tw, const LimbConst& lc,
                                                     const TwRegs& twr) {
@@ -101,9 +118,11 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE)) void ntt_inv_kernel(u64* __rest
     const LimbConst lc = tb.lc[limb];
     const typename B::Tw* tw = tb.inv + (size_t)limb * B::G::N;
     const InvLast<typename B::Tw> last = tb.last[limb];
+    typename B::TwRegs tw_first;   // requested before the data: load_bot waits for all of its loads (register transposition)
+    B::template load_tw<B::NPH - 1, false>(tid, tw, tw_first);
     u64 x[B::E];
     B::load_bot(tid, x, in + p * B::G::N);
-    InvChain<B, B::NPH - 1, kUnit>::run(tid, x, lds, tw, last, lc);
+    InvChain<B, B::NPH - 1, kUnit>::run_with(tid, x, lds, tw, last, lc, tw_first);
     B::inv_canon(x, lc);
     B::store_top(tid, x, out + p * B::G::N);
 }
@@ -131,6 +150,7 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE), 2) void ct_mul_kernel(u64* __re
     const size_t cstride = L * N;
     const InvLast<typename B::Tw> last = tb.last[limb];
     constexpr bool kLazy = Arith::kFold && !OUT_NTT;   // products feed the inverse NTT unreduced (< 2 kMulB q/1024)
+    static_assert(!kLazy || IN_NTT || make_ct_plan(LOGN, kUnit).out_bound <= kLimitPartner, "lazy forward outputs must satisfy mul60's bound");
     constexpr int kInvIn = Arith::kFold ? 2 * kMulB : kUnit;
 
     // Schedule (F = forward NTT, I = inverse NTT + store), at most four polynomials live in registers:
@@ -138,9 +158,13 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE), 2) void ct_mul_kernel(u64* __re
     //   4: x  = F(a1); S0 += x*S1; S2 = x*S2                    5: I(S0) -> c1        6: I(S2) -> c2
     // One code instance of F and of I: the loop is not unrolled, every slot move sits under a uniform branch.
     u64 S0[E], S1[E], S2[E];
+    const typename B::Tw* const twf = tb.fwd4 + (size_t)limb * N;
+    const typename B::Tw* const twi = tb.inv4 + (size_t)limb * N;
 #pragma unroll 1
     for (int step = 0; step < 7; ++step) {
-        asm volatile("" : "+v"(tid));  // keep per-thread twiddle loads inside the loop (registers > L2 re-reads)
+        // keep per-thread twiddle loads inside the loop (registers > L2 re-reads).  Making the table pointers opaque instead
+        // (so that the thread's LDS / global offsets stay loop-invariant) was tried: the hoisted offsets spill.
+        asm volatile("" : "+v"(tid));
         u64 x[E];
         const bool fwd = (0x1B >> step) & 1;
         if (fwd) {
@@ -150,8 +174,18 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE), 2) void ct_mul_kernel(u64* __re
             } else {
                 B::load_top(tid, x, src);
                 if (step > 0) lds_barrier();  // the previous transform's last exchange is fully read
-                FwdChain<B, 0>::run(tid, x, lds, tb.fwd4 + (size_t)limb * N, lc);
-                if (step == 1 || step == 3 || !Arith::kFold) B::fwd_canon(x, lc);  // b-side operands < 2^60 for mul60
+                FwdChain<B, 0>::template run<false>(tid, x, lds, twf, lc);
+                // b-side operands of mul60 must be < 2^60 + 2^29: a partial reduce (< 2^60 + 16 d) is enough when the
+                // products feed the inverse transform lazily; NTT-domain outputs need canonical factors
+                if (!Arith::kFold) B::fwd_canon(x, lc);
+                else if (step == 1 || step == 3) {
+                    if (kLazy) {
+#pragma unroll
+                        for (int k = 0; k < E; ++k) x[k] = FoldArith::reduce(x[k], lc);
+                    } else {
+                        B::fwd_canon(x, lc);
+                    }
+                }
             }
             if (step == 0) {
 #pragma unroll
@@ -178,6 +212,8 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE), 2) void ct_mul_kernel(u64* __re
                 }
             }
         } else {
+            typename B::TwRegs tw_first;   // first inverse phase's twiddles: in flight while the dyadic products are formed
+            if (!OUT_NTT) B::template load_tw<B::NPH - 1, false>(tid, twi, tw_first);
             if (step == 2) {
 #pragma unroll
                 for (int k = 0; k < E; ++k) x[k] = kLazy ? FoldArith::mul60(S0[k], S1[k], (u32)lc.d) : Arith::mul_var(S0[k], S1[k], lc);
@@ -193,7 +229,7 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE), 2) void ct_mul_kernel(u64* __re
                 B::store_bot(tid, x, d);
             } else {
                 if (!IN_NTT || step > 2) lds_barrier();
-                InvChain<B, B::NPH - 1, kInvIn>::run(tid, x, lds, tb.inv4 + (size_t)limb * N, last, lc);
+                InvChain<B, B::NPH - 1, kInvIn>::run_with(tid, x, lds, twi, last, lc, tw_first);
                 B::inv_canon(x, lc);
                 B::store_top(tid, x, d);
             }
@@ -251,7 +287,7 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE), (Arith::kFold ? 2 : 1)) void re
 #pragma unroll
         for (int k = 0; k < E; ++k) x[k] = canon_any<Arith>(x[k], lc);   // [c2]_{q_j} mod q_i
         if (j > 0) lds_barrier();
-        FwdChain<B, 0>::run(tid, x, lds, tb.fwd4 + (size_t)limb * N, lc);
+        FwdChain<B, 0>::template run<false>(tid, x, lds, tb.fwd4 + (size_t)limb * N, lc);
         const u64* k0 = evk + (((size_t)j * 2 + 0) * L + limb) * N;      // key polynomials, NTT domain (window-0 mapping)
         const u64* k1 = evk + (((size_t)j * 2 + 1) * L + limb) * N;
         if (Arith::kFold) {

@@ -113,11 +113,12 @@ struct FoldArith {
         u64 yl = (u64)(u32)A | ((u64)((u32)B & 0x0fffffffu) << 32);
         return mad32(yh, d, yl);
     }
-    // y*w mod q for y < 15 * 2^60 (kLimit in ntt_core.h: what a transform may hand to a dyadic product) and w < 2^60.
-    // The middle column y0 w1 + y1 w0 + carry stays below 2^64 under that bound, so the four partial
-    // products chain through the 64-bit addend of v_mad_u64_u32 with no carry fix-up.
+    // y*w mod q for y < 15 * 2^60 (kLimit in ntt_core.h: what a transform may hand to a dyadic product) and w < 2^60,
+    // or y < 14 * 2^60 (kLimitPartner) and w only partially reduced, w < 2^60 + 2^29.
+    // The middle column y0 w1 + y1 w0 + carry stays below 2^64 under either bound, so the four partial
+    // products chain through the 64-bit addend of v_mad_u64_u32 with no carry fix-up, and the product stays < 2^124.
     static DPF_HD u64 mul60(u64 y, u64 w, u32 d) {
-        DPFHE_EMU_ASSERT(y < (15ull << 60) && w < (1ull << 60));
+        DPFHE_EMU_ASSERT((y < (15ull << 60) && w < (1ull << 60)) || (y < (14ull << 60) && w < (1ull << 60) + (1ull << 29)));
         const u32 y0 = (u32)y, y1 = (u32)(y >> 32), w0 = (u32)w, w1 = (u32)(w >> 32);
         u64 p = mad32(y0, w0, 0);
         u64 m = mad32(y0, w1, p >> 32);

@@ -70,6 +70,7 @@ struct Geo {
     static constexpr int kPermStages = geo_perm_stages(LOGN, LOGE);
     // coefficient index of local element k of thread tid in a phase with window start c
     static DPF_HD int index(int c, int tid, int k) {
+        if ((1 << c) >= T) return (k << c) | tid;  // top window: tid < T = 2^c, no split (and no mask for the compiler to fold)
         return ((tid >> c) << (c + LOGE)) | (k << c) | (tid & ((1 << c) - 1));
     }
     // LDS padding of the exchange between windows clo < chi.  Bijective for any choice (monotone);
@@ -135,6 +136,7 @@ constexpr int kRedB = kUnit + 1;    // reduce output < 2^60 + 16d
 constexpr int kTwB = kRedB;         // mul_tw output < 2^60 + 13d
 constexpr int kWord = 16 * kUnit;   // 16 q < 2^64: a lazy sum must not wrap
 constexpr int kLimit = 15 * kUnit;  // < 15 q < 15 * 2^60: the precondition of FoldArith::mul60's first operand
+constexpr int kLimitPartner = 14 * kUnit;  // ... when its second operand is only partially reduced (< 2^60 + 2^29)
 
 template <int LOGE>
 struct GsPlan {  // one Gentleman-Sande phase on E local elements, up to LOGE stages

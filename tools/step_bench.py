@@ -1,0 +1,57 @@
+"""A/B timing of the bench.py step (8192 ct x ct multiplies + overlapped shard-local reduce) for another build of the
+library: DPFHE_AB_LIB=path python tools/step_bench.py [steps=8] [mode=overlap|serial|mulonly]"""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import deeppowers_amd._cabi as _cabi  # noqa: E402
+
+if os.environ.get("DPFHE_AB_LIB"):
+    _cabi.LIB_PATH = os.path.abspath(os.environ["DPFHE_AB_LIB"])
+from deeppowers_amd.evaluator import Ciphertext, Context, Evaluator  # noqa: E402
+from deeppowers_amd.params import FheParams  # noqa: E402
+
+steps = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+mode = sys.argv[2] if len(sys.argv) > 2 else "overlap"
+params = FheParams.n4096_l4()
+L, N, B = params.n_limbs, params.n, 8192
+ctx = Context(params, 0); ev = Evaluator(ctx); dev = ctx.device
+q = torch.tensor(params.moduli, dtype=torch.int64, device=dev).view(1, 1, L, 1)
+a = Ciphertext(torch.randint(0, 2**62, (B, 2, L, N), dtype=torch.int64, device=dev) % q)
+b = Ciphertext(torch.randint(0, 2**62, (B, 2, L, N), dtype=torch.int64, device=dev) % q)
+outs = [ctx.empty(B, components=3) for _ in range(2)]
+parts = [ctx.empty(components=3) for _ in range(2)]
+main = torch.cuda.current_stream(); side = torch.cuda.Stream(device=dev)
+mul_done = [torch.cuda.Event() for _ in range(2)]; red_done = [torch.cuda.Event() for _ in range(2)]
+
+
+def step(i):
+    k = i & 1
+    main.wait_event(red_done[k])
+    c = ev.multiply(a, b, out=outs[k], stream=main)
+    if mode == "mulonly":
+        return
+    if mode == "serial":
+        ev.reduce_sum(c, out=parts[k], stream=main)
+        return
+    mul_done[k].record(main)
+    side.wait_event(mul_done[k])
+    with torch.cuda.stream(side):
+        ev.reduce_sum(c, out=parts[k], stream=side)
+    red_done[k].record(side)
+
+
+for i in range(2):
+    step(i)
+torch.cuda.synchronize()
+s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+s.record(main)
+for i in range(steps):
+    step(i)
+main.wait_stream(side)
+e.record(main)
+torch.cuda.synchronize()
+ms = s.elapsed_time(e) / steps
+print(f"{os.environ.get('TAG', '')} {mode}: {ms:.3f} ms/step  -> {B / ms / 1e3:.3f} M ct-mul/s")

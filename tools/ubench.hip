@@ -197,7 +197,8 @@ static void run_bfly(const char* name, int n_cu, int blocks_per_cu) {
 // 3. HBM copy with the NTT's access pattern: one 256-thread block per 32 KiB "polynomial"
 // ---------------------------------------------------------------------------------------------------
 struct __attribute__((aligned(16))) V2 { u64 a, b; };
-template <int MODE>  // 0: 8B strided loads + 16B row-per-lane stores (the NTT pattern); 1: 16B coalesced both ways
+template <int MODE>  // 0: 8B column loads + 16B row-per-lane stores (128 B lane stride); 1: 16B coalesced both ways;
+                     // 2: 8B column loads + 16B coalesced stores; 3: 16B coalesced loads + 8B column stores
 __global__ __launch_bounds__(256) void copy_kernel(u64* __restrict__ out, const u64* __restrict__ in) {
     const size_t base = (size_t)blockIdx.x * 4096;
     const int tid = threadIdx.x;
@@ -208,6 +209,20 @@ __global__ __launch_bounds__(256) void copy_kernel(u64* __restrict__ out, const 
         V2* p = reinterpret_cast<V2*>(out + base + tid * 16);
 #pragma unroll
         for (int k = 0; k < 8; ++k) p[k] = V2{x[2 * k], x[2 * k + 1]};
+    } else if (MODE == 2) {
+        u64 x[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) x[k] = in[base + k * 256 + tid];
+        V2* po = reinterpret_cast<V2*>(out + base);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) po[k * 256 + tid] = V2{x[2 * k], x[2 * k + 1]};
+    } else if (MODE == 3) {
+        const V2* pi = reinterpret_cast<const V2*>(in + base);
+        V2 x[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) x[k] = pi[k * 256 + tid];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { out[base + (2 * k) * 256 + tid] = x[k].a; out[base + (2 * k + 1) * 256 + tid] = x[k].b; }
     } else {
         const V2* pi = reinterpret_cast<const V2*>(in + base);
         V2* po = reinterpret_cast<V2*>(out + base);
@@ -258,6 +273,10 @@ static int selftest_mul_tw() {  // host check of FoldArith::mul_tw against __int
 
 int main(int argc, char** argv) {
     if (selftest_mul_tw()) return 1;
+    if (argc > 1 && !std::strcmp(argv[1], "copy")) {
+        run_copy<0>("8B col loads + 16B row stores"); run_copy<1>("16B coalesced"); run_copy<2>("8B col loads + 16B coalesced stores"); run_copy<3>("16B coalesced loads + 8B col stores");
+        return 0;
+    }
     if (argc > 1 && !std::strcmp(argv[1], "bfly")) {
         hipDeviceProp_t pp;
         HIPCHECK(hipGetDeviceProperties(&pp, 0));
@@ -281,6 +300,6 @@ int main(int argc, char** argv) {
     std::printf("--- register-only butterflies ---\n");
     run_bfly<FoldArith>("fold", n_cu, 4); run_bfly<FoldArith>("fold", n_cu, 8); run_bfly<Mul60Arith>("mul60", n_cu, 4); run_bfly<Mul60Arith>("mul60", n_cu, 8); run_bfly<ShoupArith>("shoup", n_cu, 4); run_bfly<ShoupArith>("shoup", n_cu, 8);
     std::printf("--- HBM copy ---\n");
-    run_copy<0>("8B col loads + 16B row stores"); run_copy<1>("16B coalesced");
+    run_copy<0>("8B col loads + 16B row stores"); run_copy<1>("16B coalesced"); run_copy<2>("8B col loads + 16B coalesced stores"); run_copy<3>("16B coalesced loads + 8B col stores");
     return 0;
 }
