@@ -231,7 +231,7 @@ def main():
             "kernel": "ct_mul_kernel<FoldArith,12,4>", "bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
             "frac": achieved / HBM_PEAK, "traffic": traffic,
             "traffic_source": "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, bytes per launch)" if traffic else None,
-            "alu_roofline_note": "integer-multiply issue, not HBM, bounds this kernel: tools/ubench register-only butterflies reach 1.9-2.0 T/s = 65% of 8 TB/s NTT-equivalent (profiles/r01_ubench.log)",
+            "alu_roofline_note": "VALU issue, not HBM, bounds this kernel: it issues one VALU instruction per SIMD every ~5 cycles, the rate of the register-only butterfly loop (tools/ubench: 2.35-2.6 T butterflies/s = 78-87% of 8 TB/s NTT-equivalent; profiles/r01_ubench.log, r01_pmc_sq_ntt_bench.txt)",
             "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": k_avg * 1e3,
         },
     }
