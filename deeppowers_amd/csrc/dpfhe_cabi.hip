@@ -255,8 +255,8 @@ extern "C" int dpfhe_relinearize(dpfhe_ctx* c, uint64_t* d_out2, const uint64_t*
     const size_t blocks = batch * c->n_limbs;
     if (blocks > kMaxGrid) return fail(DPFHE_INVALID_ARGUMENT, "dpfhe_relinearize", "batch too large for one launch");
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const int rc = c->fold ? launch_relin<FoldArith>((int)c->log2n, 0, d_out2, d_in3, d_evk, blocks, c->foldt, s)
-                           : launch_relin<ShoupArith>((int)c->log2n, 0, d_out2, d_in3, d_evk, blocks, c->shoup, s);
+    const int rc = c->fold ? launch_relin<FoldArith>((int)c->log2n, 0, d_out2, d_in3, d_evk, 0, blocks, c->foldt, s)
+                           : launch_relin<ShoupArith>((int)c->log2n, 0, d_out2, d_in3, d_evk, 0, blocks, c->shoup, s);
     if (rc) return fail(DPFHE_INVALID_STATE, "dpfhe_relinearize", "no kernel geometry for this log2_n");
     return check_launch("relin kernel launch");
 }
@@ -269,8 +269,8 @@ extern "C" int dpfhe_switch_key(dpfhe_ctx* c, uint64_t* d_out2, const uint64_t* 
     const size_t blocks = batch * c->n_limbs;
     if (blocks > kMaxGrid) return fail(DPFHE_INVALID_ARGUMENT, "dpfhe_switch_key", "batch too large for one launch");
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const int rc = c->fold ? launch_relin<FoldArith>((int)c->log2n, 1, d_out2, d_in2, d_key, blocks, c->foldt, s)
-                           : launch_relin<ShoupArith>((int)c->log2n, 1, d_out2, d_in2, d_key, blocks, c->shoup, s);
+    const int rc = c->fold ? launch_relin<FoldArith>((int)c->log2n, 1, d_out2, d_in2, d_key, 0, blocks, c->foldt, s)
+                           : launch_relin<ShoupArith>((int)c->log2n, 1, d_out2, d_in2, d_key, 0, blocks, c->shoup, s);
     if (rc) return fail(DPFHE_INVALID_STATE, "dpfhe_switch_key", "no kernel geometry for this log2_n");
     return check_launch("switch_key kernel launch");
 }
@@ -292,7 +292,7 @@ extern "C" int dpfhe_rescale(dpfhe_ctx* c, uint64_t* d_out, const uint64_t* d_in
 
 // hybrid key switching = inner product over all L limbs (relin_kernel MODE 2/3) + divide by the special prime and add (c0, c1)
 static int hybrid_entry(dpfhe_ctx* c, const char* what, int in_comps, uint64_t* d_out2, const uint64_t* d_in, const uint64_t* d_key,
-                        uint64_t* d_work, size_t batch, void* stream) {
+                        uint64_t* d_work, size_t batch, void* stream, size_t key_stride = 0) {
     if (!c) return fail(DPFHE_INVALID_ARGUMENT, what, "null context");
     if (c->n_limbs < 2) return fail(DPFHE_INVALID_STATE, what, "the extended context needs at least one data limb and the special prime");
     if (batch == 0) return DPFHE_SUCCESS;
@@ -304,8 +304,8 @@ static int hybrid_entry(dpfhe_ctx* c, const char* what, int in_comps, uint64_t* 
     if (blocks > kMaxGrid) return fail(DPFHE_INVALID_ARGUMENT, what, "batch too large for one launch");
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int mode = in_comps == 3 ? 2 : 3;
-    const int rc = c->fold ? launch_relin<FoldArith>((int)c->log2n, mode, d_work, d_in, d_key, blocks, c->foldt, s)
-                           : launch_relin<ShoupArith>((int)c->log2n, mode, d_work, d_in, d_key, blocks, c->shoup, s);
+    const int rc = c->fold ? launch_relin<FoldArith>((int)c->log2n, mode, d_work, d_in, d_key, key_stride, blocks, c->foldt, s)
+                           : launch_relin<ShoupArith>((int)c->log2n, mode, d_work, d_in, d_key, key_stride, blocks, c->shoup, s);
     if (rc) return fail(DPFHE_INVALID_STATE, what, "no kernel geometry for this log2_n");
     int e = check_launch("hybrid key-switch kernel launch");
     if (e) return e;
@@ -328,6 +328,44 @@ extern "C" int dpfhe_switch_key_hybrid(dpfhe_ctx* c, uint64_t* d_out2, const uin
     return hybrid_entry(c, "dpfhe_switch_key_hybrid", 2, d_out2, d_in2, d_key, d_work, batch, stream);
 }
 
+static unsigned galois_inverse(unsigned g, unsigned two_n) {  // g^-1 mod 2N by Newton iteration (g odd): x <- x (2 - g x)
+    unsigned inv = 1;
+    for (int i = 0; i < 5; ++i) inv *= 2u - g * inv;
+    return inv & (two_n - 1u);
+}
+
+// N3: `batch` rotations in one pass - item i = key-switched sigma_{g_i}(input item i, or the single input when n_in == 1)
+extern "C" int dpfhe_rotate_hybrid_batch(dpfhe_ctx* c, uint64_t* d_out2, const uint64_t* d_in2, size_t n_in, const uint32_t* galois_elts,
+                                         const uint64_t* d_keys, uint64_t* d_work, uint64_t* d_rotated, size_t batch, void* stream) {
+    const char* what = "dpfhe_rotate_hybrid_batch";
+    if (!c) return fail(DPFHE_INVALID_ARGUMENT, what, "null context");
+    if (c->n_limbs < 2) return fail(DPFHE_INVALID_STATE, what, "the extended context needs at least one data limb and the special prime");
+    if (batch == 0) return DPFHE_SUCCESS;
+    if (n_in != 1 && n_in != batch) return fail(DPFHE_INVALID_ARGUMENT, what, "n_in must be 1 (one input, many rotations) or equal to batch");
+    if (!d_out2 || !d_in2 || !galois_elts || !d_keys || !d_work || !d_rotated || misaligned(d_out2) || misaligned(d_in2) || misaligned(d_keys) ||
+        misaligned(d_work) || misaligned(d_rotated) || d_rotated == d_in2)
+        return fail(DPFHE_INVALID_ARGUMENT, what, "null, misaligned or aliased buffer");
+    const size_t L = c->n_limbs, Ld = L - 1;
+    const int n = 1 << c->log2n;
+    const unsigned two_n = 2u << c->log2n;
+    for (size_t i = 0; i < batch; ++i)
+        if (!(galois_elts[i] & 1u) || galois_elts[i] >= two_n) return fail(DPFHE_INVALID_ARGUMENT, what, "galois elements must be odd and < 2N");
+    const size_t ct_words = 2 * Ld * (size_t)n, key_words = Ld * 2 * L * (size_t)n;
+    const LimbConst* lc = c->fold ? c->foldt.lc : c->shoup.lc;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    for (size_t first = 0; first < batch; first += kMaxGaloisBatch) {   // the elements travel as kernel arguments, 64 at a time
+        const size_t cnt = batch - first < (size_t)kMaxGaloisBatch ? batch - first : (size_t)kMaxGaloisBatch;
+        GaloisInvs inv{};
+        for (size_t i = 0; i < cnt; ++i) inv.v[i] = galois_inverse(galois_elts[first + i], two_n);
+        const uint64_t* src = d_in2 + (n_in == 1 ? 0 : first * ct_words);
+        hipLaunchKernelGGL(galois_multi_kernel, dim3((unsigned)(cnt * 2 * Ld)), dim3(256), 0, s, d_rotated + first * ct_words, src,
+                           n_in == 1 ? (size_t)0 : ct_words, lc, (int)Ld, n, (int)(2 * Ld), inv);
+        int e = check_launch("galois kernel launch");
+        if (e) return e;
+    }
+    return hybrid_entry(c, what, 2, d_out2, d_rotated, d_keys, d_work, batch, stream, key_words);
+}
+
 extern "C" int dpfhe_apply_galois(dpfhe_ctx* c, uint64_t* d_out, const uint64_t* d_in, size_t n_rns_polys, uint32_t galois_elt, void* stream) {
     if (!c) return fail(DPFHE_INVALID_ARGUMENT, "dpfhe_apply_galois", "null context");
     const unsigned two_n = 2u << c->log2n;
@@ -337,9 +375,7 @@ extern "C" int dpfhe_apply_galois(dpfhe_ctx* c, uint64_t* d_out, const uint64_t*
         return fail(DPFHE_INVALID_ARGUMENT, "dpfhe_apply_galois", "null, misaligned or aliased buffer");
     const size_t npolys = n_rns_polys * c->n_limbs;
     if (npolys > kMaxGrid) return fail(DPFHE_INVALID_ARGUMENT, "dpfhe_apply_galois", "batch too large for one launch");
-    unsigned inv = 1;  // g^-1 mod 2N by Newton iteration (g odd): x <- x (2 - g x)
-    for (int i = 0; i < 5; ++i) inv *= 2u - galois_elt * inv;
-    inv &= two_n - 1u;
+    const unsigned inv = galois_inverse(galois_elt, two_n);
     const LimbConst* lc = c->fold ? c->foldt.lc : c->shoup.lc;
     hipLaunchKernelGGL(galois_kernel, dim3((unsigned)npolys), dim3(256), 0, static_cast<hipStream_t>(stream), d_out, d_in, lc, (int)c->n_limbs,
                        1 << c->log2n, inv);

@@ -378,6 +378,13 @@ Big big_sub(const Big& a, const Big& b) {  // a >= b
     }
     return r;
 }
+uint64_t big_divmod_small(Big& a, uint64_t m) {  // a = floor(a / m), returns a mod m
+    u128 rem = 0;
+    for (size_t i = a.size(); i-- > 0;) { u128 cur = (rem << 64) | a[i]; a[i] = (uint64_t)(cur / m); rem = cur % m; }
+    while (a.size() > 1 && a.back() == 0) a.pop_back();
+    return (uint64_t)rem;
+}
+uint64_t big_mod_small(const Big& a, uint64_t m) { Big t(a); return big_divmod_small(t, m); }
 void big_shr_round(Big& a, unsigned sh) {  // a = floor((a + 2^(sh-1)) / 2^sh)
     if (sh) {
         Big half((sh - 1) / 64 + 1, 0);
@@ -533,11 +540,11 @@ Encryptor::Encryptor(const Context& ctx, const SecretKey& sk, uint64_t seed) : i
 }
 Encryptor::~Encryptor() = default;
 
-void Encryptor::encrypt(const int64_t* messages, unsigned log2_scale, Ciphertext& out) {
-    if (!messages) throw Exception(ErrorCode::INVALID_ARGUMENT, "encrypt: null messages");
-    if (out.size() != 2) throw Exception(ErrorCode::INVALID_ARGUMENT, "encrypt: output must be a 2-component ciphertext");
-    if (log2_scale > 200) throw Exception(ErrorCode::INVALID_ARGUMENT, "encrypt: log2_scale too large");
-    const Context& ctx = *impl_->ctx;
+namespace {
+// c0 = -(a s) + e + scale * m, c1 = a with scale given per limb (2^log2_scale for the approximate flavour, floor(Q/t) for
+// the exact one)
+template <class Rng>
+void encrypt_scaled(const Context& ctx, const SecretKey& sk, Rng& rng, const int64_t* messages, const std::vector<uint64_t>& scale, Ciphertext& out) {
     const FheParams& p = ctx.params();
     const size_t n = p.n(), L = p.n_limbs(), poly = L * n;
     dpfhe_ctx* h = static_cast<dpfhe_ctx*>(ctx.handle());
@@ -546,26 +553,53 @@ void Encryptor::encrypt(const int64_t* messages, unsigned log2_scale, Ciphertext
     for (size_t item = 0; item < out.batch(); ++item) {
         for (size_t l = 0; l < L; ++l) {
             const uint64_t q = p.moduli[l];
-            const uint64_t scale = powmod(2, log2_scale, q);
-            for (size_t k = 0; k < n; ++k) ha[l * n + k] = impl_->rng.below(q);
-            for (size_t k = 0; k < n; ++k) hm[l * n + k] = (uint64_t)((u128)lift_signed(messages[item * n + k], q) * scale % q);
+            for (size_t k = 0; k < n; ++k) ha[l * n + k] = rng.below(q);
+            for (size_t k = 0; k < n; ++k) hm[l * n + k] = (uint64_t)((u128)lift_signed(messages[item * n + k], q) * scale[l] % q);
         }
         for (size_t k = 0; k < n; ++k) {   // + e, the same small integer in every limb
-            const int64_t ev = (int64_t)impl_->rng.below(17) - 8;
+            const int64_t ev = (int64_t)rng.below(17) - 8;
             for (size_t l = 0; l < L; ++l) { const uint64_t q = p.moduli[l]; uint64_t v = hm[l * n + k] + lift_signed(ev, q); hm[l * n + k] = v >= q ? v - q : v; }
         }
         uint64_t* c0 = out.data() + (item * 2 + 0) * poly;
         uint64_t* c1 = out.data() + (item * 2 + 1) * poly;
         a.copy_from_host(ha.data());                       // c1 = a (coefficient domain)
         hip_check(hipMemcpy(c1, a.data(), poly * sizeof(uint64_t), hipMemcpyDeviceToDevice), "hipMemcpy D2D");
-        t.copy_from_host(hm.data());                       // e + 2^scale m
+        t.copy_from_host(hm.data());                       // e + scale m
         check(dpfhe_ntt_fwd(h, a.data(), 1, nullptr), "dpfhe_ntt_fwd");
-        check(dpfhe_dyadic_mul(h, a.data(), a.data(), impl_->sk->ntt(), 1, nullptr), "dpfhe_dyadic_mul");
+        check(dpfhe_dyadic_mul(h, a.data(), a.data(), sk.ntt(), 1, nullptr), "dpfhe_dyadic_mul");
         check(dpfhe_ntt_inv(h, a.data(), 1, nullptr), "dpfhe_ntt_inv");          // a s
-        check(dpfhe_sub(h, c0, t.data(), a.data(), 1, nullptr), "dpfhe_sub");     // c0 = e + 2^scale m - a s
+        check(dpfhe_sub(h, c0, t.data(), a.data(), 1, nullptr), "dpfhe_sub");     // c0 = e + scale m - a s
         ctx.synchronize();
     }
     out.set_ntt(false);
+}
+Big modulus_product(const FheParams& p) {
+    Big Q{1};
+    for (uint64_t q : p.moduli) big_mul_small(Q, q);
+    return Q;
+}
+}  // namespace
+
+void Encryptor::encrypt(const int64_t* messages, unsigned log2_scale, Ciphertext& out) {
+    if (!messages) throw Exception(ErrorCode::INVALID_ARGUMENT, "encrypt: null messages");
+    if (out.size() != 2) throw Exception(ErrorCode::INVALID_ARGUMENT, "encrypt: output must be a 2-component ciphertext");
+    if (log2_scale > 200) throw Exception(ErrorCode::INVALID_ARGUMENT, "encrypt: log2_scale too large");
+    const FheParams& p = impl_->ctx->params();
+    std::vector<uint64_t> scale(p.n_limbs());
+    for (size_t l = 0; l < p.n_limbs(); ++l) scale[l] = powmod(2, log2_scale, p.moduli[l]);
+    encrypt_scaled(*impl_->ctx, *impl_->sk, impl_->rng, messages, scale, out);
+}
+
+void Encryptor::encrypt_exact(const int64_t* messages, uint64_t t, Ciphertext& out) {
+    if (!messages) throw Exception(ErrorCode::INVALID_ARGUMENT, "encrypt_exact: null messages");
+    if (out.size() != 2) throw Exception(ErrorCode::INVALID_ARGUMENT, "encrypt_exact: output must be a 2-component ciphertext");
+    if (t < 2) throw Exception(ErrorCode::INVALID_ARGUMENT, "encrypt_exact: plaintext modulus must be >= 2");
+    const FheParams& p = impl_->ctx->params();
+    Big delta = modulus_product(p);
+    big_divmod_small(delta, t);   // floor(Q / t)
+    std::vector<uint64_t> scale(p.n_limbs());
+    for (size_t l = 0; l < p.n_limbs(); ++l) scale[l] = big_mod_small(delta, p.moduli[l]);
+    encrypt_scaled(*impl_->ctx, *impl_->sk, impl_->rng, messages, scale, out);
 }
 
 // ---- Decryptor --------------------------------------------------------------------------------------------------------------
@@ -593,10 +627,11 @@ Decryptor::Decryptor(const Context& ctx, const SecretKey& sk) : impl_(new Impl) 
 }
 Decryptor::~Decryptor() = default;
 
-void Decryptor::decrypt(const Ciphertext& ct, unsigned log2_scale, int64_t* out) {
-    if (!out) throw Exception(ErrorCode::INVALID_ARGUMENT, "decrypt: null output");
-    if (ct.is_ntt()) throw Exception(ErrorCode::INVALID_STATE, "decrypt: ciphertext must be in the coefficient domain");
-    const Context& ctx = *impl_->ctx;
+namespace {
+// phase = c0 + c1 s (+ c2 s^2) per item on the device (NTT domain), then per coefficient the Garner mixed-radix digits
+// x = v0 + v1 q0 + v2 q0 q1 + ... of its CRT composition in [0, Q); f(item, k, digits) consumes them
+template <class F>
+void for_each_phase(const Context& ctx, const SecretKey& sk, const std::vector<uint64_t>& garner_inv, const Ciphertext& ct, F f) {
     const FheParams& p = ctx.params();
     const size_t n = p.n(), L = p.n_limbs(), poly = L * n;
     dpfhe_ctx* h = static_cast<dpfhe_ctx*>(ctx.handle());
@@ -604,40 +639,66 @@ void Decryptor::decrypt(const Ciphertext& ct, unsigned log2_scale, int64_t* out)
     std::vector<uint64_t> ph(poly), digit(L);
     for (size_t item = 0; item < ct.batch(); ++item) {
         const uint64_t* c = ct.data() + item * ct.size() * poly;
-        // phase = c0 + c1 s (+ c2 s^2), evaluated in the NTT domain
         check(dpfhe_ntt_fwd_oop(h, t.data(), c + poly, 1, nullptr), "dpfhe_ntt_fwd_oop");
-        check(dpfhe_dyadic_mul(h, acc.data(), t.data(), impl_->sk->ntt(), 1, nullptr), "dpfhe_dyadic_mul");
+        check(dpfhe_dyadic_mul(h, acc.data(), t.data(), sk.ntt(), 1, nullptr), "dpfhe_dyadic_mul");
         if (ct.size() == 3) {
             check(dpfhe_ntt_fwd_oop(h, t.data(), c + 2 * poly, 1, nullptr), "dpfhe_ntt_fwd_oop");
-            check(dpfhe_dyadic_mul_add(h, acc.data(), t.data(), impl_->sk->ntt_squared(), 1, nullptr), "dpfhe_dyadic_mul_add");
+            check(dpfhe_dyadic_mul_add(h, acc.data(), t.data(), sk.ntt_squared(), 1, nullptr), "dpfhe_dyadic_mul_add");
         }
         check(dpfhe_ntt_inv(h, acc.data(), 1, nullptr), "dpfhe_ntt_inv");
         check(dpfhe_add(h, acc.data(), acc.data(), c, 1, nullptr), "dpfhe_add");
         ctx.synchronize();
         hip_check(hipMemcpy(ph.data(), acc.data(), poly * sizeof(uint64_t), hipMemcpyDeviceToHost), "hipMemcpy D2H");
         for (size_t k = 0; k < n; ++k) {
-            // Garner mixed radix: x = v0 + v1 q0 + v2 q0 q1 + ...
             for (size_t i = 0; i < L; ++i) {
                 const uint64_t qi = p.moduli[i];
                 uint64_t v = ph[i * n + k] % qi;
                 for (size_t j = 0; j < i; ++j) {
                     const uint64_t dj = digit[j] % qi;
                     v = v >= dj ? v - dj : v + qi - dj;
-                    v = (uint64_t)((u128)v * impl_->garner_inv[i * L + j] % qi);
+                    v = (uint64_t)((u128)v * garner_inv[i * L + j] % qi);
                 }
                 digit[i] = v;
             }
-            Big x{0};
-            for (size_t i = L; i-- > 0;) { big_mul_small(x, p.moduli[i]); big_add(x, Big{digit[i]}); }
-            const bool neg = big_cmp(x, impl_->halfQ) > 0;
-            if (neg) x = big_sub(impl_->Q, x);
-            big_shr_round(x, log2_scale);
-            for (size_t i = 1; i < x.size(); ++i)
-                if (x[i]) throw Exception(ErrorCode::RUNTIME_ERROR, "decrypt: value does not fit 62 bits (scale or noise overflow)");
-            if (x[0] >> 62) throw Exception(ErrorCode::RUNTIME_ERROR, "decrypt: value does not fit 62 bits (scale or noise overflow)");
-            out[item * n + k] = neg ? -(int64_t)x[0] : (int64_t)x[0];
+            f(item, k, digit);
         }
     }
+}
+}  // namespace
+
+void Decryptor::decrypt(const Ciphertext& ct, unsigned log2_scale, int64_t* out) {
+    if (!out) throw Exception(ErrorCode::INVALID_ARGUMENT, "decrypt: null output");
+    if (ct.is_ntt()) throw Exception(ErrorCode::INVALID_STATE, "decrypt: ciphertext must be in the coefficient domain");
+    const FheParams& p = impl_->ctx->params();
+    const size_t n = p.n(), L = p.n_limbs();
+    for_each_phase(*impl_->ctx, *impl_->sk, impl_->garner_inv, ct, [&](size_t item, size_t k, const std::vector<uint64_t>& digit) {
+        Big x{0};
+        for (size_t i = L; i-- > 0;) { big_mul_small(x, p.moduli[i]); big_add(x, Big{digit[i]}); }
+        const bool neg = big_cmp(x, impl_->halfQ) > 0;
+        if (neg) x = big_sub(impl_->Q, x);
+        big_shr_round(x, log2_scale);
+        for (size_t i = 1; i < x.size(); ++i)
+            if (x[i]) throw Exception(ErrorCode::RUNTIME_ERROR, "decrypt: value does not fit 62 bits (scale or noise overflow)");
+        if (x[0] >> 62) throw Exception(ErrorCode::RUNTIME_ERROR, "decrypt: value does not fit 62 bits (scale or noise overflow)");
+        out[item * n + k] = neg ? -(int64_t)x[0] : (int64_t)x[0];
+    });
+}
+
+void Decryptor::decrypt_exact(const Ciphertext& ct, uint64_t t, uint64_t* out) {
+    if (!out) throw Exception(ErrorCode::INVALID_ARGUMENT, "decrypt_exact: null output");
+    if (ct.is_ntt()) throw Exception(ErrorCode::INVALID_STATE, "decrypt_exact: ciphertext must be in the coefficient domain");
+    if (t < 2 || t >> 32) throw Exception(ErrorCode::INVALID_ARGUMENT, "decrypt_exact: plaintext modulus must be in [2, 2^32)");
+    const FheParams& p = impl_->ctx->params();
+    const size_t n = p.n(), L = p.n_limbs();
+    for_each_phase(*impl_->ctx, *impl_->sk, impl_->garner_inv, ct, [&](size_t item, size_t k, const std::vector<uint64_t>& digit) {
+        // x / Q = (v0 + q0 (v1 + q1 (...))) / (q0 q1 ...) evaluated from the lowest digit: f <- (v_i + f) / q_i.  The phase is
+        // floor(Q/t) m + small noise, so t x / Q sits within ~2^-200 of an integer and 64-bit long double rounding is exact.
+        long double f = 0.0L;
+        for (size_t i = 0; i < L; ++i) f = ((long double)digit[i] + f) / (long double)p.moduli[i];
+        const long double r = f * (long double)t;
+        uint64_t m = (uint64_t)(r + 0.5L);
+        out[item * n + k] = m >= t ? m - t : m;
+    });
 }
 
 // ---- HybridKeySwitcher ---------------------------------------------------------------------------------------------------
@@ -648,6 +709,7 @@ public:
     std::unique_ptr<SecretKey> sk_ext;
     std::unique_ptr<PolyBuffer> relin;                       // [Ld][2][L][N]
     std::vector<std::pair<uint32_t, std::unique_ptr<PolyBuffer>>> galois;
+    std::vector<std::pair<std::vector<uint32_t>, std::unique_ptr<PolyBuffer>>> packed;   // element list -> its keys back to back
     SplitMix rng{0};
     uint64_t p_special = 0;
 
@@ -727,6 +789,211 @@ void HybridKeySwitcher::apply_galois(const Ciphertext& in2, uint32_t g, Cipherte
           "dpfhe_switch_key_hybrid");
     hip_check(hipStreamSynchronize(static_cast<hipStream_t>(s)), "hipStreamSynchronize");
     out2.set_ntt(false);
+}
+
+void HybridKeySwitcher::apply_galois_many(const Ciphertext& in2, const std::vector<uint32_t>& elts, Ciphertext& out2, size_t out_first, Stream* s) const {
+    const size_t k = elts.size();
+    if (k == 0) return;
+    if (in2.is_ntt() || in2.size() != 2 || out2.size() != 2 || (in2.batch() != 1 && in2.batch() != k) || out_first + k > out2.batch())
+        throw Exception(ErrorCode::INVALID_ARGUMENT, "HybridKeySwitcher::apply_galois_many: input of 1 or k items, output with room for k items");
+    const FheParams& pe = impl_->ext->params();
+    const size_t L = pe.n_limbs(), Ld = L - 1, n = pe.n(), key_words = Ld * 2 * L * n, ct_words = 2 * Ld * n;
+    const PolyBuffer* keys = nullptr;
+    for (auto& kv : impl_->packed) if (kv.first == elts) keys = kv.second.get();
+    if (!keys) {
+        std::unique_ptr<PolyBuffer> buf(new PolyBuffer(*impl_->ext, k * Ld, 2, true));
+        for (size_t i = 0; i < k; ++i) {
+            const PolyBuffer* key = nullptr;
+            for (auto& kv : impl_->galois) if (kv.first == elts[i]) key = kv.second.get();
+            if (!key) throw Exception(ErrorCode::INVALID_STATE, "HybridKeySwitcher::apply_galois_many: no key for an element (add_galois_element first)");
+            hip_check(hipMemcpy(buf->data() + i * key_words, key->data(), key_words * sizeof(uint64_t), hipMemcpyDeviceToDevice), "hipMemcpy D2D");
+        }
+        keys = buf.get();
+        impl_->packed.emplace_back(elts, std::move(buf));
+    }
+    PolyBuffer work(*impl_->ext, k, 2, false);
+    Ciphertext rotated(*impl_->data_ctx, 2, k);
+    check(dpfhe_rotate_hybrid_batch(static_cast<dpfhe_ctx*>(impl_->ext->handle()), out2.data() + out_first * ct_words, in2.data(), in2.batch(), elts.data(),
+                                    keys->data(), work.data(), rotated.data(), k, s), "dpfhe_rotate_hybrid_batch");
+    hip_check(hipStreamSynchronize(static_cast<hipStream_t>(s)), "hipStreamSynchronize");   // scratch is freed on return
+    out2.set_ntt(false);
+}
+
+// ---- N3: slot packing --------------------------------------------------------------------------------------------------------
+class BatchEncoder::Impl {
+public:
+    uint64_t t = 0;
+    size_t n = 0;
+    int logn = 0;
+    uint64_t n_inv = 0;
+    std::vector<uint64_t> rp, irp;       // zeta^brv(i), zeta^-brv(i) mod t  (the library's NTT convention, over Z_t)
+    std::vector<uint32_t> idx;           // slot -> NTT index: row 0 slots, then row 1 slots
+
+    static uint32_t brv(uint32_t x, int bits) { uint32_t r = 0; for (int i = 0; i < bits; ++i) { r = (r << 1) | (x & 1); x >>= 1; } return r; }
+    uint64_t mul(uint64_t a, uint64_t b) const { return (uint64_t)((u128)a * b % t); }
+    void ntt_fwd(std::vector<uint64_t>& a) const {   // natural in -> bit-reversed out: a^[k] = a(zeta^(2 brv(k) + 1))
+        for (size_t m = 1, len = n / 2; m < n; m <<= 1, len >>= 1)
+            for (size_t i = 0; i < m; ++i) {
+                const uint64_t w = rp[m + i];
+                for (size_t j = 2 * i * len; j < 2 * i * len + len; ++j) {
+                    const uint64_t u = a[j], v = mul(a[j + len], w);
+                    a[j] = u + v >= t ? u + v - t : u + v;
+                    a[j + len] = u >= v ? u - v : u + t - v;
+                }
+            }
+    }
+    void ntt_inv(std::vector<uint64_t>& a) const {
+        for (size_t m = n / 2, len = 1; m >= 1; m >>= 1, len <<= 1)
+            for (size_t i = 0; i < m; ++i) {
+                const uint64_t w = irp[m + i];
+                for (size_t j = 2 * i * len; j < 2 * i * len + len; ++j) {
+                    const uint64_t u = a[j], v = a[j + len];
+                    a[j] = u + v >= t ? u + v - t : u + v;
+                    a[j + len] = mul(u >= v ? u - v : u + t - v, w);
+                }
+            }
+        for (auto& v : a) v = mul(v, n_inv);
+    }
+};
+
+BatchEncoder::BatchEncoder(const Context& ctx, uint64_t t) : impl_(new Impl) {
+    const size_t n = ctx.params().n();
+    if (t < 3 || (t >> 32) || (t - 1) % (2 * n) != 0) throw Exception(ErrorCode::INVALID_ARGUMENT, "BatchEncoder: plaintext modulus must be a prime = 1 mod 2N below 2^32");
+    impl_->t = t; impl_->n = n; impl_->logn = (int)ctx.params().log2_n;
+    uint64_t zeta = 0;
+    for (uint64_t g = 2; g < t && !zeta; ++g) {   // zeta = g^((t-1)/2N) has order exactly 2N iff zeta^N = -1
+        const uint64_t z = powmod(g, (t - 1) / (2 * n), t);
+        if (powmod(z, n, t) == t - 1) zeta = z;
+    }
+    if (!zeta) throw Exception(ErrorCode::INVALID_ARGUMENT, "BatchEncoder: no primitive 2N-th root of unity mod t (t not prime?)");
+    const uint64_t izeta = powmod(zeta, t - 2, t);
+    impl_->rp.assign(n, 0); impl_->irp.assign(n, 0);
+    uint64_t pw = 1, ipw = 1;
+    for (size_t i = 0; i < n; ++i) {
+        const uint32_t r = Impl::brv((uint32_t)i, impl_->logn);
+        impl_->rp[r] = pw; impl_->irp[r] = ipw;
+        pw = impl_->mul(pw, zeta); ipw = impl_->mul(ipw, izeta);
+    }
+    impl_->n_inv = powmod(n % t, t - 2, t);
+    impl_->idx.assign(n, 0);
+    uint64_t e = 1;
+    for (size_t i = 0; i < n / 2; ++i) {
+        impl_->idx[i] = Impl::brv((uint32_t)((e - 1) / 2), impl_->logn);                  // zeta^(3^i)
+        impl_->idx[n / 2 + i] = Impl::brv((uint32_t)((2 * n - e - 1) / 2), impl_->logn);  // zeta^(-3^i)
+        e = e * 3 % (2 * n);
+    }
+}
+BatchEncoder::~BatchEncoder() = default;
+uint64_t BatchEncoder::plain_modulus() const { return impl_->t; }
+size_t BatchEncoder::slot_count() const { return impl_->n; }
+size_t BatchEncoder::row_size() const { return impl_->n / 2; }
+
+void BatchEncoder::encode(const uint64_t* slots, int64_t* coeffs) const {
+    if (!slots || !coeffs) throw Exception(ErrorCode::INVALID_ARGUMENT, "BatchEncoder::encode: null argument");
+    const size_t n = impl_->n;
+    std::vector<uint64_t> a(n);
+    for (size_t i = 0; i < n; ++i) {
+        if (slots[i] >= impl_->t) throw Exception(ErrorCode::INVALID_ARGUMENT, "BatchEncoder::encode: slot value >= plaintext modulus");
+        a[impl_->idx[i]] = slots[i];
+    }
+    impl_->ntt_inv(a);
+    for (size_t i = 0; i < n; ++i) coeffs[i] = a[i] > impl_->t / 2 ? (int64_t)a[i] - (int64_t)impl_->t : (int64_t)a[i];
+}
+void BatchEncoder::decode(const uint64_t* coeffs, uint64_t* slots) const {
+    if (!slots || !coeffs) throw Exception(ErrorCode::INVALID_ARGUMENT, "BatchEncoder::decode: null argument");
+    const size_t n = impl_->n;
+    std::vector<uint64_t> a(coeffs, coeffs + n);
+    for (auto& v : a) v %= impl_->t;
+    impl_->ntt_fwd(a);
+    for (size_t i = 0; i < n; ++i) slots[i] = a[impl_->idx[i]];
+}
+uint32_t BatchEncoder::galois_element(int left_rotation) const {
+    const long long row = (long long)impl_->n / 2;
+    const uint64_t s = (uint64_t)(((left_rotation % row) + row) % row);
+    return (uint32_t)powmod(3, s, 2 * impl_->n);
+}
+
+// ---- N3: packed matrix-vector product (diagonal method, baby-step / giant-step) -------------------------------------------
+class PackedLinear::Impl {
+public:
+    const Context* ctx = nullptr;
+    const BatchEncoder* enc = nullptr;
+    HybridKeySwitcher* ks = nullptr;
+    size_t d = 0, n1 = 0, n2 = 0;
+    std::unique_ptr<Plaintext> diag;   // [n2][n1] pre-rotated diagonals, NTT domain
+    std::vector<uint32_t> baby_elts, giant_elts;
+};
+
+PackedLinear::PackedLinear(const Context& ctx, const BatchEncoder& enc, HybridKeySwitcher& ks, const uint64_t* W, size_t d) : impl_(new Impl) {
+    const FheParams& p = ctx.params();
+    const size_t n = p.n(), L = p.n_limbs(), row = n / 2;
+    if (!W || d < 2 || (d & (d - 1)) || row % d) throw Exception(ErrorCode::INVALID_ARGUMENT, "PackedLinear: d must be a power of two dividing N/2");
+    if (enc.slot_count() != n) throw Exception(ErrorCode::INVALID_ARGUMENT, "PackedLinear: encoder and context disagree on N");
+    impl_->ctx = &ctx; impl_->enc = &enc; impl_->ks = &ks; impl_->d = d;
+    size_t n1 = 1;
+    while (n1 * n1 < d) n1 <<= 1;
+    impl_->n1 = n1; impl_->n2 = d / n1;
+    const uint64_t t = enc.plain_modulus();
+    for (size_t j = 1; j < impl_->n1; ++j) impl_->baby_elts.push_back(enc.galois_element((int)j));
+    for (size_t i = 1; i < impl_->n2; ++i) impl_->giant_elts.push_back(enc.galois_element((int)(i * n1)));
+    for (uint32_t g : impl_->baby_elts) ks.add_galois_element(g);
+    for (uint32_t g : impl_->giant_elts) ks.add_galois_element(g);
+    impl_->diag.reset(new Plaintext(ctx, impl_->n2 * n1, /*is_ntt=*/false));
+    std::vector<uint64_t> slots(n), host(n1 * L * n);
+    std::vector<int64_t> coeffs(n);
+    for (size_t i = 0; i < impl_->n2; ++i) {
+        for (size_t j = 0; j < n1; ++j) {
+            const size_t k = i * n1 + j;                 // diagonal index; stored rotated right by i*n1
+            for (size_t r = 0; r < row; ++r) {
+                const size_t rho = (r % d + d - (i * n1) % d) % d;
+                const uint64_t v = W[rho * d + (rho + k) % d];
+                if (v >= t) throw Exception(ErrorCode::INVALID_ARGUMENT, "PackedLinear: weight >= plaintext modulus");
+                slots[r] = slots[row + r] = v;
+            }
+            enc.encode(slots.data(), coeffs.data());
+            for (size_t l = 0; l < L; ++l)
+                for (size_t c = 0; c < n; ++c) host[(j * L + l) * n + c] = lift_signed(coeffs[c], p.moduli[l]);
+        }
+        hip_check(hipMemcpy(impl_->diag->data() + i * n1 * L * n, host.data(), host.size() * sizeof(uint64_t), hipMemcpyHostToDevice), "hipMemcpy H2D");
+    }
+    Evaluator ev(ctx);
+    ev.transform_to_ntt_inplace(*impl_->diag);
+    ctx.synchronize();
+}
+PackedLinear::~PackedLinear() = default;
+size_t PackedLinear::dim() const { return impl_->d; }
+size_t PackedLinear::baby_steps() const { return impl_->n1; }
+size_t PackedLinear::giant_steps() const { return impl_->n2; }
+
+void PackedLinear::apply(const Ciphertext& x, Ciphertext& y, Stream* s) const {
+    if (x.is_ntt() || x.size() != 2 || x.batch() != 1 || y.size() != 2 || y.batch() != 1)
+        throw Exception(ErrorCode::INVALID_ARGUMENT, "PackedLinear::apply: one 2-component coefficient-domain ciphertext in and out");
+    const Context& ctx = *impl_->ctx;
+    const FheParams& p = ctx.params();
+    const size_t ct_words = 2 * p.n_limbs() * p.n(), n1 = impl_->n1, n2 = impl_->n2;
+    hipStream_t hs = static_cast<hipStream_t>(s);
+    Evaluator ev(ctx);
+    // baby steps: rot_j(x), j < n1, in ONE batched rotation pass, then transformed together
+    Ciphertext babies(ctx, 2, n1);
+    hip_check(hipMemcpyAsync(babies.data(), x.data(), ct_words * sizeof(uint64_t), hipMemcpyDeviceToDevice, hs), "hipMemcpyAsync");
+    impl_->ks->apply_galois_many(x, impl_->baby_elts, babies, /*out_first=*/1, s);
+    ev.transform_to_ntt_inplace(babies, s);
+    // inner sums of all giant steps: one matrix-vector product over the pre-rotated diagonals
+    Ciphertext inner(ctx, 2, n2, /*is_ntt=*/true);
+    ev.matvec_plain(*impl_->diag, babies, inner, s);
+    ev.transform_from_ntt_inplace(inner, s);
+    // giant steps: inner sum i rotated by i*n1 (one batched pass over items 1..n2-1), then the sum over i
+    if (n2 > 1) {
+        Ciphertext tail(ctx, 2, n2 - 1), rotated(ctx, 2, n2);
+        hip_check(hipMemcpyAsync(tail.data(), inner.data() + ct_words, (n2 - 1) * ct_words * sizeof(uint64_t), hipMemcpyDeviceToDevice, hs), "hipMemcpyAsync");
+        hip_check(hipMemcpyAsync(rotated.data(), inner.data(), ct_words * sizeof(uint64_t), hipMemcpyDeviceToDevice, hs), "hipMemcpyAsync");
+        impl_->ks->apply_galois_many(tail, impl_->giant_elts, rotated, /*out_first=*/1, s);
+        ev.reduce_sum(rotated, y, s);
+    } else {
+        hip_check(hipMemcpyAsync(y.data(), inner.data(), ct_words * sizeof(uint64_t), hipMemcpyDeviceToDevice, hs), "hipMemcpyAsync");
+    }
+    y.set_ntt(false);
+    hip_check(hipStreamSynchronize(hs), "hipStreamSynchronize");   // temporaries are freed on return
 }
 
 }  // namespace fhe

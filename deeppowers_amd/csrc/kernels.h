@@ -260,7 +260,7 @@ __device__ __forceinline__ u64 canon_any(u64 v, const LimbConst& lc) {  // any v
 //         buffer [batch][2][L][N] with nothing added back; dpfhe's rescale-add pass then divides by P and adds (c0, c1).
 template <class Arith, int LOGN, int LOGE, int MODE>
 __global__ __launch_bounds__(1 << (LOGN - LOGE), (Arith::kFold ? 2 : 1)) void relin_kernel(u64* __restrict__ out2, const u64* __restrict__ in3,
-                                                                       const u64* __restrict__ evk, DevTables<Arith> tb) {
+                                                                       const u64* __restrict__ evk, size_t key_stride, DevTables<Arith> tb) {
     typedef NttBody<Arith, LOGN, LOGE> B;
     static_assert(LOGE == 4, "the fused kernels read the LOGE = 4 twiddle layout (DevTables::fwd4 / inv4)");
     constexpr int E = B::E, N = B::G::N;
@@ -275,6 +275,7 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE), (Arith::kFold ? 2 : 1)) void re
     constexpr bool kHybrid = MODE >= 2;
     const int Ld = kHybrid ? L - 1 : L;                                   // limbs of the data (= number of digits)
     const u64* c2 = in3 + ((bi * kInComps + (kInComps - 1)) * Ld) * N;  // digit j at + j*N
+    evk += bi * key_stride;                                              // per-item keys (batched rotations); 0 = one shared key
     u64 acc0[E], acc1[E];
 #pragma unroll
     for (int k = 0; k < E; ++k) acc0[k] = acc1[k] = 0;

@@ -299,4 +299,22 @@ __global__ __launch_bounds__(256) void galois_kernel(u64* out, const u64* in, co
     }
 }
 
+// batched rotations: item i applies its own element (g_inv.v[i]) to input item i (or to the single input item when
+// in_item_stride == 0); polys_per_item residue polynomials per item
+constexpr int kMaxGaloisBatch = 64;
+struct GaloisInvs { unsigned v[kMaxGaloisBatch]; };
+__global__ __launch_bounds__(256) void galois_multi_kernel(u64* out, const u64* in, size_t in_item_stride, const LimbConst* lcs, int n_limbs, int n,
+                                                           int polys_per_item, GaloisInvs g_inv) {
+    const size_t item = blockIdx.x / (unsigned)polys_per_item, p = blockIdx.x % (unsigned)polys_per_item;
+    const u64 q = lcs[p % (size_t)n_limbs].q;
+    const unsigned mask2n = 2u * (unsigned)n - 1u, gi = g_inv.v[item];
+    const u64* src = in + item * in_item_stride + p * n;
+    u64* dst = out + (item * polys_per_item + p) * n;
+    for (int k = threadIdx.x; k < n; k += 256) {
+        const unsigned j = ((unsigned)k * gi) & mask2n;
+        const u64 v = src[j & ((unsigned)n - 1u)];
+        dst[k] = (j < (unsigned)n) ? v : neg_mod(v, q);
+    }
+}
+
 }  // namespace dpfhe

@@ -18,6 +18,6 @@ template <class Arith>
 int launch_ct_mul(int log2n, unsigned flags, u64* out3, const u64* a2, const u64* b2, size_t blocks, const DevTables<Arith>& tb, hipStream_t s);
 
 template <class Arith>
-int launch_relin(int log2n, int mode, u64* out2, const u64* in3, const u64* evk, size_t blocks, const DevTables<Arith>& tb, hipStream_t s);
+int launch_relin(int log2n, int mode, u64* out2, const u64* in3, const u64* evk, size_t key_stride, size_t blocks, const DevTables<Arith>& tb, hipStream_t s);
 
 }  // namespace dpfhe

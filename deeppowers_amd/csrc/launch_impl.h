@@ -49,8 +49,8 @@ int launch_ct_mul(int log2n, unsigned flags, u64* out3, const u64* a2, const u64
 }
 
 template <class Arith>
-int launch_relin(int log2n, int mode, u64* out2, const u64* in3, const u64* evk, size_t blocks, const DevTables<Arith>& tb, hipStream_t s) {
-#define RL_ONE(LN, M) hipLaunchKernelGGL((relin_kernel<Arith, LN, 4, M>), dim3((unsigned)blocks), dim3(Geo<LN, 4>::T), 0, s, out2, in3, evk, tb)
+int launch_relin(int log2n, int mode, u64* out2, const u64* in3, const u64* evk, size_t key_stride, size_t blocks, const DevTables<Arith>& tb, hipStream_t s) {
+#define RL_ONE(LN, M) hipLaunchKernelGGL((relin_kernel<Arith, LN, 4, M>), dim3((unsigned)blocks), dim3(Geo<LN, 4>::T), 0, s, out2, in3, evk, key_stride, tb)
 #define RL_CASE(LN, LE)                \
     if (mode == 0) RL_ONE(LN, 0);      \
     else if (mode == 1) RL_ONE(LN, 1); \

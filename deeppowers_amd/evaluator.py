@@ -274,6 +274,26 @@ class Evaluator:
         _cabi.check(fn(self.ctx.handle, out.data_ptr(), d.data_ptr(), key.data_ptr(), work.data_ptr(), batch, _stream_ptr(stream)), "dpfhe_*_hybrid")
         return Ciphertext(out, False)
 
+    def rotate_hybrid_batch(self, ct: Ciphertext, galois_elts, keys: torch.Tensor, stream=None) -> Ciphertext:
+        """N3, batched rotations on the extended context: output item i = key-switched sigma_{galois_elts[i]} of input item
+        i, or of THE input item when ct holds one.  keys: [len(elts)][L-1][2][L][N] (key i switches sigma_{g_i}(s) -> s)."""
+        import ctypes as C
+        p = self.ctx.params
+        L, Ld, n = p.n_limbs, p.n_limbs - 1, p.n
+        d = ct.data
+        k = len(galois_elts)
+        if ct.is_ntt or ct.size != 2 or d.dim() != 4 or d.shape[-2] != Ld or d.shape[-1] != n or d.dtype != torch.int64 or not d.is_contiguous() or d.shape[0] not in (1, k):
+            raise _cabi.DpfheError(2000, "rotate_hybrid_batch: coefficient-domain [1 or k][2][L-1][N] ciphertexts on the extended context")
+        if tuple(keys.shape) != (k, Ld, 2, L, n) or keys.dtype != torch.int64 or not keys.is_contiguous():
+            raise _cabi.DpfheError(2000, "keys must be [k][L-1][2][L][N]")
+        out = torch.empty(k, 2, Ld, n, dtype=torch.int64, device=d.device)
+        work = torch.empty(k, 2, L, n, dtype=torch.int64, device=d.device)
+        rotated = torch.empty(k, 2, Ld, n, dtype=torch.int64, device=d.device)
+        elts = (C.c_uint32 * k)(*[int(g) for g in galois_elts])
+        _cabi.check(self._lib.dpfhe_rotate_hybrid_batch(self.ctx.handle, out.data_ptr(), d.data_ptr(), d.shape[0], elts, keys.data_ptr(), work.data_ptr(),
+                                                        rotated.data_ptr(), k, _stream_ptr(stream)), "dpfhe_rotate_hybrid_batch")
+        return Ciphertext(out, False)
+
     def rescale_words(self, t: torch.Tensor, stream=None) -> torch.Tensor:
         """[..., L, N] -> [..., L-1, N]: round(x / q_last) limb by limb (coefficient domain).  The result belongs to the
         context of the first L-1 moduli."""

@@ -229,6 +229,8 @@ public:
     Encryptor& operator=(const Encryptor&) = delete;
     // messages: out.batch() * N signed coefficients; out: 2-component ciphertext(s), coefficient domain
     void encrypt(const int64_t* messages, unsigned log2_scale, Ciphertext& out);
+    // exact integer arithmetic mod a plaintext modulus t (BFV-style scaling): c0 = -(a s) + e + floor(Q/t) * m
+    void encrypt_exact(const int64_t* messages, uint64_t plain_modulus, Ciphertext& out);
 
 private:
     class Impl;
@@ -244,6 +246,8 @@ public:
     // ct: 2 or 3 components, coefficient domain.  messages_out: ct.batch() * N values round(phase / 2^log2_scale);
     // throws RUNTIME_ERROR if a value does not fit 62 bits (wrong scale or noise overflow).
     void decrypt(const Ciphertext& ct, unsigned log2_scale, int64_t* messages_out);
+    // inverse of encrypt_exact: messages_out[k] = round(t * phase_k / Q) mod t, in [0, t)
+    void decrypt_exact(const Ciphertext& ct, uint64_t plain_modulus, uint64_t* messages_out);
 
 private:
     class Impl;
@@ -264,6 +268,57 @@ public:
     void relinearize(const Ciphertext& in3, Ciphertext& out2, Stream* stream = nullptr) const;
     // ciphertext of m(X) -> ciphertext of m(X^g); the element must have been added
     void apply_galois(const Ciphertext& in2, uint32_t galois_elt, Ciphertext& out2, Stream* stream = nullptr) const;
+    // many rotations in one pass (dpfhe_rotate_hybrid_batch): out item out_first + i = sigma_{elts[i]} of in item i, or of THE
+    // item of `in` when it holds one.  All elements must have been added; the keys of a given element list are packed
+    // back to back once and cached.
+    void apply_galois_many(const Ciphertext& in2, const std::vector<uint32_t>& galois_elts, Ciphertext& out2, size_t out_first = 0,
+                           Stream* stream = nullptr) const;
+
+private:
+    class Impl;
+    std::unique_ptr<Impl> impl_;
+};
+
+// ---- N3: slot packing and the packed matrix-vector product ------------------------------------
+// BatchEncoder: N slots of Z_t (t prime, t = 1 mod 2N) arranged as 2 rows x N/2.  Slot i of row 0 is the value of the
+// message polynomial at zeta^(3^i), row 1 at zeta^(-3^i) (zeta a primitive 2N-th root mod t), so the automorphism
+// X -> X^(3^s) rotates both rows LEFT by s slots and X -> X^(2N-1) swaps the rows.  Host-side (client-side) code.
+class BatchEncoder {
+public:
+    explicit BatchEncoder(const Context& ctx, uint64_t plain_modulus = 65537);
+    ~BatchEncoder();
+    BatchEncoder(const BatchEncoder&) = delete;
+    BatchEncoder& operator=(const BatchEncoder&) = delete;
+    uint64_t plain_modulus() const;
+    size_t slot_count() const;   // N
+    size_t row_size() const;     // N / 2
+    void encode(const uint64_t* slots /* N values < t: row 0 then row 1 */, int64_t* coeffs_out /* N, centred mod t */) const;
+    void decode(const uint64_t* coeffs_mod_t /* N */, uint64_t* slots_out /* N */) const;
+    uint32_t galois_element(int left_rotation) const;   // 3^s mod 2N (negative s rotates right)
+
+private:
+    class Impl;
+    std::unique_ptr<Impl> impl_;
+};
+
+// PackedLinear: encrypted y = W x over Z_t for a d x d matrix in slot packing (d a power of two dividing N/2; the
+// vector sits in both rows, repeated N/2/d times), by the diagonal method with baby-step / giant-step rotations:
+//   y = sum_i rot_{i n1}( sum_j rot_{-i n1}(diag_{i n1 + j}) (.) rot_j(x) ),   diag_k[r] = W[r][(r + k) mod d],  n1 n2 = d.
+// Per application: n1 - 1 + n2 - 1 rotations (automorphism + hybrid key switch, `relin_kernel` MODE 3), one batched
+// forward NTT of the n1 rotated inputs, ONE dpfhe_matvec_plain over the n2 x n1 pre-transformed diagonals, one batched
+// inverse NTT.  This is the encrypted replacement of the dense layers at the reference's matmul sites
+// (/root/reference/src/core/execution/models/gpt_model.cpp:793,848,883) for a single token.
+class PackedLinear {
+public:
+    // W: d*d values < t, row-major.  The needed Galois keys are added to `ks`.
+    PackedLinear(const Context& data_ctx, const BatchEncoder& enc, HybridKeySwitcher& ks, const uint64_t* W, size_t d);
+    ~PackedLinear();
+    PackedLinear(const PackedLinear&) = delete;
+    PackedLinear& operator=(const PackedLinear&) = delete;
+    size_t dim() const;
+    size_t baby_steps() const;
+    size_t giant_steps() const;
+    void apply(const Ciphertext& x, Ciphertext& y, Stream* stream = nullptr) const;   // 1-item, 2-component, coefficient domain
 
 private:
     class Impl;

@@ -109,6 +109,14 @@ int dpfhe_relinearize_hybrid(dpfhe_ctx* ctx_ext, uint64_t* d_out2, const uint64_
 int dpfhe_switch_key_hybrid(dpfhe_ctx* ctx_ext, uint64_t* d_out2, const uint64_t* d_in2, const uint64_t* d_key, uint64_t* d_work,
                             size_t batch, void* stream);
 
+/* -- N3, batched rotations (the baby / giant steps of a packed matrix-vector product): item i of the output is the
+ * hybrid-key-switched sigma_{galois_elts[i]} of input item i (n_in == batch) or of THE input item (n_in == 1).
+ * galois_elts: HOST array of `batch` odd elements < 2N.  d_keys: `batch` keys back to back, each [Ld][2][L][N] as for
+ * dpfhe_switch_key_hybrid, key i for element i.  d_work: batch * 2 * L * N words; d_rotated: batch * 2 * Ld * N words
+ * (scratch, must not alias the input).  One automorphism launch per 64 items + one key-switch pass for all of them. */
+int dpfhe_rotate_hybrid_batch(dpfhe_ctx* ctx_ext, uint64_t* d_out2, const uint64_t* d_in2, size_t n_in, const uint32_t* galois_elts,
+                              const uint64_t* d_keys, uint64_t* d_work, uint64_t* d_rotated, size_t batch, void* stream);
+
 /* -- N3: Galois automorphism a(X) -> a(X^galois_elt) (galois_elt odd, < 2N), coefficient domain, d_out != d_in;
  *        and the key switch that follows it:  (c0', c1') = (c0 + sum_j [c1]_{q_j} (.) key_j[0], sum_j [c1]_{q_j} (.) key_j[1]),
  *        key_j = (-(a_j s) + e_j + g_j sigma(s), a_j) in the NTT domain, layout [L][2][L][N] like the relinearisation keys. */

@@ -210,8 +210,96 @@ static void end_to_end(const FheParams& p, size_t batch) {
     try { dec.decrypt(c3, 0, out.data()); CHECK(!"expected RUNTIME_ERROR"); } catch (const Exception& e) { CHECK(e.code() == ErrorCode::RUNTIME_ERROR); }
 }
 
+// N3: slot packing, exact (mod t) encryption, slot rotations under encryption and the baby-step/giant-step packed
+// matrix-vector product, against plain modular arithmetic on the host
+static void packed(unsigned log2n, size_t d) {
+    FheParams p = FheParams::n8192_l6();          // six pinned primes = 1 mod 16384; psi_N = psi_8192^(8192/N)
+    const size_t n = (size_t)1 << log2n, row = n / 2;
+    const uint64_t special = p.moduli.back();
+    auto pw = [](uint64_t b, uint64_t e, uint64_t q) { uint64_t r = 1; for (b %= q; e; e >>= 1) { if (e & 1) r = (uint64_t)((unsigned __int128)r * b % q); b = (uint64_t)((unsigned __int128)b * b % q); } return r; };
+    for (size_t l = 0; l < p.moduli.size(); ++l) p.psi[l] = pw(p.psi[l], 8192 / n, p.moduli[l]);
+    const uint64_t special_psi = p.psi.back();
+    p.log2_n = log2n; p.moduli.pop_back(); p.psi.pop_back();    // 5 data limbs + the 6th as the special prime
+    Context ctx(p, 0);
+    KeyGenerator kg(ctx, 21);
+    Encryptor enc(ctx, kg.secret_key(), 22);
+    Decryptor dec(ctx, kg.secret_key());
+    BatchEncoder be(ctx, 65537);
+    const uint64_t t = be.plain_modulus();
+    uint64_t s = 7;
+    auto rnd = [&]() { s = s * 6364136223846793005ull + 1442695040888963407ull; return (s >> 33) % t; };
+    // encoder round trip, and slot-wise product = polynomial product
+    std::vector<uint64_t> va(n), vb(n), got(n);
+    for (auto& v : va) v = rnd();
+    for (auto& v : vb) v = rnd();
+    std::vector<int64_t> ca(n), cb(n);
+    be.encode(va.data(), ca.data());
+    be.encode(vb.data(), cb.data());
+    {
+        std::vector<uint64_t> um(n);
+        for (size_t i = 0; i < n; ++i) um[i] = (uint64_t)(ca[i] < 0 ? ca[i] + (int64_t)t : ca[i]);
+        be.decode(um.data(), got.data());
+        CHECK(got == va);
+    }
+    // exact encryption round trip, plaintext multiply in slots, rotations of the rows, row swap
+    Evaluator ev(ctx);
+    Ciphertext cx(ctx, 2, 1), cy(ctx, 2, 1);
+    enc.encrypt_exact(ca.data(), t, cx);
+    std::vector<uint64_t> dm(n);
+    dec.decrypt_exact(cx, t, dm.data());
+    be.decode(dm.data(), got.data());
+    CHECK(got == va);
+    HybridKeySwitcher hks(ctx, kg.secret_key(), special, special_psi);
+    for (int rot : {1, 5, -3}) {
+        const uint32_t g = be.galois_element(rot);
+        hks.add_galois_element(g);
+        hks.apply_galois(cx, g, cy);
+        dec.decrypt_exact(cy, t, dm.data());
+        be.decode(dm.data(), got.data());
+        bool ok = true;
+        for (size_t r = 0; r < row; ++r) {
+            const size_t src = (r + (size_t)((rot % (long long)row + (long long)row) % (long long)row)) % row;
+            ok = ok && got[r] == va[src] && got[row + r] == va[row + src];
+        }
+        CHECK(ok);                                  // both rows rotate left by `rot`
+    }
+    {
+        const uint32_t g = (uint32_t)(2 * n - 1);
+        hks.add_galois_element(g);
+        hks.apply_galois(cx, g, cy);
+        dec.decrypt_exact(cy, t, dm.data());
+        be.decode(dm.data(), got.data());
+        bool ok = true;
+        for (size_t r = 0; r < row; ++r) ok = ok && got[r] == va[row + r] && got[row + r] == va[r];
+        CHECK(ok);                                  // X -> X^(2N-1) swaps the rows
+    }
+    // packed y = W x
+    std::vector<uint64_t> W(d * d), x(d), want(d, 0), slots(n);
+    for (auto& v : W) v = rnd();
+    for (auto& v : x) v = rnd();
+    for (size_t r = 0; r < d; ++r) {
+        unsigned __int128 acc = 0;
+        for (size_t c = 0; c < d; ++c) acc += (unsigned __int128)W[r * d + c] * x[c];
+        want[r] = (uint64_t)(acc % t);
+    }
+    for (size_t r = 0; r < row; ++r) slots[r] = slots[row + r] = x[r % d];
+    std::vector<int64_t> cxv(n);
+    be.encode(slots.data(), cxv.data());
+    enc.encrypt_exact(cxv.data(), t, cx);
+    PackedLinear lin(ctx, be, hks, W.data(), d);
+    CHECK(lin.baby_steps() * lin.giant_steps() == d);
+    lin.apply(cx, cy);
+    dec.decrypt_exact(cy, t, dm.data());
+    be.decode(dm.data(), got.data());
+    bool ok = true;
+    for (size_t r = 0; r < row; ++r) ok = ok && got[r] == want[r % d] && got[row + r] == want[r % d];
+    CHECK(ok);
+}
+
 int main() {
     try {
+        packed(10, 64);
+        packed(12, 16);
         end_to_end(FheParams::n4096_l4(), 2);
         run(FheParams::config1(), 2);
         run(FheParams::n4096_l4(), 3);

@@ -33,12 +33,19 @@ def build_example(name="encrypted_multiply"):
 
 
 def test_example_compiles():
-    assert all(os.path.exists(build_example(e)) for e in ("encrypted_multiply", "bench_ct_mul", "encrypted_linear"))
+    assert all(os.path.exists(build_example(e)) for e in ("encrypted_multiply", "bench_ct_mul", "encrypted_linear", "encrypted_gpt2_linear"))
 
 
 @pytest.mark.gpu
 def test_example_encrypted_linear_layer():
     out = subprocess.run([build_example("encrypted_linear")], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "OK" in out.stdout, out.stdout + out.stderr
+
+
+@pytest.mark.gpu
+def test_example_encrypted_gpt2_linear_layer():
+    """N3: slot-packed 256 x 256 layer at N=8192 (the full 1024 x 1024 run is the example's default)"""
+    out = subprocess.run([build_example("encrypted_gpt2_linear"), "256", "1"], capture_output=True, text=True, timeout=900)
     assert out.returncode == 0 and "OK" in out.stdout, out.stdout + out.stderr
 
 

@@ -463,3 +463,32 @@ def test_hybrid_key_switching_bit_exact_vs_oracle(name):
         got = to_host(ev.keyswitch_hybrid(Ciphertext(to_device(ct, ctx.device)), to_device(key, ctx.device)).data)
         assert np.array_equal(got, want), comps
     ctx.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["n4096", "n8192"])
+def test_gpu_batched_rotations_bit_exact(name):
+    """dpfhe_rotate_hybrid_batch == per-item automorphism + hybrid key switch of the oracle, for one shared input and for
+    one input per item (70 items: more than one 64-element launch group)."""
+    from deeppowers_amd.evaluator import Ciphertext, Context, Evaluator, to_device, to_host
+    if name == "n4096":
+        pe = FheParams(12, tuple(x[0] for x in PRIMES_60[:3]), tuple(x[1] for x in PRIMES_60[:3]))     # 2 data limbs + P
+    else:
+        pe = FheParams(13, tuple(x[0] for x in PRIMES_60[:3]), tuple(x[2] for x in PRIMES_60[:3]))
+    orc = Oracle.from_params(pe)
+    L, Ld, n = pe.n_limbs, pe.n_limbs - 1, pe.n
+    data = Oracle(pe.log2_n, pe.moduli[:-1], pe.psi[:-1])
+    ctx = Context(pe, 0)
+    ev = Evaluator(ctx)
+    for k, shared in ((5, True), (70, False)):
+        elts = [pow(3, i + 1, 2 * n) for i in range(k)]
+        elts[-1] = 2 * n - 1
+        keys = orc.fill(k * Ld * 2, 601).reshape(k, Ld, 2, L, n)
+        ct = data.fill((1 if shared else k) * 2, 602).reshape(-1, 2, Ld, n)
+        got = to_host(ev.rotate_hybrid_batch(Ciphertext(to_device(ct, ctx.device)), elts, to_device(keys, ctx.device)).data)
+        for i in (range(k) if k <= 8 else (0, 1, 63, 64, 69)):
+            src = ct[0 if shared else i][None]
+            rot = data.apply_galois(src, elts[i])
+            want = orc.keyswitch_hybrid(rot, keys[i], 2, threads=0)[0]
+            assert np.array_equal(got[i], want), (k, i)
+    ctx.close()
