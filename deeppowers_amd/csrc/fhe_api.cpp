@@ -710,6 +710,14 @@ public:
     std::unique_ptr<PolyBuffer> relin;                       // [Ld][2][L][N]
     std::vector<std::pair<uint32_t, std::unique_ptr<PolyBuffer>>> galois;
     std::vector<std::pair<std::vector<uint32_t>, std::unique_ptr<PolyBuffer>>> packed;   // element list -> its keys back to back
+    std::unique_ptr<PolyBuffer> scratch_work;      // batched rotations: reused across calls (one caller at a time per switcher)
+    std::unique_ptr<Ciphertext> scratch_rotated;
+    void ensure_scratch(size_t k) {
+        if (!scratch_work || scratch_work->batch() < k) {
+            scratch_work.reset(new PolyBuffer(*ext, k, 2, false));
+            scratch_rotated.reset(new Ciphertext(*data_ctx, 2, k));
+        }
+    }
     SplitMix rng{0};
     uint64_t p_special = 0;
 
@@ -811,11 +819,9 @@ void HybridKeySwitcher::apply_galois_many(const Ciphertext& in2, const std::vect
         keys = buf.get();
         impl_->packed.emplace_back(elts, std::move(buf));
     }
-    PolyBuffer work(*impl_->ext, k, 2, false);
-    Ciphertext rotated(*impl_->data_ctx, 2, k);
+    impl_->ensure_scratch(k);   // kept for the next call: no allocation and no host synchronisation on the steady path
     check(dpfhe_rotate_hybrid_batch(static_cast<dpfhe_ctx*>(impl_->ext->handle()), out2.data() + out_first * ct_words, in2.data(), in2.batch(), elts.data(),
-                                    keys->data(), work.data(), rotated.data(), k, s), "dpfhe_rotate_hybrid_batch");
-    hip_check(hipStreamSynchronize(static_cast<hipStream_t>(s)), "hipStreamSynchronize");   // scratch is freed on return
+                                    keys->data(), impl_->scratch_work->data(), impl_->scratch_rotated->data(), k, s), "dpfhe_rotate_hybrid_batch");
     out2.set_ntt(false);
 }
 
@@ -922,6 +928,7 @@ public:
     size_t d = 0, n1 = 0, n2 = 0;
     std::unique_ptr<Plaintext> diag;   // [n2][n1] pre-rotated diagonals, NTT domain
     std::vector<uint32_t> baby_elts, giant_elts;
+    std::unique_ptr<Ciphertext> babies, inner, tail, rotated;   // per-layer scratch, reused by every apply() (one caller at a time)
 };
 
 PackedLinear::PackedLinear(const Context& ctx, const BatchEncoder& enc, HybridKeySwitcher& ks, const uint64_t* W, size_t d) : impl_(new Impl) {
@@ -958,6 +965,12 @@ PackedLinear::PackedLinear(const Context& ctx, const BatchEncoder& enc, HybridKe
     }
     Evaluator ev(ctx);
     ev.transform_to_ntt_inplace(*impl_->diag);
+    impl_->babies.reset(new Ciphertext(ctx, 2, n1));
+    impl_->inner.reset(new Ciphertext(ctx, 2, impl_->n2, /*is_ntt=*/true));
+    if (impl_->n2 > 1) {
+        impl_->tail.reset(new Ciphertext(ctx, 2, impl_->n2 - 1));
+        impl_->rotated.reset(new Ciphertext(ctx, 2, impl_->n2));
+    }
     ctx.synchronize();
 }
 PackedLinear::~PackedLinear() = default;
@@ -974,17 +987,20 @@ void PackedLinear::apply(const Ciphertext& x, Ciphertext& y, Stream* s) const {
     hipStream_t hs = static_cast<hipStream_t>(s);
     Evaluator ev(ctx);
     // baby steps: rot_j(x), j < n1, in ONE batched rotation pass, then transformed together
-    Ciphertext babies(ctx, 2, n1);
+    Ciphertext& babies = *impl_->babies;
+    Ciphertext& inner = *impl_->inner;
+    babies.set_ntt(false);
     hip_check(hipMemcpyAsync(babies.data(), x.data(), ct_words * sizeof(uint64_t), hipMemcpyDeviceToDevice, hs), "hipMemcpyAsync");
     impl_->ks->apply_galois_many(x, impl_->baby_elts, babies, /*out_first=*/1, s);
     ev.transform_to_ntt_inplace(babies, s);
     // inner sums of all giant steps: one matrix-vector product over the pre-rotated diagonals
-    Ciphertext inner(ctx, 2, n2, /*is_ntt=*/true);
+    inner.set_ntt(true);
     ev.matvec_plain(*impl_->diag, babies, inner, s);
     ev.transform_from_ntt_inplace(inner, s);
     // giant steps: inner sum i rotated by i*n1 (one batched pass over items 1..n2-1), then the sum over i
     if (n2 > 1) {
-        Ciphertext tail(ctx, 2, n2 - 1), rotated(ctx, 2, n2);
+        Ciphertext& tail = *impl_->tail;
+        Ciphertext& rotated = *impl_->rotated;
         hip_check(hipMemcpyAsync(tail.data(), inner.data() + ct_words, (n2 - 1) * ct_words * sizeof(uint64_t), hipMemcpyDeviceToDevice, hs), "hipMemcpyAsync");
         hip_check(hipMemcpyAsync(rotated.data(), inner.data(), ct_words * sizeof(uint64_t), hipMemcpyDeviceToDevice, hs), "hipMemcpyAsync");
         impl_->ks->apply_galois_many(tail, impl_->giant_elts, rotated, /*out_first=*/1, s);
@@ -993,7 +1009,7 @@ void PackedLinear::apply(const Ciphertext& x, Ciphertext& y, Stream* s) const {
         hip_check(hipMemcpyAsync(y.data(), inner.data(), ct_words * sizeof(uint64_t), hipMemcpyDeviceToDevice, hs), "hipMemcpyAsync");
     }
     y.set_ntt(false);
-    hip_check(hipStreamSynchronize(hs), "hipStreamSynchronize");   // temporaries are freed on return
+    // enqueue only: the scratch belongs to the layer, the caller synchronises (Context::synchronize) before reading y
 }
 
 }  // namespace fhe

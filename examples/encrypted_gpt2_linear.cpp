@@ -55,8 +55,10 @@ int main(int argc, char** argv) {
         enc.encrypt_exact(coeffs.data(), t, cx);
 
         layer.apply(cx, cy);                                // warm-up (code objects, allocator)
+        ctx.synchronize();
         t0 = std::chrono::steady_clock::now();
         for (int i = 0; i < reps; ++i) layer.apply(cx, cy);
+        ctx.synchronize();
         const double apply_ms = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() * 1e3 / reps;
 
         dec.decrypt_exact(cy, t, dm.data());

@@ -318,7 +318,9 @@ public:
     size_t dim() const;
     size_t baby_steps() const;
     size_t giant_steps() const;
-    void apply(const Ciphertext& x, Ciphertext& y, Stream* stream = nullptr) const;   // 1-item, 2-component, coefficient domain
+    // 1-item, 2-component, coefficient domain.  Enqueues on `stream` and returns (no allocation, no host synchronisation: the
+    // scratch belongs to the layer, so one apply() at a time per object); synchronise before reading y on the host.
+    void apply(const Ciphertext& x, Ciphertext& y, Stream* stream = nullptr) const;
 
 private:
     class Impl;

@@ -289,6 +289,7 @@ static void packed(unsigned log2n, size_t d) {
     PackedLinear lin(ctx, be, hks, W.data(), d);
     CHECK(lin.baby_steps() * lin.giant_steps() == d);
     lin.apply(cx, cy);
+    ctx.synchronize();
     dec.decrypt_exact(cy, t, dm.data());
     be.decode(dm.data(), got.data());
     bool ok = true;
