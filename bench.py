@@ -115,17 +115,21 @@ def main():
         x = torch.randint(0, 2**62, (nb, L, N), generator=g, dtype=torch.int64, device=dev) % q.view(1, L, 1)
         y = torch.empty_like(x)
         ntt = {}
-        for name, fn in (("fwd", ev.ntt_forward), ("inv", ev.ntt_inverse)):
-            for _ in range(5):
+        fns = (("fwd", ev.ntt_forward), ("inv", ev.ntt_inverse))
+        for _ in range(5):
+            for _, fn in fns:
                 fn(x, out=y)
-            # 30 launches enqueued back to back, each bracketed by its own pair of HIP events; one host sync at the end
-            # (a host sync after every launch lets the clocks ramp down and reads 10-15 % slower)
-            evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(30)]
-            for s_, e_ in evs:
+        # 30 launches of each direction, interleaved (the clocks drift by ~10 % within a second of sustained load, so
+        # measuring one direction after the other would penalise the second), enqueued back to back, each bracketed by
+        # its own pair of HIP events; one host sync at the end (a host sync after every launch reads 10-15 % slower)
+        evs = {name: [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(30)] for name, _ in fns}
+        for i in range(30):
+            for name, fn in fns:
+                s_, e_ = evs[name][i]
                 s_.record(); fn(x, out=y); e_.record()
-            torch.cuda.synchronize()
-            ts = [s_.elapsed_time(e_) * 1e-3 for s_, e_ in evs]
-            ts.sort()
+        torch.cuda.synchronize()
+        for name, _ in fns:
+            ts = sorted(s_.elapsed_time(e_) * 1e-3 for s_, e_ in evs[name])
             med = ts[len(ts) // 2]
             nbytes = 2 * N * 8 * nb * L
             ntt[name] = {"median_us": med * 1e6, "min_us": ts[0] * 1e6, "GBps": nbytes / med / 1e9, "frac_of_hbm_peak": nbytes / med / HBM_PEAK}
