@@ -171,6 +171,31 @@ def main():
         o2 = ctx.empty(nb, components=2)
         t = timed(lambda: ev.relinearize(c3, evk, out=o2), 6)
         other["relinearize"] = {"workload": f"{nb} three-component ciphertexts, RNS-digit keys, N=4096, L=4", "median_us": t * 1e6, "per_s": nb / t}
+        del c3, evk, o2, xs, y, w
+        # BASELINE configs[4] sizes (N=8192, 6 limbs): NTT / INTT / ct x ct micro-benchmarks on a second context
+        p5 = FheParams.n8192_l6()
+        ctx5 = Context(p5, local_rank)
+        ev5 = Evaluator(ctx5)
+        L5, N5 = p5.n_limbs, p5.n
+        q5 = torch.tensor(p5.moduli, dtype=torch.int64, device=dev)
+        nb5 = 256
+        x5 = torch.randint(0, 2**62, (nb5, L5, N5), generator=g, dtype=torch.int64, device=dev) % q5.view(1, L5, 1)
+        y5 = torch.empty_like(x5)
+        c5 = {"workload": "BASELINE configs[4] sizes: N=8192, 6 x 60-bit limbs (micro-benchmarks; the GPT-2 forward itself is out of reach, SURVEY.md section 7)"}
+        for name, fn in (("ntt_fwd", ev5.ntt_forward), ("ntt_inv", ev5.ntt_inverse)):
+            t = timed(lambda: fn(x5, out=y5), 10)
+            nbytes = 2 * N5 * 8 * nb5 * L5
+            c5[name] = {"rns_polys": nb5, "median_us": t * 1e6, "GBps": nbytes / t / 1e9, "frac_of_hbm_peak": nbytes / t / HBM_PEAK}
+        bb = 1024
+        a5 = Ciphertext(torch.randint(0, 2**62, (bb, 2, L5, N5), generator=g, dtype=torch.int64, device=dev) % q5.view(1, 1, L5, 1))
+        b5 = Ciphertext(torch.randint(0, 2**62, (bb, 2, L5, N5), generator=g, dtype=torch.int64, device=dev) % q5.view(1, 1, L5, 1))
+        o5 = ctx5.empty(bb, components=3)
+        t = timed(lambda: ev5.multiply(a5, b5, out=o5), 6)
+        alg5 = 7 * L5 * N5 * 8 * bb
+        c5["ct_mul"] = {"pairs": bb, "median_us": t * 1e6, "per_s": bb / t, "GBps": alg5 / t / 1e9, "frac_of_hbm_peak": alg5 / t / HBM_PEAK}
+        other["n8192_l6"] = c5
+        del a5, b5, o5, x5, y5
+        ctx5.close()
         return other
 
     ntt_result = measure_ntt() if world == 1 else None   # before the long multiply loop heats the chip into lower clocks
@@ -238,6 +263,9 @@ def main():
             "alu_roofline_note": "VALU issue, not HBM, bounds this kernel: it issues one VALU instruction per SIMD every ~5 cycles, the rate of the register-only butterfly loop (tools/ubench: 2.35-2.6 T butterflies/s = 78-87% of 8 TB/s NTT-equivalent; profiles/r01_ubench.log, r01_pmc_sq_ntt_bench.txt)",
             "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": k_avg * 1e3,
         },
+        # "report compute-only and end-to-end": `value` is end-to-end (multiply + shard-local reduce +
+        # all-gather + final sum); this is the multiply kernel alone, timed inside the same overlapped steps
+        "compute_only_ct_mul_per_s": world * B / k_avg,
     }
 
     if ntt_result is not None:
