@@ -7,8 +7,11 @@
 
 namespace dpfhe {
 
-// words-per-thread exponent of the batched NTT kernels (launch_impl.h DPFHE_GEO_SWITCH); the fused kernels use 4
-constexpr int ntt_loge(int log2n) { return log2n == 13 ? 5 : 4; }
+// words-per-thread exponent of the batched NTT kernels (launch_impl.h DPFHE_GEO_SWITCH); the fused kernels use 4.
+// dpfhe_ctx_create builds a second table layout whenever the two differ.
+// (N = 8192 was measured with 32 words per thread / 3 phases and with 16 / 4 phases: same time, the kernels are VALU-bound;
+// 16 everywhere keeps one twiddle layout per context)
+constexpr int ntt_loge(int log2n) { return (void)log2n, 4; }
 constexpr int kFusedLoge = 4;
 
 // return 0, or -1 when log2n has no compiled geometry.  Launch errors are left in hipGetLastError().

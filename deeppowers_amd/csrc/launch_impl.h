@@ -13,10 +13,10 @@ namespace dpfhe {
         case 10: MACRO(10, 4); break;  \
         case 11: MACRO(11, 4); break;  \
         case 12: MACRO(12, 4); break;  \
-        case 13: MACRO(13, 5); break;  \
+        case 13: MACRO(13, 4); break;  \
         default: return -1;            \
     }
-static_assert(ntt_loge(12) == 4 && ntt_loge(13) == 5 && ntt_loge(8) == 4, "launch.h ntt_loge must match DPFHE_GEO_SWITCH");
+static_assert(ntt_loge(12) == 4 && ntt_loge(13) == 4 && ntt_loge(8) == 4, "launch.h ntt_loge must match DPFHE_GEO_SWITCH");
 
 template <class Arith>
 int launch_ntt(int log2n, bool inverse, u64* out, const u64* in, size_t npolys, const DevTables<Arith>& tb, hipStream_t s) {
