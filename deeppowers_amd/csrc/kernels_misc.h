@@ -68,31 +68,36 @@ __global__ __launch_bounds__(256) void dyadic_kernel(u64* out, const u64* a, con
 // ------------------------------------------------------------------------------------------------
 constexpr int kReduceSplits = 15;
 
+// Work item = (512-word chunk of a residue polynomial, batch split); a workgroup walks the items with stride gridDim.x,
+// so the launch size caps how much of the chip (and of the HBM bandwidth) the reduction takes at once.
 __global__ __launch_bounds__(256) void reduce_partial_kernel(u64* out, const u64* in, const LimbConst* lcs, int n_limbs, int n, int chunks,
-                                                             size_t count, size_t words_per_item) {
-    const size_t p = blockIdx.x / chunks;  // residue polynomial within one item
-    const int w = (int)(blockIdx.x % chunks) * 512 + threadIdx.x * 2;
-    if (w >= n) return;
-    const u64 q = lcs[p % (size_t)n_limbs].q;
-    const size_t split = blockIdx.y, nsplit = gridDim.y;
-    const size_t lo = count * split / nsplit, hi = count * (split + 1) / nsplit;
-    const u64* src = in + p * n + w;
-    u64 s0 = 0, s1 = 0;
-    size_t it = lo;
-    for (; it + 4 <= hi; it += 4) {
-        U64x2 v[4];
+                                                             size_t count, size_t words_per_item, unsigned poly_chunks, unsigned nsplit) {
+    for (unsigned work = blockIdx.x; work < poly_chunks * nsplit; work += gridDim.x) {
+        const unsigned pc = work % poly_chunks;
+        const size_t split = work / poly_chunks;
+        const size_t p = pc / (unsigned)chunks;  // residue polynomial within one item
+        const int w = (int)(pc % (unsigned)chunks) * 512 + threadIdx.x * 2;
+        if (w >= n) continue;
+        const u64 q = lcs[p % (size_t)n_limbs].q;
+        const size_t lo = count * split / nsplit, hi = count * (split + 1) / nsplit;
+        const u64* src = in + p * n + w;
+        u64 s0 = 0, s1 = 0;
+        size_t it = lo;
+        for (; it + 4 <= hi; it += 4) {
+            U64x2 v[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const U64x2*>(src + (it + u) * words_per_item);
+            for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const U64x2*>(src + (it + u) * words_per_item);
 #pragma unroll
-        for (int u = 0; u < 4; ++u) { s0 = csub(s0 + v[u].a, q); s1 = csub(s1 + v[u].b, q); }
-    }
-    for (; it < hi; ++it) {
-        const U64x2 v = *reinterpret_cast<const U64x2*>(src + it * words_per_item);
-        s0 = csub(s0 + v.a, q); s1 = csub(s1 + v.b, q);
-    }
-    if (hi > lo) {
-        atomicAdd(reinterpret_cast<unsigned long long*>(out + p * n + w), (unsigned long long)s0);
-        atomicAdd(reinterpret_cast<unsigned long long*>(out + p * n + w + 1), (unsigned long long)s1);
+            for (int u = 0; u < 4; ++u) { s0 = csub(s0 + v[u].a, q); s1 = csub(s1 + v[u].b, q); }
+        }
+        for (; it < hi; ++it) {
+            const U64x2 v = *reinterpret_cast<const U64x2*>(src + it * words_per_item);
+            s0 = csub(s0 + v.a, q); s1 = csub(s1 + v.b, q);
+        }
+        if (hi > lo) {
+            atomicAdd(reinterpret_cast<unsigned long long*>(out + p * n + w), (unsigned long long)s0);
+            atomicAdd(reinterpret_cast<unsigned long long*>(out + p * n + w + 1), (unsigned long long)s1);
+        }
     }
 }
 
