@@ -488,6 +488,29 @@ void KeyGenerator::create_galois_keys(GaloisKeys& out) {
     make_switch_key(ctx, *impl_->sk, impl_->rng, target.data(), out);
 }
 
+void KeyGenerator::create_public_key(PublicKey& out) {
+    const Context& ctx = *impl_->ctx;
+    const FheParams& p = ctx.params();
+    const size_t n = p.n(), L = p.n_limbs(), poly = L * n;
+    dpfhe_ctx* h = static_cast<dpfhe_ctx*>(ctx.handle());
+    std::vector<uint64_t> ha(poly), he(poly);
+    for (size_t l = 0; l < L; ++l)
+        for (size_t k = 0; k < n; ++k) ha[l * n + k] = impl_->rng.below(p.moduli[l]);   // uniform: any domain
+    for (size_t k = 0; k < n; ++k) {
+        const int64_t ev = (int64_t)impl_->rng.below(17) - 8;
+        for (size_t l = 0; l < L; ++l) he[l * n + k] = lift_signed(ev, p.moduli[l]);
+    }
+    PolyBuffer a(ctx, 1, 1, true), e(ctx, 1, 1, false), t(ctx, 1, 1, true);
+    a.copy_from_host(ha.data());
+    e.copy_from_host(he.data());
+    check(dpfhe_ntt_fwd(h, e.data(), 1, nullptr), "dpfhe_ntt_fwd");
+    check(dpfhe_dyadic_mul(h, t.data(), a.data(), impl_->sk->ntt(), 1, nullptr), "dpfhe_dyadic_mul");   // a s
+    check(dpfhe_sub(h, out.data(), e.data(), t.data(), 1, nullptr), "dpfhe_sub");                       // pk0 = e - a s
+    hip_check(hipMemcpyAsync(out.data() + poly, a.data(), poly * sizeof(uint64_t), hipMemcpyDeviceToDevice, nullptr), "hipMemcpyAsync");
+    ctx.synchronize();
+    out.set_ntt(true);
+}
+
 void KeyGenerator::create_relin_keys(RelinKeys& out) { make_switch_key(*impl_->ctx, *impl_->sk, impl_->rng, impl_->sk->ntt_squared(), out); }
 
 namespace {
@@ -532,11 +555,16 @@ void make_switch_key(const Context& ctx, const SecretKey& sk_ref, Rng& rng_ref, 
 class Encryptor::Impl {
 public:
     const Context* ctx = nullptr;
-    const SecretKey* sk = nullptr;
+    const SecretKey* sk = nullptr;     // symmetric mode
+    const PublicKey* pk = nullptr;     // public-key mode
     SplitMix rng{0};
 };
 Encryptor::Encryptor(const Context& ctx, const SecretKey& sk, uint64_t seed) : impl_(new Impl) {
     impl_->ctx = &ctx; impl_->sk = &sk; impl_->rng = SplitMix(seed);
+}
+Encryptor::Encryptor(const Context& ctx, const PublicKey& pk, uint64_t seed) : impl_(new Impl) {
+    if (!pk.is_ntt() || pk.size() != 2 || pk.batch() != 1) throw Exception(ErrorCode::INVALID_ARGUMENT, "Encryptor: public key must be one 2-component NTT-domain item");
+    impl_->ctx = &ctx; impl_->pk = &pk; impl_->rng = SplitMix(seed);
 }
 Encryptor::~Encryptor() = default;
 
@@ -573,6 +601,37 @@ void encrypt_scaled(const Context& ctx, const SecretKey& sk, Rng& rng, const int
     }
     out.set_ntt(false);
 }
+// (c0, c1) = (u pk0 + e1 + scale m, u pk1 + e2), u ternary, e1 / e2 uniform in [-8, 8]
+template <class Rng>
+void encrypt_scaled_pk(const Context& ctx, const PublicKey& pk, Rng& rng, const int64_t* messages, const std::vector<uint64_t>& scale, Ciphertext& out) {
+    const FheParams& p = ctx.params();
+    const size_t n = p.n(), L = p.n_limbs(), poly = L * n;
+    dpfhe_ctx* h = static_cast<dpfhe_ctx*>(ctx.handle());
+    PolyBuffer u(ctx, 1, 1, false), t(ctx, 1, 2, false);
+    std::vector<uint64_t> hu(poly), ht(2 * poly);
+    for (size_t item = 0; item < out.batch(); ++item) {
+        for (size_t k = 0; k < n; ++k) {
+            const int64_t uv = (int64_t)rng.below(3) - 1, e1 = (int64_t)rng.below(17) - 8, e2 = (int64_t)rng.below(17) - 8;
+            for (size_t l = 0; l < L; ++l) {
+                const uint64_t q = p.moduli[l];
+                hu[l * n + k] = lift_signed(uv, q);
+                const uint64_t m = (uint64_t)((u128)lift_signed(messages[item * n + k], q) * scale[l] % q), v = m + lift_signed(e1, q);
+                ht[l * n + k] = v >= q ? v - q : v;                  // e1 + scale m
+                ht[poly + l * n + k] = lift_signed(e2, q);           // e2
+            }
+        }
+        uint64_t* c = out.data() + item * 2 * poly;
+        u.copy_from_host(hu.data());
+        t.copy_from_host(ht.data());
+        check(dpfhe_ntt_fwd(h, u.data(), 1, nullptr), "dpfhe_ntt_fwd");
+        check(dpfhe_dyadic_mul(h, c, u.data(), pk.data(), 1, nullptr), "dpfhe_dyadic_mul");                  // u pk0
+        check(dpfhe_dyadic_mul(h, c + poly, u.data(), pk.data() + poly, 1, nullptr), "dpfhe_dyadic_mul");    // u pk1
+        check(dpfhe_ntt_inv(h, c, 2, nullptr), "dpfhe_ntt_inv");
+        check(dpfhe_add(h, c, c, t.data(), 2, nullptr), "dpfhe_add");
+        ctx.synchronize();
+    }
+    out.set_ntt(false);
+}
 Big modulus_product(const FheParams& p) {
     Big Q{1};
     for (uint64_t q : p.moduli) big_mul_small(Q, q);
@@ -587,7 +646,8 @@ void Encryptor::encrypt(const int64_t* messages, unsigned log2_scale, Ciphertext
     const FheParams& p = impl_->ctx->params();
     std::vector<uint64_t> scale(p.n_limbs());
     for (size_t l = 0; l < p.n_limbs(); ++l) scale[l] = powmod(2, log2_scale, p.moduli[l]);
-    encrypt_scaled(*impl_->ctx, *impl_->sk, impl_->rng, messages, scale, out);
+    if (impl_->pk) encrypt_scaled_pk(*impl_->ctx, *impl_->pk, impl_->rng, messages, scale, out);
+    else encrypt_scaled(*impl_->ctx, *impl_->sk, impl_->rng, messages, scale, out);
 }
 
 void Encryptor::encrypt_exact(const int64_t* messages, uint64_t t, Ciphertext& out) {
@@ -599,7 +659,8 @@ void Encryptor::encrypt_exact(const int64_t* messages, uint64_t t, Ciphertext& o
     big_divmod_small(delta, t);   // floor(Q / t)
     std::vector<uint64_t> scale(p.n_limbs());
     for (size_t l = 0; l < p.n_limbs(); ++l) scale[l] = big_mod_small(delta, p.moduli[l]);
-    encrypt_scaled(*impl_->ctx, *impl_->sk, impl_->rng, messages, scale, out);
+    if (impl_->pk) encrypt_scaled_pk(*impl_->ctx, *impl_->pk, impl_->rng, messages, scale, out);
+    else encrypt_scaled(*impl_->ctx, *impl_->sk, impl_->rng, messages, scale, out);
 }
 
 // ---- Decryptor --------------------------------------------------------------------------------------------------------------

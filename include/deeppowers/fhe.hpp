@@ -206,6 +206,13 @@ private:
     std::unique_ptr<Impl> impl_;
 };
 
+// Public key: pk = (-(a s) + e, a), stored in the NTT domain ([1][2][L][N]).  Whoever holds it can encrypt; only the
+// secret key decrypts (the reference's story keeps the secret key with the client, README.md:57-60).
+class PublicKey : public PolyBuffer {
+public:
+    explicit PublicKey(const Context& ctx) : PolyBuffer(ctx, 1, 2, /*is_ntt=*/true) {}
+};
+
 class KeyGenerator {
 public:
     explicit KeyGenerator(const Context& ctx, uint64_t seed = 1);
@@ -215,6 +222,7 @@ public:
     const SecretKey& secret_key() const;
     void create_relin_keys(RelinKeys& out);  // evk_j = (-(a_j s) + e_j + g_j s^2, a_j), NTT domain
     void create_galois_keys(GaloisKeys& out);  // key_j = (-(a_j s) + e_j + g_j sigma_g(s), a_j) for out.galois_elt()
+    void create_public_key(PublicKey& out);    // (-(a s) + e, a), NTT domain
 
 private:
     class Impl;
@@ -223,7 +231,9 @@ private:
 
 class Encryptor {
 public:
-    Encryptor(const Context& ctx, const SecretKey& sk, uint64_t seed = 2);
+    Encryptor(const Context& ctx, const SecretKey& sk, uint64_t seed = 2);   // symmetric: c1 uniform, c0 = -(c1 s) + e + scale m
+    // public-key: (c0, c1) = (u pk0 + e1 + scale m, u pk1 + e2) with u ternary, e1, e2 small; decrypts under the same secret
+    Encryptor(const Context& ctx, const PublicKey& pk, uint64_t seed = 2);
     ~Encryptor();
     Encryptor(const Encryptor&) = delete;
     Encryptor& operator=(const Encryptor&) = delete;

@@ -145,6 +145,20 @@ static void end_to_end(const FheParams& p, size_t batch) {
     ev.relinearize(c3, rk, cr);
     dec.decrypt(cr, 2 * scale, out.data());
     CHECK(out == want);                                 // and so does its relinearisation
+    // public-key encryption: same messages, encrypted with pk only, decrypt under the secret key and multiply homomorphically
+    {
+        PublicKey pk(ctx);
+        kg.create_public_key(pk);
+        Encryptor penc(ctx, pk, /*seed=*/13);
+        Ciphertext p1(ctx, 2, batch), p2(ctx, 2, batch), p3(ctx, 3, batch);
+        penc.encrypt(m1.data(), scale, p1);
+        penc.encrypt(m2.data(), scale, p2);
+        dec.decrypt(p1, scale, out.data());
+        CHECK(out == m1);
+        ev.multiply(p1, p2, p3);
+        dec.decrypt(p3, 2 * scale, out.data());
+        CHECK(out == want);
+    }
     // N3: m(X) -> m(X^g) under encryption.  RNS-digit key switching adds ~ L N q sigma ~ 2^77 of noise, so the
     // rotated message needs a scale well above that (the product above sits at 2^90 already).
     const unsigned gscale = 100;
