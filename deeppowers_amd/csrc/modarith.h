@@ -160,7 +160,14 @@ struct FoldArith {
         const u64 R = mad32((u32)(H >> 32), 4 * (u32)c.d, L);
         return reduce(R, c);
     }
-    static DPF_HD u64 canon(u64 x, const LimbConst& c) { return csub(reduce(x, c), c.q); }
+    // r < 2^60 + 2^59  ->  r mod q in [0, q), without compare/select: r >= q  <=>  r + d >= 2^60, and then
+    // r - q = (r + d) - 2^60.  4 instructions (add, shift, multiply-add, and) against 5 for csub.
+    static DPF_HD u64 canon_small(u64 r, const LimbConst& c) {
+        DPFHE_EMU_ASSERT(r < (3ull << 59));
+        const u32 k = (u32)((r + c.d) >> 60);
+        return mad32(k, (u32)c.d, r) & 0x0fffffffffffffffull;
+    }
+    static DPF_HD u64 canon(u64 x, const LimbConst& c) { return canon_small(reduce(x, c), c); }
     // a*b mod q, canonical; a < 2^64, b < 2^60
     static DPF_HD u64 mul_var(u64 a, u64 b, const LimbConst& c) { return csub(mul60(a, b, (u32)c.d), c.q); }
 };

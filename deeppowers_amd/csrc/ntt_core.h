@@ -446,7 +446,7 @@ struct NttBody {
     // inverse output (all words are outputs of the last-stage multiplies, < 2q) -> canonical
     static DPF_HD void inv_canon(u64 (&x)[E], const LimbConst& lc) {
 #pragma clang loop unroll(full)
-        for (int k = 0; k < E; ++k) x[k] = csub(x[k], lc.q);
+        for (int k = 0; k < E; ++k) x[k] = Arith::kFold ? FoldArith::canon_small(x[k], lc) : csub(x[k], lc.q);
     }
 };
 
