@@ -154,51 +154,52 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE), 2) void ct_mul_kernel(u64* __re
     constexpr int kInvIn = Arith::kFold ? 2 * kMulB : kUnit;
 
     // Schedule (F = forward NTT, I = inverse NTT + store), at most four polynomials live in registers:
-    //   0: S0 = F(a0)    1: S1 = F(b0)    2: I(S0*S1) -> c0     3: S2 = F(b1); S0 = S0*S2
-    //   4: x  = F(a1); S0 += x*S1; S2 = x*S2                    5: I(S0) -> c1        6: I(S2) -> c2
-    // One code instance of F and of I: the loop is not unrolled, every slot move sits under a uniform branch.
+    //   round 0: S0 = F(a0);  S1 = F(b0);                                 I(S0*S1) -> c0
+    //   round 1: S2 = F(b1), S0 = S0*S2;  x = F(a1), S0 += x*S1, S2 = x*S2;   I(S0) -> c1
+    //   round 2:                                                           I(S2) -> c2
+    // A loop of three rounds holding two inlined instances of F and one of I (44 KiB of code).  (A loop of seven single
+    // steps with one instance each was 2.5 % slower: hipcc copied all three kept polynomials at every loop latch.)
     u64 S0[E], S1[E], S2[E];
     const typename B::Tw* const twf = tb.fwd4 + (size_t)limb * N;
     const typename B::Tw* const twi = tb.inv4 + (size_t)limb * N;
+    auto forward = [&](u64 (&x)[E], const u64* src, bool reduce_out, bool first) {
+        if (IN_NTT) { B::load_bot(tid, x, src); return; }
+        B::load_top(tid, x, src);
+        if (!first) lds_barrier();
+        FwdChain<B, 0>::template run<false>(tid, x, lds, twf, lc);
+        if (!Arith::kFold) B::fwd_canon(x, lc);
+        else if (reduce_out) {
+            if (kLazy) {
+#pragma unroll
+                for (int k = 0; k < E; ++k) x[k] = FoldArith::reduce(x[k], lc);
+            } else {
+                B::fwd_canon(x, lc);
+            }
+        }
+    };
 #pragma unroll 1
-    for (int step = 0; step < 7; ++step) {
-        // keep per-thread twiddle loads inside the loop (registers > L2 re-reads).  Making the table pointers opaque instead
-        // (so that the thread's LDS / global offsets stay loop-invariant) was tried: the hoisted offsets spill.
+    for (int round = 0; round < 3; ++round) {
+        // an opaque thread id keeps the per-thread twiddle fetches of every transform where they are used (left visible,
+        // hipcc hoists and shares them across transforms and the ~60 registers they then pin spill)
         asm volatile("" : "+v"(tid));
         u64 x[E];
-        const bool fwd = (0x1B >> step) & 1;
-        if (fwd) {
-            const u64* src = step == 0 ? src_a : step == 1 ? src_b : step == 3 ? src_b + cstride : src_a + cstride;
-            if (IN_NTT) {
-                B::load_bot(tid, x, src);
-            } else {
-                B::load_top(tid, x, src);
-                if (step > 0) lds_barrier();  // the previous transform's last exchange is fully read
-                FwdChain<B, 0>::template run<false>(tid, x, lds, twf, lc);
-                // b-side operands of mul60 must be < 2^60 + 2^29: a partial reduce (< 2^60 + 16 d) is enough when the
-                // products feed the inverse transform lazily; NTT-domain outputs need canonical factors
-                if (!Arith::kFold) B::fwd_canon(x, lc);
-                else if (step == 1 || step == 3) {
-                    if (kLazy) {
-#pragma unroll
-                        for (int k = 0; k < E; ++k) x[k] = FoldArith::reduce(x[k], lc);
-                    } else {
-                        B::fwd_canon(x, lc);
-                    }
-                }
-            }
-            if (step == 0) {
+        if (round < 2) {
+            forward(x, round == 0 ? src_a : src_b + cstride, round == 1, round == 0);      // a0 | b1
+            if (round == 0) {
 #pragma unroll
                 for (int k = 0; k < E; ++k) S0[k] = x[k];
-            } else if (step == 1) {
-#pragma unroll
-                for (int k = 0; k < E; ++k) S1[k] = x[k];
-            } else if (step == 3) {
+            } else {
 #pragma unroll
                 for (int k = 0; k < E; ++k) {
                     S2[k] = x[k];
                     S0[k] = kLazy ? FoldArith::mul60(S0[k], x[k], (u32)lc.d) : Arith::mul_var(S0[k], x[k], lc);
                 }
+            }
+            asm volatile("" : "+v"(tid));   // the two forward instances must not share (and keep alive) their twiddle fetches
+            forward(x, round == 0 ? src_b : src_a + cstride, round == 0, false);           // b0 | a1
+            if (round == 0) {
+#pragma unroll
+                for (int k = 0; k < E; ++k) S1[k] = x[k];
             } else {
 #pragma unroll
                 for (int k = 0; k < E; ++k) {
@@ -211,28 +212,28 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE), 2) void ct_mul_kernel(u64* __re
                     }
                 }
             }
+        }
+        asm volatile("" : "+v"(tid));
+        typename B::TwRegs tw_first;
+        if (!OUT_NTT) B::template load_tw<B::NPH - 1, false>(tid, twi, tw_first);
+        if (round == 0) {
+#pragma unroll
+            for (int k = 0; k < E; ++k) x[k] = kLazy ? FoldArith::mul60(S0[k], S1[k], (u32)lc.d) : Arith::mul_var(S0[k], S1[k], lc);
+        } else if (round == 1) {
+#pragma unroll
+            for (int k = 0; k < E; ++k) x[k] = S0[k];
         } else {
-            typename B::TwRegs tw_first;   // first inverse phase's twiddles: in flight while the dyadic products are formed
-            if (!OUT_NTT) B::template load_tw<B::NPH - 1, false>(tid, twi, tw_first);
-            if (step == 2) {
 #pragma unroll
-                for (int k = 0; k < E; ++k) x[k] = kLazy ? FoldArith::mul60(S0[k], S1[k], (u32)lc.d) : Arith::mul_var(S0[k], S1[k], lc);
-            } else if (step == 5) {
-#pragma unroll
-                for (int k = 0; k < E; ++k) x[k] = S0[k];
-            } else {
-#pragma unroll
-                for (int k = 0; k < E; ++k) x[k] = S2[k];
-            }
-            u64* d = dst + (size_t)(step == 2 ? 0 : step == 5 ? 1 : 2) * cstride;
-            if (OUT_NTT) {
-                B::store_bot(tid, x, d);
-            } else {
-                if (!IN_NTT || step > 2) lds_barrier();
-                InvChain<B, B::NPH - 1, kInvIn>::run_with(tid, x, lds, twi, last, lc, tw_first);
-                B::inv_canon(x, lc);
-                B::store_top(tid, x, d);
-            }
+            for (int k = 0; k < E; ++k) x[k] = S2[k];
+        }
+        u64* d = dst + (size_t)round * cstride;
+        if (OUT_NTT) {
+            B::store_bot(tid, x, d);
+        } else {
+            if (!IN_NTT || round > 0) lds_barrier();
+            InvChain<B, B::NPH - 1, kInvIn>::run_with(tid, x, lds, twi, last, lc, tw_first);
+            B::inv_canon(x, lc);
+            B::store_top(tid, x, d);
         }
     }
 }
