@@ -129,8 +129,8 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE)) void ntt_inv_kernel(u64* __rest
 
 // ------------------------------------------------------------------------------------------------
 // A6: fused ciphertext x ciphertext multiply.  One workgroup per (ciphertext pair, limb).
-//   4 forward NTTs (one code instance, looped) -> register-resident dyadic tensor product ->
-//   3 inverse NTTs (one code instance, looped).  HBM traffic: 4 reads + 3 writes of a residue poly.
+//   4 forward NTTs -> register-resident dyadic tensor product -> 3 inverse NTTs, as three rounds of
+//   [forward, forward, inverse].  HBM traffic: 4 reads + 3 writes of a residue poly.
 // ------------------------------------------------------------------------------------------------
 template <class Arith, int LOGN, int LOGE, bool IN_NTT, bool OUT_NTT>
 __global__ __launch_bounds__(1 << (LOGN - LOGE), 2) void ct_mul_kernel(u64* __restrict__ out3, const u64* __restrict__ a2,
