@@ -177,7 +177,7 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE), 2) void ct_mul_kernel(u64* __re
             }
         }
     };
-#pragma unroll 1
+#pragma unroll 1   // fully unrolled (4 forward + 3 inverse instances, ~80 KiB of code) it overflows the instruction cache: 12 % slower
     for (int round = 0; round < 3; ++round) {
         // an opaque thread id keeps the per-thread twiddle fetches of every transform where they are used (left visible,
         // hipcc hoists and shares them across transforms and the ~60 registers they then pin spill)
