@@ -61,7 +61,9 @@ struct FwdChain {
     }
 };
 
-template <class B, int P, int IN>
+// BARRIER_FIRST: the caller staged data through the LDS buffer (load_bot_lds) right before the chain, so the first exchange
+// must wait until every wave has read its rows back
+template <class B, int P, int IN, bool BARRIER_FIRST = false>
 struct InvChain {
     typedef typename B::TwRegs TwRegs;
     static __device__ __forceinline__ void run(int tid, u64 (&x)[B::E], u64* lds, const typename B::Tw* tw,
@@ -76,11 +78,11 @@ struct InvChain {
         if constexpr (P > 0) {
             TwRegs nxt;
             B::template load_tw<P - 1, false>(tid, tw, nxt);
-            if (P < B::NPH - 1) lds_barrier();
+            if (P < B::NPH - 1 || BARRIER_FIRST) lds_barrier();
             B::template lds_write<P - 1, P, false>(tid, x, lds);
             lds_barrier();
             B::template lds_read<P - 1, P - 1, false>(tid, x, lds);
-            InvChain<B, P - 1, IN>::run_with(tid, x, lds, tw, last, lc, nxt);
+            InvChain<B, P - 1, IN, BARRIER_FIRST>::run_with(tid, x, lds, tw, last, lc, nxt);
         }
     }
 };
@@ -104,7 +106,8 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE)) void ntt_fwd_kernel(u64* __rest
     B::load_top(tid, x, in + p * B::G::N);
     FwdChain<B, 0>::run(tid, x, lds, tw, lc);
     B::fwd_canon(x, lc);
-    B::store_bot(tid, x, out + p * B::G::N);
+    if constexpr (B::kLdsIO) B::store_bot_lds(tid, x, out + p * B::G::N, lds);   // rows == what this wave read in the last exchange
+    else B::store_bot(tid, x, out + p * B::G::N);
 }
 
 template <class Arith, int LOGN, int LOGE>
@@ -121,8 +124,13 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE)) void ntt_inv_kernel(u64* __rest
     typename B::TwRegs tw_first;   // requested before the data: load_bot waits for all of its loads (register transposition)
     B::template load_tw<B::NPH - 1, false>(tid, tw, tw_first);
     u64 x[B::E];
-    B::load_bot(tid, x, in + p * B::G::N);
-    InvChain<B, B::NPH - 1, kUnit>::run_with(tid, x, lds, tw, last, lc, tw_first);
+    if constexpr (B::kLdsIO) {
+        B::load_bot_lds(tid, x, in + p * B::G::N, lds);
+        InvChain<B, B::NPH - 1, kUnit, true>::run_with(tid, x, lds, tw, last, lc, tw_first);
+    } else {
+        B::load_bot(tid, x, in + p * B::G::N);
+        InvChain<B, B::NPH - 1, kUnit>::run_with(tid, x, lds, tw, last, lc, tw_first);
+    }
     B::inv_canon(x, lc);
     B::store_top(tid, x, out + p * B::G::N);
 }
@@ -304,12 +312,15 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE), (Arith::kFold ? 2 : 1)) void re
         }
         {   // one key polynomial at a time keeps the live set at x + acc0 + acc1 + one key (no spills at 2 waves/SIMD)
             u64 e[E];
-            B::load_bot(tid, e, k0);
+            // key polynomials are NTT-domain tiles: transposed through LDS (rows private to the wave) where that measured
+            // faster (N = 8192: -7 %), in registers otherwise (N = 4096: the LDS path is 5 % slower at 2 waves per SIMD)
+            constexpr bool kLdsKeys = B::kLdsIO && LOGN >= 13;
+            if constexpr (kLdsKeys) B::load_bot_lds(tid, e, k0, lds); else B::load_bot(tid, e, k0);
 #pragma unroll
             for (int k = 0; k < E; ++k)
                 acc0[k] = Arith::kFold ? acc0[k] + FoldArith::mul60(x[k], e[k], (u32)lc.d) : add_mod(acc0[k], ShoupArith::mul_var(x[k], e[k], lc), lc.q);
             asm volatile("" ::: "memory");
-            B::load_bot(tid, e, k1);
+            if constexpr (kLdsKeys) B::load_bot_lds(tid, e, k1, lds); else B::load_bot(tid, e, k1);
 #pragma unroll
             for (int k = 0; k < E; ++k)
                 acc1[k] = Arith::kFold ? acc1[k] + FoldArith::mul60(x[k], e[k], (u32)lc.d) : add_mod(acc1[k], ShoupArith::mul_var(x[k], e[k], lc), lc.q);

@@ -218,13 +218,15 @@ struct NttBody {
     struct alignas(16) V2 {
         u64 a, b;
     };
+    static constexpr int PC = E / 2, LP = LOGE - 1, kLow = 6 - LP;   // pieces per thread; lane bits [kLow, 6) <-> piece index
+    static constexpr bool kWaveIO = (T % 64 == 0) && LP >= 1 && LP <= 4;   // register transposition available
+    static constexpr bool kLdsIO = kWaveIO && PC == 8 && NPH >= 2;         // LDS transposition available (load_bot_lds / store_bot_lds)
+    static_assert(!kLdsIO || T * (E + 2) <= G::lds_words(), "the row layout must fit the exchange buffer");
 #if defined(__HIP_DEVICE_COMPILE__)
     // Device path: a thread's E words are 8E contiguous bytes, so plain 16-byte accesses put the 64 lanes of one
     // instruction on 64 different 128-byte lines.  The wave instead moves 1 KiB-contiguous slices (lane L, slice r:
     // piece L >> kLow of thread (r << kLow) | (L & (2^kLow - 1)), a piece = 16 bytes) and transposes pieces <-> lanes
     // in registers: one swap stage per piece-index bit (v_permlane32_swap, v_permlane16_swap, row DPP), an involution.
-    static constexpr int PC = E / 2, LP = LOGE - 1, kLow = 6 - LP;   // pieces per thread; lane bits [kLow, 6) <-> piece index
-    static constexpr bool kWaveIO = (T % 64 == 0) && LP >= 1 && LP <= 4;
     template <int LANEBIT>
     static __device__ __forceinline__ void lane_swap(u32& a, u32& b) {  // lanes with LANEBIT clear: b <- partner's a; set: a <- partner's b
         if constexpr (LANEBIT == 5) { auto v = __builtin_amdgcn_permlane32_swap(a, b, false, false); a = v[0]; b = v[1]; }
@@ -263,6 +265,41 @@ struct NttBody {
         const unsigned t = wave_thread0 + (((unsigned)r << kLow) | (lane & ((1u << kLow) - 1u)));
         return t * PC + (lane >> kLow);
     }
+    // The same transposition through LDS instead of registers: no VALU work at all (the kernels are VALU-bound, the LDS
+    // pipe is ~10 % busy).  Each thread's E words live in its own padded row (E + 2 words: conflict-free 16-byte accesses);
+    // a wave only ever touches the rows of its own 64 threads, which are also exactly what it read in the last forward
+    // exchange, so no workgroup barrier is needed around it - only before a LATER all-to-all exchange overwrites the rows.
+    // Lane L moves, in slice r, piece (L/8 + L%8) % 8 of thread 8r + L%8: the skew keeps 16 consecutive lanes on 16
+    // different 16-byte slots.
+    static __device__ __forceinline__ void lds_slice(int tid, int r, unsigned& lds_word, unsigned& piece) {
+        const unsigned lane = (unsigned)tid & 63u, wave_thread0 = (unsigned)tid & ~63u, i = lane & 7u, pc = ((lane >> 3) + i) & 7u;
+        const unsigned t = wave_thread0 + ((unsigned)r << 3) + i;
+        lds_word = t * (E + 2) + pc * 2;
+        piece = t * PC + pc;
+    }
+    static __device__ __forceinline__ void load_bot_lds(int tid, u64 (&x)[E], const u64* g, u64* lds) {
+        const V2* p = reinterpret_cast<const V2*>(g);
+        V2 v[PC];
+#pragma clang loop unroll(full)
+        for (int r = 0; r < PC; ++r) { unsigned w, pc; lds_slice(tid, r, w, pc); v[r] = p[pc]; }
+#pragma clang loop unroll(full)
+        for (int r = 0; r < PC; ++r) { unsigned w, pc; lds_slice(tid, r, w, pc); *reinterpret_cast<V2*>(lds + w) = v[r]; }
+        const V2* row = reinterpret_cast<const V2*>(lds + (unsigned)tid * (E + 2));   // same wave wrote it: program order + lgkmcnt
+#pragma clang loop unroll(full)
+        for (int k = 0; k < PC; ++k) { V2 t = row[k]; x[2 * k] = t.a; x[2 * k + 1] = t.b; }
+    }
+    static __device__ __forceinline__ void store_bot_lds(int tid, const u64 (&x)[E], u64* g, u64* lds) {
+        V2* row = reinterpret_cast<V2*>(lds + (unsigned)tid * (E + 2));
+#pragma clang loop unroll(full)
+        for (int k = 0; k < PC; ++k) row[k] = V2{x[2 * k], x[2 * k + 1]};
+        V2* p = reinterpret_cast<V2*>(g);
+#pragma clang loop unroll(full)
+        for (int r = 0; r < PC; ++r) { unsigned w, pc; lds_slice(tid, r, w, pc); p[pc] = *reinterpret_cast<const V2*>(lds + w); }
+    }
+#endif
+#if !defined(__HIP_DEVICE_COMPILE__)
+    static void load_bot_lds(int, u64 (&)[E], const u64*, u64*) {}   // device-only paths: never called on the host
+    static void store_bot_lds(int, const u64 (&)[E], u64*, u64*) {}
 #endif
     static DPF_HD void load_bot(int tid, u64 (&x)[E], const u64* g) {
         const V2* p = reinterpret_cast<const V2*>(g);
