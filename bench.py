@@ -230,6 +230,15 @@ def main():
             traffic = json.load(f)["ct_mul_kernel<FoldArith,12,4>"]["hbm_bytes_per_ct_mul"] * B
     except Exception:
         pass
+    # secondary (ALU) roofline: butterflies per second against the register-only butterfly loop of tools/ubench on this chip
+    alu_peak = None
+    try:
+        import re as _re
+        with open(os.path.join(ROOT, "profiles", "r01_ubench.log")) as f:
+            m = _re.findall(r"butterflies fold\s+8 blk/CU:.*?([0-9.]+) T bfly/s", f.read())
+        alu_peak = float(m[-1]) * 1e12 if m else None
+    except Exception:
+        pass
     kernel_ms = [s.elapsed_time(e) for s, e in zip(ev_start, ev_end)]
     k_avg = sum(kernel_ms) / len(kernel_ms) * 1e-3
     alg_bytes = 7 * L * N * 8 * B
@@ -262,6 +271,10 @@ def main():
             "traffic_source": "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, bytes per launch)" if traffic else None,
             "alu_roofline_note": "VALU issue, not HBM, bounds this kernel: it issues one VALU instruction per SIMD every ~5 cycles, the rate of the register-only butterfly loop (tools/ubench: 2.35-2.6 T butterflies/s = 78-87% of 8 TB/s NTT-equivalent; profiles/r01_ubench.log, r01_pmc_sq_ntt_bench.txt)",
             "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": k_avg * 1e3,
+            "alu": {"unit": "butterflies/s", "achieved": 7 * L * (N // 2) * 12 * B / k_avg, "peak": alu_peak,
+                    "frac": (7 * L * (N // 2) * 12 * B / k_avg / alu_peak) if alu_peak else None,
+                    "peak_source": "profiles/r01_ubench.log: register-only radix-2 butterflies, FoldArith, 8 workgroups per CU",
+                    "note": "7 transforms x L limbs x (N/2) log2 N butterflies per ct-mul; the dyadic products, canonicalisation and the lower clock under HBM load are not in the peak"},
         },
         # "report compute-only and end-to-end": `value` is end-to-end (multiply + shard-local reduce +
         # all-gather + final sum); this is the multiply kernel alone, timed inside the same overlapped steps
