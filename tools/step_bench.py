@@ -27,7 +27,36 @@ main = torch.cuda.current_stream(); side = torch.cuda.Stream(device=dev)
 mul_done = [torch.cuda.Event() for _ in range(2)]; red_done = [torch.cuda.Event() for _ in range(2)]
 
 
+chunks = int(sys.argv[3]) if len(sys.argv) > 3 else 32
+cpart = [ctx.empty(chunks, components=3) for _ in range(2)]
+
+
+def step_chunked(i):
+    """multiply and reduce chunk by chunk so that the reduce reads what the multiply just wrote (Infinity Cache)"""
+    k = i & 1
+    per = B // chunks
+    for c in range(chunks):
+        sl = slice(c * per, (c + 1) * per)
+        o = ev.multiply(Ciphertext(a.data[sl]), Ciphertext(b.data[sl]), out=outs[k][sl], stream=main)
+        if mode == "chunked":
+            ev.reduce_sum(o, out=cpart[k][c], stream=main)
+        else:  # chunked_side: reduce of chunk c on the side stream while chunk c+1 multiplies
+            e = torch.cuda.Event(); e.record(main); side.wait_event(e)
+            with torch.cuda.stream(side):
+                ev.reduce_sum(o, out=cpart[k][c], stream=side)
+    if mode == "chunked":
+        ev.reduce_sum(Ciphertext(cpart[k]), out=parts[k], stream=main)
+    else:
+        with torch.cuda.stream(side):
+            ev.reduce_sum(Ciphertext(cpart[k]), out=parts[k], stream=side)
+        red_done[k].record(side)
+
+
 def step(i):
+    if mode.startswith("chunked"):
+        if mode == "chunked_side":
+            main.wait_event(red_done[i & 1])
+        return step_chunked(i)
     k = i & 1
     main.wait_event(red_done[k])
     c = ev.multiply(a, b, out=outs[k], stream=main)
