@@ -67,3 +67,31 @@ def test_emulated_30bit_prime_uses_shoup_only(emu):
     rc, back = run(emu, 0, 10, 4, 1, PRIME_30, PSI_30_N1024, got)
     assert rc == 0 and np.array_equal(back, a)
     assert run(emu, 1, 10, 4, 0, PRIME_30, PSI_30_N1024, a)[0] == 2000  # not fold-eligible
+
+
+@pytest.mark.parametrize("ln", [8, 10, 12, 13])
+def test_emulated_ct_mul_lazy_path_matches_oracle_without_wraps(emu, ln):
+    """kernels.h ct_mul_kernel's lazy FoldArith data path (same transform code, same dyadic sequence) on the CPU with the
+    wrap-around and mul60-precondition counters armed: worst-case inputs (all q-1) and random ones."""
+    n = 1 << ln
+    emu.emu_ct_mul.argtypes = [C.c_int, C.c_uint64, C.c_uint64, U, U, U, U, U]
+    emu.emu_ct_mul.restype = C.c_int
+    before = emu.emu_overflows()
+    for limb in (0, 5):
+        q = PRIMES_60[limb][0]
+        psi = pow(PRIMES_60[limb][2], 8192 // n, q)
+        orc = Oracle(ln, [q], [psi])
+        rnd = orc.fill(4, 900 + limb).reshape(4, n)
+        cases = [rnd, np.full((4, n), q - 1, np.uint64),
+                 np.stack([np.full(n, q - 1, np.uint64), np.zeros(n, np.uint64), np.ones(n, np.uint64), np.full(n, q - 1, np.uint64)])]
+        for polys in cases:
+            polys = np.ascontiguousarray(polys, dtype=np.uint64)
+            a0, a1, b0, b1 = (np.ascontiguousarray(polys[i]) for i in range(4))
+            out = np.zeros(3 * n, np.uint64)
+            rc = emu.emu_ct_mul(ln, q, psi, a0.ctypes.data_as(U), a1.ctypes.data_as(U), b0.ctypes.data_as(U), b1.ctypes.data_as(U), out.ctypes.data_as(U))
+            assert rc == 0
+            a = np.stack([a0, a1]).reshape(1, 2, 1, n)
+            b = np.stack([b0, b1]).reshape(1, 2, 1, n)
+            want = orc.ct_mul(a, b).reshape(3 * n)
+            assert np.array_equal(out, want)
+    assert emu.emu_overflows() == before, "lazy arithmetic wrapped around 2^64 or broke a mul60 precondition"

@@ -99,6 +99,59 @@ extern "C" int emu_ntt(int arith, int log2n, int loge, int inverse, u64 q, u64 p
     return -1;
 }
 
+// The fused ct x ct kernel's lazy FoldArith data path (kernels.h ct_mul_kernel, coefficient domain in and out), run with
+// the same per-thread transform code and the same dyadic sequence, so that the bound plans and the relaxed mul60
+// precondition (lazy forward outputs < 14 q times partially reduced b-side factors) are checked on the CPU with the
+// wrap-around / precondition counters armed.  out3 = (c0, c1, c2) of one limb.
+template <int LOGN, int LOGE>
+static int emu_ct_mul_fold(u64 q, u64 psi, const u64* a0, const u64* a1, const u64* b0, const u64* b1, u64* out3) {
+    typedef NttBody<FoldArith, LOGN, LOGE> B;
+    HostLimbTables t;
+    int rc = build_limb_tables(LOGN, q, psi, t);
+    if (rc) return rc;
+    if (!fold_eligible(q)) return 2000;
+    constexpr int E = B::E, T = B::T, N = B::G::N;
+    static_assert(make_ct_plan(LOGN, kUnit).out_bound <= kLimitPartner, "lazy forward outputs must satisfy mul60's bound");
+    auto twf = TwTab<FoldArith>::make(t.rp, t.rp_sh, q), twi = TwTab<FoldArith>::make(t.irp, t.irp_sh, q);
+    permute_window0(twf, LOGN, LOGE, B::G::kPermStages);
+    permute_window0(twi, LOGN, LOGE, B::G::kPermStages);
+    const auto wl = TwTab<FoldArith>::one(t.w_last, t.w_last_sh, q), wn = TwTab<FoldArith>::one(t.lc.ninv, t.lc.ninv_sh, q);
+    const LimbConst& lc = t.lc;
+    std::vector<u64> lds(B::G::lds_words());
+    auto fwd = [&](const u64* src, bool reduce_out) {
+        std::vector<u64> regs((size_t)T * E);
+        auto X = [&](int tid) -> u64(&)[E] { return *reinterpret_cast<u64(*)[E]>(&regs[(size_t)tid * E]); };
+        for (int tid = 0; tid < T; ++tid) B::load_top(tid, X(tid), src);
+        FwdSteps<B, 0>::run(regs, lds, twf.data(), lc);
+        if (reduce_out) for (auto& v : regs) v = FoldArith::reduce(v, lc);
+        return regs;
+    };
+    auto inv = [&](std::vector<u64> regs, u64* dst) {
+        auto X = [&](int tid) -> u64(&)[E] { return *reinterpret_cast<u64(*)[E]>(&regs[(size_t)tid * E]); };
+        InvSteps<B, B::NPH - 1, 2 * kMulB>::run(regs, lds, twi.data(), wl, wn, lc);
+        for (int tid = 0; tid < T; ++tid) { B::inv_canon(X(tid), lc); B::store_top(tid, X(tid), dst); }
+    };
+    const u32 d = (u32)lc.d;
+    std::vector<u64> S0 = fwd(a0, false), S1 = fwd(b0, true), x((size_t)N);
+    for (int i = 0; i < N; ++i) x[i] = FoldArith::mul60(S0[i], S1[i], d);
+    inv(x, out3);
+    std::vector<u64> S2 = fwd(b1, true);
+    for (int i = 0; i < N; ++i) S0[i] = FoldArith::mul60(S0[i], S2[i], d);
+    x = fwd(a1, false);
+    for (int i = 0; i < N; ++i) { S0[i] = chk_add(S0[i], FoldArith::mul60(x[i], S1[i], d)); S2[i] = FoldArith::mul60(x[i], S2[i], d); }
+    inv(S0, out3 + N);
+    inv(S2, out3 + 2 * N);
+    return 0;
+}
+
+extern "C" int emu_ct_mul(int log2n, u64 q, u64 psi, const u64* a0, const u64* a1, const u64* b0, const u64* b1, u64* out3) {
+    if (log2n == 8) return emu_ct_mul_fold<8, 4>(q, psi, a0, a1, b0, b1, out3);
+    if (log2n == 10) return emu_ct_mul_fold<10, 4>(q, psi, a0, a1, b0, b1, out3);
+    if (log2n == 12) return emu_ct_mul_fold<12, 4>(q, psi, a0, a1, b0, b1, out3);
+    if (log2n == 13) return emu_ct_mul_fold<13, 4>(q, psi, a0, a1, b0, b1, out3);
+    return -1;
+}
+
 extern "C" int emu_lds_words(int log2n, int loge) {
     if (log2n == 12 && loge == 4) return Geo<12, 4>::lds_words();
     if (log2n == 13 && loge == 5) return Geo<13, 5>::lds_words();
