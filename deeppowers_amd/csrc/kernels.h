@@ -301,6 +301,7 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE), (Arith::kFold ? 2 : 1)) void re
         const u64* k0 = evk + (((size_t)j * 2 + 0) * L + limb) * N;      // key polynomials, NTT domain (window-0 mapping)
         const u64* k1 = evk + (((size_t)j * 2 + 1) * L + limb) * N;
         if (Arith::kFold) {
+            static_assert(13 * kMulB + kRedB <= kWord, "13 lazily added products + one reduced word must fit a 64-bit word");
             if (lazy_terms == 13) {  // 13 products + one reduced word stay below 15 q
 #pragma unroll
                 for (int k = 0; k < E; ++k) { acc0[k] = FoldArith::reduce(acc0[k], lc); acc1[k] = FoldArith::reduce(acc1[k], lc); }
