@@ -52,7 +52,7 @@ struct dpfhe_ctx {
 extern "C" int dpfhe_ctx_create(dpfhe_ctx** out, uint32_t log2_n, uint32_t n_limbs, const uint64_t* moduli,
                                 const uint64_t* psi, int device_id) {
     if (!out || !moduli || !psi) return fail(DPFHE_INVALID_ARGUMENT, "dpfhe_ctx_create", "null argument");
-    if (log2_n < 8 || log2_n > 13) return fail(DPFHE_INVALID_ARGUMENT, "dpfhe_ctx_create", "log2_n must be in [8, 13]");
+    if (log2_n < 8 || log2_n > (uint32_t)kMaxLog2N) return fail(DPFHE_INVALID_ARGUMENT, "dpfhe_ctx_create", "log2_n must be in [8, 14]");
     if (n_limbs == 0 || n_limbs > 1024) return fail(DPFHE_INVALID_ARGUMENT, "dpfhe_ctx_create", "n_limbs must be in [1, 1024]");
     const size_t n = (size_t)1 << log2_n, L = n_limbs;
     std::vector<HostLimbTables> ht(L);

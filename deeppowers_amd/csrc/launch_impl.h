@@ -16,14 +16,26 @@ namespace dpfhe {
         case 13: MACRO(13, 4); break;  \
         default: return -1;            \
     }
-static_assert(ntt_loge(12) == 4 && ntt_loge(13) == 4 && ntt_loge(8) == 4, "launch.h ntt_loge must match DPFHE_GEO_SWITCH");
+// the batched NTT kernels additionally cover N = 16384
+#define DPFHE_NTT_GEO_SWITCH(log2n, MACRO)  \
+    switch (log2n) {                        \
+        case 8: MACRO(8, 4); break;         \
+        case 9: MACRO(9, 4); break;         \
+        case 10: MACRO(10, 4); break;       \
+        case 11: MACRO(11, 4); break;       \
+        case 12: MACRO(12, 4); break;       \
+        case 13: MACRO(13, 4); break;       \
+        case 14: MACRO(14, 5); break;       \
+        default: return -1;                 \
+    }
+static_assert(ntt_loge(12) == 4 && ntt_loge(13) == 4 && ntt_loge(8) == 4 && ntt_loge(14) == 5, "launch.h ntt_loge must match DPFHE_NTT_GEO_SWITCH");
 
 template <class Arith>
 int launch_ntt(int log2n, bool inverse, u64* out, const u64* in, size_t npolys, const DevTables<Arith>& tb, hipStream_t s) {
 #define NTT_CASE(LN, LE)                                                                                                              \
     if (inverse) hipLaunchKernelGGL((ntt_inv_kernel<Arith, LN, LE>), dim3((unsigned)npolys), dim3(Geo<LN, LE>::T), 0, s, out, in, tb); \
     else hipLaunchKernelGGL((ntt_fwd_kernel<Arith, LN, LE>), dim3((unsigned)npolys), dim3(Geo<LN, LE>::T), 0, s, out, in, tb)
-    DPFHE_GEO_SWITCH(log2n, NTT_CASE)
+    DPFHE_NTT_GEO_SWITCH(log2n, NTT_CASE)
 #undef NTT_CASE
     return 0;
 }

@@ -58,6 +58,9 @@ def rigs():
                 p = FheParams.n4096_l4()
             elif name == "n8192":
                 p = FheParams.n8192_l6()
+            elif name == "fold14":  # N = 16384: the pinned primes that are 1 mod 32768 (transform / streaming kernels only)
+                qs = [PRIMES_60[i][0] for i in (1, 2, 4)]
+                p = FheParams(14, tuple(qs), tuple(po.min_primitive_2n_root(16384, q) for q in qs))
             elif name.startswith("shoup"):  # generic primes of several widths, 3 limbs
                 log2n = int(name[5:])
                 n = 1 << log2n
@@ -77,6 +80,7 @@ def rigs():
 
 
 ALL = ["config1", "n4096", "n8192", "fold8", "fold9", "fold10", "fold11", "shoup8", "shoup10", "shoup12", "shoup13"]
+NTT_ONLY = ["fold14", "shoup14"]   # N = 16384: no fused ct x ct / key-switch kernels
 
 
 def test_arithmetic_policy_selection(rigs):
@@ -144,7 +148,7 @@ def test_identities_on_device(rigs):
 
 
 # ---- NTT vs oracle, every geometry and both arithmetic policies ---------------------------------------------
-@pytest.mark.parametrize("name", ALL)
+@pytest.mark.parametrize("name", ALL + NTT_ONLY)
 def test_ntt_forward_inverse_vs_oracle(rigs, name):
     r = rigs(name)
     L, n = r.p.n_limbs, r.p.n
@@ -170,7 +174,7 @@ def test_ntt_forward_inverse_vs_oracle(rigs, name):
     assert L == r.p.n_limbs
 
 
-@pytest.mark.parametrize("name", ["config1", "n4096", "n8192", "fold8", "shoup10", "shoup13"])
+@pytest.mark.parametrize("name", ["config1", "n4096", "n8192", "fold8", "shoup10", "shoup13", "fold14"])
 def test_dyadic_ops_vs_oracle(rigs, name):
     r = rigs(name)
     x = r.orc.fill(9, 17)
@@ -400,3 +404,20 @@ def test_config3_full_size_matvec_linearity_and_sampled_rows(rigs):
     want_s = r.orc.matvec_scalar(to_host(w[idx]), to_host(x1), len(idx), cols, threads=0)
     assert np.array_equal(to_host(ys.data[idx]), want_s)
     del W
+
+
+def test_n16384_c_abi_refuses_fused_multiply_and_facade_composes(rigs):
+    """N = 16384 has transforms and streaming kernels only: dpfhe_ct_mul refuses (no silent fallback in the C ABI); the
+    evaluator composes the same HIP kernels (4 NTT + dyadic + 3 INTT) and matches the oracle in every domain combination"""
+    r = rigs("fold14")
+    L, n = r.p.n_limbs, r.p.n
+    ah, bh = r.orc.fill(4, 1).reshape(2, 2, L, n), r.orc.fill(4, 2).reshape(2, 2, L, n)
+    a, b = Ciphertext(r.dev(ah)), Ciphertext(r.dev(bh))
+    out = r.ctx.empty(2, components=3)
+    rc = r.ev._lib.dpfhe_ct_mul(r.ctx.handle, out.data_ptr(), a.data.data_ptr(), b.data.data_ptr(), 2, 0, None)
+    assert rc == 2002
+    want = r.orc.ct_mul(ah, bh)
+    assert np.array_equal(to_host(r.ev.multiply(a, b).data), want)
+    an, bn = Ciphertext(r.ev.ntt_forward(a.data), True), Ciphertext(r.ev.ntt_forward(b.data), True)
+    assert np.array_equal(to_host(r.ev.multiply(an, bn, out_ntt=False).data), want)
+    assert np.array_equal(to_host(r.ev.ntt_inverse(r.ev.multiply(an, bn).data)), want)
