@@ -37,7 +37,7 @@ def run(emu, arith, ln, le, inv, q, psi, a):
     return rc, out
 
 
-GEOS = [(8, 4), (10, 4), (11, 4), (12, 4), (13, 4), (13, 5), (14, 5)]
+GEOS = [(8, 4), (10, 4), (11, 4), (12, 4), (13, 4), (13, 5), (14, 4), (14, 5)]
 
 
 @pytest.mark.parametrize("ln,le", GEOS)

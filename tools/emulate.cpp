@@ -94,7 +94,7 @@ extern "C" int emu_ntt(int arith, int log2n, int loge, int inverse, u64 q, u64 p
 #define CASE(LN, LE)                                                                     \
     if (log2n == LN && loge == LE)                                                       \
         return arith ? emu<FoldArith, LN, LE>(inverse, q, psi, in, out) : emu<ShoupArith, LN, LE>(inverse, q, psi, in, out);
-    CASE(8, 4) CASE(10, 4) CASE(11, 4) CASE(12, 4) CASE(13, 5) CASE(14, 5) CASE(12, 3) CASE(12, 5) CASE(13, 4) CASE(6, 3)
+    CASE(8, 4) CASE(10, 4) CASE(11, 4) CASE(12, 4) CASE(13, 5) CASE(14, 5) CASE(14, 4) CASE(12, 3) CASE(12, 5) CASE(13, 4) CASE(6, 3)
 #undef CASE
     return -1;
 }
