@@ -112,6 +112,44 @@ static void run(const FheParams& p, size_t batch) {
     orc_ctx_destroy(orc);
 }
 
+// N = 16384: no fused kernels - Evaluator::multiply composes 4 NTT + dyadic + 3 INTT from the same HIP kernels
+static void large_ring() {
+    FheParams p;
+    p.log2_n = 14;
+    for (uint64_t q : {1152921504606748673ull, 1152921504606683137ull, 1152921504606584833ull}) {   // pinned primes = 1 mod 32768
+        auto pw = [q](uint64_t b, uint64_t e) { uint64_t r = 1; for (b %= q; e; e >>= 1) { if (e & 1) r = (uint64_t)((unsigned __int128)r * b % q); b = (uint64_t)((unsigned __int128)b * b % q); } return r; };
+        uint64_t psi = 0;
+        for (uint64_t g = 2; !psi; ++g) { const uint64_t z = pw(g, (q - 1) / 32768); if (pw(z, 16384) == q - 1) psi = z; }
+        p.moduli.push_back(q); p.psi.push_back(psi);
+    }
+    const size_t L = p.n_limbs(), n = p.n(), batch = 2;
+    orc_ctx* orc = nullptr;
+    CHECK(orc_ctx_create(&orc, p.log2_n, (uint32_t)L, p.moduli.data(), p.psi.data()) == 0);
+    std::vector<uint64_t> a(batch * 2 * L * n), b(a.size()), want(batch * 3 * L * n), got(want.size());
+    orc_fill_splitmix(orc, a.data(), batch * 2, 2001);
+    orc_fill_splitmix(orc, b.data(), batch * 2, 2002);
+    orc_ct_mul(orc, want.data(), a.data(), b.data(), batch, 0);
+    Context ctx(p, 0);
+    Evaluator ev(ctx);
+    Ciphertext A(ctx, 2, batch), B(ctx, 2, batch), C(ctx, 3, batch);
+    A.copy_from_host(a.data());
+    B.copy_from_host(b.data());
+    ev.multiply(A, B, C);
+    ctx.synchronize();
+    C.copy_to_host(got.data());
+    CHECK(got == want);
+    ev.transform_to_ntt_inplace(A);
+    ev.transform_to_ntt_inplace(B);
+    Ciphertext Cn(ctx, 3, batch, /*is_ntt=*/true);
+    ev.multiply(A, B, Cn);
+    ev.transform_from_ntt_inplace(Cn);
+    ctx.synchronize();
+    Cn.copy_to_host(got.data());
+    CHECK(got == want);
+    try { RelinKeys K(ctx); Ciphertext R(ctx, 2, batch); ev.relinearize(C, K, R); CHECK(!"expected INVALID_STATE"); } catch (const Exception& e) { CHECK(e.code() == ErrorCode::INVALID_STATE); }
+    orc_ctx_destroy(orc);
+}
+
 // N2 + N1 end to end: encrypt -> multiply -> (relinearize) -> decrypt == negacyclic product of the messages
 static void end_to_end(const FheParams& p, size_t batch) {
     const size_t n = p.n();
@@ -315,6 +353,7 @@ int main() {
     try {
         packed(10, 64);
         packed(12, 16);
+        large_ring();
         end_to_end(FheParams::n4096_l4(), 2);
         run(FheParams::config1(), 2);
         run(FheParams::n4096_l4(), 3);
