@@ -19,6 +19,12 @@ struct DevTables {
     const typename Arith::Tw* inv;          // [L][N]  psi^-brv(i)
     const typename Arith::Tw* fwd4;
     const typename Arith::Tw* inv4;
+    // split transform (N > 16384): fwd / inv / last then hold one N2-point table per (limb, block) - [L][n_sub][N2] and
+    // [L][n_sub] - and the first log2(n_sub) stages run in ntt_top_kernel with these workgroup-uniform twiddles
+    const typename Arith::Tw* top_fwd;      // [L][n_sub]  psi^brv(i), entry m + i of the full table, i < n_sub
+    const typename Arith::Tw* top_inv;      // [L][n_sub]  psi^-brv(i)
+    const InvLast<typename Arith::Tw>* top_last;  // [L]   last inverse stage with N^-1 folded in
+    int n_sub;                              // 1: single-kernel transform
     const InvLast<typename Arith::Tw>* last;  // [L]
     const LimbConst* lc;                    // [L]
     int n_limbs;

@@ -52,7 +52,7 @@ struct dpfhe_ctx {
 extern "C" int dpfhe_ctx_create(dpfhe_ctx** out, uint32_t log2_n, uint32_t n_limbs, const uint64_t* moduli,
                                 const uint64_t* psi, int device_id) {
     if (!out || !moduli || !psi) return fail(DPFHE_INVALID_ARGUMENT, "dpfhe_ctx_create", "null argument");
-    if (log2_n < 8 || log2_n > (uint32_t)kMaxLog2N) return fail(DPFHE_INVALID_ARGUMENT, "dpfhe_ctx_create", "log2_n must be in [8, 14]");
+    if (log2_n < 8 || log2_n > (uint32_t)kMaxLog2N) return fail(DPFHE_INVALID_ARGUMENT, "dpfhe_ctx_create", "log2_n must be in [8, 16]");
     if (n_limbs == 0 || n_limbs > 1024) return fail(DPFHE_INVALID_ARGUMENT, "dpfhe_ctx_create", "n_limbs must be in [1, 1024]");
     const size_t n = (size_t)1 << log2_n, L = n_limbs;
     std::vector<HostLimbTables> ht(L);
@@ -75,44 +75,54 @@ extern "C" int dpfhe_ctx_create(dpfhe_ctx** out, uint32_t log2_n, uint32_t n_lim
     { int cus = 0; if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device_id) == hipSuccess && cus > 0) c->n_cu = cus; }
 
     // blob layout (all 256-byte aligned sections).  One twiddle table pair per kernel geometry in use: slot 0 = the
-    // fused kernels' LOGE 4 layout, slot 1 = the batched NTT kernels' layout when that differs (N = 8192).
+    // fused kernels' LOGE 4 layout, slot 1 = the batched NTT kernels' layout when that differs.  Split transforms
+    // (N > 16384) store, per limb, n_sub tables of N2 points (sub-trees of the full table) plus the top-stage twiddles.
     auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
     const size_t tw_sz = fold ? sizeof(TwFold) : sizeof(TwShoup);
-    const int loge_ntt = ntt_loge((int)log2_n);
-    const bool two_geo = loge_ntt != kFusedLoge;
+    const int log_n1 = split_log_n1((int)log2_n), log_n2 = (int)log2_n - log_n1;
+    const size_t n_sub = (size_t)1 << log_n1, n2 = (size_t)1 << log_n2;
+    const int loge_ntt = ntt_loge(log_n2);
+    const bool split = log_n1 > 0, two_geo = !split && loge_ntt != kFusedLoge;
     const size_t tab = L * n * tw_sz;
     const size_t o_lc = 0, o_fwd4 = up(o_lc + L * sizeof(LimbConst)), o_inv4 = up(o_fwd4 + tab),
                  o_fwd = two_geo ? up(o_inv4 + tab) : o_fwd4, o_inv = two_geo ? up(o_fwd + tab) : o_inv4,
-                 o_last = up(o_inv + tab), o_resc = up(o_last + L * 2 * tw_sz), total = up(o_resc + L * sizeof(RescaleConst));
+                 o_last = up(o_inv + tab), o_top_fwd = up(o_last + L * n_sub * 2 * tw_sz), o_top_inv = up(o_top_fwd + L * n_sub * tw_sz),
+                 o_top_last = up(o_top_inv + L * n_sub * tw_sz), o_resc = up(o_top_last + L * 2 * tw_sz), total = up(o_resc + L * sizeof(RescaleConst));
     std::vector<unsigned char> blob(total, 0);
-    auto put = [&](size_t off, size_t l, const auto& v) { std::memcpy(&blob[off + l * n * tw_sz], v.data(), n * tw_sz); };
-    for (size_t l = 0; l < L; ++l) {
-        std::memcpy(&blob[o_lc + l * sizeof(LimbConst)], &ht[l].lc, sizeof(LimbConst));
-        const u64 q = moduli[l];
-        for (int geo = 0; geo < (two_geo ? 2 : 1); ++geo) {
-            const int loge = geo ? loge_ntt : kFusedLoge, perm = geo_perm_stages((int)log2_n, loge);
-            const size_t of = geo ? o_fwd : o_fwd4, ov = geo ? o_inv : o_inv4;
-            if (fold) {
-                std::vector<TwFold> f(n), v(n);
-                for (size_t i = 0; i < n; ++i) { f[i] = h_tw_fold(ht[l].rp[i], q); v[i] = h_tw_fold(ht[l].irp[i], q); }
-                permute_window0(f, (int)log2_n, loge, perm); permute_window0(v, (int)log2_n, loge, perm);
-                put(of, l, f); put(ov, l, v);
+    auto fill = [&](auto tw_tag) {
+        typedef decltype(tw_tag) Tw;
+        for (size_t l = 0; l < L; ++l) {
+            const u64 q = moduli[l];
+            auto pack = [&](const std::vector<u64>& words, int logn_tab, int loge, size_t off) {   // one N-point table in kernel layout
+                std::vector<Tw> t(words.size());
+                for (size_t i = 0; i < words.size(); ++i) t[i] = h_make_tw<Tw>(words[i], q);
+                permute_window0(t, logn_tab, loge, geo_perm_stages(logn_tab, loge));
+                std::memcpy(&blob[off], t.data(), t.size() * sizeof(Tw));
+            };
+            InvLast<Tw>* lasts = reinterpret_cast<InvLast<Tw>*>(&blob[o_last]);
+            if (!split) {
+                for (int geo = 0; geo < (two_geo ? 2 : 1); ++geo) {
+                    const int loge = geo ? loge_ntt : kFusedLoge;
+                    pack(ht[l].rp, (int)log2_n, loge, (geo ? o_fwd : o_fwd4) + l * n * tw_sz);
+                    pack(ht[l].irp, (int)log2_n, loge, (geo ? o_inv : o_inv4) + l * n * tw_sz);
+                }
+                lasts[l] = InvLast<Tw>{h_make_tw<Tw>(ht[l].w_last, q), h_make_tw<Tw>(ht[l].lc.ninv, q)};
             } else {
-                std::vector<TwShoup> f(n), v(n);
-                for (size_t i = 0; i < n; ++i) { f[i] = TwShoup{ht[l].rp[i], ht[l].rp_sh[i]}; v[i] = TwShoup{ht[l].irp[i], ht[l].irp_sh[i]}; }
-                permute_window0(f, (int)log2_n, loge, perm); permute_window0(v, (int)log2_n, loge, perm);
-                put(of, l, f); put(ov, l, v);
+                for (size_t r = 0; r < n_sub; ++r) {
+                    const std::vector<u64> f = subtree_table(ht[l].rp, (int)log2_n, log_n1, r), v = subtree_table(ht[l].irp, (int)log2_n, log_n1, r);
+                    pack(f, log_n2, loge_ntt, o_fwd + (l * n_sub + r) * n2 * tw_sz);
+                    pack(v, log_n2, loge_ntt, o_inv + (l * n_sub + r) * n2 * tw_sz);
+                    lasts[l * n_sub + r] = InvLast<Tw>{h_make_tw<Tw>(v[1], q), h_make_tw<Tw>(1, q)};   // no N^-1 inside a block
+                }
+                Tw* tf = reinterpret_cast<Tw*>(&blob[o_top_fwd]) + l * n_sub;
+                Tw* tv = reinterpret_cast<Tw*>(&blob[o_top_inv]) + l * n_sub;
+                for (size_t i = 1; i < n_sub; ++i) { tf[i] = h_make_tw<Tw>(ht[l].rp[i], q); tv[i] = h_make_tw<Tw>(ht[l].irp[i], q); }
+                reinterpret_cast<InvLast<Tw>*>(&blob[o_top_last])[l] = InvLast<Tw>{h_make_tw<Tw>(ht[l].w_last, q), h_make_tw<Tw>(ht[l].lc.ninv, q)};
             }
         }
-        if (fold) {
-            InvLast<TwFold>* s = reinterpret_cast<InvLast<TwFold>*>(&blob[o_last]) + l;
-            s->w_last = h_tw_fold(ht[l].w_last, q); s->w_ninv = h_tw_fold(ht[l].lc.ninv, q);
-        } else {
-            InvLast<TwShoup>* s = reinterpret_cast<InvLast<TwShoup>*>(&blob[o_last]) + l;
-            s->w_last.w = ht[l].w_last; s->w_last.wsh = ht[l].w_last_sh;
-            s->w_ninv.w = ht[l].lc.ninv; s->w_ninv.wsh = ht[l].lc.ninv_sh;
-        }
-    }
+    };
+    for (size_t l = 0; l < L; ++l) std::memcpy(&blob[o_lc + l * sizeof(LimbConst)], &ht[l].lc, sizeof(LimbConst));
+    if (fold) fill(TwFold{}); else fill(TwShoup{});
     {   // rescale constants relative to the LAST prime (used only when L >= 2)
         const u64 ql = moduli[L - 1], hh = ql / 2;
         RescaleConst* r = reinterpret_cast<RescaleConst*>(&blob[o_resc]);
@@ -138,6 +148,10 @@ extern "C" int dpfhe_ctx_create(dpfhe_ctx** out, uint32_t log2_n, uint32_t n_lim
         c->foldt.fwd4 = reinterpret_cast<const TwFold*>(d + o_fwd4);
         c->foldt.inv4 = reinterpret_cast<const TwFold*>(d + o_inv4);
         c->foldt.last = reinterpret_cast<const InvLast<TwFold>*>(d + o_last);
+        c->foldt.top_fwd = reinterpret_cast<const TwFold*>(d + o_top_fwd);
+        c->foldt.top_inv = reinterpret_cast<const TwFold*>(d + o_top_inv);
+        c->foldt.top_last = reinterpret_cast<const InvLast<TwFold>*>(d + o_top_last);
+        c->foldt.n_sub = (int)n_sub;
         c->foldt.n_limbs = (int)n_limbs;
     } else {
         c->shoup.lc = reinterpret_cast<const LimbConst*>(d + o_lc);
@@ -146,6 +160,10 @@ extern "C" int dpfhe_ctx_create(dpfhe_ctx** out, uint32_t log2_n, uint32_t n_lim
         c->shoup.fwd4 = reinterpret_cast<const TwShoup*>(d + o_fwd4);
         c->shoup.inv4 = reinterpret_cast<const TwShoup*>(d + o_inv4);
         c->shoup.last = reinterpret_cast<const InvLast<TwShoup>*>(d + o_last);
+        c->shoup.top_fwd = reinterpret_cast<const TwShoup*>(d + o_top_fwd);
+        c->shoup.top_inv = reinterpret_cast<const TwShoup*>(d + o_top_inv);
+        c->shoup.top_last = reinterpret_cast<const InvLast<TwShoup>*>(d + o_top_last);
+        c->shoup.n_sub = (int)n_sub;
         c->shoup.n_limbs = (int)n_limbs;
     }
     (void)hipSetDevice(prev);

@@ -8,6 +8,7 @@
 
 #include "devtables.h"
 #include "ntt_core.h"
+#include "ntt_top.h"
 
 namespace dpfhe {
 
@@ -98,10 +99,11 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE)) void ntt_fwd_kernel(u64* __rest
     typedef NttBody<Arith, LOGN, LOGE> B;
     __shared__ __attribute__((aligned(16))) u64 lds[B::G::lds_words()];
     const int tid = threadIdx.x;
-    const size_t p = blockIdx.x;
-    const int limb = (int)(p % (size_t)tb.n_limbs);
+    const size_t p = blockIdx.x;             // block p transforms words [p N, (p + 1) N): one polynomial, or one of its n_sub blocks
+    const size_t sub = p % (size_t)tb.n_sub;
+    const int limb = (int)((p / (size_t)tb.n_sub) % (size_t)tb.n_limbs);
     const LimbConst lc = tb.lc[limb];
-    const typename B::Tw* tw = tb.fwd + (size_t)limb * B::G::N;
+    const typename B::Tw* tw = tb.fwd + ((size_t)limb * tb.n_sub + sub) * B::G::N;
     u64 x[B::E];
     B::load_top(tid, x, in + p * B::G::N);
     FwdChain<B, 0>::run(tid, x, lds, tw, lc);
@@ -117,10 +119,11 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE)) void ntt_inv_kernel(u64* __rest
     __shared__ __attribute__((aligned(16))) u64 lds[B::G::lds_words()];
     const int tid = threadIdx.x;
     const size_t p = blockIdx.x;
-    const int limb = (int)(p % (size_t)tb.n_limbs);
+    const size_t sub = p % (size_t)tb.n_sub;
+    const int limb = (int)((p / (size_t)tb.n_sub) % (size_t)tb.n_limbs);
     const LimbConst lc = tb.lc[limb];
-    const typename B::Tw* tw = tb.inv + (size_t)limb * B::G::N;
-    const InvLast<typename B::Tw> last = tb.last[limb];
+    const typename B::Tw* tw = tb.inv + ((size_t)limb * tb.n_sub + sub) * B::G::N;
+    const InvLast<typename B::Tw> last = tb.last[(size_t)limb * tb.n_sub + sub];
     typename B::TwRegs tw_first;   // requested before the data: load_bot waits for all of its loads (register transposition)
     B::template load_tw<B::NPH - 1, false>(tid, tw, tw_first);
     u64 x[B::E];

@@ -14,7 +14,10 @@ namespace dpfhe {
 // N = 16384 (128 KiB of LDS per polynomial): 1024 threads, one workgroup per CU (16 words per thread measured 5 % faster
 // than 32 on the forward transform); the fused kernels stop at N = 8192.
 constexpr int ntt_loge(int log2n) { return (void)log2n, 4; }
-constexpr int kMaxLog2N = 14, kMaxFusedLog2N = 13;
+constexpr int kMaxLog2N = 16, kMaxFusedLog2N = 13;
+// N > 16384: split transform - log2(N1) top stages in ntt_top_kernel, then N1 transforms of N2 = 4096 points each
+constexpr int kSplitLog2N2 = 12;
+constexpr int split_log_n1(int log2n) { return log2n > 14 ? log2n - kSplitLog2N2 : 0; }
 constexpr int kFusedLoge = 4;
 
 // return 0, or -1 when log2n has no compiled geometry.  Launch errors are left in hipGetLastError().

@@ -30,8 +30,23 @@ namespace dpfhe {
     }
 static_assert(ntt_loge(12) == 4 && ntt_loge(13) == 4 && ntt_loge(8) == 4 && ntt_loge(14) == 4, "launch.h ntt_loge must match DPFHE_NTT_GEO_SWITCH");
 
+template <class Arith, int LOG_N1>
+static void launch_ntt_split(bool inverse, u64* out, const u64* in, size_t npolys, const DevTables<Arith>& tb, hipStream_t s) {
+    constexpr int LN2 = kSplitLog2N2;
+    const unsigned top_grid = (unsigned)(npolys * ((size_t)1 << LN2) / 256), sub_grid = (unsigned)(npolys << LOG_N1);
+    if (!inverse) {
+        hipLaunchKernelGGL((ntt_top_kernel<Arith, LOG_N1, true>), dim3(top_grid), dim3(256), 0, s, out, in, tb, LN2);
+        hipLaunchKernelGGL((ntt_fwd_kernel<Arith, LN2, 4>), dim3(sub_grid), dim3(Geo<LN2, 4>::T), 0, s, out, out, tb);
+    } else {
+        hipLaunchKernelGGL((ntt_inv_kernel<Arith, LN2, 4>), dim3(sub_grid), dim3(Geo<LN2, 4>::T), 0, s, out, in, tb);
+        hipLaunchKernelGGL((ntt_top_kernel<Arith, LOG_N1, false>), dim3(top_grid), dim3(256), 0, s, out, out, tb, LN2);
+    }
+}
+
 template <class Arith>
 int launch_ntt(int log2n, bool inverse, u64* out, const u64* in, size_t npolys, const DevTables<Arith>& tb, hipStream_t s) {
+    if (log2n == 15) { launch_ntt_split<Arith, 3>(inverse, out, in, npolys, tb, s); return 0; }
+    if (log2n == 16) { launch_ntt_split<Arith, 4>(inverse, out, in, npolys, tb, s); return 0; }
 #define NTT_CASE(LN, LE)                                                                                                              \
     if (inverse) hipLaunchKernelGGL((ntt_inv_kernel<Arith, LN, LE>), dim3((unsigned)npolys), dim3(Geo<LN, LE>::T), 0, s, out, in, tb); \
     else hipLaunchKernelGGL((ntt_fwd_kernel<Arith, LN, LE>), dim3((unsigned)npolys), dim3(Geo<LN, LE>::T), 0, s, out, in, tb)

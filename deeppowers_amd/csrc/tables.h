@@ -32,6 +32,21 @@ inline TwFold h_tw_fold(u64 w, u64 q) {
     return TwFold{(w & m30) | ((w >> 30) << 32), (ws & m30) | ((ws >> 30) << 32)};
 }
 
+template <class Tw> inline Tw h_make_tw(u64 w, u64 q);
+template <> inline TwFold h_make_tw<TwFold>(u64 w, u64 q) { return h_tw_fold(w, q); }
+template <> inline TwShoup h_make_tw<TwShoup>(u64 w, u64 q) { return TwShoup{w, (u64)(((u128)w << 64) / q)}; }
+
+// Split transform (N > 16384, ntt_top.h): after the first log_n1 radix-2 stages the remaining ones act inside blocks of
+// N2 = N >> log_n1 consecutive words, and block r runs an ordinary N2-point merged transform whose twiddles are the
+// sub-tree of the big table rooted at node N1 + r:  sub[m + i] = table[(N1 + r) m + i]  (m a power of two < N2, i < m).
+inline std::vector<u64> subtree_table(const std::vector<u64>& table, int log2n, int log_n1, size_t r) {
+    const size_t n2 = (size_t)1 << (log2n - log_n1), root = ((size_t)1 << log_n1) + r;
+    std::vector<u64> sub(n2, 0);
+    for (size_t m = 1; m < n2; m <<= 1)
+        for (size_t i = 0; i < m; ++i) sub[m + i] = table[root * m + i];
+    return sub;
+}
+
 // q = 2^60 - d with d < 2^24: eligible for FoldArith
 inline bool fold_eligible(u64 q) { return q < (1ull << 60) && ((1ull << 60) - q) < (1ull << 24); }
 

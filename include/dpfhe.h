@@ -56,7 +56,7 @@ enum {
 enum { DPFHE_IN_NTT = 1u, DPFHE_OUT_NTT = 2u };
 
 /* -- A0: context ----------------------------------------------------------------------------------
- * log2_n in [8, 14] (transforms and streaming kernels; the fused ct x ct / key-switch kernels stop at 13 and return
+ * log2_n in [8, 16] (transforms and streaming kernels; N > 16384 runs a two-kernel split transform; the fused ct x ct / key-switch kernels stop at 13 and return
  * DPFHE_INVALID_STATE above it); n_limbs >= 1; moduli[i] prime < 2^60 with q = 1 (mod 2N); psi[i] a primitive
  * 2N-th root of unity mod q_i (psi^N = -1).  Builds twiddle / Shoup / Barrett tables on device_id. */
 int dpfhe_ctx_create(dpfhe_ctx** out, uint32_t log2_n, uint32_t n_limbs, const uint64_t* moduli,

@@ -96,3 +96,24 @@ def test_emulated_ct_mul_lazy_path_matches_oracle_without_wraps(emu, ln):
             want = orc.ct_mul(a, b).reshape(3 * n)
             assert np.array_equal(out, want)
     assert emu.emu_overflows() == before, "lazy arithmetic wrapped around 2^64 or broke a mul60 precondition"
+
+
+@pytest.mark.parametrize("ln", [15, 16])
+@pytest.mark.parametrize("arith", [0, 1], ids=["shoup", "fold"])
+def test_emulated_split_transform_matches_oracle(emu, ln, arith):
+    """N = 2^15, 2^16: column stages (ntt_top.h) + 4096-point kernels on sub-tree tables == the oracle's one-piece transform"""
+    n = 1 << ln
+    emu.emu_ntt_split.argtypes = [C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_uint64, U, U]
+    emu.emu_ntt_split.restype = C.c_int
+    before = emu.emu_overflows()
+    # fold-eligible prime = 1 mod 2N: 2^60 - d with d = -1 mod 2N; the 5th pinned prime is 1 mod 2^16 only
+    q = next(c for c in ((1 << 60) - (k * 2 * n - 1) for k in range(1, 1 << (24 - ln - 1))) if c % (2 * n) == 1 and po.is_prime(c))
+    psi = po.min_primitive_2n_root(n, q)
+    orc = Oracle(ln, [q], [psi])
+    for a in (orc.fill(1, 31).ravel().copy(), np.full(n, q - 1, np.uint64), np.where(np.arange(n) % 3 == 0, q - 1, 1).astype(np.uint64)):
+        a = np.ascontiguousarray(a, dtype=np.uint64)
+        for inv, ref in ((0, orc.ntt_fwd), (1, orc.ntt_inv)):
+            out = np.zeros_like(a)
+            rc = emu.emu_ntt_split(arith, ln, inv, q, psi, a.ctypes.data_as(U), out.ctypes.data_as(U))
+            assert rc == 0 and np.array_equal(out, ref(a))
+    assert emu.emu_overflows() == before, "lazy arithmetic wrapped around 2^64"

@@ -35,6 +35,19 @@ def generic_prime(bits, two_n):
     return q
 
 
+def fold_primes(two_n, count):
+    """primes 2^60 - d (d < 2^24) that are 1 mod two_n: FoldArith-eligible limbs for any ring degree"""
+    out = []
+    k = 1
+    while len(out) < count:
+        c = (1 << 60) - (k * two_n - 1)
+        assert (1 << 60) - c < (1 << 24), "no more fold-eligible primes for this ring degree"
+        if po.is_prime(c):
+            out.append(c)
+        k += 1
+    return out
+
+
 class Rig:
     def __init__(self, params):
         self.p = params
@@ -58,6 +71,10 @@ def rigs():
                 p = FheParams.n4096_l4()
             elif name == "n8192":
                 p = FheParams.n8192_l6()
+            elif name in ("fold15", "fold16"):  # split transform (column stages + 4096-point kernels)
+                log2n = int(name[4:])
+                qs = fold_primes(2 << log2n, 2)
+                p = FheParams(log2n, tuple(qs), tuple(po.min_primitive_2n_root(1 << log2n, q) for q in qs))
             elif name == "fold14":  # N = 16384: the pinned primes that are 1 mod 32768 (transform / streaming kernels only)
                 qs = [PRIMES_60[i][0] for i in (1, 2, 4)]
                 p = FheParams(14, tuple(qs), tuple(po.min_primitive_2n_root(16384, q) for q in qs))
@@ -80,7 +97,7 @@ def rigs():
 
 
 ALL = ["config1", "n4096", "n8192", "fold8", "fold9", "fold10", "fold11", "shoup8", "shoup10", "shoup12", "shoup13"]
-NTT_ONLY = ["fold14", "shoup14"]   # N = 16384: no fused ct x ct / key-switch kernels
+NTT_ONLY = ["fold14", "shoup14", "fold15", "fold16", "shoup16"]   # N = 16384: no fused ct x ct / key-switch kernels
 
 
 def test_arithmetic_policy_selection(rigs):
@@ -174,7 +191,7 @@ def test_ntt_forward_inverse_vs_oracle(rigs, name):
     assert L == r.p.n_limbs
 
 
-@pytest.mark.parametrize("name", ["config1", "n4096", "n8192", "fold8", "shoup10", "shoup13", "fold14"])
+@pytest.mark.parametrize("name", ["config1", "n4096", "n8192", "fold8", "shoup10", "shoup13", "fold14", "fold16"])
 def test_dyadic_ops_vs_oracle(rigs, name):
     r = rigs(name)
     x = r.orc.fill(9, 17)

@@ -9,6 +9,7 @@
 #include <vector>
 
 #include "../deeppowers_amd/csrc/ntt_core.h"
+#include "../deeppowers_amd/csrc/ntt_top.h"
 #include "../deeppowers_amd/csrc/tables.h"
 
 namespace dpfhe { long g_emu_overflows = 0; }
@@ -96,6 +97,63 @@ extern "C" int emu_ntt(int arith, int log2n, int loge, int inverse, u64 q, u64 p
         return arith ? emu<FoldArith, LN, LE>(inverse, q, psi, in, out) : emu<ShoupArith, LN, LE>(inverse, q, psi, in, out);
     CASE(8, 4) CASE(10, 4) CASE(11, 4) CASE(12, 4) CASE(13, 5) CASE(14, 5) CASE(14, 4) CASE(12, 3) CASE(12, 5) CASE(13, 4) CASE(6, 3)
 #undef CASE
+    return -1;
+}
+
+// Split transform (N = 2^15, 2^16): ntt_top.h column stages + N1 emulated 4096-point kernels on sub-tree tables, the way
+// launch_impl.h launch_ntt_split and dpfhe_ctx_create arrange them.
+template <class Arith, int LOG_N1>
+static int emu_split(int inverse, u64 q, u64 psi, const u64* in, u64* out) {
+    constexpr int LN2 = 12, LE = 4, N1 = 1 << LOG_N1, LOGN = LN2 + LOG_N1;
+    typedef NttBody<Arith, LN2, LE> B;
+    typedef typename Arith::Tw Tw;
+    HostLimbTables t;
+    int rc = build_limb_tables(LOGN, q, psi, t);
+    if (rc) return rc;
+    if (Arith::kFold && !fold_eligible(q)) return 2000;
+    constexpr int E = B::E, T = B::T, N2 = B::G::N;
+    const size_t n = (size_t)1 << LOGN;
+    std::vector<Tw> top_f(N1), top_i(N1);
+    for (int i = 1; i < N1; ++i) { top_f[i] = h_make_tw<Tw>(t.rp[i], q); top_i[i] = h_make_tw<Tw>(t.irp[i], q); }
+    const InvLast<Tw> top_last{h_make_tw<Tw>(t.w_last, q), h_make_tw<Tw>(t.lc.ninv, q)};
+    std::vector<u64> buf(in, in + n), lds(B::G::lds_words());
+    auto columns = [&](bool fwd) {
+        for (size_t c = 0; c < (size_t)N2; ++c) {
+            u64 x[N1];
+            for (int r = 0; r < N1; ++r) x[r] = buf[(size_t)r * N2 + c];
+            if (fwd) top_forward<Arith, LOG_N1>(x, top_f.data(), t.lc); else top_inverse<Arith, LOG_N1>(x, top_i.data(), top_last, t.lc);
+            for (int r = 0; r < N1; ++r) buf[(size_t)r * N2 + c] = x[r];
+        }
+    };
+    auto blocks = [&](bool fwd) {
+        for (size_t r = 0; r < (size_t)N1; ++r) {
+            const std::vector<u64> words = subtree_table(fwd ? t.rp : t.irp, LOGN, LOG_N1, r);
+            std::vector<Tw> tw(words.size());
+            for (size_t i = 0; i < words.size(); ++i) tw[i] = h_make_tw<Tw>(words[i], q);
+            permute_window0(tw, LN2, LE, B::G::kPermStages);
+            std::vector<u64> regs((size_t)T * E), blk(buf.begin() + r * N2, buf.begin() + (r + 1) * N2), res(N2);
+            auto X = [&](int tid) -> u64(&)[E] { return *reinterpret_cast<u64(*)[E]>(&regs[(size_t)tid * E]); };
+            if (fwd) {
+                for (int tid = 0; tid < T; ++tid) B::load_top(tid, X(tid), blk.data());
+                FwdSteps<B, 0>::run(regs, lds, tw.data(), t.lc);
+                for (int tid = 0; tid < T; ++tid) { B::fwd_canon(X(tid), t.lc); B::store_bot(tid, X(tid), res.data()); }
+            } else {
+                const Tw wl = h_make_tw<Tw>(words[1], q), wn = h_make_tw<Tw>(1, q);   // no N^-1 inside a block
+                for (int tid = 0; tid < T; ++tid) B::load_bot(tid, X(tid), blk.data());
+                InvSteps<B, B::NPH - 1, kUnit>::run(regs, lds, tw.data(), wl, wn, t.lc);
+                for (int tid = 0; tid < T; ++tid) { B::inv_canon(X(tid), t.lc); B::store_top(tid, X(tid), res.data()); }
+            }
+            std::copy(res.begin(), res.end(), buf.begin() + r * N2);
+        }
+    };
+    if (!inverse) { columns(true); blocks(true); } else { blocks(false); columns(false); }
+    std::copy(buf.begin(), buf.end(), out);
+    return 0;
+}
+
+extern "C" int emu_ntt_split(int arith, int log2n, int inverse, u64 q, u64 psi, const u64* in, u64* out) {
+    if (log2n == 15) return arith ? emu_split<FoldArith, 3>(inverse, q, psi, in, out) : emu_split<ShoupArith, 3>(inverse, q, psi, in, out);
+    if (log2n == 16) return arith ? emu_split<FoldArith, 4>(inverse, q, psi, in, out) : emu_split<ShoupArith, 4>(inverse, q, psi, in, out);
     return -1;
 }
 
