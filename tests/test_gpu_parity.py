@@ -423,10 +423,11 @@ def test_config3_full_size_matvec_linearity_and_sampled_rows(rigs):
     del W
 
 
-def test_n16384_c_abi_refuses_fused_multiply_and_facade_composes(rigs):
-    """N = 16384 has transforms and streaming kernels only: dpfhe_ct_mul refuses (no silent fallback in the C ABI); the
+@pytest.mark.parametrize("name", ["fold14", "fold16"])
+def test_large_rings_c_abi_refuses_fused_multiply_and_facade_composes(rigs, name):
+    """N > 8192 has transforms and streaming kernels only: dpfhe_ct_mul refuses (no silent fallback in the C ABI); the
     evaluator composes the same HIP kernels (4 NTT + dyadic + 3 INTT) and matches the oracle in every domain combination"""
-    r = rigs("fold14")
+    r = rigs(name)
     L, n = r.p.n_limbs, r.p.n
     ah, bh = r.orc.fill(4, 1).reshape(2, 2, L, n), r.orc.fill(4, 2).reshape(2, 2, L, n)
     a, b = Ciphertext(r.dev(ah)), Ciphertext(r.dev(bh))
