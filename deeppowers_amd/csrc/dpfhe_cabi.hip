@@ -37,6 +37,32 @@ static int fail(int code, const char* what, const char* detail) {
             return fail(_e == hipErrorOutOfMemory ? DPFHE_OUT_OF_MEMORY : DPFHE_DEVICE_ERROR, #expr, hipGetErrorString(_e)); \
     } while (0)
 
+// Every compute entry point runs on the CONTEXT's device (tables and, by contract, the caller's buffers live there), whatever
+// the calling thread's current device is: the guard switches to it for the duration of the call and restores the caller's
+// device afterwards.  Same device: two cheap runtime queries, no switch.
+struct DeviceGuard {
+    int prev = -1, want = -1;
+    hipError_t err = hipSuccess;
+    explicit DeviceGuard(int device) : want(device) {
+        err = hipGetDevice(&prev);
+        if (err == hipSuccess && prev != want) err = hipSetDevice(want);
+    }
+    ~DeviceGuard() {
+        if (prev >= 0 && prev != want) (void)hipSetDevice(prev);
+    }
+    DeviceGuard(const DeviceGuard&) = delete;
+    DeviceGuard& operator=(const DeviceGuard&) = delete;
+};
+#define DPFHE_ON_DEVICE(ctx, what)                                                                            \
+    DeviceGuard _guard((ctx)->device);                                                                         \
+    if (_guard.err != hipSuccess) return fail(DPFHE_DEVICE_ERROR, what, hipGetErrorString(_guard.err))
+
+// half-open word ranges [a, a + na) and [b, b + nb) intersect
+static inline bool overlaps(const uint64_t* a, size_t na, const uint64_t* b, size_t nb) {
+    const uintptr_t a0 = reinterpret_cast<uintptr_t>(a), b0 = reinterpret_cast<uintptr_t>(b);
+    return a0 < b0 + nb * 8 && b0 < a0 + na * 8;
+}
+
 struct dpfhe_ctx {
     uint32_t log2n = 0, n_limbs = 0;
     int device = 0;
@@ -58,6 +84,9 @@ extern "C" int dpfhe_ctx_create(dpfhe_ctx** out, uint32_t log2_n, uint32_t n_lim
     std::vector<HostLimbTables> ht(L);
     bool fold = true;
     for (size_t l = 0; l < L; ++l) {
+        // inverses (N^-1, psi^-1, rescale constants) are Fermat powers: a composite modulus that happens to satisfy
+        // psi^N = -1 would make them silently wrong, so primality is checked (deterministic Miller-Rabin, one-off)
+        if (!h_is_prime(moduli[l])) return fail(DPFHE_INVALID_ARGUMENT, "dpfhe_ctx_create", "modulus is not prime");
         int rc = build_limb_tables((int)log2_n, moduli[l], psi[l], ht[l]);
         if (rc) return fail(rc, "dpfhe_ctx_create", "modulus must be < 2^60 and 1 mod 2N, psi a primitive 2N-th root");
         fold = fold && fold_eligible(moduli[l]);
@@ -203,7 +232,11 @@ static int ntt_entry(dpfhe_ctx* c, bool inverse, uint64_t* out, const uint64_t* 
     if (n_rns_polys == 0) return DPFHE_SUCCESS;
     if (!out || !in || misaligned(out) || misaligned(in)) return fail(DPFHE_INVALID_ARGUMENT, "ntt", "null or misaligned buffer");
     const size_t npolys = n_rns_polys * c->n_limbs;
-    if (npolys > kMaxGrid) return fail(DPFHE_INVALID_ARGUMENT, "ntt", "batch too large for one launch");
+    // split transforms (N > 16384) launch npolys * N1 sub-transforms and npolys * N2 / 256 column workgroups
+    const int log_n1 = split_log_n1((int)c->log2n);
+    const size_t widest = log_n1 ? ((npolys << log_n1) > (npolys << (kSplitLog2N2 - 8)) ? (npolys << log_n1) : (npolys << (kSplitLog2N2 - 8))) : npolys;
+    if (npolys > kMaxGrid || widest > kMaxGrid) return fail(DPFHE_INVALID_ARGUMENT, "ntt", "batch too large for one launch");
+    DPFHE_ON_DEVICE(c, "ntt");
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int rc = c->fold ? launch_ntt<FoldArith>((int)c->log2n, inverse, out, in, npolys, c->foldt, s)
                            : launch_ntt<ShoupArith>((int)c->log2n, inverse, out, in, npolys, c->shoup, s);
@@ -230,6 +263,7 @@ static int dyadic_entry(dpfhe_ctx* c, int op, uint64_t* out, const uint64_t* a, 
         return fail(DPFHE_INVALID_ARGUMENT, "dyadic", "null or misaligned buffer");
     const size_t npolys = n_rns_polys * c->n_limbs;
     if (npolys > kMaxGrid) return fail(DPFHE_INVALID_ARGUMENT, "dyadic", "batch too large for one launch");
+    DPFHE_ON_DEVICE(c, "dyadic");
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (op == DY_NEG) b = a;
 #define DY_CASE(OP)                                                   \
@@ -261,6 +295,7 @@ extern "C" int dpfhe_ct_mul(dpfhe_ctx* c, uint64_t* d_out3, const uint64_t* d_a2
         return fail(DPFHE_INVALID_ARGUMENT, "dpfhe_ct_mul", "null or misaligned buffer");
     const size_t blocks = batch * c->n_limbs;
     if (blocks > kMaxGrid) return fail(DPFHE_INVALID_ARGUMENT, "dpfhe_ct_mul", "batch too large for one launch");
+    DPFHE_ON_DEVICE(c, "dpfhe_ct_mul");
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int rc = c->fold ? launch_ct_mul<FoldArith>((int)c->log2n, flags, d_out3, d_a2, d_b2, blocks, c->foldt, s)
                            : launch_ct_mul<ShoupArith>((int)c->log2n, flags, d_out3, d_a2, d_b2, blocks, c->shoup, s);
@@ -273,8 +308,13 @@ extern "C" int dpfhe_relinearize(dpfhe_ctx* c, uint64_t* d_out2, const uint64_t*
     if (batch == 0) return DPFHE_SUCCESS;
     if (!d_out2 || !d_in3 || !d_evk || misaligned(d_out2) || misaligned(d_in3) || misaligned(d_evk))
         return fail(DPFHE_INVALID_ARGUMENT, "dpfhe_relinearize", "null or misaligned buffer");
+    {   // input items are 3 L N words apart, output items 2 L N: any overlap lets one workgroup overwrite another's unread input
+        const size_t poly = (size_t)c->n_limbs << c->log2n;
+        if (overlaps(d_out2, batch * 2 * poly, d_in3, batch * 3 * poly)) return fail(DPFHE_INVALID_ARGUMENT, "dpfhe_relinearize", "output overlaps the input");
+    }
     const size_t blocks = batch * c->n_limbs;
     if (blocks > kMaxGrid) return fail(DPFHE_INVALID_ARGUMENT, "dpfhe_relinearize", "batch too large for one launch");
+    DPFHE_ON_DEVICE(c, "dpfhe_relinearize");
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int rc = c->fold ? launch_relin<FoldArith>((int)c->log2n, 0, d_out2, d_in3, d_evk, 0, blocks, c->foldt, s)
                            : launch_relin<ShoupArith>((int)c->log2n, 0, d_out2, d_in3, d_evk, 0, blocks, c->shoup, s);
@@ -285,10 +325,12 @@ extern "C" int dpfhe_relinearize(dpfhe_ctx* c, uint64_t* d_out2, const uint64_t*
 extern "C" int dpfhe_switch_key(dpfhe_ctx* c, uint64_t* d_out2, const uint64_t* d_in2, const uint64_t* d_key, size_t batch, void* stream) {
     if (!c) return fail(DPFHE_INVALID_ARGUMENT, "dpfhe_switch_key", "null context");
     if (batch == 0) return DPFHE_SUCCESS;
-    if (!d_out2 || !d_in2 || !d_key || misaligned(d_out2) || misaligned(d_in2) || misaligned(d_key) || d_out2 == d_in2)
+    if (!d_out2 || !d_in2 || !d_key || misaligned(d_out2) || misaligned(d_in2) || misaligned(d_key) ||
+        overlaps(d_out2, batch * 2 * ((size_t)c->n_limbs << c->log2n), d_in2, batch * 2 * ((size_t)c->n_limbs << c->log2n)))
         return fail(DPFHE_INVALID_ARGUMENT, "dpfhe_switch_key", "null, misaligned or aliased buffer");
     const size_t blocks = batch * c->n_limbs;
     if (blocks > kMaxGrid) return fail(DPFHE_INVALID_ARGUMENT, "dpfhe_switch_key", "batch too large for one launch");
+    DPFHE_ON_DEVICE(c, "dpfhe_switch_key");
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int rc = c->fold ? launch_relin<FoldArith>((int)c->log2n, 1, d_out2, d_in2, d_key, 0, blocks, c->foldt, s)
                            : launch_relin<ShoupArith>((int)c->log2n, 1, d_out2, d_in2, d_key, 0, blocks, c->shoup, s);
@@ -305,6 +347,7 @@ extern "C" int dpfhe_rescale(dpfhe_ctx* c, uint64_t* d_out, const uint64_t* d_in
     const int chunks = (n + 511) / 512;
     const size_t blocks = n_rns_polys * (c->n_limbs - 1) * (size_t)chunks;
     if (blocks > kMaxGrid) return fail(DPFHE_INVALID_ARGUMENT, "dpfhe_rescale", "batch too large for one launch");
+    DPFHE_ON_DEVICE(c, "dpfhe_rescale");
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (c->fold) hipLaunchKernelGGL((rescale_kernel<FoldArith>), dim3((unsigned)blocks), dim3(256), 0, s, d_out, d_in, (const u64*)nullptr, 0, 0, c->foldt.lc, c->d_rescale, (int)c->n_limbs, n, chunks);
     else hipLaunchKernelGGL((rescale_kernel<ShoupArith>), dim3((unsigned)blocks), dim3(256), 0, s, d_out, d_in, (const u64*)nullptr, 0, 0, c->shoup.lc, c->d_rescale, (int)c->n_limbs, n, chunks);
@@ -321,8 +364,14 @@ static int hybrid_entry(dpfhe_ctx* c, const char* what, int in_comps, uint64_t* 
         return fail(DPFHE_INVALID_ARGUMENT, what, "null or misaligned buffer");
     const size_t L = c->n_limbs, Ld = L - 1;
     const int n = 1 << c->log2n;
+    {   // the rescale-add pass reads (c0, c1) of the input while it writes the output; the work buffer is written by pass 1
+        const size_t in_words = batch * (size_t)in_comps * Ld * n, out_words = batch * 2 * Ld * n, work_words = batch * 2 * L * n;
+        if (overlaps(d_out2, out_words, d_in, in_words) || overlaps(d_work, work_words, d_in, in_words) || overlaps(d_work, work_words, d_out2, out_words))
+            return fail(DPFHE_INVALID_ARGUMENT, what, "output, input and work buffers must not overlap");
+    }
     const size_t blocks = batch * L;
     if (blocks > kMaxGrid) return fail(DPFHE_INVALID_ARGUMENT, what, "batch too large for one launch");
+    DPFHE_ON_DEVICE(c, "hybrid key switch");
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int mode = in_comps == 3 ? 2 : 3;
     const int rc = c->fold ? launch_relin<FoldArith>((int)c->log2n, mode, d_work, d_in, d_key, key_stride, blocks, c->foldt, s)
@@ -372,8 +421,10 @@ extern "C" int dpfhe_rotate_hybrid_batch(dpfhe_ctx* c, uint64_t* d_out2, const u
     for (size_t i = 0; i < batch; ++i)
         if (!(galois_elts[i] & 1u) || galois_elts[i] >= two_n) return fail(DPFHE_INVALID_ARGUMENT, what, "galois elements must be odd and < 2N");
     const size_t ct_words = 2 * Ld * (size_t)n, key_words = Ld * 2 * L * (size_t)n;
+    if (n_in == batch && overlaps(d_rotated, batch * ct_words, d_in2, batch * ct_words)) return fail(DPFHE_INVALID_ARGUMENT, what, "d_rotated overlaps the input");
     const LimbConst* lc = c->fold ? c->foldt.lc : c->shoup.lc;
     hipStream_t s = static_cast<hipStream_t>(stream);
+    DPFHE_ON_DEVICE(c, "dpfhe_rotate_hybrid_batch");
     for (size_t first = 0; first < batch; first += kMaxGaloisBatch) {   // the elements travel as kernel arguments, 64 at a time
         const size_t cnt = batch - first < (size_t)kMaxGaloisBatch ? batch - first : (size_t)kMaxGaloisBatch;
         GaloisInvs inv{};
@@ -392,10 +443,12 @@ extern "C" int dpfhe_apply_galois(dpfhe_ctx* c, uint64_t* d_out, const uint64_t*
     const unsigned two_n = 2u << c->log2n;
     if (!(galois_elt & 1u) || galois_elt >= two_n) return fail(DPFHE_INVALID_ARGUMENT, "dpfhe_apply_galois", "galois_elt must be odd and < 2N");
     if (n_rns_polys == 0) return DPFHE_SUCCESS;
-    if (!d_out || !d_in || d_out == d_in || misaligned(d_out) || misaligned(d_in))
+    if (!d_out || !d_in || misaligned(d_out) || misaligned(d_in) ||
+        overlaps(d_out, n_rns_polys * ((size_t)c->n_limbs << c->log2n), d_in, n_rns_polys * ((size_t)c->n_limbs << c->log2n)))
         return fail(DPFHE_INVALID_ARGUMENT, "dpfhe_apply_galois", "null, misaligned or aliased buffer");
     const size_t npolys = n_rns_polys * c->n_limbs;
     if (npolys > kMaxGrid) return fail(DPFHE_INVALID_ARGUMENT, "dpfhe_apply_galois", "batch too large for one launch");
+    DPFHE_ON_DEVICE(c, "dpfhe_apply_galois");
     const unsigned inv = galois_inverse(galois_elt, two_n);
     const LimbConst* lc = c->fold ? c->foldt.lc : c->shoup.lc;
     hipLaunchKernelGGL(galois_kernel, dim3((unsigned)npolys), dim3(256), 0, static_cast<hipStream_t>(stream), d_out, d_in, lc, (int)c->n_limbs,
@@ -416,6 +469,7 @@ extern "C" int dpfhe_matvec_plain(dpfhe_ctx* c, uint64_t* d_y, const uint64_t* d
     constexpr int RT = 4;
     const size_t blocks = ((rows + RT - 1) / RT) * c->n_limbs * (size_t)chunks;
     if (blocks > kMaxGrid) return fail(DPFHE_INVALID_ARGUMENT, "dpfhe_matvec_plain", "too many rows for one launch");
+    DPFHE_ON_DEVICE(c, "dpfhe_matvec_plain");
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (c->fold) hipLaunchKernelGGL((matvec_kernel<FoldArith, RT>), dim3((unsigned)blocks), dim3(256), 0, s, d_y, d_W, d_x, c->foldt.lc, (int)c->n_limbs, n, chunks, rows, cols);
     else hipLaunchKernelGGL((matvec_kernel<ShoupArith, RT>), dim3((unsigned)blocks), dim3(256), 0, s, d_y, d_W, d_x, c->shoup.lc, (int)c->n_limbs, n, chunks, rows, cols);
@@ -434,6 +488,7 @@ extern "C" int dpfhe_matvec_scalar(dpfhe_ctx* c, uint64_t* d_y, const uint64_t* 
     constexpr int RT = 8;
     const size_t blocks = ((rows + RT - 1) / RT) * c->n_limbs * (size_t)chunks;
     if (blocks > kMaxGrid) return fail(DPFHE_INVALID_ARGUMENT, "dpfhe_matvec_scalar", "too many rows for one launch");
+    DPFHE_ON_DEVICE(c, "dpfhe_matvec_scalar");
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (c->fold) hipLaunchKernelGGL((matvec_scalar_kernel<FoldArith, RT>), dim3((unsigned)blocks), dim3(256), 0, s, d_y, d_w, d_x, c->foldt.lc, (int)c->n_limbs, n, chunks, rows, cols);
     else hipLaunchKernelGGL((matvec_scalar_kernel<ShoupArith, RT>), dim3((unsigned)blocks), dim3(256), 0, s, d_y, d_w, d_x, c->shoup.lc, (int)c->n_limbs, n, chunks, rows, cols);
@@ -446,6 +501,7 @@ extern "C" int dpfhe_reduce_sum(dpfhe_ctx* c, uint64_t* d_out, const uint64_t* d
     if (!d_out || !d_in || misaligned(d_out) || misaligned(d_in)) return fail(DPFHE_INVALID_ARGUMENT, "dpfhe_reduce_sum", "null or misaligned buffer");
     const size_t blocks = components * c->n_limbs;
     if (blocks > kMaxGrid) return fail(DPFHE_INVALID_ARGUMENT, "dpfhe_reduce_sum", "too many components");
+    DPFHE_ON_DEVICE(c, "dpfhe_reduce_sum");
     const int n = 1 << c->log2n;
     const LimbConst* lc = c->fold ? c->foldt.lc : c->shoup.lc;
     const int chunks = (n + 511) / 512;
@@ -453,6 +509,7 @@ extern "C" int dpfhe_reduce_sum(dpfhe_ctx* c, uint64_t* d_out, const uint64_t* d
     const unsigned splits = (unsigned)(count < (size_t)kReduceSplits ? count : (size_t)kReduceSplits);
     hipStream_t s = static_cast<hipStream_t>(stream);
     HIP_TRY(hipMemsetAsync(d_out, 0, words_per_item * sizeof(u64), s));
+    if (blocks * (size_t)chunks * splits > kMaxGrid) return fail(DPFHE_INVALID_ARGUMENT, "dpfhe_reduce_sum", "too many components for one launch");
     const unsigned poly_chunks = (unsigned)(blocks * chunks);
     // two workgroups per CU walk the work items: as fast as an uncapped launch when alone (537 vs 551 us for 8192 x 3
     // components at N=4096) and 2 % faster for the multiply it overlaps with in bench.py
@@ -460,6 +517,7 @@ extern "C" int dpfhe_reduce_sum(dpfhe_ctx* c, uint64_t* d_out, const uint64_t* d
     if (grid > 2u * (unsigned)c->n_cu) grid = 2u * (unsigned)c->n_cu;
     hipLaunchKernelGGL(reduce_partial_kernel, dim3(grid), dim3(256), 0, s, d_out, d_in, lc, (int)c->n_limbs, n, chunks, count, words_per_item,
                        poly_chunks, splits);
+    if (int e = check_launch("reduce_sum partial kernel launch")) return e;
     hipLaunchKernelGGL(reduce_final_kernel, dim3((unsigned)(blocks * chunks)), dim3(256), 0, s, d_out, lc, (int)c->n_limbs, n, chunks);
     return check_launch("reduce_sum kernel launch");
 }
@@ -544,6 +602,8 @@ extern "C" int dpfhe_comm_destroy(dpfhe_comm* c) {
 extern "C" int dpfhe_comm_allgather(dpfhe_comm* c, uint64_t* d_recv, const uint64_t* d_send, size_t words_per_rank, void* stream) {
     if (!c || !d_recv || !d_send) return fail(DPFHE_INVALID_ARGUMENT, "dpfhe_comm_allgather", "null argument");
     if (words_per_rank == 0) return DPFHE_SUCCESS;
+    DeviceGuard guard(c->device);
+    if (guard.err != hipSuccess) return fail(DPFHE_DEVICE_ERROR, "dpfhe_comm_allgather", hipGetErrorString(guard.err));
     int rc = rccl().AllGather(d_send, d_recv, words_per_rank, kNcclUint64, c->comm, static_cast<hipStream_t>(stream));
     if (rc) return rccl_fail("ncclAllGather", rc);
     return DPFHE_SUCCESS;

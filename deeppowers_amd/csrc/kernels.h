@@ -12,10 +12,32 @@
 
 namespace dpfhe {
 
-// Workgroup barrier of the LDS exchanges.  (A barrier that waits for LDS traffic only - s_waitcnt lgkmcnt(0); s_barrier,
-// leaving the prefetched twiddle loads in flight - was measured: equal on ct_mul and the forward NTT, 7 % slower on
-// the inverse NTT, so the plain barrier stays.)
+// Workgroup barrier of the ALL-TO-ALL LDS exchange (top window <-> next window), the only one that crosses waves.
+// (A barrier that waits for LDS traffic only - s_waitcnt lgkmcnt(0); s_barrier, leaving the prefetched twiddle loads in
+// flight - was measured in round 1: equal on ct_mul and the forward NTT, 7 % slower on the inverse NTT, so the plain
+// barrier stays.)
 __device__ __forceinline__ void lds_barrier() { __syncthreads(); }
+// Wave-local exchanges (ntt_core.h Geo::exch_wave_local) live in the wave's private LDS region: the LDS executes one
+// wave's DS instructions in order, so no hardware synchronisation is needed - only the compiler must not move the
+// wave's LDS reads above its LDS writes (it cannot see that OTHER lanes' stores feed this lane's loads).
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+// Barrier contract of the chains below.  FwdChain: its first exchange writes into EVERY wave's region, so a caller that
+// used the LDS buffer before (a previous transform, staged tiles) places one lds_barrier() in front of the chain; the
+// chain itself has one barrier (after the all-to-all write).  InvChain: everything before its last exchange stays in
+// the wave's own region, the last exchange writes the own region and reads every region after the chain's single
+// barrier; a caller running two inverse chains back to back places one lds_barrier() between them (the second chain's
+// wave-local writes would otherwise overwrite words other waves are still reading).
+template <class G, int P>
+__device__ __forceinline__ void exch_sync_before_write() {
+    if constexpr (G::exch_wave_local(P)) wave_sync();
+}
+template <class G, int P>
+__device__ __forceinline__ void exch_sync_after_write() {
+    if constexpr (G::exch_wave_local(P)) wave_sync(); else lds_barrier();
+}
 
 // ------------------------------------------------------------------------------------------------
 // register-resident transforms shared by the NTT kernels and the fused ct x ct kernel
@@ -38,9 +60,9 @@ struct FwdChain {
             TwRegs nxt;
             B::template load_tw<P + 1, true>(tid, tw, nxt);
             B::template fwd_phase_r<P>(x, twr, lc);
-            if (P > 0) lds_barrier();
+            exch_sync_before_write<typename B::G, P>();
             B::template lds_write<P, P, true>(tid, x, lds);
-            lds_barrier();
+            exch_sync_after_write<typename B::G, P>();
             B::template lds_read<P, P + 1, true>(tid, x, lds);
             FwdChain<B, P + 1>::run_with(tid, x, lds, tw, lc, nxt);
         } else {
@@ -53,18 +75,17 @@ struct FwdChain {
         if constexpr (P + 1 < B::NPH) {
             TwRegs nxt;
             B::template load_tw<P + 1, true>(tid, tw, nxt);
-            if (P > 0) lds_barrier();  // previous exchange fully read before the buffer is rewritten
+            static_assert(P == 0 || B::G::exch_wave_local(P), "only the first forward exchange may cross waves");
+            exch_sync_before_write<typename B::G, P>();
             B::template lds_write<P, P, true>(tid, x, lds);
-            lds_barrier();
+            exch_sync_after_write<typename B::G, P>();
             B::template lds_read<P, P + 1, true>(tid, x, lds);
             FwdChain<B, P + 1>::run_with(tid, x, lds, tw, lc, nxt);
         }
     }
 };
 
-// BARRIER_FIRST: the caller staged data through the LDS buffer (load_bot_lds) right before the chain, so the first exchange
-// must wait until every wave has read its rows back
-template <class B, int P, int IN, bool BARRIER_FIRST = false>
+template <class B, int P, int IN>
 struct InvChain {
     typedef typename B::TwRegs TwRegs;
     static __device__ __forceinline__ void run(int tid, u64 (&x)[B::E], u64* lds, const typename B::Tw* tw,
@@ -79,11 +100,12 @@ struct InvChain {
         if constexpr (P > 0) {
             TwRegs nxt;
             B::template load_tw<P - 1, false>(tid, tw, nxt);
-            if (P < B::NPH - 1 || BARRIER_FIRST) lds_barrier();
+            static_assert(P - 1 == 0 || B::G::exch_wave_local(P - 1), "only the last inverse exchange may cross waves");
+            exch_sync_before_write<typename B::G, P - 1>();    // all-to-all: writes the wave's OWN region - nothing to wait for
             B::template lds_write<P - 1, P, false>(tid, x, lds);
-            lds_barrier();
+            exch_sync_after_write<typename B::G, P - 1>();
             B::template lds_read<P - 1, P - 1, false>(tid, x, lds);
-            InvChain<B, P - 1, IN, BARRIER_FIRST>::run_with(tid, x, lds, tw, last, lc, nxt);
+            InvChain<B, P - 1, IN>::run_with(tid, x, lds, tw, last, lc, nxt);
         }
     }
 };
@@ -129,7 +151,7 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE)) void ntt_inv_kernel(u64* __rest
     u64 x[B::E];
     if constexpr (B::kLdsIO) {
         B::load_bot_lds(tid, x, in + p * B::G::N, lds);
-        InvChain<B, B::NPH - 1, kUnit, true>::run_with(tid, x, lds, tw, last, lc, tw_first);
+        InvChain<B, B::NPH - 1, kUnit>::run_with(tid, x, lds, tw, last, lc, tw_first);   // the staged rows are the wave's own
     } else {
         B::load_bot(tid, x, in + p * B::G::N);
         InvChain<B, B::NPH - 1, kUnit>::run_with(tid, x, lds, tw, last, lc, tw_first);
@@ -161,7 +183,7 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE), 2) void ct_mul_kernel(u64* __re
     const size_t cstride = L * N;
     const InvLast<typename B::Tw> last = tb.last[limb];
     constexpr bool kLazy = Arith::kFold && !OUT_NTT;   // products feed the inverse NTT unreduced (< 2 kMulB q/1024)
-    static_assert(!kLazy || IN_NTT || make_ct_plan(LOGN, kUnit).out_bound <= kLimitPartner, "lazy forward outputs must satisfy mul60's bound");
+    static_assert(!kLazy || IN_NTT || B::kFwdOutBound <= kLimitPartner, "lazy forward outputs must satisfy mul60's bound");
     constexpr int kInvIn = Arith::kFold ? 2 * kMulB : kUnit;
 
     // Schedule (F = forward NTT, I = inverse NTT + store), at most four polynomials live in registers:
@@ -177,15 +199,14 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE), 2) void ct_mul_kernel(u64* __re
         if (IN_NTT) { B::load_bot(tid, x, src); return; }
         B::load_top(tid, x, src);
         if (!first) lds_barrier();
-        FwdChain<B, 0>::template run<false>(tid, x, lds, twf, lc);
+#ifndef DPFHE_FUSED_EARLY_TW
+#define DPFHE_FUSED_EARLY_TW 0
+#endif
+        FwdChain<B, 0>::template run<DPFHE_FUSED_EARLY_TW != 0>(tid, x, lds, twf, lc);
         if (!Arith::kFold) B::fwd_canon(x, lc);
         else if (reduce_out) {
-            if (kLazy) {
-#pragma unroll
-                for (int k = 0; k < E; ++k) x[k] = FoldArith::reduce(x[k], lc);
-            } else {
-                B::fwd_canon(x, lc);
-            }
+            if constexpr (kLazy) B::fwd_reduce_partner(x, lc);
+            else B::fwd_canon(x, lc);
         }
     };
 #pragma unroll 1   // fully unrolled (4 forward + 3 inverse instances, ~80 KiB of code) it overflows the instruction cache: 12 % slower
@@ -241,7 +262,9 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE), 2) void ct_mul_kernel(u64* __re
         if (OUT_NTT) {
             B::store_bot(tid, x, d);
         } else {
-            if (!IN_NTT || round > 0) lds_barrier();
+            // after a forward chain the wave's region is its own again; after another inverse chain other waves may still be
+            // reading it (the inverse's last exchange is all-to-all)
+            if (IN_NTT ? round > 0 : round == 2) lds_barrier();
             InvChain<B, B::NPH - 1, kInvIn>::run_with(tid, x, lds, twi, last, lc, tw_first);
             B::inv_canon(x, lc);
             B::store_top(tid, x, d);
@@ -344,10 +367,10 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE), (Arith::kFold ? 2 : 1)) void re
         const bool add_back = (MODE == 0) || (MODE == 1 && c == 0);
         // the word to add back is fetched ahead of the transform where registers allow (MODE 1: one accumulator is
         // dead by then); MODE 0 with 16-byte FoldArith twiddles would spill, so it fetches afterwards
-        constexpr bool kPrefetch = !(Arith::kFold && MODE == 0);
+        constexpr bool kPrefetch = !Arith::kFold;
         u64 orig[E];
         if (add_back && kPrefetch) B::load_top(tid, orig, in3 + ((bi * kInComps + c) * L + limb) * N);
-        lds_barrier();
+        if (c > 0) lds_barrier();   // the first inverse follows wave-local work only; the second follows an all-to-all read
         InvChain<B, B::NPH - 1, kInvIn>::run(tid, x, lds, tb.inv4 + (size_t)limb * N, last, lc);
         if (add_back && !kPrefetch) B::load_top(tid, orig, in3 + ((bi * kInComps + c) * L + limb) * N);
         B::inv_canon(x, lc);

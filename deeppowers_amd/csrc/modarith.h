@@ -58,6 +58,18 @@ DPF_HD u64 mulhi64(u64 a, u64 b) {
 #endif
 }
 
+// 2a + c in one v_lshl_add_u64 (hipcc emits a 64-bit shift and an add for the C expression).
+// c must be WAVE-UNIFORM (a limb constant): it is passed as a scalar register pair.
+DPF_HD u64 shl1_add(u64 a, u64 c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    u64 r;
+    asm("v_lshl_add_u64 %0, %1, 1, %2" : "=v"(r) : "v"(a), "s"(c));
+    return r;
+#else
+    return (a << 1) + c;
+#endif
+}
+
 // x >= m ? x - m : x
 DPF_HD u64 csub(u64 x, u64 m) {
     u64 t = x - m;
@@ -157,6 +169,24 @@ struct FoldArith {
         asm("s_mov_b32 %0, 0x40000000" : "=s"(two30));  // opaque: hipcc would turn H.lo * 2^30 into shift + zero-extend + add
 #endif
         const u64 L = mad32(y1, as, mad32(y0, a, mad32((u32)H, two30, 0)));
+        const u64 R = mad32((u32)(H >> 32), 4 * (u32)c.d, L);
+        return reduce(R, c);
+    }
+    // addend + y*w mod q in ONE fold: the first multiply-add of mul_tw's chain has a free 64-bit addend, so the butterfly
+    // sum x' = a + y w costs nothing beyond the product and comes out already reduced (< 2^60 + 16 d).
+    // Precondition (units of 2^60):  addend + y/4 < 8 - 2^-6   (L = H.lo 2^30 + y0 a + y1 a' + addend must stay < 2^64 - 2^54:
+    // H.lo 2^30 < 4, y0 a < 4, y1 a' < y/4);  any 64-bit y allows addend < 2^62 - 2^54.  ntt_core.h make_ctf_plan tracks it.
+    static DPF_HD u64 mul_tw_add(u64 y, const Tw& t, const LimbConst& c, u64 addend) {
+        const u32 y0 = (u32)y, y1 = (u32)(y >> 32);
+        const u32 a = (u32)t.w, b = (u32)(t.w >> 32), as = (u32)t.ws, bs = (u32)(t.ws >> 32);
+        DPFHE_EMU_ASSERT(((a | b | as | bs) >> 30) == 0);
+        DPFHE_EMU_ASSERT((unsigned __int128)addend + ((unsigned __int128)y0 << 30) + ((unsigned __int128)y1 << 30) + (1ull << 62) + (1ull << 54) < ((unsigned __int128)1 << 64));
+        const u64 H = mad32(y1, bs, mad32(y0, b, 0));
+        u32 two30 = 1u << 30;
+#if defined(__HIP_DEVICE_COMPILE__)
+        asm("s_mov_b32 %0, 0x40000000" : "=s"(two30));
+#endif
+        const u64 L = mad32(y1, as, mad32(y0, a, mad32((u32)H, two30, addend)));
         const u64 R = mad32((u32)(H >> 32), 4 * (u32)c.d, L);
         return reduce(R, c);
     }

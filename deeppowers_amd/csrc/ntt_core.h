@@ -11,6 +11,11 @@
 // walks the same phase list backwards, so the forward OUTPUT register mapping equals the inverse
 // INPUT mapping and a fused ct x ct multiply never leaves registers between them.
 //
+// Only the FIRST exchange of the forward transform (last of the inverse) moves words between waves: in every window
+// starting at or below lane bit 6 a wave owns the same 64 E consecutive coefficients, so all later exchanges are
+// transpositions inside a wave.  Each wave therefore owns a private, padded LDS region (Geo::kWaveStride words) and the
+// wave-local exchanges need no workgroup barrier - one s_barrier per transform instead of three or four.
+//
 // Every function takes `tid` explicitly and LDS as a plain pointer, so tools/emulate.cpp can run
 // the very same code thread-by-thread on the CPU and compare with the oracle.
 #pragma once
@@ -26,7 +31,13 @@ inline u64 chk_sub_add(u64 a, u64 b, u64 off) {  // a - b + off must stay in [0,
     if (v < 0 || (v >> 64)) ++g_emu_overflows;
     return a - b + off;
 }
+inline u64 chk_shl1_add_sub(u64 a, u64 c, u64 s) {  // 2a + c - s must stay in [0, 2^64)
+    __int128 v = 2 * (__int128)a + (__int128)c - (__int128)s;
+    if (v < 0 || (v >> 64) || ((unsigned __int128)2 * a + c) >> 64) ++g_emu_overflows;
+    return shl1_add(a, c) - s;
+}
 #else
+DPF_HD u64 chk_shl1_add_sub(u64 a, u64 c, u64 s) { return shl1_add(a, c) - s; }
 DPF_HD u64 chk_add(u64 a, u64 b) { return a + b; }
 DPF_HD u64 chk_sub_add(u64 a, u64 b, u64 off) { return a - b + off; }
 #endif
@@ -73,30 +84,51 @@ struct Geo {
         if ((1 << c) >= T) return (k << c) | tid;  // top window: tid < T = 2^c, no split (and no mask for the compiler to fold)
         return ((tid >> c) << (c + LOGE)) | (k << c) | (tid & ((1 << c) - 1));
     }
-    // LDS padding of the exchange between windows clo < chi.  Bijective for any choice (monotone);
-    // chosen so that both access patterns of the N=4096 / N=8192 kernels are bank-conflict free:
+    // ---- LDS layout: one private region per wave --------------------------------------------------------------
+    // In any window c <= 6 the 64 threads of wave w hold coefficients [w 64E, (w+1) 64E), so the exchange between
+    // windows clo < chi <= 6 only permutes words inside a wave.
+    static constexpr int LOGW = 6 + LOGE, kWaveWords = 1 << LOGW;
+    static constexpr int kWaves = T >= 64 ? T / 64 : 1;
+    static constexpr bool exch_wave_local(int p) { return T <= 64 || phase(p).c <= 6; }   // exchange between phases p and p + 1
+    // Padding inside a wave's region.  Bijective for any choice (monotone); chosen so that both access patterns of the
+    // N=4096 / N=8192 kernels are bank-conflict free:
     //  * window 0 side: a thread touches E consecutive words with 16-byte accesses; a lane stride of
     //    E+2 words spreads a ds_read/write_b128 lane group over all 16-byte slots;
     //  * window chi side: lanes are 2^chi-word runs at a 2^(chi+LOGE)-word stride; +16 words per
     //    stride puts the two runs of a 32-lane ds_read_b64 group on opposite halves of the bank row.
-    template <int CLO, int CHI, bool FWD>
-    static DPF_HD int lds_addr(int j) {
-        int a = j;
-        if (CLO == 0) a += (j >> LOGE) << 1;
-        if (CLO != 0 || !FWD) a += (j >> (CHI + LOGE)) << 4;
-        return a;
-    }
-    static constexpr int lds_words() {  // largest padded address over all exchanges (+ slack)
-        int mx = N;
+    static constexpr int wave_extent() {   // largest padded local address over all wave-local exchanges, both directions, + 1
+        int mx = kWaveWords;
+        const int last = (N < kWaveWords ? N : kWaveWords) - 1;
         for (int p = 0; p + 1 < NPH; ++p) {
+            if (!exch_wave_local(p)) continue;
             const int chi = phase(p).c, clo = phase(p + 1).c;
-            int a = N - 1;
-            if (clo == 0) a += ((N - 1) >> LOGE) << 1;
-            a += ((N - 1) >> (chi + LOGE)) << 4;
+            int a = last;
+            if (clo == 0) a += (last >> LOGE) << 1;
+            a += (last >> (chi + LOGE)) << 4;    // inverse direction (a superset of the forward padding)
             if (a + 1 > mx) mx = a + 1;
         }
-        return (mx + 15) & ~15;
+        if ((64 * (E + 2)) > mx) mx = 64 * (E + 2);   // row layout of load_bot_lds / store_bot_lds
+        return mx;
     }
+    // region stride: a multiple of 32 words (256 bytes = one bank row), so the all-to-all exchange - which only adds the
+    // region offset to the plain index - keeps the bank pattern of an unpadded buffer
+    static constexpr int kWaveStride = (wave_extent() + 31) & ~31;
+    // lds_addr is ADDITIVE over disjoint bit fields of j (shifts, masks and constant multiples only), which is what lets
+    // NttBody split every address into a per-thread base and a compile-time offset per local element.
+    template <int CLO, int CHI, bool FWD>
+    static constexpr int lds_addr(int j) {
+        const int w = j >> LOGW, jl = j & (kWaveWords - 1);
+        if (CHI <= 6 || T <= 64) {   // wave-local exchange
+            int a = jl;
+            if (CLO == 0) a += (jl >> LOGE) << 1;
+            if (CLO != 0 || !FWD) a += (jl >> (CHI + LOGE)) << 4;
+            return w * kWaveStride + a;
+        }
+        static_assert(CHI <= 6 || CLO != 0, "the all-to-all exchange is never the one into window 0");
+        return w * kWaveStride + jl;   // all-to-all (top window -> next): plain index inside each region
+    }
+    static DPF_HD int lds_row(int tid) { return (tid >> 6) * kWaveStride + (tid & 63) * (E + 2); }   // private row of a thread (kLdsIO)
+    static constexpr int lds_words() { return kWaves * kWaveStride; }
 };
 
 // twiddle table index of the butterfly whose lower element is local k, at global bit position `pos`
@@ -178,18 +210,50 @@ constexpr GsPlan<LOGE> make_gs_plan(int lb0, int r, int in_bound, int out_bound,
     return p;
 }
 
-struct CtPlan {  // Cooley-Tukey: bounds are uniform over the polynomial, one flag per global stage
-    bool red[32];
-    int out_bound;
+// Cooley-Tukey with the FUSED sum (FoldArith::mul_tw_add):  x' = reduce(a + w y) comes out of the product's own
+// multiply-add chain already reduced, and y' = a - w y = 2a + 2q - x' costs one v_lshl_add_u64 and one 64-bit subtract:
+// 12 VALU per butterfly instead of 13, and no separate reductions of the sums.  Bounds (units of q/1024): x' -> kRedB,
+// y' -> 2 A + 2048, so a word is at 1, 4 or 10 q; the fused chain needs  A + Y/4 <= kFuseLimit  (modarith.h), which only
+// fails for an `a` at 10 q: such words (a quarter of the butterflies from the third stage of a phase on) are reduced
+// first.  Bounds are tracked per local element inside a phase and handed over as one uniform bound at the LDS exchanges
+// (the element <-> thread mapping changes there), capped at kCtfMid = 4 q by reducing the few words above it.
+constexpr int kFuseLimit = 8 * kUnit - 16;   // addend + y/4 < 8 * 2^60 - 2^54
+constexpr int kCtfMid = 2 * kRedB + 2 * kUnit;
+
+template <int LOGE>
+struct CtfPlan {
+    bool red_a[LOGE][1 << LOGE];   // reduce the upper word a of the butterfly with lower-index element k before stage u
+    bool red_end[1 << LOGE];       // reduce element k after the last stage (phase hand-over above out_cap)
+    int out[1 << LOGE];            // bound of element k when the phase ends
+    int out_bound;                 // max of out[]
 };
-constexpr CtPlan make_ct_plan(int logn, int in_bound) {
-    CtPlan p{};
-    int b = in_bound;
-    for (int s = 0; s < logn; ++s) {
-        if (b + 2 * kUnit > kWord) { p.red[s] = true; b = kRedB; }
-        b += 2 * kUnit;   // x' = x + t, y' = x - t + 2q with t < 2q
+
+// stages u = 0 .. r-1 act on local bits lb_top, lb_top - 1, ...; every input < in_bound; words above out_cap are reduced at the end
+template <int LOGE>
+constexpr CtfPlan<LOGE> make_ctf_plan(int lb_top, int r, int in_bound, int out_cap) {
+    CtfPlan<LOGE> p{};
+    constexpr int E = 1 << LOGE;
+    int bnd[E] = {};
+    for (int k = 0; k < E; ++k) bnd[k] = in_bound;
+    for (int u = 0; u < r; ++u) {
+        const int bit = 1 << (lb_top - u);
+        for (int k = 0; k < E; ++k) {
+            if (k & bit) continue;
+            int A = bnd[k];
+            const int Y = bnd[k | bit];
+            // reduce a when the fused chain would not fit, or when the phase's last stage would hand over y' above the cap
+            if (A + Y / 4 + 1 > kFuseLimit || (u == r - 1 && A > kRedB && 2 * A + 2 * kUnit > out_cap)) { p.red_a[u][k] = true; A = kRedB; }
+            bnd[k] = kRedB;
+            bnd[k | bit] = 2 * A + 2 * kUnit;
+        }
     }
-    p.out_bound = b;
+    int mx = 0;
+    for (int k = 0; k < E; ++k) {
+        if (bnd[k] > out_cap) { p.red_end[k] = true; bnd[k] = kRedB; }
+        p.out[k] = bnd[k];
+        if (bnd[k] > mx) mx = bnd[k];
+    }
+    p.out_bound = mx;
     return p;
 }
 
@@ -206,13 +270,25 @@ struct NttBody {
     // window-top mapping (forward input / inverse output): word j = k*T + tid, 8 B per lane, coalesced
     // (unsigned index on a workgroup-uniform base: hipcc then uses the SGPR-base + 32-bit VGPR offset form and
     //  spends no VALU on 64-bit address arithmetic)
+    // Rows that the 13-bit immediate offset cannot reach get their own SCALAR base (SALU adds, free on a VALU-bound
+    // kernel): left to itself hipcc builds 64-bit per-lane addresses with v_add_co / v_addc pairs.
+    static DPF_HD unsigned row_base(int k) {   // word offset of the immediate-offset window that holds row k, kept in a scalar register
+        constexpr int kReach = 4096 / (T * 8) > 0 ? 4096 / (T * 8) : 1;   // rows per window
+        unsigned b = (unsigned)(k / kReach * kReach) * T;
+#if defined(__HIP_DEVICE_COMPILE__)
+        asm("" : "+s"(b));   // opaque (not volatile: a side-effect asm would stop hipcc from using scalar loads for the uniform twiddles): the access becomes (scalar base + b) + 32-bit lane offset + immediate
+#endif
+        return b;
+    }
     static DPF_HD void load_top(int tid, u64 (&x)[E], const u64* g) {
+        constexpr int kReach = 4096 / (T * 8) > 0 ? 4096 / (T * 8) : 1;
 #pragma clang loop unroll(full)
-        for (int k = 0; k < E; ++k) x[k] = g[(unsigned)(k * T) + (unsigned)tid];
+        for (int k = 0; k < E; ++k) x[k] = (g + row_base(k))[(unsigned)((k % kReach) * T) + (unsigned)tid];
     }
     static DPF_HD void store_top(int tid, const u64 (&x)[E], u64* g) {
+        constexpr int kReach = 4096 / (T * 8) > 0 ? 4096 / (T * 8) : 1;
 #pragma clang loop unroll(full)
-        for (int k = 0; k < E; ++k) g[(unsigned)(k * T) + (unsigned)tid] = x[k];
+        for (int k = 0; k < E; ++k) (g + row_base(k))[(unsigned)((k % kReach) * T) + (unsigned)tid] = x[k];
     }
     // window-0 mapping (forward output / inverse input): thread owns words [tid*E, tid*E + E)
     struct alignas(16) V2 {
@@ -221,7 +297,7 @@ struct NttBody {
     static constexpr int PC = E / 2, LP = LOGE - 1, kLow = 6 - LP;   // pieces per thread; lane bits [kLow, 6) <-> piece index
     static constexpr bool kWaveIO = (T % 64 == 0) && LP >= 1 && LP <= 4;   // register transposition available
     static constexpr bool kLdsIO = kWaveIO && PC == 8 && NPH >= 2;         // LDS transposition available (load_bot_lds / store_bot_lds)
-    static_assert(!kLdsIO || T * (E + 2) <= G::lds_words(), "the row layout must fit the exchange buffer");
+    static_assert(!kLdsIO || 64 * (E + 2) <= G::kWaveStride, "the row layout must fit the wave's region");
 #if defined(__HIP_DEVICE_COMPILE__)
     // Device path: a thread's E words are 8E contiguous bytes, so plain 16-byte accesses put the 64 lanes of one
     // instruction on 64 different 128-byte lines.  The wave instead moves 1 KiB-contiguous slices (lane L, slice r:
@@ -274,7 +350,7 @@ struct NttBody {
     static __device__ __forceinline__ void lds_slice(int tid, int r, unsigned& lds_word, unsigned& piece) {
         const unsigned lane = (unsigned)tid & 63u, wave_thread0 = (unsigned)tid & ~63u, i = lane & 7u, pc = ((lane >> 3) + i) & 7u;
         const unsigned t = wave_thread0 + ((unsigned)r << 3) + i;
-        lds_word = t * (E + 2) + pc * 2;
+        lds_word = (unsigned)G::lds_row((int)t) + pc * 2;
         piece = t * PC + pc;
     }
     static __device__ __forceinline__ void load_bot_lds(int tid, u64 (&x)[E], const u64* g, u64* lds) {
@@ -284,12 +360,12 @@ struct NttBody {
         for (int r = 0; r < PC; ++r) { unsigned w, pc; lds_slice(tid, r, w, pc); v[r] = p[pc]; }
 #pragma clang loop unroll(full)
         for (int r = 0; r < PC; ++r) { unsigned w, pc; lds_slice(tid, r, w, pc); *reinterpret_cast<V2*>(lds + w) = v[r]; }
-        const V2* row = reinterpret_cast<const V2*>(lds + (unsigned)tid * (E + 2));   // same wave wrote it: program order + lgkmcnt
+        const V2* row = reinterpret_cast<const V2*>(lds + (unsigned)G::lds_row(tid));   // same wave wrote it: program order + lgkmcnt
 #pragma clang loop unroll(full)
         for (int k = 0; k < PC; ++k) { V2 t = row[k]; x[2 * k] = t.a; x[2 * k + 1] = t.b; }
     }
     static __device__ __forceinline__ void store_bot_lds(int tid, const u64 (&x)[E], u64* g, u64* lds) {
-        V2* row = reinterpret_cast<V2*>(lds + (unsigned)tid * (E + 2));
+        V2* row = reinterpret_cast<V2*>(lds + (unsigned)G::lds_row(tid));
 #pragma clang loop unroll(full)
         for (int k = 0; k < PC; ++k) row[k] = V2{x[2 * k], x[2 * k + 1]};
         V2* p = reinterpret_cast<V2*>(g);
@@ -337,7 +413,9 @@ struct NttBody {
     static DPF_HD int xaddr(int tid, int k) {
         constexpr int chi = G::phase(P).c, clo = G::phase(P + 1).c;
         constexpr int c = (SIDE == P) ? chi : clo;
-        return G::template lds_addr<clo, chi, FWD>(G::index(c, tid, k));
+        // index(c, tid, k) = index(c, tid, 0) | (k << c) with disjoint bits: base(tid) + offset(k), the offset a constant
+        // after unrolling, so one address register and immediate offsets serve all E accesses
+        return G::template lds_addr<clo, chi, FWD>(G::index(c, tid, 0)) + G::template lds_addr<clo, chi, FWD>(k << c);
     }
     template <int P, int SIDE, bool FWD>
     static DPF_HD void lds_write(int tid, const u64 (&x)[E], u64* lds) {
@@ -348,7 +426,7 @@ struct NttBody {
             for (int k = 0; k < E / 2; ++k) p[k] = V2{x[2 * k], x[2 * k + 1]};
         } else {
 #pragma clang loop unroll(full)
-            for (int k = 0; k < E; ++k) lds[xaddr<P, SIDE, FWD>(tid, k)] = x[k];
+            for (int k = 0; k < E; ++k) lds[(unsigned)xaddr<P, SIDE, FWD>(tid, k)] = x[k];
         }
     }
     template <int P, int SIDE, bool FWD>
@@ -360,7 +438,7 @@ struct NttBody {
             for (int k = 0; k < E / 2; ++k) { V2 v = p[k]; x[2 * k] = v.a; x[2 * k + 1] = v.b; }
         } else {
 #pragma clang loop unroll(full)
-            for (int k = 0; k < E; ++k) x[k] = lds[xaddr<P, SIDE, FWD>(tid, k)];
+            for (int k = 0; k < E; ++k) x[k] = lds[(unsigned)xaddr<P, SIDE, FWD>(tid, k)];
         }
     }
 
@@ -383,30 +461,56 @@ struct NttBody {
         }
     }
 
+    // bound plan of forward phase P (FoldArith): canonical input to phase 0, kCtfMid at every exchange, nothing capped after the last
+    template <int P>
+    static constexpr CtfPlan<LOGE> ctf_plan() {
+        constexpr Phase ph = G::phase(P);
+        int in = kUnit;
+        for (int i = 0; i < P; ++i) {   // hand-over bound of the previous phase
+            const Phase pi = G::phase(i);
+            in = make_ctf_plan<LOGE>(pi.b - pi.c + pi.r - 1, pi.r, in, kCtfMid).out_bound;
+        }
+        return make_ctf_plan<LOGE>(ph.b - ph.c + ph.r - 1, ph.r, in, (P == NPH - 1) ? kWord : kCtfMid);
+    }
+    // bound of every word a forward transform hands to a dyadic product when its output is left lazy
+    static constexpr int kFwdOutBound = Arith::kFold ? ctf_plan<NPH - 1>().out_bound : 4 * kUnit;
+    static_assert(!Arith::kFold || kFwdOutBound <= kLimitPartner, "lazy forward outputs must satisfy mul60's bound");
+
     template <int P>
     static DPF_HD void fwd_phase_r(u64 (&x)[E], const TwRegs& twr, const LimbConst& lc) {
         constexpr Phase ph = G::phase(P);
-        constexpr CtPlan kCt = make_ct_plan(LOGN, kUnit);  // canonical input
         const u64 two_q = 2 * lc.q;
+        if constexpr (Arith::kFold) {
+            constexpr CtfPlan<LOGE> plan = ctf_plan<P>();
 #pragma clang loop unroll(full)
-        for (int u = 0; u < ph.r; ++u) {
-            const int pos = ph.b + ph.r - 1 - u;        // bit position = distance exponent
-            const int sigma = LOGN - 1 - pos;           // global stage number
-            const int lb = pos - ph.c;
-            if (Arith::kFold && kCt.red[sigma]) {
+            for (int u = 0; u < ph.r; ++u) {
+                const int lb = ph.b + ph.r - 1 - u - ph.c;
 #pragma clang loop unroll(full)
-                for (int k = 0; k < E; ++k)
-                    if (!(k & (1 << lb))) x[k] = FoldArith::reduce(x[k], lc);
+                for (int k = 0; k < E; ++k) {
+                    if (k & (1 << lb)) continue;
+                    const int kk = k | (1 << lb);
+                    u64 a = x[k];
+                    if (plan.red_a[u][k]) a = FoldArith::reduce(a, lc);
+                    const u64 s = FoldArith::mul_tw_add(x[kk], twr[u][k >> (lb + 1)], lc, a);
+                    x[k] = s;                                   // a + w y, < 2^60 + 16 d
+                    x[kk] = chk_shl1_add_sub(a, two_q, s);      // a - w y = 2a + 2q - x'
+                }
             }
 #pragma clang loop unroll(full)
-            for (int k = 0; k < E; ++k) {
-                if (k & (1 << lb)) continue;
-                const Tw w = twr[u][k >> (lb + 1)];
-                u64 a = x[k];
-                if (!Arith::kFold) a = csub(a, two_q);  // Harvey: [0,4q) -> [0,2q)
-                const u64 t = Arith::mul_tw(x[k | (1 << lb)], w, lc);
-                x[k] = chk_add(a, t);
-                x[k | (1 << lb)] = chk_sub_add(a, t, two_q);
+            for (int k = 0; k < E; ++k)
+                if (plan.red_end[k]) x[k] = FoldArith::reduce(x[k], lc);
+        } else {
+#pragma clang loop unroll(full)
+            for (int u = 0; u < ph.r; ++u) {
+                const int lb = ph.b + ph.r - 1 - u - ph.c;
+#pragma clang loop unroll(full)
+                for (int k = 0; k < E; ++k) {
+                    if (k & (1 << lb)) continue;
+                    const u64 a = csub(x[k], two_q);            // Harvey: [0,4q) -> [0,2q)
+                    const u64 t = Arith::mul_tw(x[k | (1 << lb)], twr[u][k >> (lb + 1)], lc);
+                    x[k] = a + t;
+                    x[k | (1 << lb)] = a - t + two_q;
+                }
             }
         }
     }
@@ -418,11 +522,24 @@ struct NttBody {
     }
     // forward output -> canonical residues
     static DPF_HD void fwd_canon(u64 (&x)[E], const LimbConst& lc) {
+        if constexpr (Arith::kFold) {
+            constexpr CtfPlan<LOGE> plan = ctf_plan<NPH - 1>();   // sums leave the last stage reduced: 4 instructions instead of 7
 #pragma clang loop unroll(full)
-        for (int k = 0; k < E; ++k) {
-            if (Arith::kFold) x[k] = FoldArith::canon(x[k], lc);
-            else x[k] = csub(csub(x[k], 2 * lc.q), lc.q);
+            for (int k = 0; k < E; ++k) x[k] = plan.out[k] <= kRedB ? FoldArith::canon_small(x[k], lc) : FoldArith::canon(x[k], lc);
+        } else {
+#pragma clang loop unroll(full)
+            for (int k = 0; k < E; ++k) x[k] = csub(csub(x[k], 2 * lc.q), lc.q);
         }
+    }
+
+    // forward output left lazy for a dyadic product, but every word < 2^60 + 2^29 (mul60's bound on its SECOND operand):
+    // only the differences (y') need the 3-instruction reduction, the sums are reduced already
+    static DPF_HD void fwd_reduce_partner(u64 (&x)[E], const LimbConst& lc) {
+        static_assert(Arith::kFold, "FoldArith only");
+        constexpr CtfPlan<LOGE> plan = ctf_plan<NPH - 1>();
+#pragma clang loop unroll(full)
+        for (int k = 0; k < E; ++k)
+            if (plan.out[k] > kRedB) x[k] = FoldArith::reduce(x[k], lc);
     }
 
     // ---------------- inverse (Gentleman-Sande) phase; forward phase list walked backwards -------

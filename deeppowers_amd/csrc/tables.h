@@ -19,6 +19,29 @@ inline u64 h_powmod(u64 b, u64 e, u64 q) {
     }
     return r;
 }
+// deterministic Miller-Rabin for n < 2^64 (the first twelve primes as bases suffice below 3.3 * 10^24)
+inline bool h_is_prime(u64 n) {
+    if (n < 2) return false;
+    const u64 bases[12] = {2, 3, 5, 7, 11, 13, 17, 19, 23, 29, 31, 37};
+    for (u64 p : bases) {
+        if (n == p) return true;
+        if (n % p == 0) return false;
+    }
+    u64 d = n - 1;
+    int r = 0;
+    while (!(d & 1)) { d >>= 1; ++r; }
+    for (u64 a : bases) {
+        u64 x = h_powmod(a, d, n);
+        if (x == 1 || x == n - 1) continue;
+        bool witness = true;
+        for (int i = 1; i < r && witness; ++i) {
+            x = h_mulmod(x, x, n);
+            if (x == n - 1) witness = false;
+        }
+        if (witness) return false;
+    }
+    return true;
+}
 inline u64 h_shoup(u64 w, u64 q) { return (u64)(((u128)w << 64) / q); }
 inline u32 h_brv(u32 x, int bits) {
     u32 r = 0;

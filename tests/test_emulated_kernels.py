@@ -21,7 +21,7 @@ U = C.POINTER(C.c_uint64)
 def emu():
     so = os.path.join(ROOT, "tools", "libemu.so")
     src = os.path.join(ROOT, "tools", "emulate.cpp")
-    deps = [src] + [os.path.join(ROOT, "deeppowers_amd", "csrc", f) for f in ("ntt_core.h", "modarith.h", "tables.h")]
+    deps = [src] + [os.path.join(ROOT, "deeppowers_amd", "csrc", f) for f in ("ntt_core.h", "ntt_top.h", "modarith.h", "tables.h")]
     if not os.path.exists(so) or any(os.path.getmtime(d) > os.path.getmtime(so) for d in deps):
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-o", so, src])
     lib = C.CDLL(so)
@@ -58,6 +58,15 @@ def test_emulated_ntt_matches_oracle(emu, ln, le, arith):
             rc, got = run(emu, arith, ln, le, 1, q, psi, a)
             assert rc == 0 and np.array_equal(got, orc.ntt_inv(a))
     assert emu.emu_overflows() == before, "lazy arithmetic wrapped around 2^64"
+
+
+@pytest.mark.parametrize("ln,le", GEOS + [(9, 4), (12, 3), (12, 5)])
+def test_lds_regions_are_wave_private(emu, ln, le):
+    """The kernels run every exchange but the first (forward) / last (inverse) without a workgroup barrier.  That is only
+    legal if those exchanges read and write nothing outside the issuing wave's private LDS region, if the forward all-to-all
+    exchange is READ inside the own region and the inverse one WRITTEN inside it, and if every address map is injective:
+    tools/emulate.cpp enumerates every (thread, word) address of every exchange in both directions."""
+    assert emu.emu_check_lds_regions(ln, le) == 0
 
 
 def test_emulated_30bit_prime_uses_shoup_only(emu):

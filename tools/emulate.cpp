@@ -34,6 +34,27 @@ template <> struct TwTab<FoldArith> {
     static TwFold one(u64 w, u64, u64 q) { return h_tw_fold(w, q); }
 };
 
+template <class B> static constexpr int E_of() { return B::E; }
+// Exchanges are run the way the kernels synchronise them: the all-to-all exchange as "all threads write, barrier, all
+// threads read"; a wave-local exchange (Geo::exch_wave_local) one WAVE at a time - write then read - in DESCENDING wave
+// order, with no barrier, so a word that had to cross waves, or a region that another wave's exchange clobbers, shows up
+// as a mismatch against the oracle (emu_check_lds_regions below proves the address sets disjoint as well).
+template <class B, int P, int SIDE_W, int SIDE_R, bool FWD>
+static void emu_exchange(std::vector<u64>& regs, std::vector<u64>& lds) {
+    constexpr int E = B::E, T = B::T;
+    auto X = [&](int tid) -> u64(&)[E] { return *reinterpret_cast<u64(*)[E]>(&regs[(size_t)tid * E]); };
+    if (!B::G::exch_wave_local(P)) {
+        for (int tid = 0; tid < T; ++tid) B::template lds_write<P, SIDE_W, FWD>(tid, X(tid), lds.data());
+        for (int tid = 0; tid < T; ++tid) B::template lds_read<P, SIDE_R, FWD>(tid, X(tid), lds.data());
+        return;
+    }
+    for (int w = (T + 63) / 64 - 1; w >= 0; --w) {
+        const int t0 = w * 64, t1 = (t0 + 64 < T) ? t0 + 64 : T;
+        for (int tid = t0; tid < t1; ++tid) B::template lds_write<P, SIDE_W, FWD>(tid, X(tid), lds.data());
+        for (int tid = t0; tid < t1; ++tid) B::template lds_read<P, SIDE_R, FWD>(tid, X(tid), lds.data());
+    }
+}
+
 template <class B, int P>
 struct FwdSteps {
     static void run(std::vector<u64>& regs, std::vector<u64>& lds, const typename B::Tw* tw, const LimbConst& lc) {
@@ -41,8 +62,7 @@ struct FwdSteps {
         auto X = [&](int tid) -> u64(&)[E] { return *reinterpret_cast<u64(*)[E]>(&regs[(size_t)tid * E]); };
         for (int tid = 0; tid < T; ++tid) B::template fwd_phase<P>(tid, X(tid), tw, lc);
         if constexpr (P + 1 < B::NPH) {
-            for (int tid = 0; tid < T; ++tid) B::template lds_write<P, P, true>(tid, X(tid), lds.data());
-            for (int tid = 0; tid < T; ++tid) B::template lds_read<P, P + 1, true>(tid, X(tid), lds.data());
+            emu_exchange<B, P, P, P + 1, true>(regs, lds);
             FwdSteps<B, P + 1>::run(regs, lds, tw, lc);
         }
     }
@@ -56,12 +76,68 @@ struct InvSteps {
         auto X = [&](int tid) -> u64(&)[E] { return *reinterpret_cast<u64(*)[E]>(&regs[(size_t)tid * E]); };
         for (int tid = 0; tid < T; ++tid) B::template inv_phase<P, IN>(tid, X(tid), tw, wl, wn, lc);
         if constexpr (P > 0) {
-            for (int tid = 0; tid < T; ++tid) B::template lds_write<P - 1, P, false>(tid, X(tid), lds.data());
-            for (int tid = 0; tid < T; ++tid) B::template lds_read<P - 1, P - 1, false>(tid, X(tid), lds.data());
+            emu_exchange<B, P - 1, P, P - 1, false>(regs, lds);
             InvSteps<B, P - 1, IN>::run(regs, lds, tw, wl, wn, lc);
         }
     }
 };
+
+// The barrier-free protocol rests on address-set facts; check them exhaustively for one geometry.  For every exchange X
+// (forward and inverse direction) let W(X, w) / R(X, w) be the LDS words wave w writes / reads.  Returns 0 when
+//   (1) wave-local X:  R(X, w) is a subset of W(X, w), and W(X, w) lies inside wave w's region [w S, (w+1) S)  (S = kWaveStride);
+//   (2) the all-to-all exchange, forward direction: every wave READS only its own region (so later wave-local writes need no
+//       barrier), inverse direction: every wave WRITES only its own region (so no barrier is needed before it);
+//   (3) every address map is injective and inside the buffer.
+// A negative return value names the failed check.
+template <class B, int P>
+static int check_exchanges() {
+    constexpr int E = B::E, T = B::T, S = B::G::kWaveStride, W = B::G::kWaves;
+    const int words = B::G::lds_words();
+    for (int fwd = 0; fwd < 2; ++fwd) {
+        std::vector<int> owner_w(words, -1), seen(words, 0);
+        // write side / read side register mappings of exchange P in this direction
+        for (int pass = 0; pass < 2; ++pass) {   // 0: writes, 1: reads
+            std::fill(seen.begin(), seen.end(), 0);
+            for (int tid = 0; tid < T; ++tid) {
+                const int w = tid / 64;
+                for (int k = 0; k < E; ++k) {
+                    int a;
+                    if (fwd) a = pass == 0 ? B::template xaddr<P, P, true>(tid, k) : B::template xaddr<P, P + 1, true>(tid, k);
+                    else a = pass == 0 ? B::template xaddr<P, P + 1, false>(tid, k) : B::template xaddr<P, P, false>(tid, k);
+                    if (a < 0 || a >= words) return -3;
+                    if (seen[a]++) return -3;                       // injective
+                    const bool own = a >= w * S && a < (w + 1) * S;
+                    if (B::G::exch_wave_local(P)) {
+                        if (!own) return -1;
+                        if (pass == 0) owner_w[a] = w; else if (owner_w[a] != w) return -1;
+                    } else {
+                        if (fwd && pass == 1 && !own) return -2;     // forward all-to-all: reads stay in the own region
+                        if (!fwd && pass == 0 && !own) return -2;    // inverse all-to-all: writes stay in the own region
+                        if (pass == 0) owner_w[a] = w; else if (owner_w[a] < 0) return -3;   // every word read was written
+                    }
+                }
+            }
+        }
+    }
+    (void)W;
+    if constexpr (P + 2 < B::NPH) return check_exchanges<B, P + 1>();
+    return 0;
+}
+template <int LOGN, int LOGE>
+static int check_geo() {
+    typedef NttBody<FoldArith, LOGN, LOGE> B;
+    if constexpr (B::NPH >= 2) {
+        // only the first exchange may cross waves (the chains in kernels.h static_assert the same)
+        for (int p = 1; p + 1 < B::NPH; ++p) if (!B::G::exch_wave_local(p)) return -4;
+        // the kLdsIO rows of a wave lie in its region
+        for (int tid = 0; tid < B::T; ++tid) {
+            const int r = B::G::lds_row(tid), w = tid / 64;
+            if (r < w * B::G::kWaveStride || r + E_of<B>() + 2 > (w + 1) * B::G::kWaveStride) return -5;
+        }
+        return check_exchanges<B, 0>();
+    }
+    return 0;
+}
 
 template <class Arith, int LOGN, int LOGE>
 static int emu(int inverse, u64 q, u64 psi, const u64* in, u64* out) {
@@ -169,7 +245,7 @@ static int emu_ct_mul_fold(u64 q, u64 psi, const u64* a0, const u64* a1, const u
     if (rc) return rc;
     if (!fold_eligible(q)) return 2000;
     constexpr int E = B::E, T = B::T, N = B::G::N;
-    static_assert(make_ct_plan(LOGN, kUnit).out_bound <= kLimitPartner, "lazy forward outputs must satisfy mul60's bound");
+    static_assert(B::kFwdOutBound <= kLimitPartner, "lazy forward outputs must satisfy mul60's bound");
     auto twf = TwTab<FoldArith>::make(t.rp, t.rp_sh, q), twi = TwTab<FoldArith>::make(t.irp, t.irp_sh, q);
     permute_window0(twf, LOGN, LOGE, B::G::kPermStages);
     permute_window0(twi, LOGN, LOGE, B::G::kPermStages);
@@ -181,7 +257,7 @@ static int emu_ct_mul_fold(u64 q, u64 psi, const u64* a0, const u64* a1, const u
         auto X = [&](int tid) -> u64(&)[E] { return *reinterpret_cast<u64(*)[E]>(&regs[(size_t)tid * E]); };
         for (int tid = 0; tid < T; ++tid) B::load_top(tid, X(tid), src);
         FwdSteps<B, 0>::run(regs, lds, twf.data(), lc);
-        if (reduce_out) for (auto& v : regs) v = FoldArith::reduce(v, lc);
+        if (reduce_out) for (int tid = 0; tid < T; ++tid) B::fwd_reduce_partner(X(tid), lc);
         return regs;
     };
     auto inv = [&](std::vector<u64> regs, u64* dst) {
@@ -208,6 +284,13 @@ extern "C" int emu_ct_mul(int log2n, u64 q, u64 psi, const u64* a0, const u64* a
     if (log2n == 12) return emu_ct_mul_fold<12, 4>(q, psi, a0, a1, b0, b1, out3);
     if (log2n == 13) return emu_ct_mul_fold<13, 4>(q, psi, a0, a1, b0, b1, out3);
     return -1;
+}
+
+extern "C" int emu_check_lds_regions(int log2n, int loge) {
+#define CASE(LN, LE) if (log2n == LN && loge == LE) return check_geo<LN, LE>();
+    CASE(8, 4) CASE(9, 4) CASE(10, 4) CASE(11, 4) CASE(12, 4) CASE(13, 4) CASE(14, 4) CASE(13, 5) CASE(14, 5) CASE(12, 3) CASE(12, 5)
+#undef CASE
+    return -100;
 }
 
 extern "C" int emu_lds_words(int log2n, int loge) {
