@@ -36,6 +36,8 @@ def main():
     ap.add_argument("--batch-per-gpu", type=int, default=8192)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU-baseline sample duration")
+    ap.add_argument("--native-comm", action="store_true",
+                    help="all-gather through the library's own communicator (dpfhe_comm_*, RCCL behind the C ABI) instead of torch.distributed")
     args = ap.parse_args()
 
     import numpy as np
@@ -44,7 +46,7 @@ def main():
 
     from deeppowers_amd.evaluator import Ciphertext, Context, Evaluator, to_host
     from deeppowers_amd.params import FheParams
-    from deeppowers_amd.sharding import allgather_partials
+    from deeppowers_amd.sharding import NativeComm, ShardedMultiplyReduce
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -70,42 +72,30 @@ def main():
     q = torch.tensor(params.moduli, dtype=torch.int64, device=dev).view(1, 1, L, 1)
     a = Ciphertext(torch.randint(0, 2**62, (B, 2, L, N), generator=g, dtype=torch.int64, device=dev) % q)
     b = Ciphertext(torch.randint(0, 2**62, (B, 2, L, N), generator=g, dtype=torch.int64, device=dev) % q)
-    # Two output buffers and two HIP streams: the VALU-bound multiply of step i+1 runs on the main stream
-    # while the HBM-bound shard-local reduce + all-gather + final sum of step i run on the side stream.
-    outs = [ctx.empty(B, components=3) for _ in range(2)]
-    partials = [ctx.empty(components=3) for _ in range(2)]
-    totals = [ctx.empty(components=3) for _ in range(2)]
-    main = torch.cuda.current_stream()
-    side = torch.cuda.Stream(device=dev)
-    mul_done = [torch.cuda.Event() for _ in range(2)]
-    red_done = [torch.cuda.Event() for _ in range(2)]
+    # The step is deeppowers_amd.sharding.ShardedMultiplyReduce (also what tests/test_gpu_parity.py checks at this size):
+    # multiply on the main stream; shard-local reduce -> all-gather of one partial per rank -> final sum on a side stream,
+    # double-buffered so that they overlap the next step's multiply.
+    comm = NativeComm.from_process_group(local_rank) if args.native_comm else None
+    pipe = ShardedMultiplyReduce(ev, B, comm=comm)
+    main = pipe.main
+    outs, totals = pipe.outs, pipe.totals
 
     ev_start = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
     ev_end = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
-    counter = [0]
+    ev_gather = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
 
     def step(i=None):
-        k = counter[0] & 1
-        counter[0] += 1
-        main.wait_event(red_done[k])              # the reduce that read outs[k] two steps ago has finished
-        if i is not None:
-            ev_start[i].record(main)
-        c = ev.multiply(a, b, out=outs[k], stream=main)
-        if i is not None:
-            ev_end[i].record(main)
-        mul_done[k].record(main)
-        side.wait_event(mul_done[k])
-        with torch.cuda.stream(side):
-            p = ev.reduce_sum(c, out=partials[k], stream=side)
-            gathered = allgather_partials(p.data)  # RCCL all-gather of one partial per rank (no-op at N=1)
-            ev.reduce_sum(Ciphertext(gathered), out=totals[k], stream=side)
-        red_done[k].record(side)
-        return k
+        pipe.gather_events = ev_gather[i] if i is not None else None
+        return pipe.step(a, b, timing=(ev_start[i], ev_end[i]) if i is not None else None)
 
     # one-off initialisation that is not part of any step: RCCL communicator creation and code-object loading
-    if dist.is_initialized():
-        allgather_partials(partials[0])
-        dist.barrier()
+    if dist.is_initialized() or comm is not None:
+        warm = ShardedMultiplyReduce(ev, 1, comm=comm)
+        warm.step(Ciphertext(a.data[:1]), Ciphertext(b.data[:1]))
+        torch.cuda.synchronize()
+        if dist.is_initialized():
+            dist.barrier()
+        del warm
     ev.reduce_sum(ev.multiply(Ciphertext(a.data[:1]), Ciphertext(b.data[:1])))
     torch.cuda.synchronize()
 
@@ -198,7 +188,9 @@ def main():
         ctx5.close()
         return other
 
-    ntt_result = measure_ntt() if world == 1 else None   # before the long multiply loop heats the chip into lower clocks
+    # before the long multiply loop heats the chip into lower clocks; every rank measures (same thermal history on every GPU),
+    # rank 0 reports
+    ntt_result = measure_ntt()
     other_result = measure_other_configs() if world == 1 else None
 
     for _ in range(args.warmup):
@@ -222,27 +214,42 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    def first_profile(*names):
+        for nm in names:
+            path = os.path.join(ROOT, "profiles", nm)
+            if os.path.exists(path):
+                return path
+        return None
+
     # HBM traffic of the dominant kernel from the committed PMC passes (collected with rocprofv3 --pmc in their own
     # runs, corrected as MI355X_MICROARCH.md prescribes); scaled per ct-mul because traffic is linear in the batch.
-    traffic = None
+    traffic, traffic_src = None, first_profile("r02_pmc_traffic.json", "r01_pmc_traffic.json")
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+        with open(traffic_src) as f:
             traffic = json.load(f)["ct_mul_kernel<FoldArith,12,4>"]["hbm_bytes_per_ct_mul"] * B
     except Exception:
         pass
-    # secondary (ALU) roofline: butterflies per second against the register-only butterfly loop of tools/ubench on this chip
-    alu_peak = None
+    # The bound of this kernel is VALU issue (integer multiply-adds), not HBM: its ceiling is the register-only butterfly loop
+    # of tools/ubench2 (same 12-instruction butterfly, no memory traffic), measured with in-kernel clocks.
+    alu_peak, alu_clock, alu_src = None, None, first_profile("r02_ubench2.log", "r01_ubench.log")
     try:
         import re as _re
-        with open(os.path.join(ROOT, "profiles", "r01_ubench.log")) as f:
-            m = _re.findall(r"butterflies fold\s+8 blk/CU:.*?([0-9.]+) T bfly/s", f.read())
-        alu_peak = float(m[-1]) * 1e12 if m else None
+        with open(alu_src) as f:
+            txt = f.read()
+        m = _re.findall(r"butterflies fused12\s+8 blk/CU:.*?clock\s+([0-9.]+) MHz.*?([0-9.]+) T bfly/s", txt)
+        if m:
+            alu_clock, alu_peak = float(m[-1][0]), float(m[-1][1]) * 1e12
+        else:
+            m = _re.findall(r"butterflies fold\s+8 blk/CU:.*?([0-9.]+) T bfly/s", txt)
+            alu_peak = float(m[-1]) * 1e12 if m else None
     except Exception:
         pass
     kernel_ms = [s.elapsed_time(e) for s, e in zip(ev_start, ev_end)]
     k_avg = sum(kernel_ms) / len(kernel_ms) * 1e-3
+    gather_us = sorted(s.elapsed_time(e) * 1e3 for s, e in ev_gather)
     alg_bytes = 7 * L * N * 8 * B
     achieved = alg_bytes / k_avg
+    bfly_per_s = 7 * L * (N // 2) * 12 * B / k_avg
 
     result = {
         "metric": "ciphertext-mul/s (N=4096, 4 RNS limbs)",
@@ -263,53 +270,90 @@ def main():
                         f"all-gather of one partial ct per GPU (reduce/gather of step i overlapped with the multiply of step i+1 on a second stream)",
             "log2_n": 12, "n_limbs": 4, "batch_per_gpu": B, "global_batch": B * world,
             "parallelism": f"batch-sharded x{world}, one process per GPU" + (", RCCL all-gather" if world > 1 else ""),
+            "collective": ("dpfhe_comm_allgather (RCCL behind the C ABI)" if comm is not None else "torch.distributed all_gather_into_tensor (RCCL)") if (world > 1 or comm is not None or dist.is_initialized()) else "none (one rank)",
             "arith": "fold(2^60-d)" if ctx.uses_fold else "shoup",
         },
+        # `frac` keeps the contract's meaning (algorithmic bytes / launch time / HBM peak); the kernel's real bound is VALU issue,
+        # so both fractions are first-class: frac_hbm (= frac) and frac_alu (butterflies/s over the register-only ceiling).
         "roofline": {
-            "kernel": "ct_mul_kernel<FoldArith,12,4>", "bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-            "frac": achieved / HBM_PEAK, "traffic": traffic,
-            "traffic_source": "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, bytes per launch)" if traffic else None,
-            "alu_roofline_note": "VALU issue, not HBM, bounds this kernel: it issues one VALU instruction per SIMD every ~5 cycles, the rate of the register-only butterfly loop (tools/ubench: 2.35-2.6 T butterflies/s = 78-87% of 8 TB/s NTT-equivalent; profiles/r01_ubench.log, r01_pmc_sq_ntt_bench.txt)",
+            "kernel": "ct_mul_kernel<FoldArith,12,4>", "bound": "valu", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+            "frac": achieved / HBM_PEAK, "frac_hbm": achieved / HBM_PEAK, "frac_alu": (bfly_per_s / alu_peak) if alu_peak else None,
+            "traffic": traffic,
+            "traffic_source": (os.path.relpath(traffic_src, ROOT) + " (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, bytes per launch)") if traffic else None,
             "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": k_avg * 1e3,
-            "alu": {"unit": "butterflies/s", "achieved": 7 * L * (N // 2) * 12 * B / k_avg, "peak": alu_peak,
-                    "frac": (7 * L * (N // 2) * 12 * B / k_avg / alu_peak) if alu_peak else None,
-                    "peak_source": "profiles/r01_ubench.log: register-only radix-2 butterflies, FoldArith, 8 workgroups per CU",
-                    "note": "7 transforms x L limbs x (N/2) log2 N butterflies per ct-mul; the dyadic products, canonicalisation and the lower clock under HBM load are not in the peak"},
+            "alu": {"unit": "butterflies/s", "achieved": bfly_per_s, "peak": alu_peak, "peak_clock_mhz": alu_clock,
+                    "frac": (bfly_per_s / alu_peak) if alu_peak else None,
+                    "peak_source": (os.path.relpath(alu_src, ROOT) + ": register-only radix-2 butterflies (the kernels' 12-instruction fused butterfly), 8 workgroups per CU, shader clock measured inside the kernel") if alu_src else None,
+                    "note": "7 transforms x L limbs x (N/2) log2 N butterflies per ct-mul.  Not in the peak: the dyadic products, canonicalisation, addressing (~15 % of the kernel's VALU instructions) and the clock the chip sustains under HBM load (1.9-2.1 GHz against the loop's 2.3 GHz) - see DESIGN.md section 5"},
         },
         # "report compute-only and end-to-end": `value` is end-to-end (multiply + shard-local reduce +
         # all-gather + final sum); this is the multiply kernel alone, timed inside the same overlapped steps
         "compute_only_ct_mul_per_s": world * B / k_avg,
+        # the collective alone (side stream, HIP events around it), per step: latency-bound (one 384 KiB partial per rank)
+        "allgather_us": {"median": gather_us[len(gather_us) // 2], "min": gather_us[0], "max": gather_us[-1]} if (world > 1 or comm is not None or dist.is_initialized()) else None,
     }
 
     if ntt_result is not None:
         result["ntt"] = ntt_result
+    if other_result is not None:
         result["other_configs"] = other_result
-    if world == 1:
-        # the reduced result of the last step equals a recomputation of the reduction on the main stream
-        chk = ev.reduce_sum(Ciphertext(out), stream=main)
+    # the reduced result of the last step equals a recomputation of the same sequence on the main stream (every rank checks,
+    # rank 0 reports; at N>1 the recomputation repeats the all-gather, so all ranks must take part)
+    chk = ev.reduce_sum(Ciphertext(out), stream=main)
+    if world == 1 and comm is None and not dist.is_initialized():
         torch.cuda.synchronize()
         result["reduce_consistent"] = bool(torch.equal(chk.data, totals[last]))
+    else:
+        from deeppowers_amd.sharding import allgather_partials
+        gathered = allgather_partials(chk.data, comm=comm)
+        tot = ev.reduce_sum(Ciphertext(gathered), stream=main)
+        torch.cuda.synchronize()
+        ok = torch.tensor([int(torch.equal(tot.data, totals[last]))], device=dev)
+        if dist.is_initialized():
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        result["reduce_consistent"] = bool(ok.item())
 
     if world == 1:
         if not args.no_cpu_baseline:
             from oracle.cbind import Oracle
             orc = Oracle.from_params(params)
-            cores = orc.max_threads()
-            probe = max(cores, 4)
-            ah, bh = to_host(a.data[:probe]), to_host(b.data[:probe])
-            t1 = time.perf_counter(); orc.ct_mul(ah, bh, threads=cores); t_probe = time.perf_counter() - t1
-            n_s = int(min(B, max(probe, probe * args.cpu_seconds / max(t_probe, 1e-6))))
+            # CPUs this process may actually use: the scheduler affinity AND the cgroup CPU quota (the GPU boxes of this pool are
+            # 2 x 64-core hosts whose containers get cpu.max = 16 CPUs: 128 threads there measure CFS throttling, not arithmetic)
+            hw = len(os.sched_getaffinity(0))
+            quota = None
+            try:
+                q_us, period_us = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+                if q_us != "max":
+                    quota = int(q_us) / int(period_us)
+            except Exception:
+                pass
+            cores = max(1, min(orc.max_threads(), hw, int(quota) if quota else hw))
+            # single-thread rate first (2 passes over a few pairs), then a SUSTAINED all-thread sample sized from it: three timed
+            # passes of ~cpu_seconds/3 each (many scheduler periods long), best pass reported
+            n_1 = min(B, 24)
+            _, t_one = orc.ct_mul_timed(to_host(a.data[:n_1]), to_host(b.data[:n_1]), threads=1, reps=2)
+            single = n_1 / t_one
+            n_s = int(min(B, max(cores, single * cores * args.cpu_seconds / 3.0)))
+            n_s -= n_s % cores if n_s > cores else 0
             ah, bh = to_host(a.data[:n_s]), to_host(b.data[:n_s])
-            t1 = time.perf_counter(); cpu_out = orc.ct_mul(ah, bh, threads=cores); t_all = time.perf_counter() - t1
+            cpu_out, t_all = orc.ct_mul_timed(ah, bh, threads=cores, reps=3)
             # the CPU baseline leg doubles as the checker of the timed GPU output: every word of the sample must match
             result["bit_exact_sample"] = bool(np.array_equal(to_host(out[:n_s]), cpu_out))
-            n_1 = max(1, n_s // cores)
-            t1 = time.perf_counter(); orc.ct_mul(ah[:n_1], bh[:n_1], threads=1); t_one = time.perf_counter() - t1
+            try:
+                cpu_model = next(l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name"))
+            except Exception:
+                cpu_model = "unknown"
             result["cpu_baseline"] = {
                 "value": n_s / t_all, "unit": "ct-mul/s", "cores": cores, "kind": "port",
-                "sample": f"first {n_s} ciphertext pairs of the same batch, oracle/oracle.c Harvey-NTT evaluator, OpenMP over "
-                          f"{cores} threads, {t_all:.1f} s (reference has no CPU evaluator: build CPU evaluator)",
-                "single_thread_value": n_1 / t_one,
+                "sample": f"first {n_s} ciphertext pairs of the same batch, oracle/oracle.c Harvey-NTT evaluator, OpenMP static schedule over "
+                          f"{cores} threads on NUMA-local, pre-touched buffers, best of 3 passes of {t_all:.2f} s "
+                          f"(reference has no CPU evaluator: build CPU evaluator)",
+                "host": f"{cpu_model}; {hw} hardware threads visible, cgroup cpu.max = " + (f"{quota:g} CPUs" if quota else "unlimited")
+                        + f" -> {cores} threads used (more threads than the quota only measure scheduler throttling)",
+                "isa": orc.isa(),
+                "single_thread_value": single,
+                "threads_over_single": (n_s / t_all) / single,
+                "parallel_efficiency": (n_s / t_all) / single / cores,
             }
             result["gpu_over_cpu"] = result["value"] / result["cpu_baseline"]["value"]
 

@@ -4,6 +4,10 @@
 #define __HIP_PLATFORM_AMD__ 1
 #include <hip/hip_runtime_api.h>
 
+#include <sys/random.h>
+
+#include <cerrno>
+#include <cstdio>
 #include <cstring>
 #include <istream>
 #include <ostream>
@@ -347,22 +351,123 @@ void Evaluator::reduce_sum(const PolyBuffer& in, PolyBuffer& out, Stream* s) con
 }
 
 // =====================================================================================================================
+// (e) Communicator: dpfhe_comm_* behind the facade
+// =====================================================================================================================
+class Communicator::Impl {
+public:
+    dpfhe_comm* h = nullptr;
+    int rank = 0, world = 1;
+};
+std::vector<uint8_t> Communicator::unique_id() {
+    std::vector<uint8_t> id(128);
+    check(dpfhe_comm_unique_id(id.data()), "dpfhe_comm_unique_id");
+    return id;
+}
+Communicator::Communicator(const std::vector<uint8_t>& id, int rank, int world_size, int device_id) : impl_(new Impl) {
+    if (id.size() != 128) throw Exception(ErrorCode::INVALID_ARGUMENT, "Communicator: the id is 128 bytes");
+    check(dpfhe_comm_create(&impl_->h, id.data(), rank, world_size, device_id), "dpfhe_comm_create");
+    impl_->rank = rank; impl_->world = world_size;
+}
+Communicator::~Communicator() { if (impl_ && impl_->h) dpfhe_comm_destroy(impl_->h); }
+int Communicator::rank() const { return impl_->rank; }
+int Communicator::world_size() const { return impl_->world; }
+void Communicator::all_gather(const PolyBuffer& send, PolyBuffer& recv, Stream* stream) const {
+    if (recv.batch() != send.batch() * (size_t)impl_->world || recv.size() != send.size())
+        throw Exception(ErrorCode::INVALID_ARGUMENT, "all_gather: recv must hold world_size x send items of the same size");
+    check(dpfhe_comm_allgather(impl_->h, recv.data(), send.data(), send.words(), stream), "dpfhe_comm_allgather");
+    recv.set_ntt(send.is_ntt());
+}
+
+// =====================================================================================================================
 // N2: keys, encryption, decryption (host side)
 // =====================================================================================================================
 namespace {
 typedef unsigned __int128 u128;
 
-struct SplitMix {  // deterministic host RNG (same generator as the synthetic-data spec)
-    uint64_t s;
-    explicit SplitMix(uint64_t seed) : s(seed) {}
-    uint64_t next() {
-        s += 0x9E3779B97F4A7C15ull;
-        uint64_t z = s;
-        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-        return z ^ (z >> 31);
+// Randomness of keys and encryptions.  Default: ChaCha20 keyed with 48 bytes from the operating system's CSPRNG
+// (getrandom(2), /dev/urandom as fallback) - uniform values by rejection sampling, ternary secrets, centred-binomial errors
+// (eta = 21: sigma = 3.24, |e| <= 21).  The TestSeed constructors of the public classes switch to SplitMix64 so that tests
+// and examples are reproducible; that generator is invertible with 64 bits of state and must never protect real data.
+struct Sampler {
+    bool secure = true;
+    uint64_t sm = 0;          // SplitMix64 state (testing)
+    uint32_t st[16] = {};     // ChaCha20 state: constants | key | counter | nonce
+    uint32_t blk[16] = {};
+    int used = 16;            // 32-bit words of blk already handed out
+
+    Sampler() { key_from_os(); }
+    explicit Sampler(TestSeed seed) : secure(false), sm(seed.value) {}
+
+    void key_from_os() {
+        unsigned char buf[48];
+        size_t got = 0;
+        while (got < sizeof(buf)) {
+            const ssize_t r = getrandom(buf + got, sizeof(buf) - got, 0);
+            if (r > 0) { got += (size_t)r; continue; }
+            if (r < 0 && errno == EINTR) continue;
+            break;
+        }
+        if (got < sizeof(buf)) {   // kernels without getrandom(2)
+            FILE* f = std::fopen("/dev/urandom", "rb");
+            if (f) { got += std::fread(buf + got, 1, sizeof(buf) - got, f); std::fclose(f); }
+        }
+        if (got < sizeof(buf)) throw Exception(ErrorCode::RUNTIME_ERROR, "no operating-system randomness available (getrandom, /dev/urandom)");
+        static const uint32_t sigma[4] = {0x61707865u, 0x3320646eu, 0x79622d32u, 0x6b206574u};   // "expand 32-byte k"
+        std::memcpy(st, sigma, 16);
+        std::memcpy(st + 4, buf, 32);          // key
+        st[12] = 0; st[13] = 0;                // 64-bit block counter
+        std::memcpy(st + 14, buf + 32, 8);     // nonce
+        // the remaining 8 bytes perturb the counter start so that equal (key, nonce) - impossible in practice - still differ
+        uint32_t c[2]; std::memcpy(c, buf + 40, 8); st[12] = c[0]; st[13] = c[1];
+        volatile unsigned char* wipe = buf;
+        for (size_t i = 0; i < sizeof(buf); ++i) wipe[i] = 0;
     }
-    uint64_t below(uint64_t bound) { return (uint64_t)(((u128)next() * bound) >> 64); }  // unbiased enough for tests/examples
+    static uint32_t rotl(uint32_t v, int c) { return (v << c) | (v >> (32 - c)); }
+    void refill() {   // one ChaCha20 block (RFC 8439 section 2.3), 64-bit counter
+        uint32_t x[16];
+        std::memcpy(x, st, 64);
+        auto qr = [&](int a, int b, int c, int d) {
+            x[a] += x[b]; x[d] = rotl(x[d] ^ x[a], 16);
+            x[c] += x[d]; x[b] = rotl(x[b] ^ x[c], 12);
+            x[a] += x[b]; x[d] = rotl(x[d] ^ x[a], 8);
+            x[c] += x[d]; x[b] = rotl(x[b] ^ x[c], 7);
+        };
+        for (int i = 0; i < 10; ++i) {
+            qr(0, 4, 8, 12); qr(1, 5, 9, 13); qr(2, 6, 10, 14); qr(3, 7, 11, 15);
+            qr(0, 5, 10, 15); qr(1, 6, 11, 12); qr(2, 7, 8, 13); qr(3, 4, 9, 14);
+        }
+        for (int i = 0; i < 16; ++i) blk[i] = x[i] + st[i];
+        if (++st[12] == 0) ++st[13];
+        used = 0;
+    }
+    uint64_t next() {
+        if (!secure) {   // SplitMix64 (same generator as the synthetic-data spec)
+            sm += 0x9E3779B97F4A7C15ull;
+            uint64_t z = sm;
+            z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+            z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+            return z ^ (z >> 31);
+        }
+        if (used > 14) refill();
+        const uint64_t v = (uint64_t)blk[used] | ((uint64_t)blk[used + 1] << 32);
+        used += 2;
+        return v;
+    }
+    // uniform in [0, bound): rejection sampling on the smallest covering power of two (no modulo bias)
+    uint64_t below(uint64_t bound) {
+        if (bound <= 1) return 0;
+        const uint64_t mask = ~0ull >> __builtin_clzll(bound - 1);
+        for (;;) {
+            const uint64_t v = next() & mask;
+            if (v < bound) return v;
+        }
+    }
+    int ternary() { return (int)below(3) - 1; }
+    // centred binomial, eta = 21: popcount(21 bits) - popcount(21 bits); variance 10.5 (sigma 3.24)
+    int64_t error() {
+        const uint64_t v = next();
+        return (int64_t)__builtin_popcountll(v & 0x1fffffull) - (int64_t)__builtin_popcountll((v >> 21) & 0x1fffffull);
+    }
 };
 
 uint64_t lift_signed(int64_t v, uint64_t q) { return v >= 0 ? (uint64_t)v % q : q - ((uint64_t)(-v) % q == 0 ? q : (uint64_t)(-v) % q); }
@@ -434,15 +539,15 @@ public:
 };
 
 namespace {
-std::vector<int8_t> sample_ternary(size_t n, uint64_t seed) {
-    SplitMix rng(seed);
+std::vector<int8_t> sample_ternary(size_t n, Sampler rng) {
     std::vector<int8_t> s(n);
-    for (auto& v : s) v = (int8_t)((int)rng.below(3) - 1);
+    for (auto& v : s) v = (int8_t)rng.ternary();
     return s;
 }
 }  // namespace
 
-SecretKey::SecretKey(const Context& ctx, uint64_t seed) : SecretKey(ctx, sample_ternary(ctx.params().n(), seed)) {}
+SecretKey::SecretKey(const Context& ctx) : SecretKey(ctx, sample_ternary(ctx.params().n(), Sampler())) {}
+SecretKey::SecretKey(const Context& ctx, TestSeed seed) : SecretKey(ctx, sample_ternary(ctx.params().n(), Sampler(seed))) {}
 
 SecretKey::SecretKey(const Context& ctx, const std::vector<int8_t>& coeffs) : impl_(new Impl) {
     impl_->ctx = &ctx;
@@ -473,13 +578,17 @@ class KeyGenerator::Impl {
 public:
     const Context* ctx = nullptr;
     std::unique_ptr<SecretKey> sk;
-    SplitMix rng{0};
+    Sampler rng;
 };
 
-KeyGenerator::KeyGenerator(const Context& ctx, uint64_t seed) : impl_(new Impl) {
+KeyGenerator::KeyGenerator(const Context& ctx) : impl_(new Impl) {
+    impl_->ctx = &ctx;
+    impl_->sk.reset(new SecretKey(ctx));
+}
+KeyGenerator::KeyGenerator(const Context& ctx, TestSeed seed) : impl_(new Impl) {
     impl_->ctx = &ctx;
     impl_->sk.reset(new SecretKey(ctx, seed));
-    impl_->rng = SplitMix(seed ^ 0xD1B54A32D192ED03ull);
+    impl_->rng = Sampler(TestSeed{seed.value ^ 0xD1B54A32D192ED03ull});
 }
 KeyGenerator::~KeyGenerator() = default;
 const SecretKey& KeyGenerator::secret_key() const { return *impl_->sk; }
@@ -521,7 +630,7 @@ void KeyGenerator::create_public_key(PublicKey& out) {
     for (size_t l = 0; l < L; ++l)
         for (size_t k = 0; k < n; ++k) ha[l * n + k] = impl_->rng.below(p.moduli[l]);   // uniform: any domain
     for (size_t k = 0; k < n; ++k) {
-        const int64_t ev = (int64_t)impl_->rng.below(17) - 8;
+        const int64_t ev = impl_->rng.error();
         for (size_t l = 0; l < L; ++l) he[l * n + k] = lift_signed(ev, p.moduli[l]);
     }
     PolyBuffer a(ctx, 1, 1, true), e(ctx, 1, 1, false), t(ctx, 1, 1, true);
@@ -554,7 +663,7 @@ void make_switch_key(const Context& ctx, const SecretKey& sk_ref, Rng& rng_ref, 
         for (size_t l = 0; l < L; ++l)
             for (size_t k = 0; k < n; ++k) ha[l * n + k] = impl_->rng->below(p.moduli[l]);      // uniform: any domain
         for (size_t k = 0; k < n; ++k) {
-            const int64_t ev = (int64_t)impl_->rng->below(17) - 8;
+            const int64_t ev = impl_->rng->error();
             for (size_t l = 0; l < L; ++l) he[l * n + k] = lift_signed(ev, p.moduli[l]);
         }
         a.copy_from_host(ha.data());
@@ -581,14 +690,22 @@ public:
     const Context* ctx = nullptr;
     const SecretKey* sk = nullptr;     // symmetric mode
     const PublicKey* pk = nullptr;     // public-key mode
-    SplitMix rng{0};
+    Sampler rng;
 };
-Encryptor::Encryptor(const Context& ctx, const SecretKey& sk, uint64_t seed) : impl_(new Impl) {
-    impl_->ctx = &ctx; impl_->sk = &sk; impl_->rng = SplitMix(seed);
+Encryptor::Encryptor(const Context& ctx, const SecretKey& sk) : impl_(new Impl) { impl_->ctx = &ctx; impl_->sk = &sk; }
+Encryptor::Encryptor(const Context& ctx, const SecretKey& sk, TestSeed seed) : impl_(new Impl) {
+    impl_->ctx = &ctx; impl_->sk = &sk; impl_->rng = Sampler(seed);
 }
-Encryptor::Encryptor(const Context& ctx, const PublicKey& pk, uint64_t seed) : impl_(new Impl) {
+static void check_public_key(const PublicKey& pk) {
     if (!pk.is_ntt() || pk.size() != 2 || pk.batch() != 1) throw Exception(ErrorCode::INVALID_ARGUMENT, "Encryptor: public key must be one 2-component NTT-domain item");
-    impl_->ctx = &ctx; impl_->pk = &pk; impl_->rng = SplitMix(seed);
+}
+Encryptor::Encryptor(const Context& ctx, const PublicKey& pk) : impl_(new Impl) {
+    check_public_key(pk);
+    impl_->ctx = &ctx; impl_->pk = &pk;
+}
+Encryptor::Encryptor(const Context& ctx, const PublicKey& pk, TestSeed seed) : impl_(new Impl) {
+    check_public_key(pk);
+    impl_->ctx = &ctx; impl_->pk = &pk; impl_->rng = Sampler(seed);
 }
 Encryptor::~Encryptor() = default;
 
@@ -609,7 +726,7 @@ void encrypt_scaled(const Context& ctx, const SecretKey& sk, Rng& rng, const int
             for (size_t k = 0; k < n; ++k) hm[l * n + k] = (uint64_t)((u128)lift_signed(messages[item * n + k], q) * scale[l] % q);
         }
         for (size_t k = 0; k < n; ++k) {   // + e, the same small integer in every limb
-            const int64_t ev = (int64_t)rng.below(17) - 8;
+            const int64_t ev = rng.error();
             for (size_t l = 0; l < L; ++l) { const uint64_t q = p.moduli[l]; uint64_t v = hm[l * n + k] + lift_signed(ev, q); hm[l * n + k] = v >= q ? v - q : v; }
         }
         uint64_t* c0 = out.data() + (item * 2 + 0) * poly;
@@ -635,7 +752,7 @@ void encrypt_scaled_pk(const Context& ctx, const PublicKey& pk, Rng& rng, const 
     std::vector<uint64_t> hu(poly), ht(2 * poly);
     for (size_t item = 0; item < out.batch(); ++item) {
         for (size_t k = 0; k < n; ++k) {
-            const int64_t uv = (int64_t)rng.below(3) - 1, e1 = (int64_t)rng.below(17) - 8, e2 = (int64_t)rng.below(17) - 8;
+            const int64_t uv = rng.ternary(), e1 = rng.error(), e2 = rng.error();
             for (size_t l = 0; l < L; ++l) {
                 const uint64_t q = p.moduli[l];
                 hu[l * n + k] = lift_signed(uv, q);
@@ -797,13 +914,14 @@ public:
     std::vector<std::pair<std::vector<uint32_t>, std::unique_ptr<PolyBuffer>>> packed;   // element list -> its keys back to back
     std::unique_ptr<PolyBuffer> scratch_work;      // batched rotations: reused across calls (one caller at a time per switcher)
     std::unique_ptr<Ciphertext> scratch_rotated;
+    void init(const Context& data_ctx, const SecretKey& sk, uint64_t special_prime, uint64_t special_psi);
     void ensure_scratch(size_t k) {
         if (!scratch_work || scratch_work->batch() < k) {
             scratch_work.reset(new PolyBuffer(*ext, k, 2, false));
             scratch_rotated.reset(new Ciphertext(*data_ctx, 2, k));
         }
     }
-    SplitMix rng{0};
+    Sampler rng;
     uint64_t p_special = 0;
 
     // target (NTT domain on ext, all limbs) scaled by P limb-wise: P mod q_i for data limbs, 0 for the P limb
@@ -822,15 +940,23 @@ public:
     }
 };
 
-HybridKeySwitcher::HybridKeySwitcher(const Context& data_ctx, const SecretKey& sk, uint64_t special_prime, uint64_t special_psi, uint64_t seed)
+HybridKeySwitcher::HybridKeySwitcher(const Context& data_ctx, const SecretKey& sk, uint64_t special_prime, uint64_t special_psi)
     : impl_(new Impl) {
+    impl_->init(data_ctx, sk, special_prime, special_psi);
+}
+HybridKeySwitcher::HybridKeySwitcher(const Context& data_ctx, const SecretKey& sk, uint64_t special_prime, uint64_t special_psi, TestSeed seed)
+    : impl_(new Impl) {
+    impl_->rng = Sampler(seed);
+    impl_->init(data_ctx, sk, special_prime, special_psi);
+}
+void HybridKeySwitcher::Impl::init(const Context& data_ctx, const SecretKey& sk, uint64_t special_prime, uint64_t special_psi) {
+    Impl* impl_ = this;
     impl_->data_ctx = &data_ctx;
     FheParams pe = data_ctx.params();
     pe.moduli.push_back(special_prime);
     pe.psi.push_back(special_psi);
     impl_->ext.reset(new Context(pe, data_ctx.device_id()));
     impl_->sk_ext.reset(new SecretKey(*impl_->ext, sk.coefficients()));
-    impl_->rng = SplitMix(seed);
     impl_->p_special = special_prime;
     impl_->relin.reset(new PolyBuffer(*impl_->ext, pe.n_limbs() - 1, 2, true));
     impl_->make_key(impl_->sk_ext->ntt_squared(), *impl_->relin);

@@ -13,7 +13,6 @@ libdpfhe_hip.so.  Words are u64 residues stored in int64 tensors (bit pattern), 
 """
 from __future__ import annotations
 
-import contextlib
 import ctypes as C
 
 import numpy as np
@@ -23,9 +22,9 @@ from . import _cabi
 from .params import FheParams
 
 
-def _stream_ptr(stream) -> int:
-    s = torch.cuda.current_stream() if stream is None else stream
-    return s.cuda_stream
+def _resolve_stream(stream, device):
+    """`stream=None` means the CURRENT stream OF THE CONTEXT'S DEVICE (not of whatever device is current)."""
+    return torch.cuda.current_stream(device) if stream is None else stream
 
 
 def to_device(words: np.ndarray, device) -> torch.Tensor:
@@ -36,10 +35,6 @@ def to_device(words: np.ndarray, device) -> torch.Tensor:
 
 def to_host(t: torch.Tensor) -> np.ndarray:
     return t.detach().cpu().contiguous().numpy().view(np.uint64)
-
-
-def _null_ctx():
-    return contextlib.nullcontext()
 
 
 class Context:
@@ -113,6 +108,22 @@ class Evaluator:
         self.ctx = ctx
         self._lib = ctx._lib
 
+    # ---- streams and stream-ordered temporaries ---------------------------------------------------------
+    def _sp(self, stream) -> int:
+        return _resolve_stream(stream, self.ctx.device).cuda_stream
+
+    def _on(self, stream):
+        """Context manager: torch work and allocations inside it belong to `stream` on the context's device, so the caching
+        allocator never hands a temporary to another stream while the kernels enqueued here still use it."""
+        return torch.cuda.stream(_resolve_stream(stream, self.ctx.device))
+
+    def _empty(self, shape, stream) -> torch.Tensor:
+        with self._on(stream):
+            return torch.empty(tuple(shape), dtype=torch.int64, device=self.ctx.device)
+
+    def _empty_like(self, t: torch.Tensor, stream) -> torch.Tensor:
+        return self._empty(t.shape, stream)
+
     # ---- checks -------------------------------------------------------------------------------------
     def _chk(self, *tensors):
         p = self.ctx.params
@@ -130,24 +141,24 @@ class Evaluator:
     # ---- A1 / A2 --------------------------------------------------------------------------------------
     def ntt_forward_(self, t: torch.Tensor, stream=None) -> torch.Tensor:
         self._chk(t)
-        _cabi.check(self._lib.dpfhe_ntt_fwd(self.ctx.handle, t.data_ptr(), self._npolys(t), _stream_ptr(stream)), "dpfhe_ntt_fwd")
+        _cabi.check(self._lib.dpfhe_ntt_fwd(self.ctx.handle, t.data_ptr(), self._npolys(t), self._sp(stream)), "dpfhe_ntt_fwd")
         return t
 
     def ntt_inverse_(self, t: torch.Tensor, stream=None) -> torch.Tensor:
         self._chk(t)
-        _cabi.check(self._lib.dpfhe_ntt_inv(self.ctx.handle, t.data_ptr(), self._npolys(t), _stream_ptr(stream)), "dpfhe_ntt_inv")
+        _cabi.check(self._lib.dpfhe_ntt_inv(self.ctx.handle, t.data_ptr(), self._npolys(t), self._sp(stream)), "dpfhe_ntt_inv")
         return t
 
     def ntt_forward(self, t: torch.Tensor, out: torch.Tensor | None = None, stream=None) -> torch.Tensor:
-        out = torch.empty_like(t) if out is None else out
+        out = self._empty_like(t, stream) if out is None else out
         self._chk(t, out)
-        _cabi.check(self._lib.dpfhe_ntt_fwd_oop(self.ctx.handle, out.data_ptr(), t.data_ptr(), self._npolys(t), _stream_ptr(stream)), "dpfhe_ntt_fwd_oop")
+        _cabi.check(self._lib.dpfhe_ntt_fwd_oop(self.ctx.handle, out.data_ptr(), t.data_ptr(), self._npolys(t), self._sp(stream)), "dpfhe_ntt_fwd_oop")
         return out
 
     def ntt_inverse(self, t: torch.Tensor, out: torch.Tensor | None = None, stream=None) -> torch.Tensor:
-        out = torch.empty_like(t) if out is None else out
+        out = self._empty_like(t, stream) if out is None else out
         self._chk(t, out)
-        _cabi.check(self._lib.dpfhe_ntt_inv_oop(self.ctx.handle, out.data_ptr(), t.data_ptr(), self._npolys(t), _stream_ptr(stream)), "dpfhe_ntt_inv_oop")
+        _cabi.check(self._lib.dpfhe_ntt_inv_oop(self.ctx.handle, out.data_ptr(), t.data_ptr(), self._npolys(t), self._sp(stream)), "dpfhe_ntt_inv_oop")
         return out
 
     def transform_to_ntt_(self, x, stream=None):
@@ -168,23 +179,23 @@ class Evaluator:
         if a.shape != out.shape or (b is not None and b.shape != a.shape):
             raise _cabi.DpfheError(2000, "operand shapes differ")
         args = (self.ctx.handle, out.data_ptr(), a.data_ptr()) + (() if b is None else (b.data_ptr(),))
-        _cabi.check(fn(*args, self._npolys(a), _stream_ptr(stream)), name)
+        _cabi.check(fn(*args, self._npolys(a), self._sp(stream)), name)
         return out
 
     def dyadic_mul(self, a, b, out=None, stream=None):
-        return self._dy(self._lib.dpfhe_dyadic_mul, "dpfhe_dyadic_mul", torch.empty_like(a) if out is None else out, a, b, stream)
+        return self._dy(self._lib.dpfhe_dyadic_mul, "dpfhe_dyadic_mul", self._empty_like(a, stream) if out is None else out, a, b, stream)
 
     def dyadic_mul_add_(self, acc, a, b, stream=None):
         return self._dy(self._lib.dpfhe_dyadic_mul_add, "dpfhe_dyadic_mul_add", acc, a, b, stream)
 
     def add_words(self, a, b, out=None, stream=None):
-        return self._dy(self._lib.dpfhe_add, "dpfhe_add", torch.empty_like(a) if out is None else out, a, b, stream)
+        return self._dy(self._lib.dpfhe_add, "dpfhe_add", self._empty_like(a, stream) if out is None else out, a, b, stream)
 
     def sub_words(self, a, b, out=None, stream=None):
-        return self._dy(self._lib.dpfhe_sub, "dpfhe_sub", torch.empty_like(a) if out is None else out, a, b, stream)
+        return self._dy(self._lib.dpfhe_sub, "dpfhe_sub", self._empty_like(a, stream) if out is None else out, a, b, stream)
 
     def negate_words(self, a, out=None, stream=None):
-        return self._dy(self._lib.dpfhe_negate, "dpfhe_negate", torch.empty_like(a) if out is None else out, a, None, stream)
+        return self._dy(self._lib.dpfhe_negate, "dpfhe_negate", self._empty_like(a, stream) if out is None else out, a, None, stream)
 
     # ---- A8: ciphertext add/sub/negate/reduce --------------------------------------------------------------
     def add(self, a: Ciphertext, b: Ciphertext, stream=None) -> Ciphertext:
@@ -203,9 +214,9 @@ class Evaluator:
         self._chk(cts.data)
         comps = cts.size
         if out is None:
-            out = self.ctx.empty(components=comps)
+            out = self._empty((comps, self.ctx.params.n_limbs, self.ctx.params.n), stream)
         self._chk(out)
-        _cabi.check(self._lib.dpfhe_reduce_sum(self.ctx.handle, out.data_ptr(), cts.data.data_ptr(), cts.batch, comps, _stream_ptr(stream)), "dpfhe_reduce_sum")
+        _cabi.check(self._lib.dpfhe_reduce_sum(self.ctx.handle, out.data_ptr(), cts.data.data_ptr(), cts.batch, comps, self._sp(stream)), "dpfhe_reduce_sum")
         return Ciphertext(out, cts.is_ntt)
 
     @staticmethod
@@ -225,12 +236,12 @@ class Evaluator:
         out_ntt = a.is_ntt if out_ntt is None else bool(out_ntt)
         lead = a.data.shape[:-3]
         if out is None:
-            out = self.ctx.empty(*lead, components=3)
+            out = self._empty(tuple(lead) + (3, self.ctx.params.n_limbs, self.ctx.params.n), stream)
         self._chk(out)
         if self.ctx.params.log2_n > 13:   # no fused kernel above N = 8192: the same HIP kernels, composed (4 NTT + dyadic + 3 INTT)
             return self._multiply_unfused(a, b, out, out_ntt, stream)
         flags = (_cabi.IN_NTT if a.is_ntt else 0) | (_cabi.OUT_NTT if out_ntt else 0)
-        _cabi.check(self._lib.dpfhe_ct_mul(self.ctx.handle, out.data_ptr(), a.data.data_ptr(), b.data.data_ptr(), a.batch, flags, _stream_ptr(stream)), "dpfhe_ct_mul")
+        _cabi.check(self._lib.dpfhe_ct_mul(self.ctx.handle, out.data_ptr(), a.data.data_ptr(), b.data.data_ptr(), a.batch, flags, self._sp(stream)), "dpfhe_ct_mul")
         return Ciphertext(out, out_ntt)
 
     def _multiply_unfused(self, a: Ciphertext, b: Ciphertext, out: torch.Tensor, out_ntt: bool, stream=None) -> Ciphertext:
@@ -238,7 +249,7 @@ class Evaluator:
         ad = a.data.reshape(-1, 2, p.n_limbs, p.n)
         bd = b.data.reshape(-1, 2, p.n_limbs, p.n)
         od = out.view(-1, 3, p.n_limbs, p.n)
-        with torch.cuda.stream(stream) if isinstance(stream, torch.cuda.Stream) else _null_ctx():
+        with self._on(stream):
             fa = ad if a.is_ntt else self.ntt_forward(ad, stream=stream)
             fb = bd if b.is_ntt else self.ntt_forward(bd, stream=stream)
             a0, a1, b0, b1 = (t.contiguous() for t in (fa[:, 0], fa[:, 1], fb[:, 0], fb[:, 1]))
@@ -259,9 +270,9 @@ class Evaluator:
             raise _cabi.DpfheError(2000, "matvec_scalar: w [rows][cols][L] int64 cuda, x [cols][2][L][N]")
         rows, cols = w.shape[0], w.shape[1]
         if out is None:
-            out = self.ctx.empty(rows, components=2)
+            out = self._empty((rows, 2, self.ctx.params.n_limbs, self.ctx.params.n), stream)
         self._chk(out)
-        _cabi.check(self._lib.dpfhe_matvec_scalar(self.ctx.handle, out.data_ptr(), w.data_ptr(), x.data.data_ptr(), rows, cols, _stream_ptr(stream)), "dpfhe_matvec_scalar")
+        _cabi.check(self._lib.dpfhe_matvec_scalar(self.ctx.handle, out.data_ptr(), w.data_ptr(), x.data.data_ptr(), rows, cols, self._sp(stream)), "dpfhe_matvec_scalar")
         return Ciphertext(out, x.is_ntt)
 
     # ---- N1: relinearisation ---------------------------------------------------------------
@@ -275,9 +286,9 @@ class Evaluator:
             raise _cabi.DpfheError(2000, "evk must be [L][2][L][N]")
         lead = ct3.data.shape[:-3]
         if out is None:
-            out = self.ctx.empty(*lead, components=2)
+            out = self._empty(tuple(lead) + (2, self.ctx.params.n_limbs, self.ctx.params.n), stream)
         self._chk(out)
-        _cabi.check(self._lib.dpfhe_relinearize(self.ctx.handle, out.data_ptr(), ct3.data.data_ptr(), evk.data_ptr(), ct3.batch, _stream_ptr(stream)), "dpfhe_relinearize")
+        _cabi.check(self._lib.dpfhe_relinearize(self.ctx.handle, out.data_ptr(), ct3.data.data_ptr(), evk.data_ptr(), ct3.batch, self._sp(stream)), "dpfhe_relinearize")
         return Ciphertext(out, False)
 
     def keyswitch_hybrid(self, ct: Ciphertext, key: torch.Tensor, stream=None) -> Ciphertext:
@@ -292,10 +303,10 @@ class Evaluator:
         if tuple(key.shape) != (Ld, 2, L, n):
             raise _cabi.DpfheError(2000, "key must be [L-1][2][L][N]")
         batch = d.shape[0]
-        out = torch.empty(batch, 2, Ld, n, dtype=torch.int64, device=d.device)
-        work = torch.empty(batch, 2, L, n, dtype=torch.int64, device=d.device)
+        out = self._empty((batch, 2, Ld, n), stream)
+        work = self._empty((batch, 2, L, n), stream)
         fn = self._lib.dpfhe_relinearize_hybrid if ct.size == 3 else self._lib.dpfhe_switch_key_hybrid
-        _cabi.check(fn(self.ctx.handle, out.data_ptr(), d.data_ptr(), key.data_ptr(), work.data_ptr(), batch, _stream_ptr(stream)), "dpfhe_*_hybrid")
+        _cabi.check(fn(self.ctx.handle, out.data_ptr(), d.data_ptr(), key.data_ptr(), work.data_ptr(), batch, self._sp(stream)), "dpfhe_*_hybrid")
         return Ciphertext(out, False)
 
     def rotate_hybrid_batch(self, ct: Ciphertext, galois_elts, keys: torch.Tensor, stream=None) -> Ciphertext:
@@ -310,12 +321,12 @@ class Evaluator:
             raise _cabi.DpfheError(2000, "rotate_hybrid_batch: coefficient-domain [1 or k][2][L-1][N] ciphertexts on the extended context")
         if tuple(keys.shape) != (k, Ld, 2, L, n) or keys.dtype != torch.int64 or not keys.is_contiguous():
             raise _cabi.DpfheError(2000, "keys must be [k][L-1][2][L][N]")
-        out = torch.empty(k, 2, Ld, n, dtype=torch.int64, device=d.device)
-        work = torch.empty(k, 2, L, n, dtype=torch.int64, device=d.device)
-        rotated = torch.empty(k, 2, Ld, n, dtype=torch.int64, device=d.device)
+        out = self._empty((k, 2, Ld, n), stream)
+        work = self._empty((k, 2, L, n), stream)
+        rotated = self._empty((k, 2, Ld, n), stream)
         elts = (C.c_uint32 * k)(*[int(g) for g in galois_elts])
         _cabi.check(self._lib.dpfhe_rotate_hybrid_batch(self.ctx.handle, out.data_ptr(), d.data_ptr(), d.shape[0], elts, keys.data_ptr(), work.data_ptr(),
-                                                        rotated.data_ptr(), k, _stream_ptr(stream)), "dpfhe_rotate_hybrid_batch")
+                                                        rotated.data_ptr(), k, self._sp(stream)), "dpfhe_rotate_hybrid_batch")
         return Ciphertext(out, False)
 
     def rescale_words(self, t: torch.Tensor, stream=None) -> torch.Tensor:
@@ -323,16 +334,16 @@ class Evaluator:
         context of the first L-1 moduli."""
         self._chk(t)
         p = self.ctx.params
-        out = torch.empty(t.shape[:-2] + (p.n_limbs - 1, p.n), dtype=torch.int64, device=t.device)
-        _cabi.check(self._lib.dpfhe_rescale(self.ctx.handle, out.data_ptr(), t.data_ptr(), self._npolys(t), _stream_ptr(stream)), "dpfhe_rescale")
+        out = self._empty(tuple(t.shape[:-2]) + (p.n_limbs - 1, p.n), stream)
+        _cabi.check(self._lib.dpfhe_rescale(self.ctx.handle, out.data_ptr(), t.data_ptr(), self._npolys(t), self._sp(stream)), "dpfhe_rescale")
         return out
 
     # ---- N3 (SURVEY.md 8f): Galois automorphism + key switch ----------------------------------------------------
     def apply_galois_words(self, t: torch.Tensor, galois_elt: int, out: torch.Tensor | None = None, stream=None) -> torch.Tensor:
         """a(X) -> a(X^galois_elt) on every RNS polynomial of t (coefficient domain, out of place)."""
-        out = torch.empty_like(t) if out is None else out
+        out = self._empty_like(t, stream) if out is None else out
         self._chk(t, out)
-        _cabi.check(self._lib.dpfhe_apply_galois(self.ctx.handle, out.data_ptr(), t.data_ptr(), self._npolys(t), int(galois_elt), _stream_ptr(stream)), "dpfhe_apply_galois")
+        _cabi.check(self._lib.dpfhe_apply_galois(self.ctx.handle, out.data_ptr(), t.data_ptr(), self._npolys(t), int(galois_elt), self._sp(stream)), "dpfhe_apply_galois")
         return out
 
     def apply_galois(self, ct: Ciphertext, galois_elt: int, key: torch.Tensor, stream=None) -> Ciphertext:
@@ -345,8 +356,8 @@ class Evaluator:
         if tuple(key.shape) != (p.n_limbs, 2, p.n_limbs, p.n):
             raise _cabi.DpfheError(2000, "key must be [L][2][L][N]")
         rotated = self.apply_galois_words(ct.data, galois_elt, stream=stream)
-        out = torch.empty_like(rotated)
-        _cabi.check(self._lib.dpfhe_switch_key(self.ctx.handle, out.data_ptr(), rotated.data_ptr(), key.data_ptr(), ct.batch, _stream_ptr(stream)), "dpfhe_switch_key")
+        out = self._empty_like(rotated, stream)
+        _cabi.check(self._lib.dpfhe_switch_key(self.ctx.handle, out.data_ptr(), rotated.data_ptr(), key.data_ptr(), ct.batch, self._sp(stream)), "dpfhe_switch_key")
         return Ciphertext(out, False)
 
     # ---- A7 -------------------------------------------------------------------------------------------
@@ -354,7 +365,8 @@ class Evaluator:
         """ct (.) pt, both in the NTT domain: every component times the plaintext polynomial."""
         if not (a.is_ntt and p.is_ntt):
             raise _cabi.DpfheError(2002, "multiply_plain needs NTT-domain operands")
-        pt = p.data.expand(a.data.shape).contiguous()
+        with self._on(stream):   # the broadcast copy is torch work: it must run on (and belong to) the same stream
+            pt = p.data.expand(a.data.shape).contiguous()
         return Ciphertext(self.dyadic_mul(a.data, pt, stream=stream), True)
 
     def matvec_plain(self, W: Plaintext, x: Ciphertext, out: torch.Tensor | None = None, stream=None) -> Ciphertext:
@@ -366,7 +378,7 @@ class Evaluator:
             raise _cabi.DpfheError(2000, "matvec_plain: W [rows][cols][L][N], x [cols][2][L][N]")
         rows, cols = W.data.shape[0], W.data.shape[1]
         if out is None:
-            out = self.ctx.empty(rows, components=2)
+            out = self._empty((rows, 2, self.ctx.params.n_limbs, self.ctx.params.n), stream)
         self._chk(out)
-        _cabi.check(self._lib.dpfhe_matvec_plain(self.ctx.handle, out.data_ptr(), W.data.data_ptr(), x.data.data_ptr(), rows, cols, _stream_ptr(stream)), "dpfhe_matvec_plain")
+        _cabi.check(self._lib.dpfhe_matvec_plain(self.ctx.handle, out.data_ptr(), W.data.data_ptr(), x.data.data_ptr(), rows, cols, self._sp(stream)), "dpfhe_matvec_plain")
         return Ciphertext(out, True)

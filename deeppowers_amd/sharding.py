@@ -7,10 +7,20 @@ north star keeps: each rank reduces its shard's outputs to ONE partial ciphertex
 kept collective, /root/reference/src/core/distributed/distributed_context.cpp:97-122), after which every
 rank sums the `world` partials mod q locally.  Payload is latency-bound, not bandwidth-bound.
 
-The collective goes through torch.distributed (backend "nccl" IS RCCL on ROCm; "gloo" in the CPU
-tests); libdpfhe_hip.so also exports the same step natively (dpfhe_comm_allgather).
+Two transports for the one collective:
+  * torch.distributed (backend "nccl" IS RCCL on ROCm; "gloo" in the CPU tests) - `allgather_partials(t, group)`;
+  * the library's own communicator, dpfhe_comm_* (include/dpfhe.h): RCCL called from the C ABI on the caller's HIP
+    stream, no torch.distributed on the data path - `NativeComm`.  The 128-byte RCCL id is shipped by whatever
+    rendezvous the host program has (here: a torch.distributed broadcast, or a file for the C++ example
+    examples/sharded_ct_mul.cpp).
+
+`ShardedMultiplyReduce` is the step bench.py times and tests/test_gpu_parity.py checks at BASELINE configs[3]'s
+per-GPU shard: multiply on the main stream, shard-local reduce -> all-gather -> final sum on a side stream,
+double-buffered so that the reduce of step i overlaps the multiply of step i+1.
 """
 from __future__ import annotations
+
+import ctypes as C
 
 import torch
 import torch.distributed as dist
@@ -25,8 +35,64 @@ def shard_bounds(total: int, world: int, rank: int) -> tuple[int, int]:
     return lo, lo + base + (1 if rank < extra else 0)
 
 
-def allgather_partials(partial: torch.Tensor, group=None) -> torch.Tensor:
-    """[...] -> [world, ...]; rank r's partial lands at index r on every rank."""
+class NativeComm:
+    """dpfhe_comm_* (librccl behind the C ABI).  Rank 0 creates the id; `exchange_id` ships it to the other ranks."""
+
+    def __init__(self, rank: int, world: int, device_id: int, unique_id: bytes):
+        from . import _cabi
+        self._lib = _cabi.load()
+        self.rank, self.world, self.device_id = int(rank), int(world), int(device_id)
+        if len(unique_id) != 128:
+            raise ValueError("the RCCL unique id is 128 bytes")
+        uid = (C.c_uint8 * 128).from_buffer_copy(unique_id)
+        h = C.c_void_p()
+        _cabi.check(self._lib.dpfhe_comm_create(C.byref(h), uid, self.rank, self.world, self.device_id), "dpfhe_comm_create")
+        self._h = h
+
+    @staticmethod
+    def new_unique_id() -> bytes:
+        from . import _cabi
+        uid = (C.c_uint8 * 128)()
+        _cabi.check(_cabi.load().dpfhe_comm_unique_id(uid), "dpfhe_comm_unique_id")
+        return bytes(uid)
+
+    @classmethod
+    def from_process_group(cls, device_id: int, group=None) -> "NativeComm":
+        """Rendezvous over an existing torch.distributed group (any backend): rank 0's id is broadcast as 128 bytes."""
+        rank, world = (dist.get_rank(group), dist.get_world_size(group)) if dist.is_initialized() else (0, 1)
+        box = [cls.new_unique_id() if rank == 0 else None]
+        if dist.is_initialized() and world > 1:
+            dist.broadcast_object_list(box, src=0, group=group)
+        return cls(rank, world, device_id, box[0])
+
+    def allgather(self, partial: torch.Tensor, out: torch.Tensor | None = None, stream=None) -> torch.Tensor:
+        """[...] int64 CUDA tensor -> [world, ...], enqueued on `stream` (default: the current stream of the tensor's device)."""
+        from . import _cabi
+        if partial.dtype != torch.int64 or not partial.is_cuda or not partial.is_contiguous():
+            raise _cabi.DpfheError(2000, "allgather: contiguous int64 CUDA tensor expected")
+        s = torch.cuda.current_stream(partial.device) if stream is None else stream
+        if out is None:
+            with torch.cuda.stream(s):
+                out = torch.empty((self.world,) + tuple(partial.shape), dtype=partial.dtype, device=partial.device)
+        _cabi.check(self._lib.dpfhe_comm_allgather(self._h, out.data_ptr(), partial.data_ptr(), partial.numel(), s.cuda_stream), "dpfhe_comm_allgather")
+        return out
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.dpfhe_comm_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def allgather_partials(partial: torch.Tensor, group=None, comm: NativeComm | None = None, stream=None) -> torch.Tensor:
+    """[...] -> [world, ...]; rank r's partial lands at index r on every rank.  `comm` selects the native transport."""
+    if comm is not None:
+        return comm.allgather(partial, stream=stream)
     if not dist.is_initialized():
         return partial.unsqueeze(0)
     world = dist.get_world_size(group)
@@ -36,15 +102,71 @@ def allgather_partials(partial: torch.Tensor, group=None) -> torch.Tensor:
     return out.view((world,) + tuple(partial.shape))
 
 
-def sharded_multiply_reduce(ev, a, b, group=None, stream=None):
+def sharded_multiply_reduce(ev, a, b, group=None, stream=None, comm: NativeComm | None = None):
     """Encrypted-logits style reduction: sum_i a_i (x) b_i over the GLOBAL batch, given this rank's shard.
 
     a, b: Ciphertext shards (leading batch dim).  Returns (local_outputs, global_sum) where global_sum is
-    a 3-component Ciphertext identical on every rank."""
+    a 3-component Ciphertext identical on every rank.  Everything is enqueued on one stream (see
+    ShardedMultiplyReduce for the overlapped, buffer-reusing form)."""
     from .evaluator import Ciphertext
 
     local = ev.multiply(a, b, stream=stream)
     partial = ev.reduce_sum(local, stream=stream)
-    gathered = allgather_partials(partial.data, group)
+    with ev._on(stream):
+        gathered = allgather_partials(partial.data, group, comm, stream)
     total = ev.reduce_sum(Ciphertext(gathered, local.is_ntt), stream=stream)
     return local, total
+
+
+class ShardedMultiplyReduce:
+    """The BASELINE configs[3] step for one rank: multiply its shard, reduce to one partial, all-gather, sum.
+
+    Two output buffers and two HIP streams: the (VALU-bound) multiply of step i+1 runs on `main` while the (HBM-bound)
+    shard-local reduce + all-gather + final sum of step i run on `side`.  No allocation after construction."""
+
+    def __init__(self, ev, batch: int, group=None, comm: NativeComm | None = None, main=None):
+        self.ev, self.group, self.comm = ev, group, comm
+        ctx = ev.ctx
+        self.world = comm.world if comm is not None else (dist.get_world_size(group) if dist.is_initialized() else 1)
+        p = ctx.params
+        self.outs = [ctx.empty(batch, components=3) for _ in range(2)]
+        self.partials = [ctx.empty(components=3) for _ in range(2)]
+        self.gathered = [torch.empty((self.world, 3, p.n_limbs, p.n), dtype=torch.int64, device=ctx.device) for _ in range(2)]
+        self.totals = [ctx.empty(components=3) for _ in range(2)]
+        self.main = torch.cuda.current_stream(ctx.device) if main is None else main
+        self.side = torch.cuda.Stream(device=ctx.device)
+        self.mul_done = [torch.cuda.Event() for _ in range(2)]
+        self.red_done = [torch.cuda.Event() for _ in range(2)]
+        self.gather_events = None   # optional (start, end) timing events of the collective, set by the caller
+        self._count = 0
+
+    def step(self, a, b, timing=None) -> int:
+        """Enqueues one step; returns the buffer index k: outs[k] / totals[k] hold its results once `red_done[k]` fires.
+        timing: optional (start_event, end_event) recorded around the multiply on the main stream."""
+        from .evaluator import Ciphertext
+        ev, k = self.ev, self._count & 1
+        self._count += 1
+        self.main.wait_event(self.red_done[k])              # the reduce that read outs[k] two steps ago has finished
+        if timing is not None:
+            timing[0].record(self.main)
+        c = ev.multiply(a, b, out=self.outs[k], stream=self.main)
+        if timing is not None:
+            timing[1].record(self.main)
+        self.mul_done[k].record(self.main)
+        self.side.wait_event(self.mul_done[k])
+        with torch.cuda.stream(self.side):
+            part = ev.reduce_sum(c, out=self.partials[k], stream=self.side)
+            if self.gather_events is not None:
+                self.gather_events[0].record(self.side)
+            if self.comm is not None:
+                g = self.comm.allgather(part.data, out=self.gathered[k], stream=self.side)
+            elif dist.is_initialized():
+                dist.all_gather_into_tensor(self.gathered[k].view(-1), part.data.view(-1), group=self.group)
+                g = self.gathered[k]
+            else:
+                g = part.data.unsqueeze(0)
+            if self.gather_events is not None:
+                self.gather_events[1].record(self.side)
+            ev.reduce_sum(Ciphertext(g, c.is_ntt), out=self.totals[k], stream=self.side)
+        self.red_done[k].record(self.side)
+        return k

@@ -23,8 +23,8 @@ int main(int argc, char** argv) {
         p.moduli.pop_back(); p.psi.pop_back();
         const size_t n = p.n(), row = n / 2;
         Context ctx(p, 0);
-        KeyGenerator kg(ctx, 31);
-        Encryptor enc(ctx, kg.secret_key(), 32);
+        KeyGenerator kg(ctx);   // OS CSPRNG (TestSeed{..} would make the run reproducible)
+        Encryptor enc(ctx, kg.secret_key());
         Decryptor dec(ctx, kg.secret_key());
         BatchEncoder be(ctx, 65537);
         const uint64_t t = be.plain_modulus();

@@ -184,15 +184,46 @@ private:
     std::unique_ptr<Impl> impl_;
 };
 
+// ---- (e) SURVEY.md section 8e: the one collective of the sharded path -------------------------------------------------
+// One process per GPU.  Rank 0 obtains an id, ships its 128 bytes to the other ranks by the host program's own rendezvous
+// (a file, a pipe, MPI ...), every rank constructs a Communicator.  all_gather is RCCL's all-gather over xGMI on the caller's
+// stream: rank r's `send` lands at item range [r * send.batch(), (r + 1) * send.batch()) of `recv` on every rank.  Stands in for
+// /root/reference/src/core/distributed/distributed_context.cpp:97-122 (ncclAllGather + stream create + synchronise per call).
+class Communicator {
+public:
+    static std::vector<uint8_t> unique_id();   // 128 bytes
+    Communicator(const std::vector<uint8_t>& id, int rank, int world_size, int device_id);
+    ~Communicator();
+    Communicator(const Communicator&) = delete;
+    Communicator& operator=(const Communicator&) = delete;
+    int rank() const;
+    int world_size() const;
+    // recv.batch() == world_size * send.batch(), same components; the domain flag is copied
+    void all_gather(const PolyBuffer& send, PolyBuffer& recv, Stream* stream = nullptr) const;
+
+private:
+    class Impl;
+    std::unique_ptr<Impl> impl_;
+};
+
+// Randomness.  Keys, encryption randomness and errors are drawn from ChaCha20 keyed by the operating system's CSPRNG
+// (getrandom(2)): uniform values by rejection sampling, ternary secrets, centred-binomial errors (sigma = 3.24).
+// TestSeed selects a DETERMINISTIC, NON-CRYPTOGRAPHIC generator (SplitMix64) instead - for reproducible tests, examples
+// and benchmarks ONLY: anyone who knows the seed (64 bits, invertible) knows the secret key and every encryption.
+struct TestSeed {
+    uint64_t value;
+};
+
 // ---- N2: secret key, encryption, decryption, key generation -------------------------------
 // Host-side (client-side in the reference's story, /root/reference/README.md:57-60): sampling and CRT decoding run on
 // the CPU, polynomial arithmetic goes through the same C ABI as everything else.  Symmetric RLWE:
-//   ct = (c0, c1) = (-(a s) + e + 2^log2_scale * m,  a),   s ternary, e uniform in [-8, 8].
+//   ct = (c0, c1) = (-(a s) + e + 2^log2_scale * m,  a),   s ternary, e centred binomial (sigma = 3.24, |e| <= 21).
 // Messages are integer polynomials (N signed coefficients per item); decryption returns round(phase / 2^log2_scale),
 // where phase = c0 + c1 s (+ c2 s^2) is CRT-composed over all limbs and centred mod Q = prod q_i.
 class SecretKey {
 public:
-    SecretKey(const Context& ctx, uint64_t seed);
+    explicit SecretKey(const Context& ctx);            // fresh ternary secret from the OS CSPRNG
+    SecretKey(const Context& ctx, TestSeed seed);      // deterministic - tests only
     SecretKey(const Context& ctx, const std::vector<int8_t>& ternary_coefficients);  // the same secret on another context
     ~SecretKey();
     SecretKey(const SecretKey&) = delete;
@@ -215,7 +246,8 @@ public:
 
 class KeyGenerator {
 public:
-    explicit KeyGenerator(const Context& ctx, uint64_t seed = 1);
+    explicit KeyGenerator(const Context& ctx);          // secret key and all key randomness from the OS CSPRNG
+    KeyGenerator(const Context& ctx, TestSeed seed);    // deterministic - tests only
     ~KeyGenerator();
     KeyGenerator(const KeyGenerator&) = delete;
     KeyGenerator& operator=(const KeyGenerator&) = delete;
@@ -231,9 +263,11 @@ private:
 
 class Encryptor {
 public:
-    Encryptor(const Context& ctx, const SecretKey& sk, uint64_t seed = 2);   // symmetric: c1 uniform, c0 = -(c1 s) + e + scale m
+    Encryptor(const Context& ctx, const SecretKey& sk);   // symmetric: c1 uniform, c0 = -(c1 s) + e + scale m
+    Encryptor(const Context& ctx, const SecretKey& sk, TestSeed seed);   // deterministic - tests only
     // public-key: (c0, c1) = (u pk0 + e1 + scale m, u pk1 + e2) with u ternary, e1, e2 small; decrypts under the same secret
-    Encryptor(const Context& ctx, const PublicKey& pk, uint64_t seed = 2);
+    Encryptor(const Context& ctx, const PublicKey& pk);
+    Encryptor(const Context& ctx, const PublicKey& pk, TestSeed seed);   // deterministic - tests only
     ~Encryptor();
     Encryptor(const Encryptor&) = delete;
     Encryptor& operator=(const Encryptor&) = delete;
@@ -269,7 +303,8 @@ private:
 class HybridKeySwitcher {
 public:
     // data_ctx: the level the ciphertexts live on; (special_prime, special_psi): one more NTT prime and its 2N-th root
-    HybridKeySwitcher(const Context& data_ctx, const SecretKey& sk, uint64_t special_prime, uint64_t special_psi, uint64_t seed = 3);
+    HybridKeySwitcher(const Context& data_ctx, const SecretKey& sk, uint64_t special_prime, uint64_t special_psi);
+    HybridKeySwitcher(const Context& data_ctx, const SecretKey& sk, uint64_t special_prime, uint64_t special_psi, TestSeed seed);   // tests only
     ~HybridKeySwitcher();
     HybridKeySwitcher(const HybridKeySwitcher&) = delete;
     HybridKeySwitcher& operator=(const HybridKeySwitcher&) = delete;

@@ -34,6 +34,9 @@ def _load():
     lib.orc_ntt_inv.argtypes = [C.c_void_p, _U64P, C.c_size_t, C.c_int]
     lib.orc_dyadic.argtypes = [C.c_void_p, C.c_int, _U64P, _U64P, _U64P, C.c_size_t, C.c_int]
     lib.orc_ct_mul.argtypes = [C.c_void_p, _U64P, _U64P, _U64P, C.c_size_t, C.c_int]
+    lib.orc_ct_mul_timed.argtypes = [C.c_void_p, _U64P, _U64P, _U64P, C.c_size_t, C.c_int, C.c_int]
+    lib.orc_ct_mul_timed.restype = C.c_double
+    lib.orc_isa.restype = C.c_char_p
     lib.orc_ct_mul_schoolbook.argtypes = [C.c_void_p, _U64P, _U64P, _U64P, C.c_size_t, C.c_int]
     lib.orc_relinearize.argtypes = [C.c_void_p, _U64P, _U64P, _U64P, C.c_size_t, C.c_int]
     lib.orc_keyswitch_hybrid.argtypes = [C.c_void_p, _U64P, _U64P, _U64P, C.c_size_t, C.c_int, C.c_int]
@@ -128,6 +131,19 @@ class Oracle:
         f = lib().orc_ct_mul_schoolbook if schoolbook else lib().orc_ct_mul
         f(self._h, _p(out), _p(a2), _p(b2), batch, threads)
         return out.reshape(batch, 3, self.L, self.n)
+
+    def ct_mul_timed(self, a2, b2, threads=1, reps=3):
+        """bench.py's CPU column: (result, best wall seconds of `reps` passes) with NUMA-local, pre-touched working copies."""
+        batch = a2.size // (2 * self.L * self.n)
+        out = np.empty(batch * 3 * self.L * self.n, np.uint64)
+        t = lib().orc_ct_mul_timed(self._h, _p(out), _p(np.ascontiguousarray(a2)), _p(np.ascontiguousarray(b2)), batch, threads, reps)
+        if t < 0:
+            raise MemoryError("orc_ct_mul_timed: allocation failed")
+        return out.reshape(batch, 3, self.L, self.n), t
+
+    @staticmethod
+    def isa() -> str:
+        return lib().orc_isa().decode()
 
     def relinearize(self, ct3, evk, threads=1):
         batch = ct3.size // (3 * self.L * self.n)

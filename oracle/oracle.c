@@ -302,6 +302,54 @@ void orc_ct_mul(const orc_ctx* c, uint64_t* out3, const uint64_t* a2, const uint
     }
 }
 
+/* Timed variant for bench.py's cpu_baseline leg: the same evaluator (orc_ct_mul), but measured the way a CPU deployment
+ * would run it - private, page-aligned working copies first-touched by the thread that will use them (static schedule:
+ * thread t owns a contiguous range of (ciphertext, limb) items, so its pages sit on its own NUMA node), `reps` timed
+ * passes, best pass reported.  Without this the all-threads figure measured first-touch page faults on one node's
+ * memory, not arithmetic (round-1 VERDICT).  Returns the best wall time of one pass in seconds; out3 receives the result. */
+double orc_ct_mul_timed(const orc_ctx* c, uint64_t* out3, const uint64_t* a2, const uint64_t* b2, size_t batch, int threads, int reps) {
+    const size_t n = 1ull << c->log2n, L = c->n_limbs;
+    const size_t in_words = batch * 2 * L * n, out_words = batch * 3 * L * n;
+    threads = clamp_threads(threads);
+    if (reps < 1) reps = 1;
+    uint64_t *a = NULL, *b = NULL, *o = NULL;
+    if (posix_memalign((void**)&a, 4096, in_words * 8) || posix_memalign((void**)&b, 4096, in_words * 8) || posix_memalign((void**)&o, 4096, out_words * 8)) {
+        free(a); free(b); free(o);
+        return -1.0;
+    }
+    /* first touch with the schedule of the compute loop: item (bi, l) touches its 2 + 2 input and 3 output polynomials */
+#pragma omp parallel for num_threads(threads) schedule(static)
+    for (long long it = 0; it < (long long)(batch * L); ++it) {
+        const size_t bi = (size_t)it / L, l = (size_t)it % L;
+        for (int comp = 0; comp < 2; ++comp) {
+            memcpy(a + ((bi * 2 + comp) * L + l) * n, a2 + ((bi * 2 + comp) * L + l) * n, n * 8);
+            memcpy(b + ((bi * 2 + comp) * L + l) * n, b2 + ((bi * 2 + comp) * L + l) * n, n * 8);
+        }
+        for (int comp = 0; comp < 3; ++comp) memset(o + ((bi * 3 + comp) * L + l) * n, 0, n * 8);
+    }
+    double best = 1e30;
+    for (int r = 0; r < reps; ++r) {
+        const double t0 = omp_get_wtime();
+        orc_ct_mul(c, o, a, b, batch, threads);
+        const double t = omp_get_wtime() - t0;
+        if (t < best) best = t;
+    }
+    memcpy(out3, o, out_words * 8);
+    free(a); free(b); free(o);
+    return best;
+}
+
+/* what the hot loops of this build run on (reported next to the CPU baseline) */
+const char* orc_isa(void) {
+#if defined(__AVX512F__)
+    return "x86-64 scalar 64x64->128 multiplies (mulx), compiled with AVX-512 enabled but not used by the modular arithmetic";
+#elif defined(__BMI2__)
+    return "x86-64-v3 scalar code: 64x64->128 multiplies (mulx/BMI2), Harvey lazy butterflies; no SIMD (60-bit moduli do not fit AVX-512 IFMA's 52-bit lanes)";
+#else
+    return "baseline x86-64 scalar code";
+#endif
+}
+
 /* same tensor product by schoolbook convolution (ground truth; O(N^2), small sizes only) */
 void orc_ct_mul_schoolbook(const orc_ctx* c, uint64_t* out3, const uint64_t* a2, const uint64_t* b2, size_t batch, int threads) {
     const size_t n = 1ull << c->log2n, L = c->n_limbs;

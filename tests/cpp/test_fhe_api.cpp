@@ -150,13 +150,50 @@ static void large_ring() {
     orc_ctx_destroy(orc);
 }
 
+// default-constructed key material must come from the OS CSPRNG - two generators never agree, two encryptions
+// of one message never agree, errors are small and centred, and everything still decrypts.
+static void os_randomness(const FheParams& p) {
+    const size_t n = p.n();
+    Context ctx(p, 0);
+    KeyGenerator kg1(ctx), kg2(ctx);
+    CHECK(kg1.secret_key().coefficients() != kg2.secret_key().coefficients());
+    long nz = 0;
+    for (int8_t v : kg1.secret_key().coefficients()) { CHECK(v >= -1 && v <= 1); nz += v != 0; }
+    CHECK(nz > (long)n / 2 && nz < (long)n * 5 / 6);          // ~2/3 non-zero
+    KeyGenerator det1(ctx, TestSeed{5}), det2(ctx, TestSeed{5});
+    CHECK(det1.secret_key().coefficients() == det2.secret_key().coefficients());   // the testing path stays reproducible
+    Encryptor e1(ctx, kg1.secret_key()), e2(ctx, kg1.secret_key());
+    Decryptor dec(ctx, kg1.secret_key());
+    std::vector<int64_t> m(n), out(n);
+    for (size_t i = 0; i < n; ++i) m[i] = (int64_t)(i % 199) - 99;
+    Ciphertext c1(ctx, 2, 1), c2(ctx, 2, 1);
+    e1.encrypt(m.data(), 40, c1);
+    e2.encrypt(m.data(), 40, c2);
+    std::vector<uint64_t> h1(c1.words()), h2(c2.words());
+    c1.copy_to_host(h1.data()); c2.copy_to_host(h2.data());
+    size_t same = 0;
+    for (size_t i = 0; i < h1.size(); ++i) same += h1[i] == h2[i];
+    CHECK(same < 4);                                            // independent (a, e): no word-level coincidences beyond chance
+    dec.decrypt(c1, 40, out.data()); CHECK(out == m);
+    dec.decrypt(c2, 40, out.data()); CHECK(out == m);
+    // the noise itself: decrypt at scale 0 -> m * 2^40 + e, |e| <= 21, mean ~ 0
+    dec.decrypt(c1, 0, out.data());
+    double mean = 0;
+    for (size_t i = 0; i < n; ++i) {
+        const int64_t e = out[i] - m[i] * (int64_t(1) << 40);
+        CHECK(e >= -21 && e <= 21);
+        mean += (double)e;
+    }
+    CHECK(std::abs(mean / (double)n) < 0.5);
+}
+
 // N2 + N1 end to end: encrypt -> multiply -> (relinearize) -> decrypt == negacyclic product of the messages
 static void end_to_end(const FheParams& p, size_t batch) {
     const size_t n = p.n();
     Context ctx(p, 0);
     Evaluator ev(ctx);
-    KeyGenerator kg(ctx, /*seed=*/11);
-    Encryptor enc(ctx, kg.secret_key(), /*seed=*/12);
+    KeyGenerator kg(ctx, TestSeed{11});
+    Encryptor enc(ctx, kg.secret_key(), TestSeed{12});
     Decryptor dec(ctx, kg.secret_key());
     RelinKeys rk(ctx);
     kg.create_relin_keys(rk);
@@ -187,7 +224,7 @@ static void end_to_end(const FheParams& p, size_t batch) {
     {
         PublicKey pk(ctx);
         kg.create_public_key(pk);
-        Encryptor penc(ctx, pk, /*seed=*/13);
+        Encryptor penc(ctx, pk, TestSeed{13});
         Ciphertext p1(ctx, 2, batch), p2(ctx, 2, batch), p3(ctx, 3, batch);
         penc.encrypt(m1.data(), scale, p1);
         penc.encrypt(m2.data(), scale, p2);
@@ -219,7 +256,7 @@ static void end_to_end(const FheParams& p, size_t batch) {
     // hybrid key switching (special prime = the 6th pinned prime): the product decrypts at scale 2^60 already,
     // a rotation of a FRESH ciphertext at scale 2^30 - impossible with the plain RNS-digit keys above (noise ~2^77)
     {
-        HybridKeySwitcher hks(ctx, kg.secret_key(), 1152921504606109697ull, /*psi for N=4096:*/ 279138086580908ull);
+        HybridKeySwitcher hks(ctx, kg.secret_key(), 1152921504606109697ull, /*psi for N=4096:*/ 279138086580908ull, TestSeed{3});
         Ciphertext lo1(ctx, 2, batch), lo2(ctx, 2, batch), lo3(ctx, 3, batch), lor(ctx, 2, batch), rot(ctx, 2, batch);
         enc.encrypt(m1.data(), 30, lo1);
         enc.encrypt(m2.data(), 30, lo2);
@@ -243,7 +280,7 @@ static void end_to_end(const FheParams& p, size_t batch) {
     {
         const FheParams p2 = p.drop_last_limb();
         Context ctx2(p2, 0);
-        KeyGenerator kg2(ctx2, /*seed=*/11);             // same seed -> same ternary secret
+        KeyGenerator kg2(ctx2, TestSeed{11});             // same seed -> same ternary secret
         Decryptor dec2(ctx2, kg2.secret_key());
         Ciphertext low(ctx2, 2, batch);
         ev.rescale(cr, low);
@@ -273,8 +310,8 @@ static void packed(unsigned log2n, size_t d) {
     const uint64_t special_psi = p.psi.back();
     p.log2_n = log2n; p.moduli.pop_back(); p.psi.pop_back();    // 5 data limbs + the 6th as the special prime
     Context ctx(p, 0);
-    KeyGenerator kg(ctx, 21);
-    Encryptor enc(ctx, kg.secret_key(), 22);
+    KeyGenerator kg(ctx, TestSeed{21});
+    Encryptor enc(ctx, kg.secret_key(), TestSeed{22});
     Decryptor dec(ctx, kg.secret_key());
     BatchEncoder be(ctx, 65537);
     const uint64_t t = be.plain_modulus();
@@ -301,7 +338,7 @@ static void packed(unsigned log2n, size_t d) {
     dec.decrypt_exact(cx, t, dm.data());
     be.decode(dm.data(), got.data());
     CHECK(got == va);
-    HybridKeySwitcher hks(ctx, kg.secret_key(), special, special_psi);
+    HybridKeySwitcher hks(ctx, kg.secret_key(), special, special_psi, TestSeed{3});
     for (int rot : {1, 5, -3}) {
         const uint32_t g = be.galois_element(rot);
         hks.add_galois_element(g);
@@ -355,6 +392,12 @@ int main() {
         packed(12, 16);
         large_ring();
         end_to_end(FheParams::n4096_l4(), 2);
+        os_randomness(FheParams::n4096_l4());
+        {   // a composite modulus with a root of order 2N must be rejected (inverses are Fermat powers)
+            FheParams p = FheParams::n4096_l4();
+            p.moduli[0] = 8193ull * 40961ull;   // both factors are 1 mod 8192; primality is checked before psi is even looked at
+            try { Context bad(p, 0); CHECK(!"expected INVALID_ARGUMENT"); } catch (const Exception& e) { CHECK(e.code() == ErrorCode::INVALID_ARGUMENT); }
+        }
         run(FheParams::config1(), 2);
         run(FheParams::n4096_l4(), 3);
         run(FheParams::n8192_l6(), 2);

@@ -56,6 +56,9 @@ def test_ctx_create_rejects_bad_parameters_before_touching_the_device(lib):
     assert _create(lib, 12, [(1 << 61) + 1], [3])[0] == 2000          # modulus too wide
     assert b"psi" in lib.dpfhe_last_error() or b"modulus" in lib.dpfhe_last_error()
     assert lib.dpfhe_ctx_create(None, 12, 1, None, None, 0) == 2000
+    # composite modulus, 1 mod 2N, below 2^60: rejected by the Miller-Rabin check (inverses are Fermat powers)
+    assert _create(lib, 12, [8193 * 40961], [3])[0] == 2000 and b"not prime" in lib.dpfhe_last_error()
+    assert _create(lib, 8, [(1 << 32) + 1], [3])[0] == 2000          # 641 * 6700417 = 1 mod 512, composite (Fermat number F5)
 
 
 def test_null_context_and_destroy_are_safe(lib):

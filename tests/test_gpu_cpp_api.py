@@ -33,7 +33,7 @@ def build_example(name="encrypted_multiply"):
 
 
 def test_example_compiles():
-    assert all(os.path.exists(build_example(e)) for e in ("encrypted_multiply", "bench_ct_mul", "encrypted_linear", "encrypted_gpt2_linear"))
+    assert all(os.path.exists(build_example(e)) for e in ("encrypted_multiply", "bench_ct_mul", "encrypted_linear", "encrypted_gpt2_linear", "sharded_ct_mul"))
 
 
 @pytest.mark.gpu
@@ -46,6 +46,14 @@ def test_example_encrypted_linear_layer():
 def test_example_encrypted_gpt2_linear_layer():
     """N3: slot-packed 256 x 256 layer at N=8192 (the full 1024 x 1024 run is the example's default)"""
     out = subprocess.run([build_example("encrypted_gpt2_linear"), "256", "1"], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0 and "OK" in out.stdout, out.stdout + out.stderr
+
+
+@pytest.mark.gpu
+def test_cpp_sharded_ct_mul_native_comm_world_size_one():
+    """(e) in pure C++: one process per GPU, dpfhe_comm_* all-gather, id shipped through a file.  World size 1 here (one GPU
+    on the test box); `sharded_ct_mul 8` is the 8-GPU form."""
+    out = subprocess.run([build_example("sharded_ct_mul"), "1", "96", "2"], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "OK" in out.stdout, out.stdout + out.stderr
 
 

@@ -349,6 +349,85 @@ def test_ct_mul_large_batch_checksum_of_checksums(rigs):
     assert np.array_equal(to_host(c.data[idx]), want)
 
 
+def test_config4_per_gpu_shard_full_size_through_the_bench_step(rigs):
+    """BASELINE configs[3], one GPU's share: 8192 ct-muls at N=4096 / L=4 through deeppowers_amd.sharding.ShardedMultiplyReduce
+    - the very object bench.py times (multiply on the main stream, shard-local reduce -> all-gather -> final sum on the side
+    stream, double-buffered).  Size-independent properties at FULL size + sampled pairs against the oracle:
+      * canonical range of every output word;
+      * bilinearity: sum_i a_i (x) b == (sum_i a_i) (x) b  (all 8192 pairs share b in the second step);
+      * the pipelined total equals a serial recomputation, and the serial helper sharded_multiply_reduce agrees;
+      * steps are independent: running two steps back to back (buffer reuse, overlap) changes nothing."""
+    from deeppowers_amd.sharding import ShardedMultiplyReduce, sharded_multiply_reduce
+    r = rigs("n4096")
+    L, n, batch = 4, 4096, 8192
+    dev = r.ctx.device
+    g = torch.Generator(device=dev).manual_seed(41)
+    q = torch.tensor(r.p.moduli, dtype=torch.int64, device=dev).view(1, 1, L, 1)
+    a = Ciphertext(torch.randint(0, 2**62, (batch, 2, L, n), generator=g, dtype=torch.int64, device=dev) % q)
+    b = Ciphertext(torch.randint(0, 2**62, (batch, 2, L, n), generator=g, dtype=torch.int64, device=dev) % q)
+    b1 = b.data[:1].clone()
+    bsame = Ciphertext(b1.expand(batch, 2, L, n).contiguous())
+    pipe = ShardedMultiplyReduce(r.ev, batch)
+    k0 = pipe.step(a, b)
+    k1 = pipe.step(a, bsame)            # overlaps the reduce of step 0
+    torch.cuda.synchronize()
+    out0, tot0, out1, tot1 = pipe.outs[k0], pipe.totals[k0], pipe.outs[k1], pipe.totals[k1]
+    for t in (out0, out1, tot0, tot1):
+        assert int(t.min()) >= 0 and bool((t < q.view(1, L, 1) if t.dim() == 3 else t < q).all())    # canonical
+    assert torch.equal(tot0, r.ev.reduce_sum(Ciphertext(out0)).data)                                     # pipelined == serial
+    asum = r.ev.reduce_sum(a)
+    rhs = r.ev.multiply(Ciphertext(asum.data.unsqueeze(0)), Ciphertext(b1))
+    assert torch.equal(tot1, rhs.data[0])                                                                 # bilinearity at full size
+    idx = [0, 1, 4095, 8191]
+    want = r.orc.ct_mul(to_host(a.data[idx]), to_host(b.data[idx]), threads=0)
+    assert np.array_equal(to_host(out0[idx]), want)                                                      # sampled pairs vs oracle
+    local, total = sharded_multiply_reduce(r.ev, a, b)
+    assert torch.equal(local.data, out0) and torch.equal(total.data, tot0)
+    del pipe, local, total
+
+
+def test_native_comm_world_size_one_through_the_step(rigs):
+    """dpfhe_comm_* (RCCL behind the C ABI) as the transport of the same step, on a non-default stream - world size 1 because the
+    test box has one GPU; the multi-rank form is examples/sharded_ct_mul.cpp and bench.py --native-comm."""
+    from deeppowers_amd.sharding import NativeComm, ShardedMultiplyReduce
+    r = rigs("n4096")
+    L, n, batch = 4, 4096, 64
+    ah, bh = r.orc.fill(batch * 2, 91).reshape(batch, 2, L, n), r.orc.fill(batch * 2, 92).reshape(batch, 2, L, n)
+    a, b = Ciphertext(r.dev(ah)), Ciphertext(r.dev(bh))
+    comm = NativeComm(0, 1, 0, NativeComm.new_unique_id())
+    pipe = ShardedMultiplyReduce(r.ev, batch, comm=comm)
+    k = pipe.step(a, b)
+    torch.cuda.synchronize()
+    want = r.orc.ct_mul(ah, bh, threads=0)
+    assert np.array_equal(to_host(pipe.outs[k]), want)
+    assert np.array_equal(to_host(pipe.totals[k]), r.orc.reduce_sum(want.ravel(), 3))
+    g = comm.allgather(pipe.partials[k], stream=pipe.side)
+    torch.cuda.synchronize()
+    assert g.shape == (1, 3, L, n) and torch.equal(g[0], pipe.partials[k])
+    comm.close()
+
+
+def test_evaluator_temporaries_follow_the_stream(rigs):
+    """default outputs and temporaries are allocated on the stream the kernels run on.  Run key switching /
+    multiply_plain on a side stream while the main stream churns the caching allocator with same-sized blocks: results must
+    equal the default-stream run."""
+    r = rigs("n4096")
+    L, n = 4, 4096
+    ch = r.orc.fill(8 * 3, 55).reshape(8, 3, L, n)
+    evkh = r.orc.fill(L * 2, 56).reshape(L, 2, L, n)
+    c3, evk = Ciphertext(r.dev(ch)), r.dev(evkh)
+    want = r.ev.relinearize(c3, evk)
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    outs = []
+    for _ in range(8):
+        outs.append(r.ev.relinearize(c3, evk, stream=side))
+        junk = [torch.full_like(want.data, 7) for _ in range(4)]    # same size class, main stream
+        del junk
+    torch.cuda.synchronize()
+    assert all(torch.equal(o.data, want.data) for o in outs)
+
+
 def test_streams_and_concurrent_contexts(rigs):
     r = rigs("n4096")
     x = r.orc.fill(8, 71)
@@ -394,7 +473,13 @@ def test_bench_distributed_path_world_size_one():
     line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
     d = json.loads(line)
     assert d["n_gpus"] == 1 and d["reduce_consistent"] is True and d["value"] > 0 and d["unit"] == "ct-mul/s"
-    assert set(("roofline", "config", "metric", "ms_per_step", "scaling", "dtype", "data")) <= set(d)
+    assert set(("roofline", "config", "metric", "ms_per_step", "scaling", "dtype", "data", "ntt", "allgather_us")) <= set(d)
+    assert d["roofline"]["bound"] == "valu" and d["roofline"]["frac_hbm"] == d["roofline"]["frac"] and d["allgather_us"]["median"] > 0
+    # the same launch with the library's own communicator as the transport
+    out = subprocess.run(cmd[:-1] + ["--no-cpu-baseline", "--native-comm"], capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["reduce_consistent"] is True and "dpfhe_comm_allgather" in d["config"]["collective"]
 
 
 def test_config3_full_size_matvec_linearity_and_sampled_rows(rigs):
