@@ -1011,10 +1011,17 @@ void HybridKeySwitcher::apply_galois(const Ciphertext& in2, uint32_t g, Cipherte
 }
 
 void HybridKeySwitcher::apply_galois_many(const Ciphertext& in2, const std::vector<uint32_t>& elts, Ciphertext& out2, size_t out_first, Stream* s) const {
+    if (in2.batch() != 1 && in2.batch() != elts.size())
+        throw Exception(ErrorCode::INVALID_ARGUMENT, "HybridKeySwitcher::apply_galois_many: input of 1 or k items, output with room for k items");
+    apply_galois_range(in2, 0, in2.batch() == 1 && elts.size() != 1, elts, out2, out_first, s);
+}
+
+void HybridKeySwitcher::apply_galois_range(const Ciphertext& in2, size_t in_first, bool broadcast, const std::vector<uint32_t>& elts, Ciphertext& out2,
+                                           size_t out_first, Stream* s) const {
     const size_t k = elts.size();
     if (k == 0) return;
-    if (in2.is_ntt() || in2.size() != 2 || out2.size() != 2 || (in2.batch() != 1 && in2.batch() != k) || out_first + k > out2.batch())
-        throw Exception(ErrorCode::INVALID_ARGUMENT, "HybridKeySwitcher::apply_galois_many: input of 1 or k items, output with room for k items");
+    if (in2.is_ntt() || in2.size() != 2 || out2.size() != 2 || in_first + (broadcast ? 1 : k) > in2.batch() || out_first + k > out2.batch())
+        throw Exception(ErrorCode::INVALID_ARGUMENT, "HybridKeySwitcher::apply_galois_range: input range of 1 (broadcast) or k items, output with room for k items");
     const FheParams& pe = impl_->ext->params();
     const size_t L = pe.n_limbs(), Ld = L - 1, n = pe.n(), key_words = Ld * 2 * L * n, ct_words = 2 * Ld * n;
     const PolyBuffer* keys = nullptr;
@@ -1031,8 +1038,9 @@ void HybridKeySwitcher::apply_galois_many(const Ciphertext& in2, const std::vect
         impl_->packed.emplace_back(elts, std::move(buf));
     }
     impl_->ensure_scratch(k);   // kept for the next call: no allocation and no host synchronisation on the steady path
-    check(dpfhe_rotate_hybrid_batch(static_cast<dpfhe_ctx*>(impl_->ext->handle()), out2.data() + out_first * ct_words, in2.data(), in2.batch(), elts.data(),
-                                    keys->data(), impl_->scratch_work->data(), impl_->scratch_rotated->data(), k, s), "dpfhe_rotate_hybrid_batch");
+    check(dpfhe_rotate_hybrid_batch(static_cast<dpfhe_ctx*>(impl_->ext->handle()), out2.data() + out_first * ct_words, in2.data() + in_first * ct_words,
+                                    broadcast ? 1 : k, elts.data(), keys->data(), impl_->scratch_work->data(), impl_->scratch_rotated->data(), k, s),
+          "dpfhe_rotate_hybrid_batch");
     out2.set_ntt(false);
 }
 
@@ -1136,88 +1144,167 @@ public:
     const Context* ctx = nullptr;
     const BatchEncoder* enc = nullptr;
     HybridKeySwitcher* ks = nullptr;
-    size_t d = 0, n1 = 0, n2 = 0;
-    std::unique_ptr<Plaintext> diag;   // [n2][n1] pre-rotated diagonals, NTT domain
-    std::vector<uint32_t> baby_elts, giant_elts;
-    std::unique_ptr<Ciphertext> babies, inner, tail, rotated;   // per-layer scratch, reused by every apply() (one caller at a time)
+    size_t out_dim = 0, in_dim = 0;
+    size_t n = 0;        // input period: the input vector repeats every n slots of a row (power of two >= in_dim)
+    size_t m = 0;        // diagonals per pass = output period (n, or the padded out_dim of a wide-input layer)
+    size_t copies = 0;   // independent n-slot windows per ciphertext = N / n
+    size_t blocks = 0;   // output row blocks of m rows
+    size_t passes = 0;   // output ciphertexts
+    bool replicate = false;   // one block: every window computes it (the output is again a periodic vector)
+    size_t n1 = 0, n2 = 0;
+    std::unique_ptr<Plaintext> diag;   // [passes][n2][n1] pre-rotated diagonals, NTT domain
+    std::vector<uint32_t> baby_elts, giant_elts, fold_elts;
+    std::unique_ptr<Ciphertext> babies, inner, rotated, fold;   // per-layer scratch, reused by every apply() (one caller at a time)
+
+    // which output row a slot of pass `pass` holds (or npos)
+    size_t row_of_slot(size_t pass, size_t slot) const {
+        const size_t row = enc->row_size(), r = slot % row, rho = slot / row;
+        const size_t c = r / n + rho * (row / n);
+        const size_t b = replicate || m < n ? 0 : pass * copies + c;
+        const size_t R = b * m + r % m;
+        return R < out_dim ? R : (size_t)-1;
+    }
 };
 
-PackedLinear::PackedLinear(const Context& ctx, const BatchEncoder& enc, HybridKeySwitcher& ks, const uint64_t* W, size_t d) : impl_(new Impl) {
+PackedLinear::PackedLinear(const Context& ctx, const BatchEncoder& enc, HybridKeySwitcher& ks, const uint64_t* W, size_t d)
+    : PackedLinear(ctx, enc, ks, W, d, d) {
+    if (d < 2 || (d & (d - 1))) throw Exception(ErrorCode::INVALID_ARGUMENT, "PackedLinear: d must be a power of two dividing N/2");
+}
+
+PackedLinear::PackedLinear(const Context& ctx, const BatchEncoder& enc, HybridKeySwitcher& ks, const uint64_t* W, size_t out_dim, size_t in_dim)
+    : impl_(new Impl) {
     const FheParams& p = ctx.params();
-    const size_t n = p.n(), L = p.n_limbs(), row = n / 2;
-    if (!W || d < 2 || (d & (d - 1)) || row % d) throw Exception(ErrorCode::INVALID_ARGUMENT, "PackedLinear: d must be a power of two dividing N/2");
-    if (enc.slot_count() != n) throw Exception(ErrorCode::INVALID_ARGUMENT, "PackedLinear: encoder and context disagree on N");
-    impl_->ctx = &ctx; impl_->enc = &enc; impl_->ks = &ks; impl_->d = d;
+    const size_t N = p.n(), L = p.n_limbs(), row = N / 2;
+    if (!W || out_dim == 0 || in_dim == 0) throw Exception(ErrorCode::INVALID_ARGUMENT, "PackedLinear: empty matrix");
+    if (enc.slot_count() != N) throw Exception(ErrorCode::INVALID_ARGUMENT, "PackedLinear: encoder and context disagree on N");
+    auto pow2 = [](size_t v) { size_t x = 1; while (x < v) x <<= 1; return x; };
+    Impl& I = *impl_;
+    I.ctx = &ctx; I.enc = &enc; I.ks = &ks; I.out_dim = out_dim; I.in_dim = in_dim;
+    I.n = pow2(in_dim) < 2 ? 2 : pow2(in_dim);
+    if (I.n > row) throw Exception(ErrorCode::INVALID_ARGUMENT, "PackedLinear: in_dim (padded to a power of two) must be <= N/2");
+    I.copies = N / I.n;
+    const size_t mo = pow2(out_dim) < 2 ? 2 : pow2(out_dim);
+    I.m = mo < I.n ? mo : I.n;                                  // wide-input layer: only m wrapped diagonals, folded afterwards
+    I.blocks = (out_dim + I.m - 1) / I.m;
+    I.replicate = I.blocks == 1;
+    I.passes = I.replicate ? 1 : (I.blocks + I.copies - 1) / I.copies;
     size_t n1 = 1;
-    while (n1 * n1 < d) n1 <<= 1;
-    impl_->n1 = n1; impl_->n2 = d / n1;
+    while (n1 * n1 < I.m) n1 <<= 1;
+    I.n1 = n1; I.n2 = I.m / n1;
     const uint64_t t = enc.plain_modulus();
-    for (size_t j = 1; j < impl_->n1; ++j) impl_->baby_elts.push_back(enc.galois_element((int)j));
-    for (size_t i = 1; i < impl_->n2; ++i) impl_->giant_elts.push_back(enc.galois_element((int)(i * n1)));
-    for (uint32_t g : impl_->baby_elts) ks.add_galois_element(g);
-    for (uint32_t g : impl_->giant_elts) ks.add_galois_element(g);
-    impl_->diag.reset(new Plaintext(ctx, impl_->n2 * n1, /*is_ntt=*/false));
-    std::vector<uint64_t> slots(n), host(n1 * L * n);
-    std::vector<int64_t> coeffs(n);
-    for (size_t i = 0; i < impl_->n2; ++i) {
-        for (size_t j = 0; j < n1; ++j) {
-            const size_t k = i * n1 + j;                 // diagonal index; stored rotated right by i*n1
-            for (size_t r = 0; r < row; ++r) {
-                const size_t rho = (r % d + d - (i * n1) % d) % d;
-                const uint64_t v = W[rho * d + (rho + k) % d];
-                if (v >= t) throw Exception(ErrorCode::INVALID_ARGUMENT, "PackedLinear: weight >= plaintext modulus");
-                slots[r] = slots[row + r] = v;
+    for (size_t j = 1; j < I.n1; ++j) I.baby_elts.push_back(enc.galois_element((int)j));
+    for (size_t i = 1; i < I.n2; ++i) I.giant_elts.push_back(enc.galois_element((int)(i * n1)));
+    for (size_t sft = I.m; sft < I.n; sft <<= 1) I.fold_elts.push_back(enc.galois_element((int)sft));
+    for (uint32_t g : I.baby_elts) ks.add_galois_element(g);
+    for (uint32_t g : I.giant_elts) ks.add_galois_element(g);
+    for (uint32_t g : I.fold_elts) ks.add_galois_element(g);
+    for (size_t i = 0; i < out_dim * in_dim; ++i)
+        if (W[i] >= t) throw Exception(ErrorCode::INVALID_ARGUMENT, "PackedLinear: weight >= plaintext modulus");
+
+    // Pre-rotated diagonals.  The product of giant step i lands on output slot r = r' - i n1 (row rotation), so position r' of
+    // diagonal (i, j) carries the weight of the output row that slot r holds and of input index (r + k) mod n, k = i n1 + j.
+    I.diag.reset(new Plaintext(ctx, I.passes * I.n2 * n1, /*is_ntt=*/false));
+    std::vector<uint64_t> slots(N), host(n1 * L * N);
+    std::vector<int64_t> coeffs(N);
+    for (size_t pass = 0; pass < I.passes; ++pass) {
+        for (size_t i = 0; i < I.n2; ++i) {
+            for (size_t j = 0; j < n1; ++j) {
+                const size_t k = i * n1 + j;
+                for (size_t rho = 0; rho < 2; ++rho)
+                    for (size_t rp = 0; rp < row; ++rp) {
+                        const size_t r = (rp + row - (i * n1) % row) % row;
+                        const size_t R = I.row_of_slot(pass, rho * row + r), col = (r + k) % I.n;
+                        slots[rho * row + rp] = (R != (size_t)-1 && col < in_dim) ? W[R * in_dim + col] : 0;
+                    }
+                enc.encode(slots.data(), coeffs.data());
+                for (size_t l = 0; l < L; ++l)
+                    for (size_t c = 0; c < N; ++c) host[(j * L + l) * N + c] = lift_signed(coeffs[c], p.moduli[l]);
             }
-            enc.encode(slots.data(), coeffs.data());
-            for (size_t l = 0; l < L; ++l)
-                for (size_t c = 0; c < n; ++c) host[(j * L + l) * n + c] = lift_signed(coeffs[c], p.moduli[l]);
+            hip_check(hipMemcpy(I.diag->data() + ((pass * I.n2 + i) * n1) * L * N, host.data(), host.size() * sizeof(uint64_t), hipMemcpyHostToDevice), "hipMemcpy H2D");
         }
-        hip_check(hipMemcpy(impl_->diag->data() + i * n1 * L * n, host.data(), host.size() * sizeof(uint64_t), hipMemcpyHostToDevice), "hipMemcpy H2D");
     }
     Evaluator ev(ctx);
-    ev.transform_to_ntt_inplace(*impl_->diag);
-    impl_->babies.reset(new Ciphertext(ctx, 2, n1));
-    impl_->inner.reset(new Ciphertext(ctx, 2, impl_->n2, /*is_ntt=*/true));
-    if (impl_->n2 > 1) {
-        impl_->tail.reset(new Ciphertext(ctx, 2, impl_->n2 - 1));
-        impl_->rotated.reset(new Ciphertext(ctx, 2, impl_->n2));
-    }
+    ev.transform_to_ntt_inplace(*I.diag);
+    I.babies.reset(new Ciphertext(ctx, 2, n1));
+    I.inner.reset(new Ciphertext(ctx, 2, I.passes * I.n2, /*is_ntt=*/true));
+    if (I.n2 > 1) I.rotated.reset(new Ciphertext(ctx, 2, I.passes * I.n2));
+    if (!I.fold_elts.empty()) I.fold.reset(new Ciphertext(ctx, 2, 2));
     ctx.synchronize();
 }
 PackedLinear::~PackedLinear() = default;
-size_t PackedLinear::dim() const { return impl_->d; }
+size_t PackedLinear::dim() const { return impl_->m; }
+size_t PackedLinear::in_dim() const { return impl_->in_dim; }
+size_t PackedLinear::out_dim() const { return impl_->out_dim; }
+size_t PackedLinear::input_period() const { return impl_->n; }
+size_t PackedLinear::output_ciphertexts() const { return impl_->passes; }
 size_t PackedLinear::baby_steps() const { return impl_->n1; }
 size_t PackedLinear::giant_steps() const { return impl_->n2; }
+size_t PackedLinear::key_switches_per_apply() const {
+    return impl_->baby_elts.size() + impl_->passes * impl_->giant_elts.size() + impl_->fold_elts.size();
+}
+
+void PackedLinear::pack_input(const uint64_t* x, uint64_t* slots) const {
+    const size_t N = impl_->enc->slot_count();
+    for (size_t s = 0; s < N; ++s) {
+        const size_t c = (s % (N / 2)) % impl_->n;
+        slots[s] = c < impl_->in_dim ? x[c] : 0;
+    }
+}
+void PackedLinear::unpack_output(const uint64_t* slots, uint64_t* y) const {
+    const size_t N = impl_->enc->slot_count();
+    std::vector<char> seen(impl_->out_dim, 0);
+    for (size_t pass = 0; pass < impl_->passes; ++pass)
+        for (size_t s = 0; s < N; ++s) {
+            const size_t R = impl_->row_of_slot(pass, s);
+            if (R != (size_t)-1 && !seen[R]) { y[R] = slots[pass * N + s]; seen[R] = 1; }
+        }
+}
 
 void PackedLinear::apply(const Ciphertext& x, Ciphertext& y, Stream* s) const {
-    if (x.is_ntt() || x.size() != 2 || x.batch() != 1 || y.size() != 2 || y.batch() != 1)
-        throw Exception(ErrorCode::INVALID_ARGUMENT, "PackedLinear::apply: one 2-component coefficient-domain ciphertext in and out");
-    const Context& ctx = *impl_->ctx;
+    const Impl& I = *impl_;
+    if (x.is_ntt() || x.size() != 2 || x.batch() != 1 || y.size() != 2 || y.batch() != I.passes)
+        throw Exception(ErrorCode::INVALID_ARGUMENT, "PackedLinear::apply: one 2-component coefficient-domain ciphertext in, output_ciphertexts() out");
+    const Context& ctx = *I.ctx;
     const FheParams& p = ctx.params();
-    const size_t ct_words = 2 * p.n_limbs() * p.n(), n1 = impl_->n1, n2 = impl_->n2;
+    const size_t ct_words = 2 * p.n_limbs() * p.n(), n1 = I.n1, n2 = I.n2;
     hipStream_t hs = static_cast<hipStream_t>(s);
+    dpfhe_ctx* h = static_cast<dpfhe_ctx*>(ctx.handle());
     Evaluator ev(ctx);
-    // baby steps: rot_j(x), j < n1, in ONE batched rotation pass, then transformed together
-    Ciphertext& babies = *impl_->babies;
-    Ciphertext& inner = *impl_->inner;
+    // baby steps: rot_j(x), j < n1, in ONE batched rotation pass, then transformed together - shared by every output block
+    Ciphertext& babies = *I.babies;
+    Ciphertext& inner = *I.inner;
     babies.set_ntt(false);
     hip_check(hipMemcpyAsync(babies.data(), x.data(), ct_words * sizeof(uint64_t), hipMemcpyDeviceToDevice, hs), "hipMemcpyAsync");
-    impl_->ks->apply_galois_many(x, impl_->baby_elts, babies, /*out_first=*/1, s);
+    I.ks->apply_galois_many(x, I.baby_elts, babies, /*out_first=*/1, s);
     ev.transform_to_ntt_inplace(babies, s);
-    // inner sums of all giant steps: one matrix-vector product over the pre-rotated diagonals
+    // inner sums of all giant steps of all passes: ONE matrix-vector product over the pre-rotated diagonals
     inner.set_ntt(true);
-    ev.matvec_plain(*impl_->diag, babies, inner, s);
+    ev.matvec_plain(*I.diag, babies, inner, s);
     ev.transform_from_ntt_inplace(inner, s);
-    // giant steps: inner sum i rotated by i*n1 (one batched pass over items 1..n2-1), then the sum over i
+    // giant steps: inner sum (pass, i) rotated by i*n1 (one batched rotation pass per output ciphertext), then the sum over i
+    Ciphertext* sums = &y;
+    if (!I.fold_elts.empty()) sums = I.fold.get();     // wide-input layer: the block sum is folded below before it becomes y
     if (n2 > 1) {
-        Ciphertext& tail = *impl_->tail;
-        Ciphertext& rotated = *impl_->rotated;
-        hip_check(hipMemcpyAsync(tail.data(), inner.data() + ct_words, (n2 - 1) * ct_words * sizeof(uint64_t), hipMemcpyDeviceToDevice, hs), "hipMemcpyAsync");
-        hip_check(hipMemcpyAsync(rotated.data(), inner.data(), ct_words * sizeof(uint64_t), hipMemcpyDeviceToDevice, hs), "hipMemcpyAsync");
-        impl_->ks->apply_galois_many(tail, impl_->giant_elts, rotated, /*out_first=*/1, s);
-        ev.reduce_sum(rotated, y, s);
+        Ciphertext& rotated = *I.rotated;
+        for (size_t pass = 0; pass < I.passes; ++pass) {
+            hip_check(hipMemcpyAsync(rotated.data() + pass * n2 * ct_words, inner.data() + pass * n2 * ct_words, ct_words * sizeof(uint64_t), hipMemcpyDeviceToDevice, hs),
+                      "hipMemcpyAsync");
+            I.ks->apply_galois_range(inner, pass * n2 + 1, false, I.giant_elts, rotated, pass * n2 + 1, s);
+            check(dpfhe_reduce_sum(h, sums->data() + pass * ct_words, rotated.data() + pass * n2 * ct_words, n2, 2, s), "dpfhe_reduce_sum");
+        }
     } else {
-        hip_check(hipMemcpyAsync(y.data(), inner.data(), ct_words * sizeof(uint64_t), hipMemcpyDeviceToDevice, hs), "hipMemcpyAsync");
+        hip_check(hipMemcpyAsync(sums->data(), inner.data(), I.passes * ct_words * sizeof(uint64_t), hipMemcpyDeviceToDevice, hs), "hipMemcpyAsync");
+    }
+    // wide input (m < n): slot r holds the partial sum over input indices congruent to r + k; fold the n/m windows together
+    if (!I.fold_elts.empty()) {
+        Ciphertext& f = *I.fold;   // item 0: running sum, item 1: its rotation
+        f.set_ntt(false);
+        for (size_t e = 0; e < I.fold_elts.size(); ++e) {
+            const std::vector<uint32_t> one(1, I.fold_elts[e]);
+            I.ks->apply_galois_range(f, 0, false, one, f, 1, s);
+            const bool last = e + 1 == I.fold_elts.size();
+            check(dpfhe_add(h, last ? y.data() : f.data(), f.data(), f.data() + ct_words, 2, s), "dpfhe_add");
+        }
     }
     y.set_ntt(false);
     // enqueue only: the scratch belongs to the layer, the caller synchronises (Context::synchronize) before reading y

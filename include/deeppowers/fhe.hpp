@@ -318,6 +318,10 @@ public:
     // back to back once and cached.
     void apply_galois_many(const Ciphertext& in2, const std::vector<uint32_t>& galois_elts, Ciphertext& out2, size_t out_first = 0,
                            Stream* stream = nullptr) const;
+    // same on item ranges: out item out_first + i = sigma_{elts[i]} of in item in_first + i (or of in item in_first when `broadcast`).
+    // `in2` and `out2` may be the same buffer as long as the two ranges do not overlap.
+    void apply_galois_range(const Ciphertext& in2, size_t in_first, bool broadcast, const std::vector<uint32_t>& galois_elts, Ciphertext& out2,
+                            size_t out_first, Stream* stream = nullptr) const;
 
 private:
     class Impl;
@@ -346,25 +350,46 @@ private:
     std::unique_ptr<Impl> impl_;
 };
 
-// PackedLinear: encrypted y = W x over Z_t for a d x d matrix in slot packing (d a power of two dividing N/2; the
-// vector sits in both rows, repeated N/2/d times), by the diagonal method with baby-step / giant-step rotations:
-//   y = sum_i rot_{i n1}( sum_j rot_{-i n1}(diag_{i n1 + j}) (.) rot_j(x) ),   diag_k[r] = W[r][(r + k) mod d],  n1 n2 = d.
-// Per application: n1 - 1 + n2 - 1 rotations (automorphism + hybrid key switch, `relin_kernel` MODE 3), one batched
-// forward NTT of the n1 rotated inputs, ONE dpfhe_matvec_plain over the n2 x n1 pre-transformed diagonals, one batched
-// inverse NTT.  This is the encrypted replacement of the dense layers at the reference's matmul sites
-// (/root/reference/src/core/execution/models/gpt_model.cpp:793,848,883) for a single token.
+// PackedLinear: encrypted y = W x over Z_t for an out_dim x in_dim matrix in slot packing - the encrypted replacement of the
+// dense layers at the reference's matmul sites for a single token (/root/reference/src/core/execution/models/gpt_model.cpp:793
+// QKV 768 -> 2304, :848 FFN 768 -> 3072 -> 768, :883 LM head 768 -> 50257; dims /root/reference/src/core/execution/model.hpp:47-50).
+//
+// Input packing: the vector repeats with period n = 2^ceil(log2 in_dim) along both slot rows (pack_input), so a ciphertext
+// holds N / n identical windows.  Diagonal method with baby-step / giant-step rotations over m diagonals:
+//   sum_i rot_{i n1}( sum_j rot_{-i n1}(diag_{i n1 + j}) (.) rot_j(x) ),   n1 n2 = m,
+//   * out_dim >= n  (m = n): every window computes a DIFFERENT block of n output rows, so one ciphertext delivers N outputs and
+//     ceil(out_dim / N) output ciphertexts share the n1 - 1 baby-step rotations; each costs n2 - 1 giant-step rotations;
+//   * out_dim <  n  (m = 2^ceil(log2 out_dim)): only the m wrapped diagonals diag_k[r] = W[r mod m][(r + k) mod n] are used and the
+//     n / m partial sums are folded with log2(n / m) more rotations; the result repeats with period m (it is a valid input
+//     of the next layer);
+//   * one block (out_dim <= m = n): every window computes the same block, the result repeats with period n.
+// Per application: ONE batched rotation pass for the baby steps (automorphism + hybrid key switch, `relin_kernel` MODE 3), one
+// batched forward NTT, ONE dpfhe_matvec_plain over all pre-transformed diagonals of all output ciphertexts, one batched inverse
+// NTT, one batched rotation pass + one reduce_sum per output ciphertext.
 class PackedLinear {
 public:
-    // W: d*d values < t, row-major.  The needed Galois keys are added to `ks`.
+    // W: out_dim * in_dim values < t, row-major.  The needed Galois keys are added to `ks`.
+    PackedLinear(const Context& data_ctx, const BatchEncoder& enc, HybridKeySwitcher& ks, const uint64_t* W, size_t out_dim, size_t in_dim);
+    // square d x d (d a power of two dividing N/2)
     PackedLinear(const Context& data_ctx, const BatchEncoder& enc, HybridKeySwitcher& ks, const uint64_t* W, size_t d);
     ~PackedLinear();
     PackedLinear(const PackedLinear&) = delete;
     PackedLinear& operator=(const PackedLinear&) = delete;
-    size_t dim() const;
+    size_t dim() const;                 // m: diagonals per output ciphertext
+    size_t in_dim() const;
+    size_t out_dim() const;
+    size_t input_period() const;        // n
+    size_t output_ciphertexts() const;  // batch of y
     size_t baby_steps() const;
     size_t giant_steps() const;
-    // 1-item, 2-component, coefficient domain.  Enqueues on `stream` and returns (no allocation, no host synchronisation: the
-    // scratch belongs to the layer, so one apply() at a time per object); synchronise before reading y on the host.
+    size_t key_switches_per_apply() const;
+    // slot vectors (N values each) <-> plain vectors: x (in_dim values) -> the N slots to encode and encrypt;
+    // output_ciphertexts() * N decoded slots -> y (out_dim values)
+    void pack_input(const uint64_t* x, uint64_t* slots) const;
+    void unpack_output(const uint64_t* slots, uint64_t* y) const;
+    // x: 1 item, y: output_ciphertexts() items; 2 components, coefficient domain.  Enqueues on `stream` and returns (no allocation,
+    // no host synchronisation: the scratch belongs to the layer, so one apply() at a time per object); synchronise before
+    // reading y on the host.
     void apply(const Ciphertext& x, Ciphertext& y, Stream* stream = nullptr) const;
 
 private:

@@ -150,6 +150,57 @@ static void large_ring() {
     orc_ctx_destroy(orc);
 }
 
+// N3: rectangular packed layers (row blocks in the windows of one ciphertext, several output ciphertexts, wrapped diagonals +
+// folding for wide inputs) against plain modular arithmetic, at a small ring so that every case takes well under a second
+static void packed_rect(unsigned log2n) {
+    FheParams p = FheParams::n8192_l6();
+    const size_t n = (size_t)1 << log2n;
+    const uint64_t special = p.moduli.back();
+    auto pw = [](uint64_t b, uint64_t e, uint64_t q) { uint64_t r = 1; for (b %= q; e; e >>= 1) { if (e & 1) r = (uint64_t)((unsigned __int128)r * b % q); b = (uint64_t)((unsigned __int128)b * b % q); } return r; };
+    for (size_t l = 0; l < p.moduli.size(); ++l) p.psi[l] = pw(p.psi[l], 8192 / n, p.moduli[l]);
+    const uint64_t special_psi = p.psi.back();
+    p.log2_n = log2n; p.moduli.pop_back(); p.psi.pop_back();
+    Context ctx(p, 0);
+    KeyGenerator kg(ctx, TestSeed{31});
+    Encryptor enc(ctx, kg.secret_key(), TestSeed{32});
+    Decryptor dec(ctx, kg.secret_key());
+    BatchEncoder be(ctx, 65537);
+    const uint64_t t = be.plain_modulus();
+    HybridKeySwitcher hks(ctx, kg.secret_key(), special, special_psi, TestSeed{33});
+    uint64_t s = 17;
+    auto rnd = [&]() { s = s * 6364136223846793005ull + 1442695040888963407ull; return (s >> 33) % t; };
+    // (out, in): blocks sharing one ciphertext | ragged sizes | more blocks than windows (2 outputs) | one block | wide input
+    // with folding | wide input, ragged | single-row output
+    const size_t shapes[][2] = {{96, 32}, {77, 24}, {n + 40, 16}, {20, 32}, {16, 128}, {12, 100}, {1, 64}, {n / 2, n / 2}};
+    for (auto& sh : shapes) {
+        const size_t out = sh[0], in = sh[1];
+        std::vector<uint64_t> W(out * in), x(in), want(out), slots(n);
+        for (auto& v : W) v = rnd();
+        for (auto& v : x) v = rnd();
+        for (size_t r = 0; r < out; ++r) {
+            unsigned __int128 acc = 0;
+            for (size_t c = 0; c < in; ++c) acc += (unsigned __int128)W[r * in + c] * x[c];
+            want[r] = (uint64_t)(acc % t);
+        }
+        PackedLinear lin(ctx, be, hks, W.data(), out, in);
+        const size_t outs = lin.output_ciphertexts();
+        CHECK(lin.baby_steps() * lin.giant_steps() == lin.dim());
+        std::vector<int64_t> cx(n);
+        lin.pack_input(x.data(), slots.data());
+        be.encode(slots.data(), cx.data());
+        Ciphertext ct(ctx, 2, 1), cy(ctx, 2, outs);
+        enc.encrypt_exact(cx.data(), t, ct);
+        lin.apply(ct, cy);
+        lin.apply(ct, cy);           // scratch reuse: a second application gives the same answer
+        ctx.synchronize();
+        std::vector<uint64_t> dm(outs * n), got(outs * n), y(out);
+        dec.decrypt_exact(cy, t, dm.data());
+        for (size_t o = 0; o < outs; ++o) be.decode(dm.data() + o * n, got.data() + o * n);
+        lin.unpack_output(got.data(), y.data());
+        CHECK(y == want);
+    }
+}
+
 // default-constructed key material must come from the OS CSPRNG - two generators never agree, two encryptions
 // of one message never agree, errors are small and centred, and everything still decrypts.
 static void os_randomness(const FheParams& p) {
@@ -390,6 +441,7 @@ int main() {
     try {
         packed(10, 64);
         packed(12, 16);
+        packed_rect(10);
         large_ring();
         end_to_end(FheParams::n4096_l4(), 2);
         os_randomness(FheParams::n4096_l4());

@@ -43,10 +43,20 @@ def test_example_encrypted_linear_layer():
 
 
 @pytest.mark.gpu
-def test_example_encrypted_gpt2_linear_layer():
-    """N3: slot-packed 256 x 256 layer at N=8192 (the full 1024 x 1024 run is the example's default)"""
-    out = subprocess.run([build_example("encrypted_gpt2_linear"), "256", "1"], capture_output=True, text=True, timeout=900)
-    assert out.returncode == 0 and "OK" in out.stdout, out.stdout + out.stderr
+@pytest.mark.parametrize("layer", ["qkv", "ffn_up", "ffn_down", "square"])
+def test_example_encrypted_gpt2_layers_full_size(layer):
+    """N3 at the reference's real shapes (gpt_model.cpp:793 QKV 768 -> 2304, :848 FFN 768 -> 3072 -> 768; attention output
+    768 -> 768): N=8192, 5 data limbs + special prime; the decrypted, unpacked result must equal W x mod t in every output."""
+    out = subprocess.run([build_example("encrypted_gpt2_linear"), layer, "1"], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0 and "OK" in out.stdout and "MISMATCH" not in out.stdout, out.stdout + out.stderr
+
+
+@pytest.mark.gpu
+def test_example_encrypted_gpt2_lm_head_tile():
+    """gpt_model.cpp:883 logits: 768 -> 50257 is 7 output ciphertexts sharing the baby steps; a 3-ciphertext tile (768 -> 20000)
+    runs here, the full head in examples/encrypted_gpt2_linear lm_head (2.3 GB of diagonals, ~1 min of host-side encoding)."""
+    out = subprocess.run([build_example("encrypted_gpt2_linear"), "20000x768", "1"], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0 and "OK" in out.stdout and "3 output ciphertext" in out.stdout, out.stdout + out.stderr
 
 
 @pytest.mark.gpu
