@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 
 #include "devtables.h"
+#include "launch.h"
 #include "ntt_core.h"
 #include "ntt_top.h"
 
@@ -30,13 +31,21 @@ __device__ __forceinline__ void wave_sync() {
 // the wave's own region, the last exchange writes the own region and reads every region after the chain's single
 // barrier; a caller running two inverse chains back to back places one lds_barrier() between them (the second chain's
 // wave-local writes would otherwise overwrite words other waves are still reading).
-template <class G, int P>
+// (Geometries with 8 words per thread at N >= 8192 have a second exchange that crosses waves; it is bracketed by barriers.)
+template <class G, int X, bool FWD>
 __device__ __forceinline__ void exch_sync_before_write() {
-    if constexpr (G::exch_wave_local(P)) wave_sync();
+    if constexpr (G::exch_wave_local(X)) {
+        wave_sync();
+    } else {
+        // forward: exchange 0 opens the chain (the caller vouches for the buffer); inverse: the first cross-wave exchange met
+        // (the highest index) is WRITTEN inside the wave's own region; any further cross-wave exchange must wait for the readers
+        constexpr bool first = FWD ? X == 0 : G::highest_cross_wave_exchange() == X;
+        if constexpr (!first) lds_barrier();
+    }
 }
-template <class G, int P>
+template <class G, int X>
 __device__ __forceinline__ void exch_sync_after_write() {
-    if constexpr (G::exch_wave_local(P)) wave_sync(); else lds_barrier();
+    if constexpr (G::exch_wave_local(X)) wave_sync(); else lds_barrier();
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -60,7 +69,7 @@ struct FwdChain {
             TwRegs nxt;
             B::template load_tw<P + 1, true>(tid, tw, nxt);
             B::template fwd_phase_r<P>(x, twr, lc);
-            exch_sync_before_write<typename B::G, P>();
+            exch_sync_before_write<typename B::G, P, true>();
             B::template lds_write<P, P, true>(tid, x, lds);
             exch_sync_after_write<typename B::G, P>();
             B::template lds_read<P, P + 1, true>(tid, x, lds);
@@ -75,8 +84,7 @@ struct FwdChain {
         if constexpr (P + 1 < B::NPH) {
             TwRegs nxt;
             B::template load_tw<P + 1, true>(tid, tw, nxt);
-            static_assert(P == 0 || B::G::exch_wave_local(P), "only the first forward exchange may cross waves");
-            exch_sync_before_write<typename B::G, P>();
+            exch_sync_before_write<typename B::G, P, true>();
             B::template lds_write<P, P, true>(tid, x, lds);
             exch_sync_after_write<typename B::G, P>();
             B::template lds_read<P, P + 1, true>(tid, x, lds);
@@ -100,8 +108,7 @@ struct InvChain {
         if constexpr (P > 0) {
             TwRegs nxt;
             B::template load_tw<P - 1, false>(tid, tw, nxt);
-            static_assert(P - 1 == 0 || B::G::exch_wave_local(P - 1), "only the last inverse exchange may cross waves");
-            exch_sync_before_write<typename B::G, P - 1>();    // all-to-all: writes the wave's OWN region - nothing to wait for
+            exch_sync_before_write<typename B::G, P - 1, false>();    // first cross-wave exchange: writes the wave's OWN region
             B::template lds_write<P - 1, P, false>(tid, x, lds);
             exch_sync_after_write<typename B::G, P - 1>();
             B::template lds_read<P - 1, P - 1, false>(tid, x, lds);
@@ -166,10 +173,10 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE)) void ntt_inv_kernel(u64* __rest
 //   [forward, forward, inverse].  HBM traffic: 4 reads + 3 writes of a residue poly.
 // ------------------------------------------------------------------------------------------------
 template <class Arith, int LOGN, int LOGE, bool IN_NTT, bool OUT_NTT>
-__global__ __launch_bounds__(1 << (LOGN - LOGE), 2) void ct_mul_kernel(u64* __restrict__ out3, const u64* __restrict__ a2,
+__global__ __launch_bounds__(1 << (LOGN - LOGE), (LOGE <= 3 && LOGN - LOGE <= 9) ? 4 : 2) void ct_mul_kernel(u64* __restrict__ out3, const u64* __restrict__ a2,
                                                                         const u64* __restrict__ b2, DevTables<Arith> tb) {
     typedef NttBody<Arith, LOGN, LOGE> B;
-    static_assert(LOGE == 4, "the fused kernels read the LOGE = 4 twiddle layout (DevTables::fwd4 / inv4)");
+    static_assert(LOGE == kFusedLoge, "the fused kernels read the fused twiddle layout (DevTables::fwd4 / inv4)");
     constexpr int E = B::E, N = B::G::N;
     __shared__ __attribute__((aligned(16))) u64 lds[(IN_NTT && OUT_NTT) ? 16 : B::G::lds_words()];
     int tid = threadIdx.x;
@@ -197,7 +204,7 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE), 2) void ct_mul_kernel(u64* __re
     const typename B::Tw* const twi = tb.inv4 + (size_t)limb * N;
     auto forward = [&](u64 (&x)[E], const u64* src, bool reduce_out, bool first) {
         if (IN_NTT) { B::load_bot(tid, x, src); return; }
-        B::load_top(tid, x, src);
+        B::template load_top<true>(tid, x, src);   // streamed once: non-temporal
         if (!first) lds_barrier();
 #ifndef DPFHE_FUSED_EARLY_TW
 #define DPFHE_FUSED_EARLY_TW 0
@@ -267,7 +274,7 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE), 2) void ct_mul_kernel(u64* __re
             if (IN_NTT ? round > 0 : round == 2) lds_barrier();
             InvChain<B, B::NPH - 1, kInvIn>::run_with(tid, x, lds, twi, last, lc, tw_first);
             B::inv_canon(x, lc);
-            B::store_top(tid, x, d);
+            B::template store_top<true>(tid, x, d);
         }
     }
 }
@@ -297,7 +304,7 @@ template <class Arith, int LOGN, int LOGE, int MODE>
 __global__ __launch_bounds__(1 << (LOGN - LOGE), (Arith::kFold ? 2 : 1)) void relin_kernel(u64* __restrict__ out2, const u64* __restrict__ in3,
                                                                        const u64* __restrict__ evk, size_t key_stride, DevTables<Arith> tb) {
     typedef NttBody<Arith, LOGN, LOGE> B;
-    static_assert(LOGE == 4, "the fused kernels read the LOGE = 4 twiddle layout (DevTables::fwd4 / inv4)");
+    static_assert(LOGE == kFusedLoge, "the fused kernels read the fused twiddle layout (DevTables::fwd4 / inv4)");
     constexpr int E = B::E, N = B::G::N;
     __shared__ __attribute__((aligned(16))) u64 lds[B::G::lds_words()];
     int tid = threadIdx.x;

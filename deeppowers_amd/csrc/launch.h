@@ -18,7 +18,10 @@ constexpr int kMaxLog2N = 16, kMaxFusedLog2N = 13;
 // N > 16384: split transform - log2(N1) top stages in ntt_top_kernel, then N1 transforms of N2 = 4096 points each
 constexpr int kSplitLog2N2 = 12;
 constexpr int split_log_n1(int log2n) { return log2n > 14 ? log2n - kSplitLog2N2 : 0; }
-constexpr int kFusedLoge = 4;
+#ifndef DPFHE_FUSED_LOGE
+#define DPFHE_FUSED_LOGE 4   // words-per-thread exponent of the fused kernels (tools/ab_variant.sh builds -DDPFHE_FUSED_LOGE=3 for A/B runs)
+#endif
+constexpr int kFusedLoge = DPFHE_FUSED_LOGE;
 
 // return 0, or -1 when log2n has no compiled geometry.  Launch errors are left in hipGetLastError().
 template <class Arith>

@@ -59,7 +59,7 @@ template <class Arith, bool IN_NTT, bool OUT_NTT>
 static int launch_ct_mul_dom(int log2n, u64* out3, const u64* a2, const u64* b2, size_t blocks, const DevTables<Arith>& tb, hipStream_t s) {
     // the fused kernel keeps up to four transformed polynomials in registers: always E = 16 words per thread
 #define CT_CASE(LN, LE) \
-    hipLaunchKernelGGL((ct_mul_kernel<Arith, LN, 4, IN_NTT, OUT_NTT>), dim3((unsigned)blocks), dim3(Geo<LN, 4>::T), 0, s, out3, a2, b2, tb)
+    hipLaunchKernelGGL((ct_mul_kernel<Arith, LN, kFusedLoge, IN_NTT, OUT_NTT>), dim3((unsigned)blocks), dim3(Geo<LN, kFusedLoge>::T), 0, s, out3, a2, b2, tb)
     DPFHE_GEO_SWITCH(log2n, CT_CASE)
 #undef CT_CASE
     return 0;
@@ -77,7 +77,7 @@ int launch_ct_mul(int log2n, unsigned flags, u64* out3, const u64* a2, const u64
 
 template <class Arith>
 int launch_relin(int log2n, int mode, u64* out2, const u64* in3, const u64* evk, size_t key_stride, size_t blocks, const DevTables<Arith>& tb, hipStream_t s) {
-#define RL_ONE(LN, M) hipLaunchKernelGGL((relin_kernel<Arith, LN, 4, M>), dim3((unsigned)blocks), dim3(Geo<LN, 4>::T), 0, s, out2, in3, evk, key_stride, tb)
+#define RL_ONE(LN, M) hipLaunchKernelGGL((relin_kernel<Arith, LN, kFusedLoge, M>), dim3((unsigned)blocks), dim3(Geo<LN, kFusedLoge>::T), 0, s, out2, in3, evk, key_stride, tb)
 #define RL_CASE(LN, LE)                \
     if (mode == 0) RL_ONE(LN, 0);      \
     else if (mode == 1) RL_ONE(LN, 1); \

@@ -90,6 +90,11 @@ struct Geo {
     static constexpr int LOGW = 6 + LOGE, kWaveWords = 1 << LOGW;
     static constexpr int kWaves = T >= 64 ? T / 64 : 1;
     static constexpr bool exch_wave_local(int p) { return T <= 64 || phase(p).c <= 6; }   // exchange between phases p and p + 1
+    static constexpr int highest_cross_wave_exchange() {
+        int h = -1;
+        for (int p = 0; p + 1 < NPH; ++p) if (!exch_wave_local(p)) h = p;
+        return h;
+    }
     // Padding inside a wave's region.  Bijective for any choice (monotone); chosen so that both access patterns of the
     // N=4096 / N=8192 kernels are bank-conflict free:
     //  * window 0 side: a thread touches E consecutive words with 16-byte accesses; a lane stride of
@@ -280,15 +285,34 @@ struct NttBody {
 #endif
         return b;
     }
+    // NT: non-temporal accesses for data that is read once and written once and does not fit the 256 MiB Infinity Cache (the
+    // fused multiply's 5 GiB working set: -2.4 %).  The batched NTT kernels keep plain accesses: at BASELINE configs[1]'s
+    // 128 MiB + 128 MiB the cache holds the stream and non-temporal accesses measured 6 % slower.
+    template <bool NT, class V>
+    static DPF_HD V ld_stream(const V* p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        if (NT) return __builtin_nontemporal_load(p);
+#endif
+        return *p;
+    }
+    template <bool NT, class V>
+    static DPF_HD void st_stream(V* p, V v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        if (NT) { __builtin_nontemporal_store(v, p); return; }
+#endif
+        *p = v;
+    }
+    template <bool NT = false>
     static DPF_HD void load_top(int tid, u64 (&x)[E], const u64* g) {
         constexpr int kReach = 4096 / (T * 8) > 0 ? 4096 / (T * 8) : 1;
 #pragma clang loop unroll(full)
-        for (int k = 0; k < E; ++k) x[k] = (g + row_base(k))[(unsigned)((k % kReach) * T) + (unsigned)tid];
+        for (int k = 0; k < E; ++k) x[k] = ld_stream<NT>(&(g + row_base(k))[(unsigned)((k % kReach) * T) + (unsigned)tid]);
     }
+    template <bool NT = false>
     static DPF_HD void store_top(int tid, const u64 (&x)[E], u64* g) {
         constexpr int kReach = 4096 / (T * 8) > 0 ? 4096 / (T * 8) : 1;
 #pragma clang loop unroll(full)
-        for (int k = 0; k < E; ++k) (g + row_base(k))[(unsigned)((k % kReach) * T) + (unsigned)tid] = x[k];
+        for (int k = 0; k < E; ++k) st_stream<NT>(&(g + row_base(k))[(unsigned)((k % kReach) * T) + (unsigned)tid], x[k]);
     }
     // window-0 mapping (forward output / inverse input): thread owns words [tid*E, tid*E + E)
     struct alignas(16) V2 {

@@ -111,8 +111,10 @@ static int check_exchanges() {
                         if (!own) return -1;
                         if (pass == 0) owner_w[a] = w; else if (owner_w[a] != w) return -1;
                     } else {
-                        if (fwd && pass == 1 && !own) return -2;     // forward all-to-all: reads stay in the own region
-                        if (!fwd && pass == 0 && !own) return -2;    // inverse all-to-all: writes stay in the own region
+                        // forward: the LAST cross-wave exchange is read inside the own region (the wave-local exchanges that follow
+                        // need no barrier); inverse: the FIRST one met (highest index) is written inside the own region
+                        if (fwd && pass == 1 && !own && P == B::G::highest_cross_wave_exchange()) return -2;
+                        if (!fwd && pass == 0 && !own && P == B::G::highest_cross_wave_exchange()) return -2;
                         if (pass == 0) owner_w[a] = w; else if (owner_w[a] < 0) return -3;   // every word read was written
                     }
                 }
@@ -127,8 +129,8 @@ template <int LOGN, int LOGE>
 static int check_geo() {
     typedef NttBody<FoldArith, LOGN, LOGE> B;
     if constexpr (B::NPH >= 2) {
-        // only the first exchange may cross waves (the chains in kernels.h static_assert the same)
-        for (int p = 1; p + 1 < B::NPH; ++p) if (!B::G::exch_wave_local(p)) return -4;
+        // cross-wave exchanges come first (forward order): everything after the last of them stays inside a wave
+        for (int p = 0; p + 1 < B::NPH; ++p) if (!B::G::exch_wave_local(p) && p > B::G::highest_cross_wave_exchange()) return -4;
         // the kLdsIO rows of a wave lie in its region
         for (int tid = 0; tid < B::T; ++tid) {
             const int r = B::G::lds_row(tid), w = tid / 64;
