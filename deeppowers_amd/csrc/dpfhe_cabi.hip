@@ -438,6 +438,68 @@ extern "C" int dpfhe_rotate_hybrid_batch(dpfhe_ctx* c, uint64_t* d_out2, const u
     return hybrid_entry(c, what, 2, d_out2, d_rotated, d_keys, d_work, batch, stream, key_words);
 }
 
+// N3, hoisted: `batch` rotations of ONE ciphertext; the digit decomposition of c1 and its Ld*L forward transforms are done once
+// (d_digits), every rotation is a permutation of those words in the NTT domain + its key inner product + two inverse transforms
+extern "C" int dpfhe_rotate_hybrid_hoisted(dpfhe_ctx* c, uint64_t* d_out2, const uint64_t* d_in2, const uint32_t* galois_elts, const uint64_t* d_keys,
+                                           uint64_t* d_work, uint64_t* d_rotated0, uint64_t* d_digits, size_t batch, void* stream) {
+    const char* what = "dpfhe_rotate_hybrid_hoisted";
+    if (!c) return fail(DPFHE_INVALID_ARGUMENT, what, "null context");
+    if (c->n_limbs < 2) return fail(DPFHE_INVALID_STATE, what, "the extended context needs at least one data limb and the special prime");
+    if (c->log2n > (uint32_t)kMaxFusedLog2N) return fail(DPFHE_INVALID_STATE, what, "no fused kernel geometry for this log2_n");
+    if (batch == 0) return DPFHE_SUCCESS;
+    if (!d_out2 || !d_in2 || !galois_elts || !d_keys || !d_work || !d_rotated0 || !d_digits || misaligned(d_out2) || misaligned(d_in2) || misaligned(d_keys) ||
+        misaligned(d_work) || misaligned(d_rotated0) || misaligned(d_digits))
+        return fail(DPFHE_INVALID_ARGUMENT, what, "null or misaligned buffer");
+    const size_t L = c->n_limbs, Ld = L - 1;
+    const int n = 1 << c->log2n;
+    const unsigned two_n = 2u << c->log2n;
+    for (size_t i = 0; i < batch; ++i)
+        if (!(galois_elts[i] & 1u) || galois_elts[i] >= two_n) return fail(DPFHE_INVALID_ARGUMENT, what, "galois elements must be odd and < 2N");
+    const size_t in_words = 2 * Ld * (size_t)n, out_words = batch * 2 * Ld * n, work_words = batch * 2 * L * n, rot_words = batch * Ld * n, dig_words = Ld * L * (size_t)n;
+    if (overlaps(d_out2, out_words, d_in2, in_words) || overlaps(d_out2, out_words, d_work, work_words) || overlaps(d_out2, out_words, d_rotated0, rot_words) ||
+        overlaps(d_work, work_words, d_rotated0, rot_words) || overlaps(d_digits, dig_words, d_work, work_words) || overlaps(d_digits, dig_words, d_out2, out_words) ||
+        overlaps(d_digits, dig_words, d_rotated0, rot_words) || overlaps(d_digits, dig_words, d_in2, in_words) || overlaps(d_rotated0, rot_words, d_in2, in_words))
+        return fail(DPFHE_INVALID_ARGUMENT, what, "buffers must not overlap");
+    const size_t key_words = Ld * 2 * L * (size_t)n;
+    const int chunks = (n + 511) / 512;
+    if (batch * 2 * Ld * (size_t)chunks > kMaxGrid || batch * L * 2 > kMaxGrid) return fail(DPFHE_INVALID_ARGUMENT, what, "batch too large for one launch");
+    const LimbConst* lc = c->fold ? c->foldt.lc : c->shoup.lc;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    DPFHE_ON_DEVICE(c, what);
+    // 1. digits of c1, lifted to every limb, then transformed (Ld RNS polynomials on the extended context)
+    const uint64_t* c1 = d_in2 + Ld * (size_t)n;
+    const unsigned lift_grid = (unsigned)(Ld * L * (size_t)chunks);
+    if (c->fold) hipLaunchKernelGGL((lift_digits_kernel<FoldArith>), dim3(lift_grid), dim3(256), 0, s, d_digits, c1, lc, (int)L, n, chunks);
+    else hipLaunchKernelGGL((lift_digits_kernel<ShoupArith>), dim3(lift_grid), dim3(256), 0, s, d_digits, c1, lc, (int)L, n, chunks);
+    if (int e = check_launch("lift_digits kernel launch")) return e;
+    {
+        const int rc = c->fold ? launch_ntt<FoldArith>((int)c->log2n, false, d_digits, d_digits, Ld * L, c->foldt, s)
+                               : launch_ntt<ShoupArith>((int)c->log2n, false, d_digits, d_digits, Ld * L, c->shoup, s);
+        if (rc) return fail(DPFHE_INVALID_STATE, what, "no kernel geometry for this log2_n");
+        if (int e = check_launch("digit NTT launch")) return e;
+    }
+    for (size_t first = 0; first < batch; first += kMaxGaloisBatch) {   // the elements travel as kernel arguments, 64 at a time
+        const size_t cnt = batch - first < (size_t)kMaxGaloisBatch ? batch - first : (size_t)kMaxGaloisBatch;
+        // 2. sigma_g(c0) for the final addition: [cnt][Ld][N]
+        GaloisInvs inv{};
+        for (size_t i = 0; i < cnt; ++i) inv.v[i] = galois_inverse(galois_elts[first + i], two_n);
+        hipLaunchKernelGGL(galois_multi_kernel, dim3((unsigned)(cnt * Ld)), dim3(256), 0, s, d_rotated0 + first * Ld * n, d_in2, (size_t)0, lc, (int)Ld, n, (int)Ld, inv);
+        if (int e = check_launch("galois kernel launch")) return e;
+        // 3. permuted digits (.) keys, two inverse transforms per (rotation, limb)
+        const int rc = c->fold ? launch_hoisted_ks<FoldArith>((int)c->log2n, d_work + first * 2 * L * n, d_digits, d_keys + first * key_words, key_words,
+                                                              galois_elts + first, cnt, c->foldt, s)
+                               : launch_hoisted_ks<ShoupArith>((int)c->log2n, d_work + first * 2 * L * n, d_digits, d_keys + first * key_words, key_words,
+                                                               galois_elts + first, cnt, c->shoup, s);
+        if (rc) return fail(DPFHE_INVALID_STATE, what, "no kernel geometry for this log2_n");
+        if (int e = check_launch("hoisted key-switch kernel launch")) return e;
+    }
+    // 4. divide by P with rounding; component 0 gets sigma_g(c0) added ([batch][1][Ld][N] addend)
+    const size_t rblocks = batch * 2 * Ld * (size_t)chunks;
+    if (c->fold) hipLaunchKernelGGL((rescale_kernel<FoldArith>), dim3((unsigned)rblocks), dim3(256), 0, s, d_out2, d_work, d_rotated0, 1, 1, c->foldt.lc, c->d_rescale, (int)L, n, chunks);
+    else hipLaunchKernelGGL((rescale_kernel<ShoupArith>), dim3((unsigned)rblocks), dim3(256), 0, s, d_out2, d_work, d_rotated0, 1, 1, c->shoup.lc, c->d_rescale, (int)L, n, chunks);
+    return check_launch("hoisted rescale launch");
+}
+
 extern "C" int dpfhe_apply_galois(dpfhe_ctx* c, uint64_t* d_out, const uint64_t* d_in, size_t n_rns_polys, uint32_t galois_elt, void* stream) {
     if (!c) return fail(DPFHE_INVALID_ARGUMENT, "dpfhe_apply_galois", "null context");
     const unsigned two_n = 2u << c->log2n;

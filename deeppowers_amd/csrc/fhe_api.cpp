@@ -914,7 +914,23 @@ public:
     std::vector<std::pair<std::vector<uint32_t>, std::unique_ptr<PolyBuffer>>> packed;   // element list -> its keys back to back
     std::unique_ptr<PolyBuffer> scratch_work;      // batched rotations: reused across calls (one caller at a time per switcher)
     std::unique_ptr<Ciphertext> scratch_rotated;
+    std::unique_ptr<PolyBuffer> scratch_digits;    // hoisted rotations: NTT of the lifted digits, [Ld][L][N]
     void init(const Context& data_ctx, const SecretKey& sk, uint64_t special_prime, uint64_t special_psi);
+    // the keys of an element list, packed back to back once and cached
+    const PolyBuffer* packed_keys(const std::vector<uint32_t>& elts) {
+        for (auto& kv : packed) if (kv.first == elts) return kv.second.get();
+        const FheParams& pe = ext->params();
+        const size_t L = pe.n_limbs(), Ld = L - 1, key_words = Ld * 2 * L * pe.n();
+        std::unique_ptr<PolyBuffer> buf(new PolyBuffer(*ext, elts.size() * Ld, 2, true));
+        for (size_t i = 0; i < elts.size(); ++i) {
+            const PolyBuffer* key = nullptr;
+            for (auto& kv : galois) if (kv.first == elts[i]) key = kv.second.get();
+            if (!key) throw Exception(ErrorCode::INVALID_STATE, "HybridKeySwitcher: no key for an element (add_galois_element first)");
+            hip_check(hipMemcpy(buf->data() + i * key_words, key->data(), key_words * sizeof(uint64_t), hipMemcpyDeviceToDevice), "hipMemcpy D2D");
+        }
+        packed.emplace_back(elts, std::move(buf));
+        return packed.back().second.get();
+    }
     void ensure_scratch(size_t k) {
         if (!scratch_work || scratch_work->batch() < k) {
             scratch_work.reset(new PolyBuffer(*ext, k, 2, false));
@@ -1023,24 +1039,29 @@ void HybridKeySwitcher::apply_galois_range(const Ciphertext& in2, size_t in_firs
     if (in2.is_ntt() || in2.size() != 2 || out2.size() != 2 || in_first + (broadcast ? 1 : k) > in2.batch() || out_first + k > out2.batch())
         throw Exception(ErrorCode::INVALID_ARGUMENT, "HybridKeySwitcher::apply_galois_range: input range of 1 (broadcast) or k items, output with room for k items");
     const FheParams& pe = impl_->ext->params();
-    const size_t L = pe.n_limbs(), Ld = L - 1, n = pe.n(), key_words = Ld * 2 * L * n, ct_words = 2 * Ld * n;
-    const PolyBuffer* keys = nullptr;
-    for (auto& kv : impl_->packed) if (kv.first == elts) keys = kv.second.get();
-    if (!keys) {
-        std::unique_ptr<PolyBuffer> buf(new PolyBuffer(*impl_->ext, k * Ld, 2, true));
-        for (size_t i = 0; i < k; ++i) {
-            const PolyBuffer* key = nullptr;
-            for (auto& kv : impl_->galois) if (kv.first == elts[i]) key = kv.second.get();
-            if (!key) throw Exception(ErrorCode::INVALID_STATE, "HybridKeySwitcher::apply_galois_many: no key for an element (add_galois_element first)");
-            hip_check(hipMemcpy(buf->data() + i * key_words, key->data(), key_words * sizeof(uint64_t), hipMemcpyDeviceToDevice), "hipMemcpy D2D");
-        }
-        keys = buf.get();
-        impl_->packed.emplace_back(elts, std::move(buf));
-    }
+    const size_t L = pe.n_limbs(), Ld = L - 1, n = pe.n(), ct_words = 2 * Ld * n;
+    const PolyBuffer* keys = impl_->packed_keys(elts);
     impl_->ensure_scratch(k);   // kept for the next call: no allocation and no host synchronisation on the steady path
     check(dpfhe_rotate_hybrid_batch(static_cast<dpfhe_ctx*>(impl_->ext->handle()), out2.data() + out_first * ct_words, in2.data() + in_first * ct_words,
                                     broadcast ? 1 : k, elts.data(), keys->data(), impl_->scratch_work->data(), impl_->scratch_rotated->data(), k, s),
           "dpfhe_rotate_hybrid_batch");
+    out2.set_ntt(false);
+}
+
+void HybridKeySwitcher::apply_galois_hoisted(const Ciphertext& in2, size_t in_item, const std::vector<uint32_t>& elts, Ciphertext& out2, size_t out_first,
+                                             Stream* s) const {
+    const size_t k = elts.size();
+    if (k == 0) return;
+    if (in2.is_ntt() || in2.size() != 2 || out2.size() != 2 || in_item >= in2.batch() || out_first + k > out2.batch())
+        throw Exception(ErrorCode::INVALID_ARGUMENT, "HybridKeySwitcher::apply_galois_hoisted: one input item, output with room for k items");
+    const FheParams& pe = impl_->ext->params();
+    const size_t L = pe.n_limbs(), Ld = L - 1, n = pe.n(), ct_words = 2 * Ld * n;
+    const PolyBuffer* keys = impl_->packed_keys(elts);
+    impl_->ensure_scratch(k);
+    if (!impl_->scratch_digits) impl_->scratch_digits.reset(new PolyBuffer(*impl_->ext, Ld, 1, true));
+    check(dpfhe_rotate_hybrid_hoisted(static_cast<dpfhe_ctx*>(impl_->ext->handle()), out2.data() + out_first * ct_words, in2.data() + in_item * ct_words, elts.data(),
+                                      keys->data(), impl_->scratch_work->data(), impl_->scratch_rotated->data(), impl_->scratch_digits->data(), k, s),
+          "dpfhe_rotate_hybrid_hoisted");
     out2.set_ntt(false);
 }
 
@@ -1275,7 +1296,7 @@ void PackedLinear::apply(const Ciphertext& x, Ciphertext& y, Stream* s) const {
     Ciphertext& inner = *I.inner;
     babies.set_ntt(false);
     hip_check(hipMemcpyAsync(babies.data(), x.data(), ct_words * sizeof(uint64_t), hipMemcpyDeviceToDevice, hs), "hipMemcpyAsync");
-    I.ks->apply_galois_many(x, I.baby_elts, babies, /*out_first=*/1, s);
+    I.ks->apply_galois_hoisted(x, 0, I.baby_elts, babies, /*out_first=*/1, s);   // one digit decomposition + NTT for all n1 - 1 rotations
     ev.transform_to_ntt_inplace(babies, s);
     // inner sums of all giant steps of all passes: ONE matrix-vector product over the pre-rotated diagonals
     inner.set_ntt(true);

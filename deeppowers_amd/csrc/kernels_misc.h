@@ -3,6 +3,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include "launch.h"
 #include "modarith.h"
 
 namespace dpfhe {
@@ -291,6 +292,23 @@ __global__ __launch_bounds__(256) void rescale_kernel(u64* out, const u64* in, c
     *reinterpret_cast<U64x2*>(out + (poly * Lo + limb) * n + w0) = r;
 }
 
+// N3, hoisted rotations: digit j of the key-switched component (limb j of c1, coefficient domain, values < q_j) lifted to every
+// limb i of the extended basis: out[j][i][k] = c1[j][k] mod q_i (canonical).  One workgroup per (digit, limb, 512-word chunk).
+template <class Arith>
+__global__ __launch_bounds__(256) void lift_digits_kernel(u64* out, const u64* c1, const LimbConst* lcs, int n_limbs, int n, int chunks) {
+    const int chunk = (int)(blockIdx.x % chunks);
+    const int limb = (int)((blockIdx.x / chunks) % n_limbs);
+    const size_t digit = blockIdx.x / chunks / n_limbs;
+    const int w0 = chunk * 512 + threadIdx.x * 2;
+    if (w0 >= n) return;
+    const LimbConst lc = lcs[limb];
+    const U64x2 v = *reinterpret_cast<const U64x2*>(c1 + digit * n + w0);
+    U64x2 r;
+    r.a = Arith::kFold ? FoldArith::canon(v.a, lc) : ShoupArith::mul_var(v.a, 1, lc);
+    r.b = Arith::kFold ? FoldArith::canon(v.b, lc) : ShoupArith::mul_var(v.b, 1, lc);
+    *reinterpret_cast<U64x2*>(out + (digit * n_limbs + limb) * n + w0) = r;
+}
+
 // N3: Galois automorphism a(X) -> a(X^g), g odd, coefficient domain (a signed permutation; HBM-bound).
 // Gather form: out[k] = +in[j] if j = k g^-1 mod 2N < N, else -in[j - N]  (coalesced writes, scattered 8-byte reads).
 __global__ __launch_bounds__(256) void galois_kernel(u64* out, const u64* in, const LimbConst* lcs, int n_limbs, int n, unsigned g_inv) {
@@ -306,7 +324,6 @@ __global__ __launch_bounds__(256) void galois_kernel(u64* out, const u64* in, co
 
 // batched rotations: item i applies its own element (g_inv.v[i]) to input item i (or to the single input item when
 // in_item_stride == 0); polys_per_item residue polynomials per item
-constexpr int kMaxGaloisBatch = 64;
 struct GaloisInvs { unsigned v[kMaxGaloisBatch]; };
 __global__ __launch_bounds__(256) void galois_multi_kernel(u64* out, const u64* in, size_t in_item_stride, const LimbConst* lcs, int n_limbs, int n,
                                                            int polys_per_item, GaloisInvs g_inv) {

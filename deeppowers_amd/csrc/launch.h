@@ -22,6 +22,7 @@ constexpr int split_log_n1(int log2n) { return log2n > 14 ? log2n - kSplitLog2N2
 #define DPFHE_FUSED_LOGE 4   // words-per-thread exponent of the fused kernels (tools/ab_variant.sh builds -DDPFHE_FUSED_LOGE=3 for A/B runs)
 #endif
 constexpr int kFusedLoge = DPFHE_FUSED_LOGE;
+constexpr int kMaxGaloisBatch = 64;   // Galois elements travel as kernel arguments, this many per launch
 
 // return 0, or -1 when log2n has no compiled geometry.  Launch errors are left in hipGetLastError().
 template <class Arith>
@@ -31,5 +32,10 @@ int launch_ct_mul(int log2n, unsigned flags, u64* out3, const u64* a2, const u64
 
 template <class Arith>
 int launch_relin(int log2n, int mode, u64* out2, const u64* in3, const u64* evk, size_t key_stride, size_t blocks, const DevTables<Arith>& tb, hipStream_t s);
+
+// hoisted rotations: work[item][2][L][N] = INTT(sum_j perm_{g_item}(digits[j]) (.) keys[item][j]); g as kernel arguments (<= 64 items)
+template <class Arith>
+int launch_hoisted_ks(int log2n, u64* work, const u64* digits, const u64* keys, size_t key_stride, const unsigned* elts, size_t count,
+                      const DevTables<Arith>& tb, hipStream_t s);
 
 }  // namespace dpfhe

@@ -89,4 +89,17 @@ int launch_relin(int log2n, int mode, u64* out2, const u64* in3, const u64* evk,
     return 0;
 }
 
+template <class Arith>
+int launch_hoisted_ks(int log2n, u64* work, const u64* digits, const u64* keys, size_t key_stride, const unsigned* elts, size_t count,
+                      const DevTables<Arith>& tb, hipStream_t s) {
+    GaloisElts ge{};
+    for (size_t i = 0; i < count && i < (size_t)kMaxGaloisBatch; ++i) ge.v[i] = elts[i];
+    const unsigned blocks = (unsigned)(count * (size_t)tb.n_limbs * 2);   // (rotation, limb, key component)
+#define HK_CASE(LN, LE) \
+    hipLaunchKernelGGL((hoisted_ks_kernel<Arith, LN, kFusedLoge>), dim3(blocks), dim3(Geo<LN, kFusedLoge>::T), 0, s, work, digits, keys, key_stride, ge, tb)
+    DPFHE_GEO_SWITCH(log2n, HK_CASE)
+#undef HK_CASE
+    return 0;
+}
+
 }  // namespace dpfhe

@@ -329,6 +329,26 @@ class Evaluator:
                                                         rotated.data_ptr(), k, self._sp(stream)), "dpfhe_rotate_hybrid_batch")
         return Ciphertext(out, False)
 
+    def rotate_hybrid_hoisted(self, ct: Ciphertext, galois_elts, keys: torch.Tensor, stream=None) -> Ciphertext:
+        """N3, hoisted rotations on the extended context: item i = key-switched sigma_{galois_elts[i]} of THE input item, the digit
+        decomposition and its forward transforms shared by all rotations.  keys: [len(elts)][L-1][2][L][N]."""
+        p = self.ctx.params
+        L, Ld, n = p.n_limbs, p.n_limbs - 1, p.n
+        d = ct.data
+        k = len(galois_elts)
+        if ct.is_ntt or ct.size != 2 or d.dim() != 4 or d.shape[0] != 1 or d.shape[-2] != Ld or d.shape[-1] != n or d.dtype != torch.int64 or not d.is_contiguous():
+            raise _cabi.DpfheError(2000, "rotate_hybrid_hoisted: one coefficient-domain [1][2][L-1][N] ciphertext on the extended context")
+        if tuple(keys.shape) != (k, Ld, 2, L, n) or keys.dtype != torch.int64 or not keys.is_contiguous():
+            raise _cabi.DpfheError(2000, "keys must be [k][L-1][2][L][N]")
+        out = self._empty((k, 2, Ld, n), stream)
+        work = self._empty((k, 2, L, n), stream)
+        rotated0 = self._empty((k, Ld, n), stream)
+        digits = self._empty((Ld, L, n), stream)
+        elts = (C.c_uint32 * k)(*[int(g) for g in galois_elts])
+        _cabi.check(self._lib.dpfhe_rotate_hybrid_hoisted(self.ctx.handle, out.data_ptr(), d.data_ptr(), elts, keys.data_ptr(), work.data_ptr(), rotated0.data_ptr(),
+                                                          digits.data_ptr(), k, self._sp(stream)), "dpfhe_rotate_hybrid_hoisted")
+        return Ciphertext(out, False)
+
     def rescale_words(self, t: torch.Tensor, stream=None) -> torch.Tensor:
         """[..., L, N] -> [..., L-1, N]: round(x / q_last) limb by limb (coefficient domain).  The result belongs to the
         context of the first L-1 moduli."""

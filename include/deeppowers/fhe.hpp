@@ -323,6 +323,12 @@ public:
     void apply_galois_range(const Ciphertext& in2, size_t in_first, bool broadcast, const std::vector<uint32_t>& galois_elts, Ciphertext& out2,
                             size_t out_first, Stream* stream = nullptr) const;
 
+    // HOISTED: many rotations of ONE item (in2 item in_item): the digit decomposition of c1 and its forward transforms are done
+    // once, each rotation is a permutation in the NTT domain + its key inner product (dpfhe_rotate_hybrid_hoisted).  A valid key
+    // switch of sigma_g(ct), not word-identical to apply_galois_many (the automorphism acts after the lift, not before it).
+    void apply_galois_hoisted(const Ciphertext& in2, size_t in_item, const std::vector<uint32_t>& galois_elts, Ciphertext& out2, size_t out_first,
+                              Stream* stream = nullptr) const;
+
 private:
     class Impl;
     std::unique_ptr<Impl> impl_;
@@ -363,7 +369,7 @@ private:
 //     n / m partial sums are folded with log2(n / m) more rotations; the result repeats with period m (it is a valid input
 //     of the next layer);
 //   * one block (out_dim <= m = n): every window computes the same block, the result repeats with period n.
-// Per application: ONE batched rotation pass for the baby steps (automorphism + hybrid key switch, `relin_kernel` MODE 3), one
+// Per application: ONE hoisted rotation pass for the baby steps (digits of c1 extended and transformed once, `hoisted_ks_kernel`), one
 // batched forward NTT, ONE dpfhe_matvec_plain over all pre-transformed diagonals of all output ciphertexts, one batched inverse
 // NTT, one batched rotation pass + one reduce_sum per output ciphertext.
 class PackedLinear {

@@ -118,6 +118,15 @@ int dpfhe_switch_key_hybrid(dpfhe_ctx* ctx_ext, uint64_t* d_out2, const uint64_t
 int dpfhe_rotate_hybrid_batch(dpfhe_ctx* ctx_ext, uint64_t* d_out2, const uint64_t* d_in2, size_t n_in, const uint32_t* galois_elts,
                               const uint64_t* d_keys, uint64_t* d_work, uint64_t* d_rotated, size_t batch, void* stream);
 
+/* -- N3, HOISTED rotations: `batch` rotations of ONE ciphertext (d_in2: [2][Ld][N], coefficient domain) sharing the digit
+ * decomposition: the Ld digits of c1 are lifted to the L limbs and transformed once (d_digits: Ld * L * N words of scratch), every
+ * rotation is then a permutation of those words in the NTT domain, its key inner product and two inverse transforms per limb
+ * (instead of Ld + 2), followed by the divide-by-P pass.  Keys and d_work as for dpfhe_rotate_hybrid_batch; d_rotated0:
+ * batch * Ld * N words of scratch (sigma_g(c0)).  The result is a valid key switch of sigma_g(ct) but NOT word-identical to
+ * dpfhe_rotate_hybrid_batch: here the automorphism acts on the lifted digits (sigma_g after the lift), there on c1 before it. */
+int dpfhe_rotate_hybrid_hoisted(dpfhe_ctx* ctx_ext, uint64_t* d_out2, const uint64_t* d_in2, const uint32_t* galois_elts, const uint64_t* d_keys,
+                                uint64_t* d_work, uint64_t* d_rotated0, uint64_t* d_digits, size_t batch, void* stream);
+
 /* -- N3: Galois automorphism a(X) -> a(X^galois_elt) (galois_elt odd, < 2N), coefficient domain, d_out != d_in;
  *        and the key switch that follows it:  (c0', c1') = (c0 + sum_j [c1]_{q_j} (.) key_j[0], sum_j [c1]_{q_j} (.) key_j[1]),
  *        key_j = (-(a_j s) + e_j + g_j sigma(s), a_j) in the NTT domain, layout [L][2][L][N] like the relinearisation keys. */

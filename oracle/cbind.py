@@ -40,6 +40,8 @@ def _load():
     lib.orc_ct_mul_schoolbook.argtypes = [C.c_void_p, _U64P, _U64P, _U64P, C.c_size_t, C.c_int]
     lib.orc_relinearize.argtypes = [C.c_void_p, _U64P, _U64P, _U64P, C.c_size_t, C.c_int]
     lib.orc_keyswitch_hybrid.argtypes = [C.c_void_p, _U64P, _U64P, _U64P, C.c_size_t, C.c_int, C.c_int]
+    lib.orc_rotate_hoisted.argtypes = [C.c_void_p, _U64P, _U64P, C.POINTER(C.c_uint32), _U64P, C.c_size_t, C.c_int]
+    lib.orc_rotate_hoisted.restype = None
     lib.orc_rescale.argtypes = [C.c_void_p, _U64P, _U64P, C.c_size_t]
     lib.orc_apply_galois.argtypes = [C.c_void_p, _U64P, _U64P, C.c_size_t, C.c_uint32]
     lib.orc_switch_key.argtypes = [C.c_void_p, _U64P, _U64P, _U64P, C.c_size_t, C.c_int]
@@ -158,6 +160,14 @@ class Oracle:
         out = np.empty(batch * 2 * (self.L - 1) * self.n, np.uint64)
         lib().orc_keyswitch_hybrid(self._h, _p(out), _p(ct), _p(np.ascontiguousarray(key)), batch, in_comps, threads)
         return out.reshape(batch, 2, self.L - 1, self.n)
+
+    def rotate_hoisted(self, ct2, elts, keys, threads=1):
+        """self is the EXTENDED context; ct2: [2][L-1][N] (one item); keys: [k][L-1][2][L][N] -> [k][2][L-1][N]"""
+        k = len(elts)
+        out = np.empty(k * 2 * (self.L - 1) * self.n, np.uint64)
+        e = (C.c_uint32 * k)(*[int(g) for g in elts])
+        lib().orc_rotate_hoisted(self._h, _p(out), _p(np.ascontiguousarray(ct2)), e, _p(np.ascontiguousarray(keys)), k, threads)
+        return out.reshape(k, 2, self.L - 1, self.n)
 
     def rescale(self, x):
         x = np.ascontiguousarray(x)

@@ -489,6 +489,71 @@ void orc_keyswitch_hybrid(const orc_ctx* c, uint64_t* out2, const uint64_t* in, 
 
 /* N3: Galois automorphism a(X) -> a(X^g) on n_rns_polys RNS polynomials (coefficient domain), scatter form:
  * coefficient i goes to index i*g mod 2N, negated when that index is >= N (X^N = -1). */
+/* N3, HOISTED rotations (Halevi-Shoup): k rotations of ONE ciphertext share the digit decomposition.  The digits of c1 are
+ * lifted to every limb of the extended basis FIRST and the automorphism is applied to the lifted digit (in the NTT domain it is
+ * a permutation, which is what the GPU exploits):  t_g = sum_j sigma_g(lift([c1]_{q_j})) (.) key_{g,j},
+ * out_g = (sigma_g(c0), 0) + round(t_g / P).  This differs from orc_keyswitch_hybrid applied to sigma_g(ct) by a multiple of
+ * q_j in the lifted digits (sigma_g negates before the lift there, after it here) - both are valid key switches of the same
+ * ciphertext, but the words differ, so the hoisted GPU path has its own restatement.
+ * c = the EXTENDED context; in2: [2][Ld][N] (one item); keys: [k][Ld][2][L][N] (NTT domain); out2: [k][2][Ld][N]. */
+void orc_rotate_hoisted(const orc_ctx* c, uint64_t* out2, const uint64_t* in2, const uint32_t* elts, const uint64_t* keys, size_t k_rot, int threads) {
+    const size_t n = 1ull << c->log2n, L = c->n_limbs, Ld = L - 1;
+    const uint64_t P = c->limb[Ld].q, h = P / 2;
+    threads = clamp_threads(threads);
+#pragma omp parallel num_threads(threads)
+    {
+        uint64_t* t = malloc((2 * L + 2) * n * sizeof(uint64_t));
+        uint64_t *d = t + 2 * L * n, *dg = d + n;
+#pragma omp for schedule(static)
+        for (long long it = 0; it < (long long)k_rot; ++it) {
+            const uint32_t g = elts[it];
+            const uint64_t* key = keys + (size_t)it * Ld * 2 * L * n;
+            const uint64_t* c1 = in2 + Ld * n;
+            for (size_t i = 0; i < L; ++i) {
+                const orc_limb* T = &c->limb[i];
+                const uint64_t q = T->q;
+                uint64_t *acc0 = t + (0 * L + i) * n, *acc1 = t + (1 * L + i) * n;
+                memset(acc0, 0, n * sizeof(uint64_t)); memset(acc1, 0, n * sizeof(uint64_t));
+                for (size_t j = 0; j < Ld; ++j) {
+                    for (size_t x = 0; x < n; ++x) d[x] = c1[j * n + x] % q;                 /* lift */
+                    for (size_t x = 0; x < n; ++x) {                                         /* then rotate, mod q_i */
+                        const size_t idx = (x * (size_t)g) & (2 * n - 1);
+                        if (idx < n) dg[idx] = d[x]; else dg[idx - n] = d[x] ? q - d[x] : 0;
+                    }
+                    ntt_fwd_poly(T, dg);
+                    const uint64_t* k0 = key + ((j * 2 + 0) * L + i) * n;
+                    const uint64_t* k1 = key + ((j * 2 + 1) * L + i) * n;
+                    for (size_t x = 0; x < n; ++x) {
+                        uint64_t s0 = acc0[x] + mulmod_barrett(dg[x], k0[x], T); acc0[x] = s0 - ((s0 >= q) ? q : 0);
+                        uint64_t s1 = acc1[x] + mulmod_barrett(dg[x], k1[x], T); acc1[x] = s1 - ((s1 >= q) ? q : 0);
+                    }
+                }
+                ntt_inv_poly(T, acc0); ntt_inv_poly(T, acc1);
+            }
+            for (int comp = 0; comp < 2; ++comp)
+                for (size_t i = 0; i < Ld; ++i) {
+                    const uint64_t q = c->limb[i].q;
+                    const uint64_t inv = powmod(P % q, q - 2, q);
+                    uint64_t* o = out2 + (((size_t)it * 2 + comp) * Ld + i) * n;
+                    for (size_t x = 0; x < n; ++x) {
+                        const uint64_t tl = (t[(comp * L + Ld) * n + x] + h) % P;
+                        const uint64_t a = (uint64_t)(((u128)t[(comp * L + i) * n + x] + h % q) % q);
+                        o[x] = mulmod_slow((a + q - tl % q) % q, inv, q);
+                    }
+                    if (comp == 0)                                                           /* + sigma_g(c0) */
+                        for (size_t x = 0; x < n; ++x) {
+                            const size_t idx = (x * (size_t)g) & (2 * n - 1);
+                            const uint64_t v = in2[i * n + x];
+                            const uint64_t sv = idx < n ? v : (v ? q - v : 0);
+                            uint64_t* dst = &o[idx & (n - 1)];
+                            uint64_t r = *dst + sv; *dst = r - ((r >= q) ? q : 0);
+                        }
+                }
+        }
+        free(t);
+    }
+}
+
 void orc_apply_galois(const orc_ctx* c, uint64_t* out, const uint64_t* in, size_t n_rns_polys, uint32_t g) {
     const size_t n = 1ull << c->log2n, L = c->n_limbs;
     for (size_t p = 0; p < n_rns_polys * L; ++p) {

@@ -492,3 +492,54 @@ def test_gpu_batched_rotations_bit_exact(name):
             want = orc.keyswitch_hybrid(rot, keys[i], 2, threads=0)[0]
             assert np.array_equal(got[i], want), (k, i)
     ctx.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["n4096", "n8192"])
+def test_gpu_hoisted_rotations_bit_exact(name):
+    """dpfhe_rotate_hybrid_hoisted == the oracle's hoisted restatement (lift the digits, THEN rotate), for 5 and for 70 rotations of
+    one ciphertext (more than one 64-element launch group); and it differs from the non-hoisted path only by a valid
+    re-decomposition: both are checked against their own oracle."""
+    from deeppowers_amd.evaluator import Ciphertext, Context, Evaluator, to_device, to_host
+    if name == "n4096":
+        pe = FheParams(12, tuple(x[0] for x in PRIMES_60[:3]), tuple(x[1] for x in PRIMES_60[:3]))     # 2 data limbs + P
+    else:
+        pe = FheParams(13, tuple(x[0] for x in PRIMES_60[:4]), tuple(x[2] for x in PRIMES_60[:4]))     # 3 data limbs + P
+    orc = Oracle.from_params(pe)
+    L, Ld, n = pe.n_limbs, pe.n_limbs - 1, pe.n
+    data = Oracle(pe.log2_n, pe.moduli[:-1], pe.psi[:-1])
+    ctx = Context(pe, 0)
+    ev = Evaluator(ctx)
+    for k in (5, 70):
+        elts = [pow(3, i + 1, 2 * n) for i in range(k)]
+        elts[-1] = 2 * n - 1
+        keys = orc.fill(k * Ld * 2, 701).reshape(k, Ld, 2, L, n)
+        ct = data.fill(2, 702).reshape(1, 2, Ld, n)
+        got = to_host(ev.rotate_hybrid_hoisted(Ciphertext(to_device(ct, ctx.device)), elts, to_device(keys, ctx.device)).data)
+        idx = list(range(k)) if k <= 8 else [0, 1, 63, 64, 69]
+        want = orc.rotate_hoisted(ct[0], [elts[i] for i in idx], keys[idx], threads=0)
+        for w, i in zip(want, idx):
+            assert np.array_equal(got[i], w), (k, i)
+    ctx.close()
+
+
+def test_hoisted_rotation_is_a_valid_key_switch_oracle():
+    """Semantics of the hoisted form on the CPU (toy scheme, big integers): phase(hoisted rotation of ct) == sigma_g(phase(ct)) up to
+    the switching noise (< 2^24), exactly like the non-hoisted form - although the two differ word by word."""
+    p = small_params()
+    pe = ext_params(p)
+    rng = np.random.default_rng(77)
+    s = rng.integers(-1, 2, p.n)
+    m1 = rng.integers(0, 1000, p.n)
+    ct1, _ = encrypt(rng, p, s, m1, 1 << 30)
+    g = pow(3, 5, 2 * p.n)
+    key_g = keygen_hybrid(rng, p, pe, s, galois_int([int(v) for v in s], g))
+    orc_e = Oracle.from_params(pe)
+    hoisted = orc_e.rotate_hoisted(np.ascontiguousarray(ct1).reshape(2, p.n_limbs, p.n), [g], np.ascontiguousarray(key_g)[None], threads=1)[0]
+    ph1, Q = phase(p, ct1, s)
+    want = galois_int(ph1, g, Q)
+    got, _ = phase(p, hoisted.reshape(np.asarray(ct1).shape), s)
+    centre = lambda v: v - Q if v > Q // 2 else v
+    assert max(abs(centre((a - b) % Q)) for a, b in zip(got, want)) < (1 << 24)
+    plain = orc_e.keyswitch_hybrid(Oracle.from_params(p).apply_galois(ct1, g), key_g, 2)
+    assert not np.array_equal(plain.reshape(hoisted.shape), hoisted)      # a different, equally valid decomposition
