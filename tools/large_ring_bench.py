@@ -1,0 +1,49 @@
+"""NTT timing at ring degrees above 8192 (tool): N = 16384 (one 1024-thread workgroup per polynomial) and the split transforms
+N = 32768 / 65536, ~1 GiB of residues each, kernel time by HIP events.  usage: python tools/large_ring_bench.py"""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import deeppowers_amd._cabi as _cabi  # noqa: E402
+
+if os.environ.get("DPFHE_AB_LIB"):
+    _cabi.LIB_PATH = os.path.abspath(os.environ["DPFHE_AB_LIB"])
+from deeppowers_amd.evaluator import Context, Evaluator  # noqa: E402
+from deeppowers_amd.params import FheParams  # noqa: E402
+from oracle import pyoracle as po  # noqa: E402  (prime search only)
+
+
+def fold_primes(two_n, count):
+    out, k = [], 1
+    while len(out) < count:
+        c = (1 << 60) - (k * two_n - 1)
+        if c % two_n == 1 and po.is_prime(c):
+            out.append(c)
+        k += 1
+    return out
+
+
+for ln, polys in ((14, 6144), (15, 4096), (16, 2048)):
+    n = 1 << ln
+    L = 2
+    qs = fold_primes(2 * n, L)
+    p = FheParams(ln, tuple(qs), tuple(po.min_primitive_2n_root(n, q) for q in qs))
+    ctx = Context(p, 0)
+    ev = Evaluator(ctx)
+    q = torch.tensor(qs, dtype=torch.int64, device=ctx.device).view(1, L, 1)
+    x = torch.randint(0, 2**62, (polys // L, L, n), dtype=torch.int64, device=ctx.device) % q
+    y = torch.empty_like(x)
+    nbytes = 2 * n * 8 * polys
+    for name, fn in (("fwd", lambda: ev.ntt_forward(x, out=y)), ("inv", lambda: ev.ntt_inverse(x, out=y))):
+        for _ in range(3):
+            fn()
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(15)]
+        for s, e in evs:
+            s.record(); fn(); e.record()
+        torch.cuda.synchronize()
+        ts = sorted(s.elapsed_time(e) * 1e3 for s, e in evs)
+        print(f"{os.path.basename(os.environ.get('DPFHE_AB_LIB', 'HEAD')):14s} N={n:6d} {polys} residue polys ntt_{name}: median {ts[7]:8.1f} us  = {nbytes / ts[7] / 8e6 * 100:5.1f}% of 8 TB/s")
+    del x, y
+    ctx.close()
