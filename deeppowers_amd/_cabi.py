@@ -29,7 +29,9 @@ SYMBOLS = {
     "dpfhe_relinearize_hybrid": ([C.c_void_p, _U64P, _U64P, _U64P, _U64P, C.c_size_t, C.c_void_p], C.c_int),
     "dpfhe_switch_key_hybrid": ([C.c_void_p, _U64P, _U64P, _U64P, _U64P, C.c_size_t, C.c_void_p], C.c_int),
     "dpfhe_rotate_hybrid_batch": ([C.c_void_p, _U64P, _U64P, C.c_size_t, C.POINTER(C.c_uint32), _U64P, _U64P, _U64P, C.c_size_t, C.c_void_p], C.c_int),
-    "dpfhe_rotate_hybrid_hoisted": ([C.c_void_p, _U64P, _U64P, C.POINTER(C.c_uint32), _U64P, _U64P, _U64P, _U64P, C.c_size_t, C.c_void_p], C.c_int),
+    "dpfhe_rotate_hybrid_hoisted": ([C.c_void_p, _U64P, _U64P, C.c_size_t, C.POINTER(C.c_uint32), _U64P, _U64P, _U64P, _U64P, C.c_size_t, C.c_void_p], C.c_int),
+    "dpfhe_rotate_hybrid_grouped": ([C.c_void_p, _U64P, _U64P, C.POINTER(C.c_uint32), C.c_size_t, C.c_size_t, _U64P, _U64P, _U64P, C.c_void_p], C.c_int),
+    "dpfhe_matvec_plain_multi": ([C.c_void_p, _U64P, _U64P, _U64P, C.c_size_t, C.c_size_t, C.c_size_t, C.c_void_p], C.c_int),
     "dpfhe_rescale": ([C.c_void_p, _U64P, _U64P, C.c_size_t, C.c_void_p], C.c_int),
     "dpfhe_apply_galois": ([C.c_void_p, _U64P, _U64P, C.c_size_t, C.c_uint32, C.c_void_p], C.c_int),
     "dpfhe_switch_key": ([C.c_void_p, _U64P, _U64P, _U64P, C.c_size_t, C.c_void_p], C.c_int),

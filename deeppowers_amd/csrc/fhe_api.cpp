@@ -338,6 +338,16 @@ void Evaluator::matvec_plain(const Plaintext& W, const Ciphertext& x, Ciphertext
     check(dpfhe_matvec_plain(impl_->h(), y.data(), W.data(), x.data(), rows, cols, s), "dpfhe_matvec_plain");
     y.set_ntt(true);
 }
+void Evaluator::matvec_plain_multi(const Plaintext& W, const Ciphertext& x, Ciphertext& y, size_t n_rhs, Stream* s) const {
+    if (!W.is_ntt() || !x.is_ntt()) throw Exception(ErrorCode::INVALID_STATE, "matvec_plain_multi needs NTT-domain operands");
+    if (n_rhs == 0 || x.size() != 2 || y.size() != 2 || x.batch() % n_rhs || y.batch() % n_rhs)
+        throw Exception(ErrorCode::INVALID_ARGUMENT, "matvec_plain_multi: x [cols][n_rhs], y [rows][n_rhs] 2-component items");
+    const size_t cols = x.batch() / n_rhs, rows = y.batch() / n_rhs;
+    if (W.batch() != rows * cols) throw Exception(ErrorCode::INVALID_ARGUMENT, "matvec_plain_multi: W must hold rows * cols plaintexts");
+    check(dpfhe_matvec_plain_multi(impl_->h(), y.data(), W.data(), x.data(), rows, cols, n_rhs, s), "dpfhe_matvec_plain_multi");
+    y.set_ntt(true);
+}
+
 void Evaluator::matvec_scalar(const ScalarMatrix& W, const Ciphertext& x, Ciphertext& y, Stream* s) const {
     if (x.size() != 2 || y.size() != 2 || x.batch() != W.cols() || y.batch() != W.rows())
         throw Exception(ErrorCode::INVALID_ARGUMENT, "matvec_scalar: x batch = cols, y batch = rows, 2-component ciphertexts");
@@ -1048,20 +1058,36 @@ void HybridKeySwitcher::apply_galois_range(const Ciphertext& in2, size_t in_firs
     out2.set_ntt(false);
 }
 
-void HybridKeySwitcher::apply_galois_hoisted(const Ciphertext& in2, size_t in_item, const std::vector<uint32_t>& elts, Ciphertext& out2, size_t out_first,
-                                             Stream* s) const {
+void HybridKeySwitcher::apply_galois_hoisted(const Ciphertext& in2, size_t in_first, size_t n_items, const std::vector<uint32_t>& elts, Ciphertext& out2,
+                                             size_t out_first, Stream* s) const {
     const size_t k = elts.size();
-    if (k == 0) return;
-    if (in2.is_ntt() || in2.size() != 2 || out2.size() != 2 || in_item >= in2.batch() || out_first + k > out2.batch())
-        throw Exception(ErrorCode::INVALID_ARGUMENT, "HybridKeySwitcher::apply_galois_hoisted: one input item, output with room for k items");
+    if (k == 0 || n_items == 0) return;
+    if (in2.is_ntt() || in2.size() != 2 || out2.size() != 2 || in_first + n_items > in2.batch() || out_first + k * n_items > out2.batch())
+        throw Exception(ErrorCode::INVALID_ARGUMENT, "HybridKeySwitcher::apply_galois_hoisted: n_items input items, output with room for k * n_items items");
     const FheParams& pe = impl_->ext->params();
     const size_t L = pe.n_limbs(), Ld = L - 1, n = pe.n(), ct_words = 2 * Ld * n;
     const PolyBuffer* keys = impl_->packed_keys(elts);
-    impl_->ensure_scratch(k);
-    if (!impl_->scratch_digits) impl_->scratch_digits.reset(new PolyBuffer(*impl_->ext, Ld, 1, true));
-    check(dpfhe_rotate_hybrid_hoisted(static_cast<dpfhe_ctx*>(impl_->ext->handle()), out2.data() + out_first * ct_words, in2.data() + in_item * ct_words, elts.data(),
-                                      keys->data(), impl_->scratch_work->data(), impl_->scratch_rotated->data(), impl_->scratch_digits->data(), k, s),
+    impl_->ensure_scratch(k * n_items);
+    if (!impl_->scratch_digits || impl_->scratch_digits->batch() < n_items * Ld) impl_->scratch_digits.reset(new PolyBuffer(*impl_->ext, n_items * Ld, 1, true));
+    check(dpfhe_rotate_hybrid_hoisted(static_cast<dpfhe_ctx*>(impl_->ext->handle()), out2.data() + out_first * ct_words, in2.data() + in_first * ct_words, n_items,
+                                      elts.data(), keys->data(), impl_->scratch_work->data(), impl_->scratch_rotated->data(), impl_->scratch_digits->data(), k, s),
           "dpfhe_rotate_hybrid_hoisted");
+    out2.set_ntt(false);
+}
+
+void HybridKeySwitcher::apply_galois_grouped(const Ciphertext& in2, size_t in_first, const std::vector<uint32_t>& elts, size_t group, Ciphertext& out2,
+                                             size_t out_first, Stream* s) const {
+    const size_t k = elts.size(), batch = k * group;
+    if (batch == 0) return;
+    if (in2.is_ntt() || in2.size() != 2 || out2.size() != 2 || in_first + batch > in2.batch() || out_first + batch > out2.batch())
+        throw Exception(ErrorCode::INVALID_ARGUMENT, "HybridKeySwitcher::apply_galois_grouped: k * group items in and out");
+    const FheParams& pe = impl_->ext->params();
+    const size_t Ld = pe.n_limbs() - 1, n = pe.n(), ct_words = 2 * Ld * n;
+    const PolyBuffer* keys = impl_->packed_keys(elts);
+    impl_->ensure_scratch(batch);
+    check(dpfhe_rotate_hybrid_grouped(static_cast<dpfhe_ctx*>(impl_->ext->handle()), out2.data() + out_first * ct_words, in2.data() + in_first * ct_words, elts.data(), k,
+                                      group, keys->data(), impl_->scratch_work->data(), impl_->scratch_rotated->data(), s),
+          "dpfhe_rotate_hybrid_grouped");
     out2.set_ntt(false);
 }
 
@@ -1176,6 +1202,15 @@ public:
     std::unique_ptr<Plaintext> diag;   // [passes][n2][n1] pre-rotated diagonals, NTT domain
     std::vector<uint32_t> baby_elts, giant_elts, fold_elts;
     std::unique_ptr<Ciphertext> babies, inner, rotated, fold;   // per-layer scratch, reused by every apply() (one caller at a time)
+    size_t tokens = 0;                                           // scratch capacity in tokens
+    void ensure_tokens(size_t T) {
+        if (T <= tokens) return;
+        babies.reset(new Ciphertext(*ctx, 2, n1 * T));                              // [n1][T]
+        inner.reset(new Ciphertext(*ctx, 2, passes * n2 * T, /*is_ntt=*/true));     // [passes * n2][T]
+        if (n2 > 1) rotated.reset(new Ciphertext(*ctx, 2, passes * n2 * T));
+        if (!fold_elts.empty()) fold.reset(new Ciphertext(*ctx, 2, 2 * T));         // [2][T]: running sums | their rotation
+        tokens = T;
+    }
 
     // which output row a slot of pass `pass` holds (or npos)
     size_t row_of_slot(size_t pass, size_t slot) const {
@@ -1246,10 +1281,7 @@ PackedLinear::PackedLinear(const Context& ctx, const BatchEncoder& enc, HybridKe
     }
     Evaluator ev(ctx);
     ev.transform_to_ntt_inplace(*I.diag);
-    I.babies.reset(new Ciphertext(ctx, 2, n1));
-    I.inner.reset(new Ciphertext(ctx, 2, I.passes * I.n2, /*is_ntt=*/true));
-    if (I.n2 > 1) I.rotated.reset(new Ciphertext(ctx, 2, I.passes * I.n2));
-    if (!I.fold_elts.empty()) I.fold.reset(new Ciphertext(ctx, 2, 2));
+    I.ensure_tokens(1);
     ctx.synchronize();
 }
 PackedLinear::~PackedLinear() = default;
@@ -1282,49 +1314,54 @@ void PackedLinear::unpack_output(const uint64_t* slots, uint64_t* y) const {
 }
 
 void PackedLinear::apply(const Ciphertext& x, Ciphertext& y, Stream* s) const {
-    const Impl& I = *impl_;
-    if (x.is_ntt() || x.size() != 2 || x.batch() != 1 || y.size() != 2 || y.batch() != I.passes)
-        throw Exception(ErrorCode::INVALID_ARGUMENT, "PackedLinear::apply: one 2-component coefficient-domain ciphertext in, output_ciphertexts() out");
+    Impl& I = *impl_;
+    const size_t T = x.batch();
+    if (x.is_ntt() || x.size() != 2 || T == 0 || y.size() != 2 || y.batch() != I.passes * T)
+        throw Exception(ErrorCode::INVALID_ARGUMENT, "PackedLinear::apply: T 2-component coefficient-domain ciphertexts in, output_ciphertexts() * T out");
+    I.ensure_tokens(T);   // (re)allocates only when a larger batch than ever before arrives
     const Context& ctx = *I.ctx;
     const FheParams& p = ctx.params();
     const size_t ct_words = 2 * p.n_limbs() * p.n(), n1 = I.n1, n2 = I.n2;
     hipStream_t hs = static_cast<hipStream_t>(s);
     dpfhe_ctx* h = static_cast<dpfhe_ctx*>(ctx.handle());
     Evaluator ev(ctx);
-    // baby steps: rot_j(x), j < n1, in ONE batched rotation pass, then transformed together - shared by every output block
+    // Layout of every intermediate: [rotation or diagonal index][token][component] - the token index sits where the plaintext
+    // matvec sees "more components", so keys and diagonals are read once for all tokens.
+    // baby steps: rot_j(x_t), j < n1, for all tokens in ONE hoisted rotation pass, then transformed together
     Ciphertext& babies = *I.babies;
     Ciphertext& inner = *I.inner;
     babies.set_ntt(false);
-    hip_check(hipMemcpyAsync(babies.data(), x.data(), ct_words * sizeof(uint64_t), hipMemcpyDeviceToDevice, hs), "hipMemcpyAsync");
-    I.ks->apply_galois_hoisted(x, 0, I.baby_elts, babies, /*out_first=*/1, s);   // one digit decomposition + NTT for all n1 - 1 rotations
-    ev.transform_to_ntt_inplace(babies, s);
-    // inner sums of all giant steps of all passes: ONE matrix-vector product over the pre-rotated diagonals
-    inner.set_ntt(true);
-    ev.matvec_plain(*I.diag, babies, inner, s);
-    ev.transform_from_ntt_inplace(inner, s);
-    // giant steps: inner sum (pass, i) rotated by i*n1 (one batched rotation pass per output ciphertext), then the sum over i
-    Ciphertext* sums = &y;
-    if (!I.fold_elts.empty()) sums = I.fold.get();     // wide-input layer: the block sum is folded below before it becomes y
+    hip_check(hipMemcpyAsync(babies.data(), x.data(), T * ct_words * sizeof(uint64_t), hipMemcpyDeviceToDevice, hs), "hipMemcpyAsync");
+    I.ks->apply_galois_hoisted(x, 0, T, I.baby_elts, babies, /*out_first=*/T, s);   // one digit decomposition + NTT per token for all n1 - 1 rotations
+    // (babies/inner may be larger than n1 * T / passes * n2 * T items after a bigger batch: only the leading items are used)
+    check(dpfhe_ntt_fwd(h, babies.data(), n1 * T * 2, s), "dpfhe_ntt_fwd");
+    // inner sums of all giant steps of all output ciphertexts of all tokens: ONE matrix-vector product over the pre-rotated diagonals
+    check(dpfhe_matvec_plain_multi(h, inner.data(), I.diag->data(), babies.data(), I.passes * n2, n1, T, s), "dpfhe_matvec_plain_multi");
+    check(dpfhe_ntt_inv(h, inner.data(), I.passes * n2 * T * 2, s), "dpfhe_ntt_inv");
+    // giant steps: inner sum (pass, i, t) rotated by i*n1 (one grouped rotation pass per output ciphertext), then the sum over i
+    uint64_t* sums = I.fold_elts.empty() ? y.data() : I.fold->data();   // wide-input layer: the block sum is folded below before it becomes y
     if (n2 > 1) {
         Ciphertext& rotated = *I.rotated;
         for (size_t pass = 0; pass < I.passes; ++pass) {
-            hip_check(hipMemcpyAsync(rotated.data() + pass * n2 * ct_words, inner.data() + pass * n2 * ct_words, ct_words * sizeof(uint64_t), hipMemcpyDeviceToDevice, hs),
+            const size_t base = pass * n2 * T;
+            hip_check(hipMemcpyAsync(rotated.data() + base * ct_words, inner.data() + base * ct_words, T * ct_words * sizeof(uint64_t), hipMemcpyDeviceToDevice, hs),
                       "hipMemcpyAsync");
-            I.ks->apply_galois_range(inner, pass * n2 + 1, false, I.giant_elts, rotated, pass * n2 + 1, s);
-            check(dpfhe_reduce_sum(h, sums->data() + pass * ct_words, rotated.data() + pass * n2 * ct_words, n2, 2, s), "dpfhe_reduce_sum");
+            inner.set_ntt(false);
+            I.ks->apply_galois_grouped(inner, base + T, I.giant_elts, T, rotated, base + T, s);
+            check(dpfhe_reduce_sum(h, sums + pass * T * ct_words, rotated.data() + base * ct_words, n2, 2 * T, s), "dpfhe_reduce_sum");
         }
     } else {
-        hip_check(hipMemcpyAsync(sums->data(), inner.data(), I.passes * ct_words * sizeof(uint64_t), hipMemcpyDeviceToDevice, hs), "hipMemcpyAsync");
+        hip_check(hipMemcpyAsync(sums, inner.data(), I.passes * T * ct_words * sizeof(uint64_t), hipMemcpyDeviceToDevice, hs), "hipMemcpyAsync");
     }
     // wide input (m < n): slot r holds the partial sum over input indices congruent to r + k; fold the n/m windows together
     if (!I.fold_elts.empty()) {
-        Ciphertext& f = *I.fold;   // item 0: running sum, item 1: its rotation
+        Ciphertext& f = *I.fold;   // items [0, T): running sums, [T, 2T): their rotation
         f.set_ntt(false);
         for (size_t e = 0; e < I.fold_elts.size(); ++e) {
             const std::vector<uint32_t> one(1, I.fold_elts[e]);
-            I.ks->apply_galois_range(f, 0, false, one, f, 1, s);
+            I.ks->apply_galois_grouped(f, 0, one, T, f, T, s);
             const bool last = e + 1 == I.fold_elts.size();
-            check(dpfhe_add(h, last ? y.data() : f.data(), f.data(), f.data() + ct_words, 2, s), "dpfhe_add");
+            check(dpfhe_add(h, last ? y.data() : f.data(), f.data(), f.data() + T * ct_words, 2 * T, s), "dpfhe_add");
         }
     }
     y.set_ntt(false);

@@ -302,7 +302,8 @@ __device__ __forceinline__ u64 canon_any(u64 v, const LimbConst& lc) {  // any v
 //         buffer [batch][2][L][N] with nothing added back; dpfhe's rescale-add pass then divides by P and adds (c0, c1).
 template <class Arith, int LOGN, int LOGE, int MODE>
 __global__ __launch_bounds__(1 << (LOGN - LOGE), (Arith::kFold ? 2 : 1)) void relin_kernel(u64* __restrict__ out2, const u64* __restrict__ in3,
-                                                                       const u64* __restrict__ evk, size_t key_stride, DevTables<Arith> tb) {
+                                                                       const u64* __restrict__ evk, size_t key_stride, unsigned key_group,
+                                                                       DevTables<Arith> tb) {
     typedef NttBody<Arith, LOGN, LOGE> B;
     static_assert(LOGE == kFusedLoge, "the fused kernels read the fused twiddle layout (DevTables::fwd4 / inv4)");
     constexpr int E = B::E, N = B::G::N;
@@ -317,7 +318,7 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE), (Arith::kFold ? 2 : 1)) void re
     constexpr bool kHybrid = MODE >= 2;
     const int Ld = kHybrid ? L - 1 : L;                                   // limbs of the data (= number of digits)
     const u64* c2 = in3 + ((bi * kInComps + (kInComps - 1)) * Ld) * N;  // digit j at + j*N
-    evk += bi * key_stride;                                              // per-item keys (batched rotations); 0 = one shared key
+    evk += (bi / key_group) * key_stride;   // per-item keys (batched rotations; key_group consecutive items share one); stride 0 = one key
     u64 acc0[E], acc1[E];
 #pragma unroll
     for (int k = 0; k < E; ++k) acc0[k] = acc1[k] = 0;
@@ -405,7 +406,7 @@ struct GaloisElts { unsigned v[kMaxGaloisBatch]; };
 template <class Arith, int LOGN, int LOGE>
 __global__ __launch_bounds__(1 << (LOGN - LOGE), (Arith::kFold ? 2 : 1)) void hoisted_ks_kernel(u64* __restrict__ work, const u64* __restrict__ digits,
                                                                                            const u64* __restrict__ keys, size_t key_stride, GaloisElts elts,
-                                                                                           DevTables<Arith> tb) {
+                                                                                           unsigned n_items, DevTables<Arith> tb) {
     typedef NttBody<Arith, LOGN, LOGE> B;
     static_assert(LOGE == kFusedLoge, "the fused kernels read the fused twiddle layout (DevTables::fwd4 / inv4)");
     constexpr int E = B::E, N = B::G::N;
@@ -414,13 +415,18 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE), (Arith::kFold ? 2 : 1)) void ho
     const int L = tb.n_limbs, Ld = L - 1;
     // one workgroup per (rotation, limb, key component): twice the workgroups of the fused key-switch kernel and half the serial
     // chain each - the k rotations of one token would otherwise fill a fraction of the chip with long-running workgroups
-    const int comp = (int)(blockIdx.x & 1u);
-    const size_t item = (blockIdx.x >> 1) / (unsigned)L;
-    const int limb = (int)((blockIdx.x >> 1) % (unsigned)L);
+    // Several input ciphertexts (tokens) share the rotations: block = ((rotation * L + limb) * 2 + comp) * n_items + token, so
+    // that the workgroups reading one key tile are neighbours in time (the tile is fetched once into L2 / Infinity Cache).
+    const unsigned token = blockIdx.x % n_items, tile = blockIdx.x / n_items;
+    const int comp = (int)(tile & 1u);
+    const size_t rot = (tile >> 1) / (unsigned)L;
+    const int limb = (int)((tile >> 1) % (unsigned)L);
+    const size_t item = rot * n_items + token;        // output / work item
+    digits += (size_t)token * (size_t)(L - 1) * L * N;
     const LimbConst lc = tb.lc[limb];
     const InvLast<typename B::Tw> last = tb.last[limb];
-    const unsigned g = elts.v[item];
-    const u64* evk = keys + item * key_stride;
+    const unsigned g = elts.v[rot];
+    const u64* evk = keys + rot * key_stride;
     // source positions of this thread's E output positions p = tid E + kk
     unsigned src[E];
 #pragma unroll

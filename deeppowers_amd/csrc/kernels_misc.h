@@ -162,17 +162,35 @@ __global__ __launch_bounds__(256) void matvec_kernel(u64* y, const u64* W, const
     const u64* wp = W + (row0 * cols * L + limb) * n + w0;
     const u64* xp = x + (size_t)limb * n + w0;
     size_t since = 0;
-    for (size_t j = 0; j < cols; ++j) {
-        const U64x2 x0 = *reinterpret_cast<const U64x2*>(xp + j * xstride);
-        const U64x2 x1 = *reinterpret_cast<const U64x2*>(xp + j * xstride + L * n);
-        U64x2 w[RT];
+#ifndef DPFHE_MATVEC_PIPELINE
+#define DPFHE_MATVEC_PIPELINE 0   // 1: request column j + 1 before the products of column j - measured SLOWER here (1.46 vs 1.38 ms at configs[2]: the 10 extra registers cost the 4th wave per SIMD); the multi-right-hand-side kernel below does pipeline
+#endif
+    U64x2 x0 = *reinterpret_cast<const U64x2*>(xp), x1 = *reinterpret_cast<const U64x2*>(xp + L * n), w[RT];
 #pragma unroll
-        for (int r = 0; r < RT; ++r)
-            w[r] = (row0 + r < rows) ? *reinterpret_cast<const U64x2*>(wp + r * rstride + j * wstride) : U64x2{0, 0};
+    for (int r = 0; r < RT; ++r) w[r] = (row0 + r < rows) ? *reinterpret_cast<const U64x2*>(wp + r * rstride) : U64x2{0, 0};
+    for (size_t j = 0; j < cols; ++j) {
+        U64x2 x0n, x1n, wn[RT];
+        if (DPFHE_MATVEC_PIPELINE) {
+            const size_t jn = j + 1 < cols ? j + 1 : j;
+            x0n = *reinterpret_cast<const U64x2*>(xp + jn * xstride);
+            x1n = *reinterpret_cast<const U64x2*>(xp + jn * xstride + L * n);
+#pragma unroll
+            for (int r = 0; r < RT; ++r) wn[r] = (row0 + r < rows) ? *reinterpret_cast<const U64x2*>(wp + r * rstride + jn * wstride) : U64x2{0, 0};
+        } else if (j > 0) {
+            x0 = *reinterpret_cast<const U64x2*>(xp + j * xstride);
+            x1 = *reinterpret_cast<const U64x2*>(xp + j * xstride + L * n);
+#pragma unroll
+            for (int r = 0; r < RT; ++r) w[r] = (row0 + r < rows) ? *reinterpret_cast<const U64x2*>(wp + r * rstride + j * wstride) : U64x2{0, 0};
+        }
 #pragma unroll
         for (int r = 0; r < RT; ++r) {
             acc_mac(acc[r][0][0], w[r].a, x0.a); acc_mac(acc[r][0][1], w[r].b, x0.b);
             acc_mac(acc[r][1][0], w[r].a, x1.a); acc_mac(acc[r][1][1], w[r].b, x1.b);
+        }
+        if (DPFHE_MATVEC_PIPELINE) {
+            x0 = x0n; x1 = x1n;
+#pragma unroll
+            for (int r = 0; r < RT; ++r) w[r] = wn[r];
         }
         if (++since == 128) {  // 128 products of < 2^120 stay below 2^128 next to a reduced value
 #pragma unroll
@@ -190,6 +208,73 @@ __global__ __launch_bounds__(256) void matvec_kernel(u64* y, const u64* W, const
         u64* yp = y + (((row0 + r) * 2) * L + limb) * n + w0;
         *reinterpret_cast<U64x2*>(yp) = U64x2{acc_reduce<Arith>(acc[r][0][0], lc, two64), acc_reduce<Arith>(acc[r][0][1], lc, two64)};
         *reinterpret_cast<U64x2*>(yp + L * n) = U64x2{acc_reduce<Arith>(acc[r][1][0], lc, two64), acc_reduce<Arith>(acc[r][1][1], lc, two64)};
+    }
+}
+
+// A7 with several right-hand sides (tokens): y[i][t] = sum_j W[i][j] (.) x[j][t], x: [cols][C/2][2][L][N], y: [rows][C/2][2][L][N]; the
+// C = 2 * tokens polynomials of a column are just more "components".  A weight tile is loaded once per RT rows and used for all
+// tokens: the W stream (the 335 MB of diagonals of a packed GPT-2 layer) is read once per launch instead of once per token.
+template <class Arith, int RT, int C>
+__global__ __launch_bounds__(256) void matvec_multi_kernel(u64* y, const u64* W, const u64* x, const LimbConst* lcs, int n_limbs, int n,
+                                                           int chunks, size_t rows, size_t cols, size_t polys_per_col /* >= C: the full [n_rhs][2] extent */) {
+    const size_t L = (size_t)n_limbs;
+    const int chunk = (int)(blockIdx.x % chunks);
+    const int limb = (int)((blockIdx.x / chunks) % L);
+    const size_t row0 = (blockIdx.x / chunks / L) * RT;
+    const int w0 = chunk * 512 + threadIdx.x * 2;
+    if (w0 >= n) return;
+    const LimbConst lc = lcs[limb];
+    const u64 two64 = lc.two64;
+    const size_t wstride = L * n, xstride = polys_per_col * L * n, rstride = cols * L * n;
+    Acc128 acc[RT][C][2];
+#pragma unroll
+    for (int r = 0; r < RT; ++r)
+#pragma unroll
+        for (int c = 0; c < C; ++c) acc[r][c][0] = acc[r][c][1] = Acc128{0, 0};
+    const u64* wp = W + (row0 * cols * L + limb) * n + w0;
+    const u64* xp = x + (size_t)limb * n + w0;
+    size_t since = 0;
+    // software pipeline: the operands of column j + 1 are requested before the RT * C multiply-accumulates of column j (there are
+    // only `cols` = 32 iterations in a packed layer and two waves per SIMD: nothing else hides the HBM latency of the W tiles)
+    U64x2 w[RT], xv[C];
+#pragma unroll
+    for (int r = 0; r < RT; ++r) w[r] = (row0 + r < rows) ? *reinterpret_cast<const U64x2*>(wp + r * rstride) : U64x2{0, 0};
+#pragma unroll
+    for (int c = 0; c < C; ++c) xv[c] = *reinterpret_cast<const U64x2*>(xp + (size_t)c * L * n);
+    for (size_t j = 0; j < cols; ++j) {
+        const size_t jn = j + 1 < cols ? j + 1 : j;
+        U64x2 wn[RT], xn[C];
+#pragma unroll
+        for (int r = 0; r < RT; ++r) wn[r] = (row0 + r < rows) ? *reinterpret_cast<const U64x2*>(wp + r * rstride + jn * wstride) : U64x2{0, 0};
+#pragma unroll
+        for (int c = 0; c < C; ++c) xn[c] = *reinterpret_cast<const U64x2*>(xp + jn * xstride + (size_t)c * L * n);
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+#pragma unroll
+            for (int r = 0; r < RT; ++r) { acc_mac(acc[r][c][0], w[r].a, xv[c].a); acc_mac(acc[r][c][1], w[r].b, xv[c].b); }
+        }
+#pragma unroll
+        for (int r = 0; r < RT; ++r) w[r] = wn[r];
+#pragma unroll
+        for (int c = 0; c < C; ++c) xv[c] = xn[c];
+        if (++since == 128) {
+#pragma unroll
+            for (int r = 0; r < RT; ++r)
+#pragma unroll
+                for (int c = 0; c < C; ++c)
+#pragma unroll
+                    for (int k = 0; k < 2; ++k) acc[r][c][k] = Acc128{acc_reduce<Arith>(acc[r][c][k], lc, two64), 0};
+            since = 0;
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < RT; ++r) {
+        if (row0 + r >= rows) break;
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            u64* yp = y + (((row0 + r) * polys_per_col + c) * L + limb) * n + w0;
+            *reinterpret_cast<U64x2*>(yp) = U64x2{acc_reduce<Arith>(acc[r][c][0], lc, two64), acc_reduce<Arith>(acc[r][c][1], lc, two64)};
+        }
     }
 }
 
@@ -295,10 +380,13 @@ __global__ __launch_bounds__(256) void rescale_kernel(u64* out, const u64* in, c
 // N3, hoisted rotations: digit j of the key-switched component (limb j of c1, coefficient domain, values < q_j) lifted to every
 // limb i of the extended basis: out[j][i][k] = c1[j][k] mod q_i (canonical).  One workgroup per (digit, limb, 512-word chunk).
 template <class Arith>
-__global__ __launch_bounds__(256) void lift_digits_kernel(u64* out, const u64* c1, const LimbConst* lcs, int n_limbs, int n, int chunks) {
+// Several input ciphertexts: item t reads c1 + t * in_item_stride and writes out + t * (n_limbs - 1) * n_limbs * n.
+__global__ __launch_bounds__(256) void lift_digits_kernel(u64* out, const u64* c1, size_t in_item_stride, const LimbConst* lcs, int n_limbs, int n, int chunks) {
     const int chunk = (int)(blockIdx.x % chunks);
     const int limb = (int)((blockIdx.x / chunks) % n_limbs);
-    const size_t digit = blockIdx.x / chunks / n_limbs;
+    const size_t dg = blockIdx.x / chunks / n_limbs, item = dg / (unsigned)(n_limbs - 1), digit = dg % (unsigned)(n_limbs - 1);
+    c1 += item * in_item_stride;
+    out += item * (size_t)(n_limbs - 1) * n_limbs * n;
     const int w0 = chunk * 512 + threadIdx.x * 2;
     if (w0 >= n) return;
     const LimbConst lc = lcs[limb];
@@ -325,12 +413,14 @@ __global__ __launch_bounds__(256) void galois_kernel(u64* out, const u64* in, co
 // batched rotations: item i applies its own element (g_inv.v[i]) to input item i (or to the single input item when
 // in_item_stride == 0); polys_per_item residue polynomials per item
 struct GaloisInvs { unsigned v[kMaxGaloisBatch]; };
+// in_mod > 0: output item i reads input item (item0 + i) % in_mod (several rotations of each of in_mod inputs: rotation-major order)
 __global__ __launch_bounds__(256) void galois_multi_kernel(u64* out, const u64* in, size_t in_item_stride, const LimbConst* lcs, int n_limbs, int n,
-                                                           int polys_per_item, GaloisInvs g_inv) {
+                                                           int polys_per_item, GaloisInvs g_inv, unsigned in_mod, unsigned item0) {
     const size_t item = blockIdx.x / (unsigned)polys_per_item, p = blockIdx.x % (unsigned)polys_per_item;
     const u64 q = lcs[p % (size_t)n_limbs].q;
     const unsigned mask2n = 2u * (unsigned)n - 1u, gi = g_inv.v[item];
-    const u64* src = in + item * in_item_stride + p * n;
+    const size_t in_item = in_mod ? (item0 + item) % in_mod : item;
+    const u64* src = in + in_item * in_item_stride + p * n;
     u64* dst = out + (item * polys_per_item + p) * n;
     for (int k = threadIdx.x; k < n; k += 256) {
         const unsigned j = ((unsigned)k * gi) & mask2n;

@@ -31,11 +31,12 @@ template <class Arith>
 int launch_ct_mul(int log2n, unsigned flags, u64* out3, const u64* a2, const u64* b2, size_t blocks, const DevTables<Arith>& tb, hipStream_t s);
 
 template <class Arith>
-int launch_relin(int log2n, int mode, u64* out2, const u64* in3, const u64* evk, size_t key_stride, size_t blocks, const DevTables<Arith>& tb, hipStream_t s);
+int launch_relin(int log2n, int mode, u64* out2, const u64* in3, const u64* evk, size_t key_stride, unsigned key_group, size_t blocks,
+                 const DevTables<Arith>& tb, hipStream_t s);
 
 // hoisted rotations: work[item][2][L][N] = INTT(sum_j perm_{g_item}(digits[j]) (.) keys[item][j]); g as kernel arguments (<= 64 items)
 template <class Arith>
 int launch_hoisted_ks(int log2n, u64* work, const u64* digits, const u64* keys, size_t key_stride, const unsigned* elts, size_t count,
-                      const DevTables<Arith>& tb, hipStream_t s);
+                      size_t n_items, const DevTables<Arith>& tb, hipStream_t s);
 
 }  // namespace dpfhe

@@ -76,8 +76,9 @@ int launch_ct_mul(int log2n, unsigned flags, u64* out3, const u64* a2, const u64
 }
 
 template <class Arith>
-int launch_relin(int log2n, int mode, u64* out2, const u64* in3, const u64* evk, size_t key_stride, size_t blocks, const DevTables<Arith>& tb, hipStream_t s) {
-#define RL_ONE(LN, M) hipLaunchKernelGGL((relin_kernel<Arith, LN, kFusedLoge, M>), dim3((unsigned)blocks), dim3(Geo<LN, kFusedLoge>::T), 0, s, out2, in3, evk, key_stride, tb)
+int launch_relin(int log2n, int mode, u64* out2, const u64* in3, const u64* evk, size_t key_stride, unsigned key_group, size_t blocks,
+                 const DevTables<Arith>& tb, hipStream_t s) {
+#define RL_ONE(LN, M) hipLaunchKernelGGL((relin_kernel<Arith, LN, kFusedLoge, M>), dim3((unsigned)blocks), dim3(Geo<LN, kFusedLoge>::T), 0, s, out2, in3, evk, key_stride, key_group ? key_group : 1u, tb)
 #define RL_CASE(LN, LE)                \
     if (mode == 0) RL_ONE(LN, 0);      \
     else if (mode == 1) RL_ONE(LN, 1); \
@@ -91,12 +92,12 @@ int launch_relin(int log2n, int mode, u64* out2, const u64* in3, const u64* evk,
 
 template <class Arith>
 int launch_hoisted_ks(int log2n, u64* work, const u64* digits, const u64* keys, size_t key_stride, const unsigned* elts, size_t count,
-                      const DevTables<Arith>& tb, hipStream_t s) {
+                      size_t n_items, const DevTables<Arith>& tb, hipStream_t s) {
     GaloisElts ge{};
     for (size_t i = 0; i < count && i < (size_t)kMaxGaloisBatch; ++i) ge.v[i] = elts[i];
-    const unsigned blocks = (unsigned)(count * (size_t)tb.n_limbs * 2);   // (rotation, limb, key component)
+    const unsigned blocks = (unsigned)(count * (size_t)tb.n_limbs * 2 * n_items);   // (rotation, limb, key component, token)
 #define HK_CASE(LN, LE) \
-    hipLaunchKernelGGL((hoisted_ks_kernel<Arith, LN, kFusedLoge>), dim3(blocks), dim3(Geo<LN, kFusedLoge>::T), 0, s, work, digits, keys, key_stride, ge, tb)
+    hipLaunchKernelGGL((hoisted_ks_kernel<Arith, LN, kFusedLoge>), dim3(blocks), dim3(Geo<LN, kFusedLoge>::T), 0, s, work, digits, keys, key_stride, ge, (unsigned)n_items, tb)
     DPFHE_GEO_SWITCH(log2n, HK_CASE)
 #undef HK_CASE
     return 0;

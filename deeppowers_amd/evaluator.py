@@ -330,24 +330,55 @@ class Evaluator:
         return Ciphertext(out, False)
 
     def rotate_hybrid_hoisted(self, ct: Ciphertext, galois_elts, keys: torch.Tensor, stream=None) -> Ciphertext:
-        """N3, hoisted rotations on the extended context: item i = key-switched sigma_{galois_elts[i]} of THE input item, the digit
-        decomposition and its forward transforms shared by all rotations.  keys: [len(elts)][L-1][2][L][N]."""
+        """N3, hoisted rotations on the extended context: output item r * T + t = key-switched sigma_{galois_elts[r]} of input item t
+        (rotation-major), the digit decomposition of each input and its forward transforms shared by all rotations.
+        keys: [len(elts)][L-1][2][L][N]."""
         p = self.ctx.params
         L, Ld, n = p.n_limbs, p.n_limbs - 1, p.n
         d = ct.data
         k = len(galois_elts)
-        if ct.is_ntt or ct.size != 2 or d.dim() != 4 or d.shape[0] != 1 or d.shape[-2] != Ld or d.shape[-1] != n or d.dtype != torch.int64 or not d.is_contiguous():
-            raise _cabi.DpfheError(2000, "rotate_hybrid_hoisted: one coefficient-domain [1][2][L-1][N] ciphertext on the extended context")
+        if ct.is_ntt or ct.size != 2 or d.dim() != 4 or d.shape[-2] != Ld or d.shape[-1] != n or d.dtype != torch.int64 or not d.is_contiguous():
+            raise _cabi.DpfheError(2000, "rotate_hybrid_hoisted: coefficient-domain [T][2][L-1][N] ciphertexts on the extended context")
+        T = d.shape[0]
         if tuple(keys.shape) != (k, Ld, 2, L, n) or keys.dtype != torch.int64 or not keys.is_contiguous():
             raise _cabi.DpfheError(2000, "keys must be [k][L-1][2][L][N]")
-        out = self._empty((k, 2, Ld, n), stream)
-        work = self._empty((k, 2, L, n), stream)
-        rotated0 = self._empty((k, Ld, n), stream)
-        digits = self._empty((Ld, L, n), stream)
+        out = self._empty((k * T, 2, Ld, n), stream)
+        work = self._empty((k * T, 2, L, n), stream)
+        rotated0 = self._empty((k * T, Ld, n), stream)
+        digits = self._empty((T, Ld, L, n), stream)
         elts = (C.c_uint32 * k)(*[int(g) for g in galois_elts])
-        _cabi.check(self._lib.dpfhe_rotate_hybrid_hoisted(self.ctx.handle, out.data_ptr(), d.data_ptr(), elts, keys.data_ptr(), work.data_ptr(), rotated0.data_ptr(),
+        _cabi.check(self._lib.dpfhe_rotate_hybrid_hoisted(self.ctx.handle, out.data_ptr(), d.data_ptr(), T, elts, keys.data_ptr(), work.data_ptr(), rotated0.data_ptr(),
                                                           digits.data_ptr(), k, self._sp(stream)), "dpfhe_rotate_hybrid_hoisted")
         return Ciphertext(out, False)
+
+    def rotate_hybrid_grouped(self, ct: Ciphertext, galois_elts, group: int, keys: torch.Tensor, stream=None) -> Ciphertext:
+        """N3, grouped rotations: ct holds len(elts) * group items, item i is rotated by galois_elts[i // group] with key i // group."""
+        p = self.ctx.params
+        L, Ld, n = p.n_limbs, p.n_limbs - 1, p.n
+        d = ct.data
+        k = len(galois_elts)
+        if ct.is_ntt or ct.size != 2 or d.dim() != 4 or d.shape[0] != k * group or d.shape[-2] != Ld or d.shape[-1] != n or d.dtype != torch.int64 or not d.is_contiguous():
+            raise _cabi.DpfheError(2000, "rotate_hybrid_grouped: coefficient-domain [k * group][2][L-1][N] ciphertexts on the extended context")
+        if tuple(keys.shape) != (k, Ld, 2, L, n) or keys.dtype != torch.int64 or not keys.is_contiguous():
+            raise _cabi.DpfheError(2000, "keys must be [k][L-1][2][L][N]")
+        out = self._empty((k * group, 2, Ld, n), stream)
+        work = self._empty((k * group, 2, L, n), stream)
+        rotated = self._empty((k * group, 2, Ld, n), stream)
+        elts = (C.c_uint32 * k)(*[int(g) for g in galois_elts])
+        _cabi.check(self._lib.dpfhe_rotate_hybrid_grouped(self.ctx.handle, out.data_ptr(), d.data_ptr(), elts, k, group, keys.data_ptr(), work.data_ptr(),
+                                                          rotated.data_ptr(), self._sp(stream)), "dpfhe_rotate_hybrid_grouped")
+        return Ciphertext(out, False)
+
+    def matvec_plain_multi(self, W: Plaintext, x: torch.Tensor, n_rhs: int, stream=None) -> torch.Tensor:
+        """y[i][t] = sum_j W[i][j] (.) x[j][t].  W.data: [rows][cols][L][N] (NTT), x: [cols][n_rhs][2][L][N] (NTT) -> [rows][n_rhs][2][L][N]."""
+        self._chk(W.data, x)
+        if W.data.dim() != 4 or x.dim() != 5 or x.shape[1] != n_rhs or x.shape[2] != 2 or W.data.shape[1] != x.shape[0]:
+            raise _cabi.DpfheError(2000, "matvec_plain_multi: W [rows][cols][L][N], x [cols][n_rhs][2][L][N]")
+        rows, cols = W.data.shape[0], W.data.shape[1]
+        out = self._empty((rows, n_rhs, 2, self.ctx.params.n_limbs, self.ctx.params.n), stream)
+        _cabi.check(self._lib.dpfhe_matvec_plain_multi(self.ctx.handle, out.data_ptr(), W.data.data_ptr(), x.data_ptr(), rows, cols, n_rhs, self._sp(stream)),
+                    "dpfhe_matvec_plain_multi")
+        return out
 
     def rescale_words(self, t: torch.Tensor, stream=None) -> torch.Tensor:
         """[..., L, N] -> [..., L-1, N]: round(x / q_last) limb by limb (coefficient domain).  The result belongs to the

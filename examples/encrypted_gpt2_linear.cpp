@@ -3,8 +3,9 @@
 // Z_65537 by the diagonal method with baby-step / giant-step rotations (deeppowers::fhe::PackedLinear).
 // The layer shapes are the reference's matmul sites (/root/reference/src/core/execution/models/gpt_model.cpp:793 QKV 768 -> 2304,
 // :848 FFN 768 -> 3072 -> 768, :883 logits 768 -> 50257; hidden_size 768, vocab 50257 at execution/model.hpp:47-50).
-//   usage: encrypted_gpt2_linear [layer = all | square | qkv | ffn_up | ffn_down | lm_head | <out>x<in>] [reps = 2] [json]
+//   usage: encrypted_gpt2_linear [layer = all | square | qkv | ffn_up | ffn_down | lm_head | <out>x<in>] [reps = 2] [json | text] [tokens = 1]
 // Prints one line per layer; with a third argument "json" the lines are JSON objects (bench.py other_configs.packed_linear).
+// tokens > 1: that many encrypted hidden states go through the layer in ONE application (keys and diagonals read once).
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -22,6 +23,7 @@ int main(int argc, char** argv) {
     const std::string which = argc > 1 ? argv[1] : "all";
     const int reps = argc > 2 ? std::atoi(argv[2]) : 2;
     const bool json = argc > 3 && !std::strcmp(argv[3], "json");
+    const size_t T = argc > 4 ? (size_t)std::atol(argv[4]) : 1;
     std::vector<Shape> shapes;
     const Shape known[] = {{"square", 768, 768}, {"qkv", 2304, 768}, {"ffn_up", 3072, 768}, {"ffn_down", 768, 3072}, {"lm_head", 50257, 768}};
     for (const Shape& k : known)
@@ -48,43 +50,48 @@ int main(int argc, char** argv) {
             // 8-bit quantised weights and activations (the reference's INT8 path: src/core/quantization), values in [-127, 127] mod t
             uint64_t s = 5 + sh.out;
             auto rnd = [&](uint64_t m) { s = s * 6364136223846793005ull + 1442695040888963407ull; return (s >> 33) % m; };
-            std::vector<uint64_t> W(sh.out * sh.in), x(sh.in), want(sh.out);
+            std::vector<uint64_t> W(sh.out * sh.in), x(T * sh.in), want(T * sh.out);
             for (auto& v : W) v = (t + rnd(255) - 127) % t;
             for (auto& v : x) v = (t + rnd(255) - 127) % t;
-            for (size_t r = 0; r < sh.out; ++r) {
-                unsigned __int128 acc = 0;
-                for (size_t c = 0; c < sh.in; ++c) acc += (unsigned __int128)W[r * sh.in + c] * x[c];
-                want[r] = (uint64_t)(acc % t);
-            }
+            for (size_t tk = 0; tk < T; ++tk)
+                for (size_t r = 0; r < sh.out; ++r) {
+                    unsigned __int128 acc = 0;
+                    for (size_t c = 0; c < sh.in; ++c) acc += (unsigned __int128)W[r * sh.in + c] * x[tk * sh.in + c];
+                    want[tk * sh.out + r] = (uint64_t)(acc % t);
+                }
             auto t0 = std::chrono::steady_clock::now();
             PackedLinear layer(ctx, be, hks, W.data(), sh.out, sh.in);     // encodes + transforms the diagonals, generates the rotation keys
             const double setup_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
             const size_t outs = layer.output_ciphertexts();
-            std::vector<uint64_t> slots(n), dm(outs * n), got(outs * n), y(sh.out);
-            std::vector<int64_t> coeffs(n);
-            layer.pack_input(x.data(), slots.data());
-            be.encode(slots.data(), coeffs.data());
-            Ciphertext cx(ctx, 2, 1), cy(ctx, 2, outs);
+            std::vector<uint64_t> slots(n), dm(outs * T * n), got(outs * n), y(sh.out);
+            std::vector<int64_t> coeffs(T * n);
+            for (size_t tk = 0; tk < T; ++tk) {
+                layer.pack_input(&x[tk * sh.in], slots.data());
+                be.encode(slots.data(), &coeffs[tk * n]);
+            }
+            Ciphertext cx(ctx, 2, T), cy(ctx, 2, outs * T);
             enc.encrypt_exact(coeffs.data(), t, cx);
             layer.apply(cx, cy);                                // warm-up (code objects, allocator)
             ctx.synchronize();
             t0 = std::chrono::steady_clock::now();
             for (int i = 0; i < reps; ++i) layer.apply(cx, cy);
             ctx.synchronize();
-            const double apply_ms = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() * 1e3 / reps;
+            const double apply_ms = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() * 1e3 / reps / (double)T;
             dec.decrypt_exact(cy, t, dm.data());
-            for (size_t o = 0; o < outs; ++o) be.decode(dm.data() + o * n, got.data() + o * n);
-            layer.unpack_output(got.data(), y.data());
             size_t bad = 0;
-            for (size_t r = 0; r < sh.out; ++r) bad += y[r] != want[r];
+            for (size_t tk = 0; tk < T; ++tk) {
+                for (size_t o = 0; o < outs; ++o) be.decode(dm.data() + (o * T + tk) * n, got.data() + o * n);
+                layer.unpack_output(got.data(), y.data());
+                for (size_t r = 0; r < sh.out; ++r) bad += y[r] != want[tk * sh.out + r];
+            }
             if (json)
                 std::printf("{\"layer\": \"%s\", \"out_dim\": %zu, \"in_dim\": %zu, \"log2_n\": 13, \"data_limbs\": %zu, \"plain_modulus\": %llu, \"baby_steps\": %zu, "
-                            "\"giant_steps\": %zu, \"output_ciphertexts\": %zu, \"key_switches\": %zu, \"setup_s\": %.2f, \"ms_per_token\": %.3f, \"correct\": %s}\n",
-                            sh.name, sh.out, sh.in, p.n_limbs(), (unsigned long long)t, layer.baby_steps(), layer.giant_steps(), outs, layer.key_switches_per_apply(),
+                            "\"giant_steps\": %zu, \"output_ciphertexts\": %zu, \"key_switches\": %zu, \"tokens_per_apply\": %zu, \"setup_s\": %.2f, \"ms_per_token\": %.3f, \"correct\": %s}\n",
+                            sh.name, sh.out, sh.in, p.n_limbs(), (unsigned long long)t, layer.baby_steps(), layer.giant_steps(), outs, layer.key_switches_per_apply(), T,
                             setup_s, apply_ms, bad ? "false" : "true");
             else
-                std::printf("%-8s %5zu <- %4zu: period %zu, %zu baby x %zu giant steps, %zu output ciphertext(s), %zu key switches; setup %.2f s, apply %.3f ms per token: %s\n",
-                            sh.name, sh.out, sh.in, layer.input_period(), layer.baby_steps(), layer.giant_steps(), outs, layer.key_switches_per_apply(), setup_s, apply_ms,
+                std::printf("%-8s %5zu <- %4zu: period %zu, %zu baby x %zu giant steps, %zu output ciphertext(s), %zu key switches, %zu token(s) per apply; setup %.2f s, apply %.3f ms per token: %s\n",
+                            sh.name, sh.out, sh.in, layer.input_period(), layer.baby_steps(), layer.giant_steps(), outs, layer.key_switches_per_apply(), T, setup_s, apply_ms,
                             bad ? "MISMATCH" : "decrypts to W x mod t");
             if (bad) rc = 1;
         }

@@ -172,6 +172,8 @@ public:
     void multiply_plain(const Ciphertext& a, const Plaintext& p, Ciphertext& out, Stream* stream = nullptr) const;
     void matvec_plain(const Plaintext& W /* batch = rows*cols */, const Ciphertext& x /* batch = cols */, Ciphertext& y /* batch = rows */,
                       Stream* stream = nullptr) const;
+    // A7 with n_rhs right-hand sides: x batch = cols * n_rhs laid out [cols][n_rhs], y batch = rows * n_rhs laid out [rows][n_rhs]
+    void matvec_plain_multi(const Plaintext& W, const Ciphertext& x, Ciphertext& y, size_t n_rhs, Stream* stream = nullptr) const;
     // A7, scalar weights: y_i = sum_j w_ij * x_j (either domain; y takes x's domain).  x: batch = cols, y: batch = rows.
     // With one ciphertext per input feature and one sample per coefficient this IS the encrypted linear layer that
     // replaces the plaintext matvec sites of the reference (gpt_model.cpp:793,848,883).
@@ -326,8 +328,12 @@ public:
     // HOISTED: many rotations of ONE item (in2 item in_item): the digit decomposition of c1 and its forward transforms are done
     // once, each rotation is a permutation in the NTT domain + its key inner product (dpfhe_rotate_hybrid_hoisted).  A valid key
     // switch of sigma_g(ct), not word-identical to apply_galois_many (the automorphism acts after the lift, not before it).
-    void apply_galois_hoisted(const Ciphertext& in2, size_t in_item, const std::vector<uint32_t>& galois_elts, Ciphertext& out2, size_t out_first,
-                              Stream* stream = nullptr) const;
+    // n_items inputs (in2 items in_first ...) share the rotations; the output is ROTATION-MAJOR: item out_first + r * n_items + t.
+    void apply_galois_hoisted(const Ciphertext& in2, size_t in_first, size_t n_items, const std::vector<uint32_t>& galois_elts, Ciphertext& out2,
+                              size_t out_first, Stream* stream = nullptr) const;
+    // k * group items, item i rotated by galois_elts[i / group] (the giant steps of `group` tokens; keys read once per element)
+    void apply_galois_grouped(const Ciphertext& in2, size_t in_first, const std::vector<uint32_t>& galois_elts, size_t group, Ciphertext& out2,
+                              size_t out_first, Stream* stream = nullptr) const;
 
 private:
     class Impl;
@@ -393,9 +399,11 @@ public:
     // output_ciphertexts() * N decoded slots -> y (out_dim values)
     void pack_input(const uint64_t* x, uint64_t* slots) const;
     void unpack_output(const uint64_t* slots, uint64_t* y) const;
-    // x: 1 item, y: output_ciphertexts() items; 2 components, coefficient domain.  Enqueues on `stream` and returns (no allocation,
-    // no host synchronisation: the scratch belongs to the layer, so one apply() at a time per object); synchronise before
-    // reading y on the host.
+    // x: T items (T tokens, each packed with pack_input), y: output_ciphertexts() * T items, output ciphertext o of token t at item
+    // o * T + t; 2 components, coefficient domain.  All tokens share ONE pass over the rotation keys and the diagonals (hoisted
+    // baby steps per token, one multi-right-hand-side matvec, grouped giant steps).  Enqueues on `stream` and returns (no host
+    // synchronisation; the scratch belongs to the layer and grows only when a larger T than ever before arrives, so one apply()
+    // at a time per object); synchronise before reading y on the host.
     void apply(const Ciphertext& x, Ciphertext& y, Stream* stream = nullptr) const;
 
 private:

@@ -124,8 +124,16 @@ int dpfhe_rotate_hybrid_batch(dpfhe_ctx* ctx_ext, uint64_t* d_out2, const uint64
  * (instead of Ld + 2), followed by the divide-by-P pass.  Keys and d_work as for dpfhe_rotate_hybrid_batch; d_rotated0:
  * batch * Ld * N words of scratch (sigma_g(c0)).  The result is a valid key switch of sigma_g(ct) but NOT word-identical to
  * dpfhe_rotate_hybrid_batch: here the automorphism acts on the lifted digits (sigma_g after the lift), there on c1 before it. */
-int dpfhe_rotate_hybrid_hoisted(dpfhe_ctx* ctx_ext, uint64_t* d_out2, const uint64_t* d_in2, const uint32_t* galois_elts, const uint64_t* d_keys,
-                                uint64_t* d_work, uint64_t* d_rotated0, uint64_t* d_digits, size_t batch, void* stream);
+int dpfhe_rotate_hybrid_hoisted(dpfhe_ctx* ctx_ext, uint64_t* d_out2, const uint64_t* d_in2, size_t n_items, const uint32_t* galois_elts,
+                                const uint64_t* d_keys, uint64_t* d_work, uint64_t* d_rotated0, uint64_t* d_digits, size_t batch, void* stream);
+/*    n_items input ciphertexts (tokens) share the `batch` rotations and their keys: d_in2 is [n_items][2][Ld][N], the output is
+ *    ROTATION-MAJOR, item r * n_items + t = sigma_{galois_elts[r]}(input t); scratch sizes scale with n_items (d_work, d_rotated0:
+ *    batch * n_items items; d_digits: n_items * Ld * L * N words).  Workgroups that read the same key tile run next to each other. */
+
+/* -- N3, grouped rotations (giant steps of several tokens): batch = n_elts * group items, item i rotated by galois_elts[i / group]
+ *    with key i / group; otherwise as dpfhe_rotate_hybrid_batch with n_in == batch. */
+int dpfhe_rotate_hybrid_grouped(dpfhe_ctx* ctx_ext, uint64_t* d_out2, const uint64_t* d_in2, const uint32_t* galois_elts, size_t n_elts, size_t group,
+                                const uint64_t* d_keys, uint64_t* d_work, uint64_t* d_rotated, void* stream);
 
 /* -- N3: Galois automorphism a(X) -> a(X^galois_elt) (galois_elt odd, < 2N), coefficient domain, d_out != d_in;
  *        and the key switch that follows it:  (c0', c1') = (c0 + sum_j [c1]_{q_j} (.) key_j[0], sum_j [c1]_{q_j} (.) key_j[1]),
@@ -138,6 +146,11 @@ int dpfhe_switch_key(dpfhe_ctx* ctx, uint64_t* d_out2, const uint64_t* d_in2, co
  * y_i = sum_j W_ij (.) x_j  with 128-bit lazy accumulation and one reduction at the end. */
 int dpfhe_matvec_plain(dpfhe_ctx* ctx, uint64_t* d_y, const uint64_t* d_W, const uint64_t* d_x, size_t rows,
                        size_t cols, void* stream);
+
+/* -- A7 with n_rhs right-hand sides (tokens): x is [cols][n_rhs][2][L][N], y is [rows][n_rhs][2][L][N] (the token index sits between
+ *    the column / row and the component); y[i][t] = sum_j W[i][j] (.) x[j][t].  W is streamed once per group of 4 right-hand sides. */
+int dpfhe_matvec_plain_multi(dpfhe_ctx* ctx, uint64_t* d_y, const uint64_t* d_W, const uint64_t* d_x, size_t rows, size_t cols, size_t n_rhs,
+                             void* stream);
 
 /* scalar-weight variant (the realistic plaintext linear layer: W_ij in Z_q, given as one residue per limb):
  * d_w: [rows][cols][L] words;  y_i = sum_j w_ij * x_j.  Works in either domain (scalars commute with the NTT). */

@@ -1,5 +1,6 @@
 // GPU test of the C++ facade (deeppowers::fhe) against the C oracle.  Built and run by
 // tests/test_gpu_cpp_api.py (-m gpu).  Exit code 0 = all checks passed.
+#include <algorithm>
 #include <cmath>
 #include <sstream>
 #include <cstdio>
@@ -194,6 +195,38 @@ static void packed_rect(unsigned log2n) {
         lin.apply(ct, cy);           // scratch reuse: a second application gives the same answer
         ctx.synchronize();
         std::vector<uint64_t> dm(outs * n), got(outs * n), y(out);
+        dec.decrypt_exact(cy, t, dm.data());
+        for (size_t o = 0; o < outs; ++o) be.decode(dm.data() + o * n, got.data() + o * n);
+        lin.unpack_output(got.data(), y.data());
+        CHECK(y == want);
+        // several tokens per launch (T = 5: the 4 + 1 grouping of the multi-right-hand-side matvec), then a single token again
+        // (scratch sized for 5 tokens, used for 1)
+        const size_t T = 5;
+        std::vector<uint64_t> xs(T * in), wants(T * out);
+        std::vector<int64_t> cxs(T * n);
+        for (size_t tk = 0; tk < T; ++tk) {
+            for (size_t c = 0; c < in; ++c) xs[tk * in + c] = rnd();
+            for (size_t r = 0; r < out; ++r) {
+                unsigned __int128 acc = 0;
+                for (size_t c = 0; c < in; ++c) acc += (unsigned __int128)W[r * in + c] * xs[tk * in + c];
+                wants[tk * out + r] = (uint64_t)(acc % t);
+            }
+            lin.pack_input(&xs[tk * in], slots.data());
+            be.encode(slots.data(), &cxs[tk * n]);
+        }
+        Ciphertext ctT(ctx, 2, T), cyT(ctx, 2, outs * T);
+        enc.encrypt_exact(cxs.data(), t, ctT);
+        lin.apply(ctT, cyT);
+        ctx.synchronize();
+        std::vector<uint64_t> dmT(outs * T * n), gotT(outs * n);
+        dec.decrypt_exact(cyT, t, dmT.data());
+        for (size_t tk = 0; tk < T; ++tk) {
+            for (size_t o = 0; o < outs; ++o) be.decode(dmT.data() + (o * T + tk) * n, gotT.data() + o * n);   // output o of token tk: item o * T + tk
+            lin.unpack_output(gotT.data(), y.data());
+            CHECK(std::equal(y.begin(), y.end(), wants.begin() + tk * out));
+        }
+        lin.apply(ct, cy);
+        ctx.synchronize();
         dec.decrypt_exact(cy, t, dm.data());
         for (size_t o = 0; o < outs; ++o) be.decode(dm.data() + o * n, got.data() + o * n);
         lin.unpack_output(got.data(), y.data());

@@ -52,6 +52,14 @@ def test_example_encrypted_gpt2_layers_full_size(layer):
 
 
 @pytest.mark.gpu
+def test_example_encrypted_gpt2_layers_eight_tokens_per_launch():
+    """The same layers with 8 encrypted hidden states per application (keys and diagonals read once for all of them): every token's
+    decrypted result equals W x mod t."""
+    out = subprocess.run([build_example("encrypted_gpt2_linear"), "all", "1", "text", "8"], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0 and "OK" in out.stdout and "MISMATCH" not in out.stdout and "8 token(s)" in out.stdout, out.stdout + out.stderr
+
+
+@pytest.mark.gpu
 def test_example_encrypted_gpt2_lm_head_tile():
     """gpt_model.cpp:883 logits: 768 -> 50257 is 7 output ciphertexts sharing the baby steps; a 3-ciphertext tile (768 -> 20000)
     runs here, the full head in examples/encrypted_gpt2_linear lm_head (2.3 GB of diagonals, ~1 min of host-side encoding)."""

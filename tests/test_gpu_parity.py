@@ -271,6 +271,20 @@ def test_matvec_plain_vs_oracle(rigs, name, rows, cols):
     assert y.is_ntt and np.array_equal(to_host(y.data), want)
 
 
+def test_matvec_plain_multi_rhs_vs_oracle(rigs):
+    """dpfhe_matvec_plain_multi: [cols][n_rhs] right-hand sides against one oracle matvec per right-hand side; n_rhs = 7 exercises
+    the 4 + 2 + 1 grouping, ragged row counts the tile tails."""
+    r = rigs("n4096")
+    L, n = r.p.n_limbs, r.p.n
+    for rows, cols, n_rhs in ((5, 3, 7), (8, 16, 4), (3, 2, 2), (2, 5, 1)):
+        W = r.orc.fill(rows * cols, 11).reshape(rows, cols, L, n)
+        x = r.orc.fill(cols * n_rhs * 2, 12).reshape(cols, n_rhs, 2, L, n)
+        got = to_host(r.ev.matvec_plain_multi(Plaintext(r.dev(W), True), r.dev(x), n_rhs))
+        for t in range(n_rhs):
+            want = r.orc.matvec_plain(W.ravel(), np.ascontiguousarray(x[:, t]).ravel(), rows, cols, threads=0)
+            assert np.array_equal(got[:, t], want), (rows, cols, n_rhs, t)
+
+
 @pytest.mark.parametrize("name,rows,cols", [("n4096", 13, 9), ("fold8", 3, 300), ("shoup10", 9, 130), ("config1", 8, 5)])
 def test_matvec_scalar_vs_oracle(rigs, name, rows, cols):
     r = rigs(name)

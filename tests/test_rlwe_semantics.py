@@ -520,6 +520,22 @@ def test_gpu_hoisted_rotations_bit_exact(name):
         want = orc.rotate_hoisted(ct[0], [elts[i] for i in idx], keys[idx], threads=0)
         for w, i in zip(want, idx):
             assert np.array_equal(got[i], w), (k, i)
+    # several inputs sharing the rotations (tokens): rotation-major output, item r * T + t = rotation r of input t; and the grouped
+    # (giant-step) form against the per-item oracle of the un-hoisted path
+    T, k = 3, 70
+    elts = [pow(3, i + 1, 2 * n) for i in range(k)]
+    keys = orc.fill(k * Ld * 2, 703).reshape(k, Ld, 2, L, n)
+    cts = data.fill(T * 2, 704).reshape(T, 2, Ld, n)
+    dk = to_device(keys, ctx.device)
+    got = to_host(ev.rotate_hybrid_hoisted(Ciphertext(to_device(cts, ctx.device)), elts, dk).data).reshape(k, T, 2, Ld, n)
+    for r in (0, 21, 22, 63, 64, 69):
+        for t in range(T):
+            assert np.array_equal(got[r, t], orc.rotate_hoisted(cts[t], [elts[r]], keys[r][None], threads=0)[0]), (r, t)
+    items = data.fill(k * T * 2, 705).reshape(k * T, 2, Ld, n)
+    got = to_host(ev.rotate_hybrid_grouped(Ciphertext(to_device(items, ctx.device)), elts, T, dk).data)
+    for i in (0, 1, 2, 3, 63, 64, 65, 191, 192, k * T - 1):
+        want = orc.keyswitch_hybrid(data.apply_galois(items[i][None], elts[i // T]), keys[i // T], 2, threads=0)[0]
+        assert np.array_equal(got[i], want), i
     ctx.close()
 
 
