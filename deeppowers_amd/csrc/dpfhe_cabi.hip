@@ -398,6 +398,15 @@ extern "C" int dpfhe_switch_key_hybrid(dpfhe_ctx* c, uint64_t* d_out2, const uin
     return hybrid_entry(c, "dpfhe_switch_key_hybrid", 2, d_out2, d_in2, d_key, d_work, batch, stream);
 }
 
+// automorphism launch: polynomials up to 64 KiB are staged through LDS, larger ones gathered from global memory
+static void launch_galois_multi(hipStream_t s, unsigned grid, u64* out, const u64* in, size_t in_item_stride, const LimbConst* lc, int n_limbs, int n,
+                                int polys_per_item, const GaloisInvs& inv, unsigned in_mod, unsigned item0) {
+    if (n <= 8192)
+        hipLaunchKernelGGL(galois_multi_kernel<true>, dim3(grid), dim3(256), (size_t)n * 8, s, out, in, in_item_stride, lc, n_limbs, n, polys_per_item, inv, in_mod, item0);
+    else
+        hipLaunchKernelGGL(galois_multi_kernel<false>, dim3(grid), dim3(256), 0, s, out, in, in_item_stride, lc, n_limbs, n, polys_per_item, inv, in_mod, item0);
+}
+
 static unsigned galois_inverse(unsigned g, unsigned two_n) {  // g^-1 mod 2N by Newton iteration (g odd): x <- x (2 - g x)
     unsigned inv = 1;
     for (int i = 0; i < 5; ++i) inv *= 2u - g * inv;
@@ -431,8 +440,7 @@ static int rotate_batch_impl(dpfhe_ctx* c, const char* what, uint64_t* d_out2, c
         GaloisInvs inv{};
         for (size_t i = 0; i < cnt; ++i) inv.v[i] = galois_inverse(galois_elts[(first + i) / group], two_n);
         const uint64_t* src = d_in2 + (n_in == 1 ? 0 : first * ct_words);
-        hipLaunchKernelGGL(galois_multi_kernel, dim3((unsigned)(cnt * 2 * Ld)), dim3(256), 0, s, d_rotated + first * ct_words, src,
-                           n_in == 1 ? (size_t)0 : ct_words, lc, (int)Ld, n, (int)(2 * Ld), inv, 0u, 0u);
+        launch_galois_multi(s, (unsigned)(cnt * 2 * Ld), d_rotated + first * ct_words, src, n_in == 1 ? (size_t)0 : ct_words, lc, (int)Ld, n, (int)(2 * Ld), inv, 0u, 0u);
         int e = check_launch("galois kernel launch");
         if (e) return e;
     }
@@ -494,8 +502,7 @@ extern "C" int dpfhe_rotate_hybrid_hoisted(dpfhe_ctx* c, uint64_t* d_out2, const
         const size_t cnt = total - first < (size_t)kMaxGaloisBatch ? total - first : (size_t)kMaxGaloisBatch;
         GaloisInvs inv{};
         for (size_t i = 0; i < cnt; ++i) inv.v[i] = galois_inverse(galois_elts[(first + i) / T], two_n);
-        hipLaunchKernelGGL(galois_multi_kernel, dim3((unsigned)(cnt * Ld)), dim3(256), 0, s, d_rotated0 + first * Ld * n, d_in2, 2 * Ld * (size_t)n, lc, (int)Ld, n, (int)Ld, inv,
-                           (unsigned)T, (unsigned)(first % T));
+        launch_galois_multi(s, (unsigned)(cnt * Ld), d_rotated0 + first * Ld * n, d_in2, 2 * Ld * (size_t)n, lc, (int)Ld, n, (int)Ld, inv, (unsigned)T, (unsigned)(first % T));
         if (int e = check_launch("galois kernel launch")) return e;
     }
     // 3. permuted digits (.) keys, one inverse transform per (rotation, limb, key component, item); 64 rotations per launch
