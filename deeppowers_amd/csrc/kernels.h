@@ -172,8 +172,11 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE)) void ntt_inv_kernel(u64* __rest
 //   4 forward NTTs -> register-resident dyadic tensor product -> 3 inverse NTTs, as three rounds of
 //   [forward, forward, inverse].  HBM traffic: 4 reads + 3 writes of a residue poly.
 // ------------------------------------------------------------------------------------------------
+#ifndef DPFHE_CTMUL_OCC
+#define DPFHE_CTMUL_OCC 2
+#endif
 template <class Arith, int LOGN, int LOGE, bool IN_NTT, bool OUT_NTT>
-__global__ __launch_bounds__(1 << (LOGN - LOGE), (LOGE <= 3 && LOGN - LOGE <= 9) ? 4 : 2) void ct_mul_kernel(u64* __restrict__ out3, const u64* __restrict__ a2,
+__global__ __launch_bounds__(1 << (LOGN - LOGE), (LOGE <= 3 && LOGN - LOGE <= 9) ? 4 : DPFHE_CTMUL_OCC) void ct_mul_kernel(u64* __restrict__ out3, const u64* __restrict__ a2,
                                                                         const u64* __restrict__ b2, DevTables<Arith> tb) {
     typedef NttBody<Arith, LOGN, LOGE> B;
     static_assert(LOGE == kFusedLoge, "the fused kernels read the fused twiddle layout (DevTables::fwd4 / inv4)");
