@@ -93,6 +93,38 @@ struct FwdChain {
     }
 };
 
+// Two transforms OF THE SAME LIMB side by side (the fused multiply's a0|b0 and a1|b1): one set of twiddle fetches and
+// twiddle addresses for both, two independent dependency chains per wave (the second polynomial's butterflies issue while
+// the first one's LDS exchange is in flight), one barrier for both all-to-all exchanges.  Two LDS buffers.
+template <class B, int P>
+struct FwdChain2 {
+    typedef typename B::TwRegs TwRegs;
+    static __device__ __forceinline__ void run(int tid, u64 (&x)[B::E], u64 (&y)[B::E], u64* lds0, u64* lds1, const typename B::Tw* tw,
+                                               const LimbConst& lc) {
+        TwRegs twr;
+        B::template load_tw<P, true>(tid, tw, twr);
+        run_with(tid, x, y, lds0, lds1, tw, lc, twr);
+    }
+    static __device__ __forceinline__ void run_with(int tid, u64 (&x)[B::E], u64 (&y)[B::E], u64* lds0, u64* lds1, const typename B::Tw* tw,
+                                                    const LimbConst& lc, const TwRegs& twr) {
+        B::template fwd_phase_r<P>(x, twr, lc);
+        if constexpr (P + 1 < B::NPH) {
+            exch_sync_before_write<typename B::G, P, true>();
+            B::template lds_write<P, P, true>(tid, x, lds0);
+            B::template fwd_phase_r<P>(y, twr, lc);
+            TwRegs nxt;
+            B::template load_tw<P + 1, true>(tid, tw, nxt);
+            B::template lds_write<P, P, true>(tid, y, lds1);
+            exch_sync_after_write<typename B::G, P>();
+            B::template lds_read<P, P + 1, true>(tid, x, lds0);
+            B::template lds_read<P, P + 1, true>(tid, y, lds1);
+            FwdChain2<B, P + 1>::run_with(tid, x, y, lds0, lds1, tw, lc, nxt);
+        } else {
+            B::template fwd_phase_r<P>(y, twr, lc);
+        }
+    }
+};
+
 template <class B, int P, int IN>
 struct InvChain {
     typedef typename B::TwRegs TwRegs;
@@ -113,6 +145,35 @@ struct InvChain {
             exch_sync_after_write<typename B::G, P - 1>();
             B::template lds_read<P - 1, P - 1, false>(tid, x, lds);
             InvChain<B, P - 1, IN>::run_with(tid, x, lds, tw, last, lc, nxt);
+        }
+    }
+};
+
+template <class B, int P, int IN>
+struct InvChain2 {
+    typedef typename B::TwRegs TwRegs;
+    static __device__ __forceinline__ void run(int tid, u64 (&x)[B::E], u64 (&y)[B::E], u64* lds0, u64* lds1, const typename B::Tw* tw,
+                                               const InvLast<typename B::Tw>& last, const LimbConst& lc) {
+        TwRegs twr;
+        B::template load_tw<P, false>(tid, tw, twr);
+        run_with(tid, x, y, lds0, lds1, tw, last, lc, twr);
+    }
+    static __device__ __forceinline__ void run_with(int tid, u64 (&x)[B::E], u64 (&y)[B::E], u64* lds0, u64* lds1, const typename B::Tw* tw,
+                                                    const InvLast<typename B::Tw>& last, const LimbConst& lc, const TwRegs& twr) {
+        B::template inv_phase_r<P, IN>(x, twr, last.w_last, last.w_ninv, lc);
+        if constexpr (P > 0) {
+            exch_sync_before_write<typename B::G, P - 1, false>();
+            B::template lds_write<P - 1, P, false>(tid, x, lds0);
+            B::template inv_phase_r<P, IN>(y, twr, last.w_last, last.w_ninv, lc);
+            TwRegs nxt;
+            B::template load_tw<P - 1, false>(tid, tw, nxt);
+            B::template lds_write<P - 1, P, false>(tid, y, lds1);
+            exch_sync_after_write<typename B::G, P - 1>();
+            B::template lds_read<P - 1, P - 1, false>(tid, x, lds0);
+            B::template lds_read<P - 1, P - 1, false>(tid, y, lds1);
+            InvChain2<B, P - 1, IN>::run_with(tid, x, y, lds0, lds1, tw, last, lc, nxt);
+        } else {
+            B::template inv_phase_r<P, IN>(y, twr, last.w_last, last.w_ninv, lc);
         }
     }
 };
@@ -278,6 +339,98 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE), (LOGE <= 3 && LOGN - LOGE <= 9)
             InvChain<B, B::NPH - 1, kInvIn>::run_with(tid, x, lds, twi, last, lc, tw_first);
             B::inv_canon(x, lc);
             B::template store_top<true>(tid, x, d);
+        }
+    }
+}
+
+
+// The same operation with the forward transforms in PAIRS (FwdChain2: a0|b0, then a1|b1) and the three inverse transforms
+// alternating between the two LDS buffers (no barrier between them).  Coefficient-domain input only.
+template <class Arith, int LOGN, int LOGE, bool OUT_NTT>
+__global__ __launch_bounds__(1 << (LOGN - LOGE), 2) void ct_mul_dual_kernel(u64* __restrict__ out3, const u64* __restrict__ a2,
+                                                                         const u64* __restrict__ b2, DevTables<Arith> tb) {
+    typedef NttBody<Arith, LOGN, LOGE> B;
+    static_assert(LOGE == kFusedLoge, "the fused kernels read the fused twiddle layout (DevTables::fwd4 / inv4)");
+    constexpr int E = B::E, N = B::G::N, W = B::G::lds_words();
+    __shared__ __attribute__((aligned(16))) u64 lds[2 * W];
+    int tid = threadIdx.x;
+    const size_t L = (size_t)tb.n_limbs;
+    const size_t bi = blockIdx.x / L;
+    const int limb = (int)(blockIdx.x % L);
+    const LimbConst lc = tb.lc[limb];
+    const u64* src_a = a2 + ((bi * 2) * L + limb) * N;
+    const u64* src_b = b2 + ((bi * 2) * L + limb) * N;
+    u64* dst = out3 + ((bi * 3) * L + limb) * N;
+    const size_t cstride = L * N;
+    const InvLast<typename B::Tw> last = tb.last[limb];
+    constexpr bool kLazy = Arith::kFold && !OUT_NTT;
+    constexpr int kInvIn = Arith::kFold ? 2 * kMulB : kUnit;
+    const typename B::Tw* const twf = tb.fwd4 + (size_t)limb * N;
+    const typename B::Tw* const twi = tb.inv4 + (size_t)limb * N;
+
+    u64 D0[E], D1[E], D2[E];
+#pragma unroll 1
+    for (int r = 0; r < 2; ++r) {
+        asm volatile("" : "+v"(tid));   // keeps the twiddle fetches of the two passes apart (see ct_mul_kernel)
+        u64 x[E], y[E];
+        B::template load_top<true>(tid, x, src_a + (size_t)r * cstride);
+        B::template load_top<true>(tid, y, src_b + (size_t)r * cstride);
+        if (r) lds_barrier();           // pass 0's last exchange was wave-local, but pass 1's first write crosses waves
+        FwdChain2<B, 0>::run(tid, x, y, lds, lds + W, twf, lc);
+        if (!Arith::kFold) { B::fwd_canon(x, lc); B::fwd_canon(y, lc); }
+        else if constexpr (kLazy) B::fwd_reduce_partner(y, lc);     // of every product below exactly one factor is reduced: b0, b1
+        else { B::fwd_canon(x, lc); B::fwd_canon(y, lc); }
+        if (r == 0) {
+#pragma unroll
+            for (int k = 0; k < E; ++k) { D0[k] = x[k]; D1[k] = y[k]; }      // a0^, b0^
+        } else {
+#pragma unroll
+            for (int k = 0; k < E; ++k) {
+                const u64 a0 = D0[k], b0 = D1[k];
+                if (kLazy) {
+                    D0[k] = FoldArith::mul60(a0, b0, (u32)lc.d);
+                    D1[k] = FoldArith::mul60(a0, y[k], (u32)lc.d) + FoldArith::mul60(x[k], b0, (u32)lc.d);
+                    D2[k] = FoldArith::mul60(x[k], y[k], (u32)lc.d);
+                } else {
+                    D0[k] = Arith::mul_var(a0, b0, lc);
+                    D1[k] = add_mod(Arith::mul_var(a0, y[k], lc), Arith::mul_var(x[k], b0, lc), lc.q);
+                    D2[k] = Arith::mul_var(x[k], y[k], lc);
+                }
+            }
+        }
+    }
+#ifndef DPFHE_CTMUL_DUAL_INV
+#define DPFHE_CTMUL_DUAL_INV 1
+#endif
+    if (OUT_NTT) {
+        B::store_bot(tid, D0, dst);
+        B::store_bot(tid, D1, dst + cstride);
+        B::store_bot(tid, D2, dst + 2 * cstride);
+    } else if (DPFHE_CTMUL_DUAL_INV) {
+        // c0 | c1 side by side, then c2.  Before the single chain: its wave-local writes go to buffer 0, which other waves read
+        // in the pair's last exchange
+        asm volatile("" : "+v"(tid));
+        InvChain2<B, B::NPH - 1, kInvIn>::run(tid, D0, D1, lds, lds + W, twi, last, lc);
+        B::inv_canon(D0, lc);
+        B::template store_top<true>(tid, D0, dst);
+        B::inv_canon(D1, lc);
+        B::template store_top<true>(tid, D1, dst + cstride);
+        asm volatile("" : "+v"(tid));
+        lds_barrier();
+        InvChain<B, B::NPH - 1, kInvIn>::run(tid, D2, lds, twi, last, lc);
+        B::inv_canon(D2, lc);
+        B::template store_top<true>(tid, D2, dst + 2 * cstride);
+    } else {
+#pragma unroll 1
+        for (int c = 0; c < 3; ++c) {
+            asm volatile("" : "+v"(tid));
+            // buffers alternate: the chain's own barrier (after its last exchange) orders inverse c+2's writes after every
+            // wave's reads of inverse c; the forward chains' last exchanges were wave-local
+            InvChain<B, B::NPH - 1, kInvIn>::run(tid, D0, lds + (c & 1) * W, twi, last, lc);
+            B::inv_canon(D0, lc);
+            B::template store_top<true>(tid, D0, dst + (size_t)c * cstride);
+#pragma unroll
+            for (int k = 0; k < E; ++k) { D0[k] = D1[k]; D1[k] = D2[k]; }
         }
     }
 }

@@ -58,8 +58,18 @@ int launch_ntt(int log2n, bool inverse, u64* out, const u64* in, size_t npolys, 
 template <class Arith, bool IN_NTT, bool OUT_NTT>
 static int launch_ct_mul_dom(int log2n, u64* out3, const u64* a2, const u64* b2, size_t blocks, const DevTables<Arith>& tb, hipStream_t s) {
     // the fused kernel keeps up to four transformed polynomials in registers: always E = 16 words per thread
-#define CT_CASE(LN, LE) \
-    hipLaunchKernelGGL((ct_mul_kernel<Arith, LN, kFusedLoge, IN_NTT, OUT_NTT>), dim3((unsigned)blocks), dim3(Geo<LN, kFusedLoge>::T), 0, s, out3, a2, b2, tb)
+#ifndef DPFHE_CTMUL_DUAL
+#define DPFHE_CTMUL_DUAL 1
+#endif
+#ifndef DPFHE_CTMUL_DUAL_MAXLOGN
+#define DPFHE_CTMUL_DUAL_MAXLOGN 13
+#endif
+    // coefficient-domain operands up to N = 4096: forward transforms in pairs (two LDS buffers of <= 39 KiB, still 2 workgroups per CU)
+#define CT_CASE(LN, LE)                                                                                                                              \
+    if constexpr (DPFHE_CTMUL_DUAL && Arith::kFold && !IN_NTT && LN <= DPFHE_CTMUL_DUAL_MAXLOGN)                                                                                          \
+        hipLaunchKernelGGL((ct_mul_dual_kernel<Arith, LN, kFusedLoge, OUT_NTT>), dim3((unsigned)blocks), dim3(Geo<LN, kFusedLoge>::T), 0, s, out3, a2, b2, tb); \
+    else                                                                                                                                             \
+        hipLaunchKernelGGL((ct_mul_kernel<Arith, LN, kFusedLoge, IN_NTT, OUT_NTT>), dim3((unsigned)blocks), dim3(Geo<LN, kFusedLoge>::T), 0, s, out3, a2, b2, tb)
     DPFHE_GEO_SWITCH(log2n, CT_CASE)
 #undef CT_CASE
     return 0;
