@@ -8,7 +8,7 @@ Weak scaling: --batch-per-gpu ciphertext pairs per GPU (default 8192 = BASELINE 
 share of 65536), inputs resident in HBM before the timed region.  `value` = ct-muls by all ranks / time.
 
 Extra objects on the JSON line:
-  roofline     - the dominant kernel of the timed region (ct_mul_kernel): algorithmic bytes
+  roofline     - the dominant kernel of the timed region (ct_mul_dual_kernel): algorithmic bytes
                  (7*L*N*8 = 917504 B per ct-mul) / HIP-event launch duration / 8 TB/s.
   ntt          - BASELINE configs[1] (batch = 1024 RNS polys x 4 limbs, N=4096): forward / inverse NTT
                  kernel time and fraction of HBM peak (2*N*8 algorithmic bytes per residue polynomial).
@@ -16,9 +16,11 @@ Extra objects on the JSON line:
                  this host's cores on a bounded sample of the same workload (rank 0, N=1 only).
 """
 import argparse
+import glob
 import json
 import os
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -26,6 +28,51 @@ sys.path.insert(0, ROOT)
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: required by RCCL across processes on this driver
 
 HBM_PEAK = 8.0e12  # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+class PowerSampler(threading.Thread):
+    """Reads power1_average|power1_input, power1_cap and freq1_input (sclk) of one HIP device from sysfs every 2 ms.  The
+    transforms run at the board's power cap (profiles/*_power_probe.txt); the bench line carries the evidence."""
+
+    def __init__(self, device):
+        super().__init__(daemon=True)
+        self.rows, self.halt, self.dir = [], False, None
+        try:
+            import torch
+            p = torch.cuda.get_device_properties(device)
+            want = f"{getattr(p, 'pci_domain_id', 0):04x}:{p.pci_bus_id:02x}:{getattr(p, 'pci_device_id', 0):02x}."
+            for d in sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*")):
+                if os.path.basename(os.path.realpath(os.path.join(d, "..", ".."))).startswith(want):
+                    self.dir = d
+        except Exception:
+            pass
+        self.pfile = next((f for f in ("power1_average", "power1_input") if self.dir and os.path.exists(os.path.join(self.dir, f))), None)
+
+    @staticmethod
+    def _read(path):
+        try:
+            with open(path) as f:
+                return int(f.read().strip())
+        except Exception:
+            return None
+
+    def run(self):
+        while not self.halt and self.pfile:
+            self.rows.append((self._read(os.path.join(self.dir, self.pfile)), self._read(os.path.join(self.dir, "freq1_input"))))
+            time.sleep(0.002)
+
+    def finish(self):
+        self.halt = True
+        if self.is_alive():
+            self.join(timeout=1.0)
+        ps = [p / 1e6 for p, _ in self.rows if p]
+        fs = [f / 1e6 for _, f in self.rows if f]
+        cap = self._read(os.path.join(self.dir, "power1_cap")) if self.dir else None
+        if not ps:
+            return None
+        return {"board_w_mean": sum(ps) / len(ps), "board_w_max": max(ps), "cap_w": cap / 1e6 if cap else None,
+                "sclk_mhz_mean": sum(fs) / len(fs) if fs else None, "samples": len(ps),
+                "source": "hwmon power1/freq1 of this GPU, 2 ms sampling over the timed steps"}
 
 
 def main():
@@ -227,11 +274,14 @@ def main():
         torch.cuda.synchronize()
 
     fence()
+    power = PowerSampler(dev)   # board power / cap / shader clock from the GPU's hwmon files while the timed steps run
+    power.start()
     t0 = time.perf_counter()
     for i in range(args.steps):
         last = step(i)
     fence()
     elapsed = time.perf_counter() - t0
+    power_result = power.finish()
     out = outs[last]
     if dist.is_initialized():
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -250,7 +300,8 @@ def main():
     traffic, traffic_src = None, first_profile("r02_pmc_traffic.json", "r01_pmc_traffic.json")
     try:
         with open(traffic_src) as f:
-            traffic = json.load(f)["ct_mul_kernel<FoldArith,12,4>"]["hbm_bytes_per_ct_mul"] * B
+            tj = json.load(f)
+            traffic = (tj.get("ct_mul_dual_kernel<FoldArith,12,4>") or tj["ct_mul_kernel<FoldArith,12,4>"])["hbm_bytes_per_ct_mul"] * B
     except Exception:
         pass
     # The bound of this kernel is VALU issue (integer multiply-adds), not HBM: its ceiling is the register-only butterfly loop
@@ -300,11 +351,12 @@ def main():
         # `frac` keeps the contract's meaning (algorithmic bytes / launch time / HBM peak); the kernel's real bound is VALU issue,
         # so both fractions are first-class: frac_hbm (= frac) and frac_alu (butterflies/s over the register-only ceiling).
         "roofline": {
-            "kernel": "ct_mul_kernel<FoldArith,12,4>", "bound": "valu", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+            "kernel": "ct_mul_dual_kernel<FoldArith,12,4>", "bound": "valu", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
             "frac": achieved / HBM_PEAK, "frac_hbm": achieved / HBM_PEAK, "frac_alu": (bfly_per_s / alu_peak) if alu_peak else None,
             "traffic": traffic,
             "traffic_source": (os.path.relpath(traffic_src, ROOT) + " (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, bytes per launch)") if traffic else None,
             "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": k_avg * 1e3,
+            "power": power_result,
             "alu": {"unit": "butterflies/s", "achieved": bfly_per_s, "peak": alu_peak, "peak_clock_mhz": alu_clock,
                     "frac": (bfly_per_s / alu_peak) if alu_peak else None,
                     "peak_source": (os.path.relpath(alu_src, ROOT) + ": register-only radix-2 butterflies (the kernels' 12-instruction fused butterfly), 8 workgroups per CU, shader clock measured inside the kernel") if alu_src else None,

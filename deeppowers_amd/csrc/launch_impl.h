@@ -90,10 +90,10 @@ int launch_relin(int log2n, int mode, u64* out2, const u64* in3, const u64* evk,
                  const DevTables<Arith>& tb, hipStream_t s) {
 #define RL_ONE(LN, M) hipLaunchKernelGGL((relin_kernel<Arith, LN, kFusedLoge, M>), dim3((unsigned)blocks), dim3(Geo<LN, kFusedLoge>::T), 0, s, out2, in3, evk, key_stride, key_group ? key_group : 1u, tb)
 #define RL_CASE(LN, LE)                \
-    if (mode == 0) RL_ONE(LN, 0);      \
-    else if (mode == 1) RL_ONE(LN, 1); \
-    else if (mode == 2) RL_ONE(LN, 2); \
-    else RL_ONE(LN, 3)
+    if (mode == 0) { RL_ONE(LN, 0); }      \
+    else if (mode == 1) { RL_ONE(LN, 1); } \
+    else if (mode == 2) { RL_ONE(LN, 2); } \
+    else { RL_ONE(LN, 3); }
     DPFHE_GEO_SWITCH(log2n, RL_CASE)
 #undef RL_CASE
 #undef RL_ONE

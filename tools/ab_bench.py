@@ -39,5 +39,19 @@ for name, params, nb, cb in (("n4096", FheParams.n4096_l4(), 1024, 8192), ("n819
     o = ctx.empty(cb, components=3)
     r = timed((("mul", lambda: ev.multiply(a, b, out=o)),), 12)
     print(f"{tag:16s} {name} ct_mul x{cb}: median {r['mul'][0]:8.1f} us min {r['mul'][1]:8.1f} us -> {cb / r['mul'][0]:6.3f} M ct-mul/s  checksum {int(o.data.sum().item()) & 0xffffffff:x}")
-    del a, b, o, x, y
+    # relinearisation (RNS-digit keys) on the products, and the hybrid key-switch inner product (special prime = last limb)
+    rb = min(cb, 2048)
+    evk = torch.randint(0, 2**62, (L, 2, L, N), generator=g, dtype=torch.int64, device=ctx.device) % q.view(1, 1, L, 1)
+    o2 = ctx.empty(rb, components=2)
+    c3 = Ciphertext(o.data[:rb].contiguous())
+    r = timed((("relin", lambda: ev.relinearize(c3, evk, out=o2)),), 12)
+    print(f"{tag:16s} {name} relinearize x{rb}: median {r['relin'][0]:8.1f} us min {r['relin'][1]:8.1f} us  checksum {int(o2.sum().item()) & 0xffffffff:x}")
+    Ld = L - 1
+    key = torch.randint(0, 2**62, (Ld, 2, L, N), generator=g, dtype=torch.int64, device=ctx.device) % q.view(1, 1, L, 1)
+    qd = q.view(1, 1, L, 1)[:, :, :Ld]
+    ctd = Ciphertext((torch.randint(0, 2**62, (rb, 2, Ld, N), generator=g, dtype=torch.int64, device=ctx.device) % qd).contiguous())
+    r = timed((("ks", lambda: ev.keyswitch_hybrid(ctd, key)),), 12)
+    ks = ev.keyswitch_hybrid(ctd, key)
+    print(f"{tag:16s} {name} keyswitch_hybrid x{rb}: median {r['ks'][0]:8.1f} us min {r['ks'][1]:8.1f} us  checksum {int(ks.data.sum().item()) & 0xffffffff:x}")
+    del a, b, o, x, y, c3, o2, ctd, ks
     ctx.close()

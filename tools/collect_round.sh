@@ -10,6 +10,7 @@ export TMPDIR=/tmp
 timeout 900 python bench.py > $OUT/bench.json 2> $OUT/bench.err; echo "bench rc=$?"
 ./tools/ubench2 > $OUT/ubench2.log 2>&1; echo "ubench2 rc=$?"
 ./tools/clock_probe > $OUT/clock_probe.txt 2>&1; echo "clock_probe rc=$?"
+python tools/power_probe.py 2>&1 | grep -v amdgpu.ids > $OUT/power_probe.txt; echo "power_probe rc=$?"
 timeout 900 rocprofv3 --kernel-trace --stats -d $OUT/prof -o bench -- python bench.py --steps 5 --warmup 1 --no-cpu-baseline > $OUT/prof_bench.json 2> $OUT/prof.err; echo "rocprof rc=$?"
 f=$(find $OUT/prof -name "*.db" | head -1); [ -n "$f" ] && python tools/prof_summary.py $f $OUT/kernel_stats.txt "rocprofv3 --kernel-trace --stats -- python bench.py --steps 5 --warmup 1 --no-cpu-baseline" > /dev/null
 timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/prof_pl -o pl -- ./examples/encrypted_gpt2_linear all 5 > $OUT/packed_linear.log 2> $OUT/prof_pl.err; echo "rocprof packed rc=$?"
@@ -34,4 +35,5 @@ for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE
 done
 find $OUT -name "*.db" -delete   # summaries are kept; raw databases exceed the 64 MiB copy-back limit
 rm -rf $OUT/prof $OUT/prof_pl $OUT/pmc[0-9] $OUT/pmcn[0-9]
+python tools/derive_round.py $OUT $TAG > /dev/null 2>&1; echo "derive rc=$?"
 ls $OUT

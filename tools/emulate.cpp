@@ -235,7 +235,8 @@ extern "C" int emu_ntt_split(int arith, int log2n, int inverse, u64 q, u64 psi, 
     return -1;
 }
 
-// The fused ct x ct kernel's lazy FoldArith data path (kernels.h ct_mul_kernel, coefficient domain in and out), run with
+// The fused ct x ct kernels' lazy FoldArith data path (kernels.h ct_mul_kernel / ct_mul_dual_kernel - the paired kernel computes
+// the same values from the same operands, only two transforms at a time -, coefficient domain in and out), run with
 // the same per-thread transform code and the same dyadic sequence, so that the bound plans and the relaxed mul60
 // precondition (lazy forward outputs < 14 q times partially reduced b-side factors) are checked on the CPU with the
 // wrap-around / precondition counters armed.  out3 = (c0, c1, c2) of one limb.

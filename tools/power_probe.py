@@ -8,6 +8,9 @@ the transforms run at a power-limited clock: the board sits at its cap and the c
 import glob, os, subprocess, sys, threading, time
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import deeppowers_amd._cabi as _cabi
+if os.environ.get("DPFHE_AB_LIB"):
+    _cabi.LIB_PATH = os.path.abspath(os.environ["DPFHE_AB_LIB"])
 from deeppowers_amd.evaluator import Ciphertext, Context, Evaluator
 from deeppowers_amd.params import FheParams
 
