@@ -8,7 +8,7 @@ Weak scaling: --batch-per-gpu ciphertext pairs per GPU (default 8192 = BASELINE 
 share of 65536), inputs resident in HBM before the timed region.  `value` = ct-muls by all ranks / time.
 
 Extra objects on the JSON line:
-  roofline     - the dominant kernel of the timed region (ct_mul_dual_kernel): algorithmic bytes
+  roofline     - the dominant kernel of the timed region (ct_mul_quad_kernel): algorithmic bytes
                  (7*L*N*8 = 917504 B per ct-mul) / HIP-event launch duration / 8 TB/s.
   ntt          - BASELINE configs[1] (batch = 1024 RNS polys x 4 limbs, N=4096): forward / inverse NTT
                  kernel time and fraction of HBM peak (2*N*8 algorithmic bytes per residue polynomial).
@@ -301,7 +301,7 @@ def main():
     try:
         with open(traffic_src) as f:
             tj = json.load(f)
-            traffic = (tj.get("ct_mul_dual_kernel<FoldArith,12,4>") or tj["ct_mul_kernel<FoldArith,12,4>"])["hbm_bytes_per_ct_mul"] * B
+            traffic = next(tj[k] for k in ("ct_mul_quad_kernel<FoldArith,12,4>", "ct_mul_dual_kernel<FoldArith,12,4>", "ct_mul_kernel<FoldArith,12,4>") if k in tj)["hbm_bytes_per_ct_mul"] * B
     except Exception:
         pass
     # The bound of this kernel is VALU issue (integer multiply-adds), not HBM: its ceiling is the register-only butterfly loop
@@ -351,7 +351,7 @@ def main():
         # `frac` keeps the contract's meaning (algorithmic bytes / launch time / HBM peak); the kernel's real bound is VALU issue,
         # so both fractions are first-class: frac_hbm (= frac) and frac_alu (butterflies/s over the register-only ceiling).
         "roofline": {
-            "kernel": "ct_mul_dual_kernel<FoldArith,12,4>", "bound": "valu", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+            "kernel": "ct_mul_quad_kernel<FoldArith,12,4>", "bound": "valu", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
             "frac": achieved / HBM_PEAK, "frac_hbm": achieved / HBM_PEAK, "frac_alu": (bfly_per_s / alu_peak) if alu_peak else None,
             "traffic": traffic,
             "traffic_source": (os.path.relpath(traffic_src, ROOT) + " (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, bytes per launch)") if traffic else None,

@@ -125,6 +125,52 @@ struct FwdChain2 {
     }
 };
 
+// FOUR transforms of one limb on TWO LDS buffers: per phase the pair (x, y) goes through the exchange first, then (z, w) reuses
+// the buffers - all four share one set of twiddle fetches.  The buffers are re-written only after every reader of the previous
+// pair is done: in program order for wave-local exchanges, behind a workgroup barrier for the all-to-all one.
+template <class G, int X>
+__device__ __forceinline__ void exch_sync_reuse() {
+    if constexpr (G::exch_wave_local(X)) wave_sync(); else lds_barrier();
+}
+template <class B, int P>
+struct FwdChain4 {
+    typedef typename B::TwRegs TwRegs;
+    static __device__ __forceinline__ void run(int tid, u64 (&x)[B::E], u64 (&y)[B::E], u64 (&z)[B::E], u64 (&w)[B::E], u64* lds0, u64* lds1,
+                                               const typename B::Tw* tw, const LimbConst& lc) {
+        TwRegs twr;
+        B::template load_tw<P, true>(tid, tw, twr);
+        run_with(tid, x, y, z, w, lds0, lds1, tw, lc, twr);
+    }
+    static __device__ __forceinline__ void run_with(int tid, u64 (&x)[B::E], u64 (&y)[B::E], u64 (&z)[B::E], u64 (&w)[B::E], u64* lds0, u64* lds1,
+                                                    const typename B::Tw* tw, const LimbConst& lc, const TwRegs& twr) {
+        B::template fwd_phase_r<P>(x, twr, lc);
+        if constexpr (P + 1 < B::NPH) {
+            exch_sync_before_write<typename B::G, P, true>();
+            B::template lds_write<P, P, true>(tid, x, lds0);
+            B::template fwd_phase_r<P>(y, twr, lc);
+            B::template lds_write<P, P, true>(tid, y, lds1);
+            exch_sync_after_write<typename B::G, P>();
+            B::template lds_read<P, P + 1, true>(tid, x, lds0);
+            B::template lds_read<P, P + 1, true>(tid, y, lds1);
+            B::template fwd_phase_r<P>(z, twr, lc);
+            exch_sync_reuse<typename B::G, P>();
+            B::template lds_write<P, P, true>(tid, z, lds0);
+            B::template fwd_phase_r<P>(w, twr, lc);
+            TwRegs nxt;
+            B::template load_tw<P + 1, true>(tid, tw, nxt);
+            B::template lds_write<P, P, true>(tid, w, lds1);
+            exch_sync_after_write<typename B::G, P>();
+            B::template lds_read<P, P + 1, true>(tid, z, lds0);
+            B::template lds_read<P, P + 1, true>(tid, w, lds1);
+            FwdChain4<B, P + 1>::run_with(tid, x, y, z, w, lds0, lds1, tw, lc, nxt);
+        } else {
+            B::template fwd_phase_r<P>(y, twr, lc);
+            B::template fwd_phase_r<P>(z, twr, lc);
+            B::template fwd_phase_r<P>(w, twr, lc);
+        }
+    }
+};
+
 template <class B, int P, int IN>
 struct InvChain {
     typedef typename B::TwRegs TwRegs;
@@ -174,6 +220,42 @@ struct InvChain2 {
             InvChain2<B, P - 1, IN>::run_with(tid, x, y, lds0, lds1, tw, last, lc, nxt);
         } else {
             B::template inv_phase_r<P, IN>(y, twr, last.w_last, last.w_ninv, lc);
+        }
+    }
+};
+
+// Three inverse transforms of one limb on two LDS buffers (x | y, then z reuses buffer 0), one set of twiddle fetches.
+template <class B, int P, int IN>
+struct InvChain3 {
+    typedef typename B::TwRegs TwRegs;
+    static __device__ __forceinline__ void run(int tid, u64 (&x)[B::E], u64 (&y)[B::E], u64 (&z)[B::E], u64* lds0, u64* lds1, const typename B::Tw* tw,
+                                               const InvLast<typename B::Tw>& last, const LimbConst& lc) {
+        TwRegs twr;
+        B::template load_tw<P, false>(tid, tw, twr);
+        run_with(tid, x, y, z, lds0, lds1, tw, last, lc, twr);
+    }
+    static __device__ __forceinline__ void run_with(int tid, u64 (&x)[B::E], u64 (&y)[B::E], u64 (&z)[B::E], u64* lds0, u64* lds1,
+                                                    const typename B::Tw* tw, const InvLast<typename B::Tw>& last, const LimbConst& lc, const TwRegs& twr) {
+        B::template inv_phase_r<P, IN>(x, twr, last.w_last, last.w_ninv, lc);
+        if constexpr (P > 0) {
+            exch_sync_before_write<typename B::G, P - 1, false>();
+            B::template lds_write<P - 1, P, false>(tid, x, lds0);
+            B::template inv_phase_r<P, IN>(y, twr, last.w_last, last.w_ninv, lc);
+            B::template lds_write<P - 1, P, false>(tid, y, lds1);
+            exch_sync_after_write<typename B::G, P - 1>();
+            B::template lds_read<P - 1, P - 1, false>(tid, x, lds0);
+            B::template lds_read<P - 1, P - 1, false>(tid, y, lds1);
+            B::template inv_phase_r<P, IN>(z, twr, last.w_last, last.w_ninv, lc);
+            TwRegs nxt;
+            B::template load_tw<P - 1, false>(tid, tw, nxt);
+            exch_sync_reuse<typename B::G, P - 1>();
+            B::template lds_write<P - 1, P, false>(tid, z, lds0);
+            exch_sync_after_write<typename B::G, P - 1>();
+            B::template lds_read<P - 1, P - 1, false>(tid, z, lds0);
+            InvChain3<B, P - 1, IN>::run_with(tid, x, y, z, lds0, lds1, tw, last, lc, nxt);
+        } else {
+            B::template inv_phase_r<P, IN>(y, twr, last.w_last, last.w_ninv, lc);
+            B::template inv_phase_r<P, IN>(z, twr, last.w_last, last.w_ninv, lc);
         }
     }
 };
@@ -369,7 +451,11 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE), 2) void ct_mul_dual_kernel(u64*
     const typename B::Tw* const twi = tb.inv4 + (size_t)limb * N;
 
     u64 D0[E], D1[E], D2[E];
+#ifdef DPFHE_CTMUL_UNROLL_R
+#pragma unroll
+#else
 #pragma unroll 1
+#endif
     for (int r = 0; r < 2; ++r) {
         asm volatile("" : "+v"(tid));   // keeps the twiddle fetches of the two passes apart (see ct_mul_kernel)
         u64 x[E], y[E];
@@ -433,6 +519,50 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE), 2) void ct_mul_dual_kernel(u64*
             for (int k = 0; k < E; ++k) { D0[k] = D1[k]; D1[k] = D2[k]; }
         }
     }
+}
+
+// All four forward transforms and all three inverse transforms of the workgroup share their twiddle fetches (FwdChain4 / InvChain3
+// on two LDS buffers): 2 x 64 KiB of per-thread twiddle reads per workgroup instead of 4 x 64 KiB in ct_mul_dual_kernel.
+template <class Arith, int LOGN, int LOGE>
+__global__ __launch_bounds__(1 << (LOGN - LOGE), 2) void ct_mul_quad_kernel(u64* __restrict__ out3, const u64* __restrict__ a2,
+                                                                         const u64* __restrict__ b2, DevTables<Arith> tb) {
+    typedef NttBody<Arith, LOGN, LOGE> B;
+    static_assert(Arith::kFold && LOGE == kFusedLoge, "FoldArith, fused twiddle layout");
+    constexpr int E = B::E, N = B::G::N, W = B::G::lds_words();
+    __shared__ __attribute__((aligned(16))) u64 lds[2 * W];
+    const int tid = threadIdx.x;
+    const size_t L = (size_t)tb.n_limbs;
+    const size_t bi = blockIdx.x / L;
+    const int limb = (int)(blockIdx.x % L);
+    const LimbConst lc = tb.lc[limb];
+    const u64* src_a = a2 + ((bi * 2) * L + limb) * N;
+    const u64* src_b = b2 + ((bi * 2) * L + limb) * N;
+    u64* dst = out3 + ((bi * 3) * L + limb) * N;
+    const size_t cstride = L * N;
+    const InvLast<typename B::Tw> last = tb.last[limb];
+    constexpr int kInvIn = 2 * kMulB;
+    u64 x[E], y[E], z[E], w[E];
+    B::template load_top<true>(tid, x, src_a);
+    B::template load_top<true>(tid, y, src_b);
+    B::template load_top<true>(tid, z, src_a + cstride);
+    B::template load_top<true>(tid, w, src_b + cstride);
+    FwdChain4<B, 0>::run(tid, x, y, z, w, lds, lds + W, tb.fwd4 + (size_t)limb * N, lc);
+    B::fwd_reduce_partner(y, lc);     // of every product below exactly one factor is reduced: b0, b1
+    B::fwd_reduce_partner(w, lc);
+#pragma unroll
+    for (int k = 0; k < E; ++k) {
+        const u64 a0 = x[k], b0 = y[k], a1 = z[k], b1 = w[k];
+        x[k] = FoldArith::mul60(a0, b0, (u32)lc.d);
+        y[k] = FoldArith::mul60(a0, b1, (u32)lc.d) + FoldArith::mul60(a1, b0, (u32)lc.d);
+        z[k] = FoldArith::mul60(a1, b1, (u32)lc.d);
+    }
+    InvChain3<B, B::NPH - 1, kInvIn>::run(tid, x, y, z, lds, lds + W, tb.inv4 + (size_t)limb * N, last, lc);
+    B::inv_canon(x, lc);
+    B::template store_top<true>(tid, x, dst);
+    B::inv_canon(y, lc);
+    B::template store_top<true>(tid, y, dst + cstride);
+    B::inv_canon(z, lc);
+    B::template store_top<true>(tid, z, dst + 2 * cstride);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -64,9 +64,16 @@ static int launch_ct_mul_dom(int log2n, u64* out3, const u64* a2, const u64* b2,
 #ifndef DPFHE_CTMUL_DUAL_MAXLOGN
 #define DPFHE_CTMUL_DUAL_MAXLOGN 13
 #endif
-    // coefficient-domain operands up to N = 4096: forward transforms in pairs (two LDS buffers of <= 39 KiB, still 2 workgroups per CU)
+    // coefficient domain in and out, N <= 4096: all four forward and all three inverse transforms share their twiddle fetches
+    // (ct_mul_quad_kernel); N = 8192 or NTT-domain output: transforms in pairs (ct_mul_dual_kernel; at N = 8192 the quad form
+    // measured equal to slightly slower: one 8-wave workgroup per CU, three barriers per all-to-all exchange)
+#ifndef DPFHE_CTMUL_QUAD
+#define DPFHE_CTMUL_QUAD 1
+#endif
 #define CT_CASE(LN, LE)                                                                                                                              \
-    if constexpr (DPFHE_CTMUL_DUAL && Arith::kFold && !IN_NTT && LN <= DPFHE_CTMUL_DUAL_MAXLOGN)                                                                                          \
+    if constexpr (DPFHE_CTMUL_QUAD && Arith::kFold && !IN_NTT && !OUT_NTT && LN <= 12)                                                           \
+        hipLaunchKernelGGL((ct_mul_quad_kernel<Arith, LN, kFusedLoge>), dim3((unsigned)blocks), dim3(Geo<LN, kFusedLoge>::T), 0, s, out3, a2, b2, tb); \
+    else if constexpr (DPFHE_CTMUL_DUAL && Arith::kFold && !IN_NTT && LN <= DPFHE_CTMUL_DUAL_MAXLOGN)                                                                                          \
         hipLaunchKernelGGL((ct_mul_dual_kernel<Arith, LN, kFusedLoge, OUT_NTT>), dim3((unsigned)blocks), dim3(Geo<LN, kFusedLoge>::T), 0, s, out3, a2, b2, tb); \
     else                                                                                                                                             \
         hipLaunchKernelGGL((ct_mul_kernel<Arith, LN, kFusedLoge, IN_NTT, OUT_NTT>), dim3((unsigned)blocks), dim3(Geo<LN, kFusedLoge>::T), 0, s, out3, a2, b2, tb)

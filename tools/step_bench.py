@@ -52,7 +52,39 @@ def step_chunked(i):
         red_done[k].record(side)
 
 
+mul_streams = [torch.cuda.Stream(device=dev) for _ in range(2)]
+chunk_done = [[torch.cuda.Event() for _ in range(64)] for _ in range(2)]
+step_start = torch.cuda.Event()
+
+
+def step_chunked_2s(i):
+    """chunks alternate between two multiply streams (the tail of one launch overlaps the head of the next); the reduce of chunk c
+    runs on a third stream as soon as chunk c is complete, while its outputs are still in the Infinity Cache"""
+    k = i & 1
+    per = B // chunks
+    step_start.record(main)
+    for ms in mul_streams:
+        ms.wait_event(step_start)
+    side.wait_event(step_start)
+    for c in range(chunks):
+        sl = slice(c * per, (c + 1) * per)
+        ms = mul_streams[c & 1]
+        o = ev.multiply(Ciphertext(a.data[sl]), Ciphertext(b.data[sl]), out=outs[k][sl], stream=ms)
+        chunk_done[k][c].record(ms)
+        side.wait_event(chunk_done[k][c])
+        with torch.cuda.stream(side):
+            ev.reduce_sum(o, out=cpart[k][c], stream=side)
+    with torch.cuda.stream(side):
+        ev.reduce_sum(Ciphertext(cpart[k]), out=parts[k], stream=side)
+    red_done[k].record(side)
+    for ms in mul_streams:
+        main.wait_stream(ms)
+
+
 def step(i):
+    if mode == "chunked_2s":
+        main.wait_event(red_done[i & 1])
+        return step_chunked_2s(i)
     if mode.startswith("chunked"):
         if mode == "chunked_side":
             main.wait_event(red_done[i & 1])
