@@ -9,6 +9,13 @@
 //   * the sweep over 1 / 2 / 4 / 8 waves per SIMD separates issue cost from dependency latency.
 // Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -o tools/ubench2 tools/ubench2.hip
 #include <hip/hip_runtime.h>
+#include <atomic>
+#include <chrono>
+#include <dirent.h>
+#include <fstream>
+#include <string>
+#include <thread>
+#include <unistd.h>
 
 #include <algorithm>
 #include <cstdio>
@@ -259,6 +266,96 @@ static void run_bfly(const char* name, int n_cu, int blocks_per_cu, int iters, d
     HIPCHECK(hipFree(d_out)); HIPCHECK(hipFree(d_st)); HIPCHECK(hipFree(d_tw));
 }
 
+// ---- energy per instruction: each rate kernel back to back for ~1.2 s while a host thread samples the board power (hwmon) ----
+static std::string hwmon_dir_of_device0() {
+    char bus[64] = {0};
+    if (hipDeviceGetPCIBusId(bus, sizeof bus, 0) != hipSuccess) return "";
+    for (char* c = bus; *c; ++c) *c = (char)tolower(*c);
+    DIR* d = opendir("/sys/class/drm");
+    if (!d) return "";
+    std::string found;
+    while (dirent* e = readdir(d)) {
+        const std::string name = e->d_name;
+        if (name.rfind("card", 0) != 0 || name.find('-') != std::string::npos) continue;
+        char real[512];
+        const std::string dev = "/sys/class/drm/" + name + "/device";
+        if (!realpath(dev.c_str(), real)) continue;
+        const std::string r = real;
+        if (r.size() < std::strlen(bus) || r.compare(r.size() - std::strlen(bus), std::strlen(bus), bus) != 0) continue;
+        DIR* h = opendir((dev + "/hwmon").c_str());
+        if (!h) continue;
+        while (dirent* he = readdir(h))
+            if (std::string(he->d_name).rfind("hwmon", 0) == 0) found = dev + "/hwmon/" + he->d_name;
+        closedir(h);
+    }
+    closedir(d);
+    return found;
+}
+static double read_num(const std::string& path) {
+    std::ifstream f(path);
+    double v = -1;
+    f >> v;
+    return v;
+}
+struct PowerStat { double watts, mhz; int n; };
+template <class Launch>
+static PowerStat sample_while(const std::string& hw, double seconds, Launch&& launch_batch) {
+    std::atomic<bool> stop{false};
+    double sum_w = 0, sum_f = 0;
+    int n = 0;
+    std::thread t([&] {
+        std::this_thread::sleep_for(std::chrono::milliseconds(300));   // let the averaged sensor settle on this load
+        while (!stop.load()) {
+            const double w = read_num(hw + "/power1_input"), f = read_num(hw + "/freq1_input");
+            if (w > 0) { sum_w += w / 1e6; sum_f += f / 1e6; ++n; }
+            std::this_thread::sleep_for(std::chrono::milliseconds(20));
+        }
+    });
+    const auto t0 = std::chrono::steady_clock::now();
+    while (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() < seconds) {
+        launch_batch();
+        HIPCHECK(hipDeviceSynchronize());
+    }
+    stop.store(true);
+    t.join();
+    return PowerStat{n ? sum_w / n : 0, n ? sum_f / n : 0, n};
+}
+template <int OP>
+static void power_rate(const std::string& hw, int n_cu, double idle_w) {
+    const int blocks = n_cu * 4, iters = 40000;
+    unsigned long long* d_out; Stamp* d_st;
+    HIPCHECK(hipMalloc(&d_out, (size_t)blocks * 256 * 8));
+    HIPCHECK(hipMalloc(&d_st, (size_t)blocks * 4 * sizeof(Stamp)));
+    hipEvent_t e0, e1;
+    HIPCHECK(hipEventCreate(&e0)); HIPCHECK(hipEventCreate(&e1));
+    double ms_sum = 0; int launches = 0;
+    const PowerStat ps = sample_while(hw, 1.3, [&] {
+        HIPCHECK(hipEventRecord(e0));
+        for (int i = 0; i < 8; ++i) hipLaunchKernelGGL(rate_kernel<OP>, dim3(blocks), dim3(256), 0, 0, d_out, d_st, iters, 7u);
+        HIPCHECK(hipEventRecord(e1));
+        HIPCHECK(hipEventSynchronize(e1));
+        float ms = 0; HIPCHECK(hipEventElapsedTime(&ms, e0, e1));
+        ms_sum += ms; launches += 8;
+    });
+    const double wave_inst = (double)blocks * 4 * iters * 16 * launches;   // 16 instructions per loop iteration and wave
+    const double rate = wave_inst / (ms_sum * 1e-3);
+    std::printf("%-28s board %7.1f W  sclk %5.0f MHz  %7.1f G wave-inst/s  -> %5.2f nJ per wave-instruction above idle (%d samples)\n", kOpName[OP], ps.watts, ps.mhz,
+                rate / 1e9, (ps.watts - idle_w) / rate * 1e9, ps.n);
+    HIPCHECK(hipFree(d_out)); HIPCHECK(hipFree(d_st));
+}
+static void power_mode(int n_cu) {
+    const std::string hw = hwmon_dir_of_device0();
+    if (hw.empty()) { std::printf("no hwmon directory for device 0\n"); return; }
+    double idle = 0; int n = 0;
+    for (int i = 0; i < 25; ++i) { const double w = read_num(hw + "/power1_input"); if (w > 0) { idle += w / 1e6; ++n; } usleep(20000); }
+    idle = n ? idle / n : 0;
+    std::printf("--- energy per VALU instruction (4 workgroups per CU, 1.3 s per op, hwmon %s), idle %.1f W ---\n", hw.c_str(), idle);
+    power_rate<MOV_B32>(hw, n_cu, idle); power_rate<AND_B32>(hw, n_cu, idle); power_rate<ADD_U32>(hw, n_cu, idle); power_rate<LSHR_B32>(hw, n_cu, idle);
+    power_rate<FMA_F32_3SRC>(hw, n_cu, idle); power_rate<FMA_F64>(hw, n_cu, idle); power_rate<MAD_U64_U32>(hw, n_cu, idle); power_rate<MAD_U64_U32_S>(hw, n_cu, idle);
+    power_rate<MUL_LO_U32>(hw, n_cu, idle); power_rate<MUL_HI_U32>(hw, n_cu, idle); power_rate<MAD_U32_U24>(hw, n_cu, idle); power_rate<LSHL_ADD_U64>(hw, n_cu, idle);
+    power_rate<SUBB_PAIR>(hw, n_cu, idle); power_rate<ADD3_U32>(hw, n_cu, idle); power_rate<ALIGNBIT>(hw, n_cu, idle); power_rate<MOV_B64>(hw, n_cu, idle);
+}
+
 int main(int argc, char** argv) {
     hipDeviceProp_t p;
     HIPCHECK(hipGetDeviceProperties(&p, 0));
@@ -266,6 +363,7 @@ int main(int argc, char** argv) {
     int wall_khz = 0;
     HIPCHECK(hipDeviceGetAttribute(&wall_khz, hipDeviceAttributeWallClockRate, 0));
     std::printf("device: %s  CUs=%d  nominal clock=%.2f GHz  wall clock rate %d kHz\n", p.name, n_cu, p.clockRate / 1e6, wall_khz);
+    if (argc > 1 && !std::strcmp(argv[1], "power")) { power_mode(n_cu); return 0; }
     const bool only_bfly = argc > 1 && !std::strcmp(argv[1], "bfly");
     if (!only_bfly) {
         std::printf("--- VALU issue, 8 independent chains per wave, in-kernel clocks ---\n");
