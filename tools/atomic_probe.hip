@@ -41,6 +41,35 @@ __global__ __launch_bounds__(T) void probe(u64* __restrict__ acc, const u64* __r
     if (MODE == 2 && s == 0x1234567) *sink = s;
 }
 
+// MODE 3 of the question: one workgroup walks `group` consecutive pairs of its limb and keeps a PRIVATE lazy accumulator in global
+// memory (first pair: plain store; later pairs: load + add + store) - no atomics, no races; the accumulator lines live in L2 /
+// the Infinity Cache between visits.
+__global__ __launch_bounds__(T) void probe_private(u64* __restrict__ acc, const u64* __restrict__ src, int group, u64* sink) {
+    const size_t g = blockIdx.x / L;
+    const int limb = blockIdx.x % L;
+    const int tid = threadIdx.x;
+#pragma unroll 1
+    for (int i = 0; i < group; ++i) {
+        const size_t bi = g * group + i;
+#pragma unroll 1
+        for (int c = 0; c < 3; ++c) {
+            const u64* p = src + ((bi * 3 + c) * L + limb) * N;
+            u64* a = acc + ((g * 3 + c) * L + limb) * N;
+            ulonglong2 x[E / 2], y[E / 2];
+#pragma unroll
+            for (int k = 0; k < E / 2; ++k) x[k] = *reinterpret_cast<const ulonglong2*>(p + k * (2 * T) + 2 * tid);
+            if (i > 0) {
+#pragma unroll
+                for (int k = 0; k < E / 2; ++k) y[k] = *reinterpret_cast<const ulonglong2*>(a + k * (2 * T) + 2 * tid);
+#pragma unroll
+                for (int k = 0; k < E / 2; ++k) { x[k].x += y[k].x; x[k].y += y[k].y; }
+            }
+#pragma unroll
+            for (int k = 0; k < E / 2; ++k) *reinterpret_cast<ulonglong2*>(a + k * (2 * T) + 2 * tid) = x[k];
+        }
+    }
+}
+
 int main() {
     const int pairs = 8192;
     const size_t words = (size_t)pairs * 3 * L * N;
@@ -67,5 +96,17 @@ int main() {
     for (int group : {1, 16, 64, 8192}) run("atomic add (agent scope, no return)", probe<0>, group);
     for (int group : {1, 16}) run("load + add + store", probe<1>, group);
     run("read only", probe<2>, 1);
+    for (int group : {4, 8, 16}) {
+        std::vector<float> ms;
+        for (int i = 0; i < 7; ++i) {
+            CK(hipEventRecord(e0));
+            probe_private<<<pairs / group * L, T>>>(acc, src, group, sink);
+            CK(hipEventRecord(e1));
+            CK(hipEventSynchronize(e1));
+            float t; CK(hipEventElapsedTime(&t, e0, e1)); ms.push_back(t);
+        }
+        std::sort(ms.begin(), ms.end());
+        printf("%-34s group %5d: median %8.1f us  min %8.1f us   (%.2f TB/s of source reads)\n", "private accumulator (RMW, no race)", group, ms[3] * 1e3, ms[0] * 1e3, words * 8 / (ms[3] * 1e-3) / 1e12);
+    }
     return 0;
 }
