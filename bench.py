@@ -252,11 +252,15 @@ def main():
         # decrypts every result and compares it with W x mod t
         try:
             import subprocess
-            exe = os.path.join(ROOT, "examples", "encrypted_gpt2_linear")
             lib = os.path.join(ROOT, "deeppowers_amd")
-            if not os.path.exists(exe) or os.path.getmtime(exe) < os.path.getmtime(os.path.join(lib, "libdpfhe_api.so")):
-                subprocess.check_call(["g++", "-O2", "-std=c++17", "-I" + os.path.join(ROOT, "include"), "-I/opt/rocm/include", exe + ".cpp", "-o", exe,
-                                       "-L" + lib, "-ldpfhe_api", "-ldpfhe_hip", "-L/opt/rocm/lib", "-lamdhip64", f"-Wl,-rpath,{lib}", "-Wl,-rpath,/opt/rocm/lib"])
+
+            def example(name):
+                exe = os.path.join(ROOT, "examples", name)
+                if not os.path.exists(exe) or os.path.getmtime(exe) < max(os.path.getmtime(os.path.join(lib, "libdpfhe_api.so")), os.path.getmtime(exe + ".cpp")):
+                    subprocess.check_call(["g++", "-O2", "-std=c++17", "-I" + os.path.join(ROOT, "include"), "-I/opt/rocm/include", exe + ".cpp", "-o", exe,
+                                           "-L" + lib, "-ldpfhe_api", "-ldpfhe_hip", "-L/opt/rocm/lib", "-lamdhip64", f"-Wl,-rpath,{lib}", "-Wl,-rpath,/opt/rocm/lib"])
+                return exe
+            exe = example("encrypted_gpt2_linear")
             torch.cuda.synchronize()
             layers, ok = [], True
             for tokens, reps in ((1, 5), (8, 3)):   # latency of one token, and throughput with 8 tokens per application
@@ -269,6 +273,10 @@ def main():
                             "hidden states, N=8192, 5 x 60-bit data limbs + special prime, t=65537; 1 and 8 tokens per application "
                             "(ms_per_token = enqueue + one sync over `reps` applications / tokens)",
                 "layers": layers, "all_correct": ok and all(l["correct"] for l in layers)}
+            # two layers chained on the device: x + W_down (W_up x), the linear path of the FFN block with its residual (examples/encrypted_gpt2_ffn.cpp)
+            run = subprocess.run([example("encrypted_gpt2_ffn"), "8", "3", "json"], capture_output=True, text=True, timeout=300)
+            got = [json.loads(l) for l in run.stdout.splitlines() if l.startswith("{")]
+            other["packed_linear"]["ffn_block"] = got[0] if got and run.returncode == 0 else {"error": (run.stdout + run.stderr)[-300:]}
         except Exception as e:   # a missing g++ must not take the headline metric down with it
             other["packed_linear"] = {"error": repr(e)[:300]}
         return other

@@ -293,6 +293,11 @@ extern "C" int dpfhe_ct_mul(dpfhe_ctx* c, uint64_t* d_out3, const uint64_t* d_a2
     if (batch == 0) return DPFHE_SUCCESS;
     if (!d_out3 || !d_a2 || !d_b2 || misaligned(d_out3) || misaligned(d_a2) || misaligned(d_b2))
         return fail(DPFHE_INVALID_ARGUMENT, "dpfhe_ct_mul", "null or misaligned buffer");
+    {   // output items are 3 L N words apart, input items 2 L N: a workgroup would overwrite operands another one has not read yet
+        const size_t poly = (size_t)c->n_limbs << c->log2n;
+        if (overlaps(d_out3, batch * 3 * poly, d_a2, batch * 2 * poly) || overlaps(d_out3, batch * 3 * poly, d_b2, batch * 2 * poly))
+            return fail(DPFHE_INVALID_ARGUMENT, "dpfhe_ct_mul", "output overlaps an operand");
+    }
     const size_t blocks = batch * c->n_limbs;
     if (blocks > kMaxGrid) return fail(DPFHE_INVALID_ARGUMENT, "dpfhe_ct_mul", "batch too large for one launch");
     DPFHE_ON_DEVICE(c, "dpfhe_ct_mul");

@@ -137,12 +137,15 @@ class Passthrough:
 class _Metrics:
     def __init__(self):
         self.lock = threading.Lock()
-        self.lat_ms, self.cts, self.t0 = [], 0, time.time()
+        self.lat_ms, self.cts, self.t0, self.requests = [], 0, time.time(), 0
         self.invalid, self.internal = 0, 0
 
     def record(self, ms, n_ct):
         with self.lock:
+            self.requests += 1
             self.lat_ms.append(ms)
+            if len(self.lat_ms) > 4096:          # percentiles over a sliding window: a long-running server must not grow without bound
+                del self.lat_ms[:2048]
             self.cts += n_ct
 
     def error(self, invalid):
@@ -157,8 +160,8 @@ class _Metrics:
             lat = sorted(self.lat_ms)
             el = max(time.time() - self.t0, 1e-9)
             pick = lambda f: lat[min(len(lat) - 1, int(f * len(lat)))] if lat else 0.0
-            return dict(avg=sum(lat) / len(lat) if lat else 0.0, p50=pick(0.5), p90=pick(0.9), p99=pick(0.99), rps=len(lat) / el, cps=self.cts / el,
-                        invalid=self.invalid, internal=self.internal, total=len(lat) + self.invalid + self.internal)
+            return dict(avg=sum(lat) / len(lat) if lat else 0.0, p50=pick(0.5), p90=pick(0.9), p99=pick(0.99), rps=self.requests / el, cps=self.cts / el,
+                        invalid=self.invalid, internal=self.internal, total=self.requests + self.invalid + self.internal)
 
 
 class EncryptedInferenceServer:
@@ -264,6 +267,7 @@ class EncryptedInferenceServer:
                     for name, req, resp in METHODS}
         self._server = grpc.server(futures.ThreadPoolExecutor(max_workers=self._workers), options=CHANNEL_OPTIONS)
         self._server.add_generic_rpc_handlers((grpc.method_handlers_generic_handler(f"{PACKAGE}.{SERVICE}", handlers),))
+        # plain TCP: the reference's optional TLS (grpc_server.cpp init_ssl) maps to add_secure_port with the deployment's credentials
         port = self._server.add_insecure_port(address)
         if port == 0:
             raise RuntimeError(f"could not bind {address}")

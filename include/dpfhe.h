@@ -83,7 +83,8 @@ int dpfhe_negate(dpfhe_ctx* ctx, uint64_t* d_out, const uint64_t* d_a, size_t n_
 /* -- A6: ciphertext x ciphertext tensor product, no relinearisation (THE METRIC OP) -----------------
  * d_a2, d_b2: [batch][2][L][N];  d_out3: [batch][3][L][N] = (a0 b0, a0 b1 + a1 b0, a1 b1) in R_q.
  * flags = 0: coefficient domain in and out (4 NTT + 4 dyadic mul + 1 add + 3 inverse NTT per limb, one
- * fused kernel: 7 residue polynomials of HBM traffic per limb). */
+ * fused kernel: 7 residue polynomials of HBM traffic per limb).  d_a2 and d_b2 may be the same buffer (squaring); d_out3 must
+ * not overlap either operand (DPFHE_INVALID_ARGUMENT). */
 int dpfhe_ct_mul(dpfhe_ctx* ctx, uint64_t* d_out3, const uint64_t* d_a2, const uint64_t* d_b2, size_t batch,
                  uint32_t flags, void* stream);
 

@@ -33,7 +33,7 @@ def build_example(name="encrypted_multiply"):
 
 
 def test_example_compiles():
-    assert all(os.path.exists(build_example(e)) for e in ("encrypted_multiply", "bench_ct_mul", "encrypted_linear", "encrypted_gpt2_linear", "sharded_ct_mul"))
+    assert all(os.path.exists(build_example(e)) for e in ("encrypted_multiply", "bench_ct_mul", "encrypted_linear", "encrypted_gpt2_linear", "encrypted_gpt2_ffn", "sharded_ct_mul"))
 
 
 @pytest.mark.gpu
@@ -96,3 +96,12 @@ def test_cpp_facade_parity_on_gpu():
     out = subprocess.run([exe], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "OK" in out.stdout
+
+
+@pytest.mark.gpu
+def test_example_encrypted_ffn_block_chained_on_the_device():
+    """Two packed layers chained under encryption at BASELINE configs[4]'s sizes (N=8192, 5 data limbs + special prime): W_up 768 -> 3072,
+    hand-over to the next layer's input packing on the device (row swap + add), W_down 3072 -> 768, residual add; 4 tokens per
+    application.  The program checks the hand-over slot by slot and the result against x + W_down (W_up x) mod t."""
+    out = subprocess.run([build_example("encrypted_gpt2_ffn"), "4", "1"], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0 and "OK" in out.stdout and "MISMATCH" not in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]

@@ -248,6 +248,13 @@ def test_ct_mul_empty_batch_and_errors(rigs):
     t = r.ctx.empty(1, components=2)
     assert lib.dpfhe_ntt_fwd(r.ctx.handle, t.data_ptr() + 8, 1, None) == 2000  # misaligned
     assert lib.dpfhe_ct_mul(r.ctx.handle, t.data_ptr(), t.data_ptr(), t.data_ptr(), 1, 4, None) == 2000  # unknown flag
+    big = r.ctx.empty(2, components=3)
+    assert lib.dpfhe_ct_mul(r.ctx.handle, big.data_ptr(), big.data_ptr(), t.data_ptr(), 1, 0, None) == 2000  # output overlaps an operand
+    assert "overlaps" in lib.dpfhe_last_error().decode()
+    # squaring (a and b the same buffer) is fine
+    sq = Ciphertext(torch.randint(0, 2**59, (1, 2, r.p.n_limbs, r.p.n), dtype=torch.int64, device=r.ctx.device))
+    assert lib.dpfhe_ct_mul(r.ctx.handle, big.data_ptr(), sq.data.data_ptr(), sq.data.data_ptr(), 1, 0, None) == 0
+    assert np.array_equal(to_host(big[:1]), r.orc.ct_mul(to_host(sq.data), to_host(sq.data), threads=0))
     with pytest.raises(_cabi.DpfheError) as e:
         r.ev.multiply(Ciphertext(t, True), Ciphertext(t, False))
     assert e.value.code == 2002
