@@ -676,6 +676,93 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE), (Arith::kFold ? 2 : 1)) void re
     }
 }
 
+// The same key switch with the digit transforms SIDE BY SIDE (round 2, after the fused multiply showed what the per-thread twiddle
+// reads cost): the first four digits go through FwdChain4 (one set of twiddle fetches, two reused LDS buffers) while the
+// accumulators are not live yet, the remaining one to three through FwdChain2 / FwdChain, the two inverse transforms through
+// InvChain2.  Ld + 2 twiddle streams become 3 (Ld <= 4: 2).  FoldArith, 4 <= Ld <= 7.
+template <class Arith, int LOGN, int LOGE, int MODE>
+__global__ __launch_bounds__(1 << (LOGN - LOGE), 2) void relin_shared_kernel(u64* __restrict__ out2, const u64* __restrict__ in3,
+                                                                           const u64* __restrict__ evk, size_t key_stride, unsigned key_group,
+                                                                           DevTables<Arith> tb) {
+    typedef NttBody<Arith, LOGN, LOGE> B;
+    static_assert(Arith::kFold && LOGE == kFusedLoge, "FoldArith, fused twiddle layout");
+    constexpr int E = B::E, N = B::G::N, W = B::G::lds_words();
+    __shared__ __attribute__((aligned(16))) u64 lds[2 * W];
+    int tid = threadIdx.x;
+    const int L = tb.n_limbs;
+    const size_t bi = blockIdx.x / (unsigned)L;
+    const int limb = (int)(blockIdx.x % (unsigned)L);
+    const LimbConst lc = tb.lc[limb];
+    const InvLast<typename B::Tw> last = tb.last[limb];
+    constexpr int kInComps = (MODE == 0 || MODE == 2) ? 3 : 2;
+    constexpr bool kHybrid = MODE >= 2;
+    const int Ld = kHybrid ? L - 1 : L;
+    const u64* c2 = in3 + ((bi * kInComps + (kInComps - 1)) * Ld) * N;
+    evk += (bi / key_group) * key_stride;
+    const typename B::Tw* const twf = tb.fwd4 + (size_t)limb * N;
+    static_assert(7 * kMulB + kRedB <= kWord, "seven lazily added products must fit a 64-bit word");
+    u64 acc0[E], acc1[E];
+    auto digit = [&](u64 (&x)[E], int j) {
+        B::load_top(tid, x, c2 + (size_t)j * N);
+#pragma unroll
+        for (int k = 0; k < E; ++k) x[k] = FoldArith::canon(x[k], lc);   // [c]_{q_j} mod q_i
+    };
+    auto mac = [&](const u64 (&d)[E], int j, bool first) {   // one key polynomial at a time
+        u64 e[E];
+        B::load_bot(tid, e, evk + (((size_t)j * 2 + 0) * L + limb) * N);
+#pragma unroll
+        for (int k = 0; k < E; ++k) acc0[k] = (first ? 0 : acc0[k]) + FoldArith::mul60(d[k], e[k], (u32)lc.d);
+        asm volatile("" ::: "memory");
+        B::load_bot(tid, e, evk + (((size_t)j * 2 + 1) * L + limb) * N);
+#pragma unroll
+        for (int k = 0; k < E; ++k) acc1[k] = (first ? 0 : acc1[k]) + FoldArith::mul60(d[k], e[k], (u32)lc.d);
+        asm volatile("" ::: "memory");
+    };
+    {
+        u64 x[E], y[E], z[E], w[E];
+        digit(x, 0); digit(y, 1); digit(z, 2); digit(w, 3);
+        FwdChain4<B, 0>::run(tid, x, y, z, w, lds, lds + W, twf, lc);
+        mac(x, 0, true); mac(y, 1, false); mac(z, 2, false); mac(w, 3, false);
+    }
+    const int rem = Ld - 4;
+    if (rem >= 2) {
+        asm volatile("" : "+v"(tid));
+        u64 x[E], y[E];
+        digit(x, 4); digit(y, 5);
+        lds_barrier();
+        FwdChain2<B, 0>::run(tid, x, y, lds, lds + W, twf, lc);
+        mac(x, 4, false); mac(y, 5, false);
+    }
+    if (rem & 1) {
+        asm volatile("" : "+v"(tid));
+        u64 x[E];
+        digit(x, Ld - 1);
+        lds_barrier();
+        FwdChain<B, 0>::template run<false>(tid, x, lds, twf, lc);
+        mac(x, Ld - 1, false);
+    }
+#pragma unroll
+    for (int k = 0; k < E; ++k) { acc0[k] = FoldArith::reduce(acc0[k], lc); acc1[k] = FoldArith::reduce(acc1[k], lc); }
+    asm volatile("" : "+v"(tid));
+    InvChain2<B, B::NPH - 1, 2 * kMulB>::run(tid, acc0, acc1, lds, lds + W, tb.inv4 + (size_t)limb * N, last, lc);
+    B::inv_canon(acc0, lc);
+    if (MODE == 0 || MODE == 1) {
+        u64 orig[E];
+        B::load_top(tid, orig, in3 + ((bi * kInComps + 0) * L + limb) * N);
+#pragma unroll
+        for (int k = 0; k < E; ++k) acc0[k] = add_mod(acc0[k], orig[k], lc.q);
+    }
+    B::store_top(tid, acc0, out2 + ((bi * 2 + 0) * L + limb) * N);
+    B::inv_canon(acc1, lc);
+    if (MODE == 0) {
+        u64 orig[E];
+        B::load_top(tid, orig, in3 + ((bi * kInComps + 1) * L + limb) * N);
+#pragma unroll
+        for (int k = 0; k < E; ++k) acc1[k] = add_mod(acc1[k], orig[k], lc.q);
+    }
+    B::store_top(tid, acc1, out2 + ((bi * 2 + 1) * L + limb) * N);
+}
+
 // ------------------------------------------------------------------------------------------------
 // N3: HOISTED rotations - k rotations of one ciphertext share the digit decomposition and its forward
 // transforms.  `digits` holds NTT(lift([c1]_{q_j})) for every digit j and limb i ([Ld][L][N], forward-output order).  In that

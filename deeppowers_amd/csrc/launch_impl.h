@@ -95,7 +95,22 @@ int launch_ct_mul(int log2n, unsigned flags, u64* out3, const u64* a2, const u64
 template <class Arith>
 int launch_relin(int log2n, int mode, u64* out2, const u64* in3, const u64* evk, size_t key_stride, unsigned key_group, size_t blocks,
                  const DevTables<Arith>& tb, hipStream_t s) {
-#define RL_ONE(LN, M) hipLaunchKernelGGL((relin_kernel<Arith, LN, kFusedLoge, M>), dim3((unsigned)blocks), dim3(Geo<LN, kFusedLoge>::T), 0, s, out2, in3, evk, key_stride, key_group ? key_group : 1u, tb)
+#ifndef DPFHE_RELIN_SHARED
+#define DPFHE_RELIN_SHARED 1
+#endif
+    // 4..7 digits at N <= 4096: digit transforms side by side (relin_shared_kernel: -10 % on relinearize at N=4096, L=4; at N=8192,
+    // where one workgroup owns the CU and the key tiles are what it streams, the same form measured -1 %: not instantiated)
+    const int n_digits = mode >= 2 ? tb.n_limbs - 1 : tb.n_limbs;
+#define RL_ONE(LN, M)                                                                                                                                    \
+    if constexpr (DPFHE_RELIN_SHARED && Arith::kFold && LN >= 10 && LN <= 12) {                                                                                   \
+        if (n_digits >= 4 && n_digits <= 7) {                                                                                                            \
+            hipLaunchKernelGGL((relin_shared_kernel<Arith, LN, kFusedLoge, M>), dim3((unsigned)blocks), dim3(Geo<LN, kFusedLoge>::T), 0, s, out2, in3, evk, \
+                               key_stride, key_group ? key_group : 1u, tb);                                                                            \
+            break;                                                                                                                                       \
+        }                                                                                                                                                \
+    }                                                                                                                                                    \
+    hipLaunchKernelGGL((relin_kernel<Arith, LN, kFusedLoge, M>), dim3((unsigned)blocks), dim3(Geo<LN, kFusedLoge>::T), 0, s, out2, in3, evk, key_stride, \
+                       key_group ? key_group : 1u, tb)
 #define RL_CASE(LN, LE)                \
     if (mode == 0) { RL_ONE(LN, 0); }      \
     else if (mode == 1) { RL_ONE(LN, 1); } \
