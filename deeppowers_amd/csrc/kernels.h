@@ -451,15 +451,11 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE), 2) void ct_mul_dual_kernel(u64*
     const typename B::Tw* const twi = tb.inv4 + (size_t)limb * N;
 
     u64 D0[E], D1[E], D2[E];
-#ifdef DPFHE_CTMUL_UNROLL_R
-#pragma unroll
-#else
 #pragma unroll 1
-#endif
     for (int r = 0; r < 2; ++r) {
         asm volatile("" : "+v"(tid));   // keeps the twiddle fetches of the two passes apart (see ct_mul_kernel)
         u64 x[E], y[E];
-        B::template load_top<true>(tid, x, src_a + (size_t)r * cstride);
+        B::template load_top<true>(tid, x, src_a + (size_t)r * cstride);   // (requesting pass 1's operands during pass 0 spills 46 registers at N = 8192: 13 % slower)
         B::template load_top<true>(tid, y, src_b + (size_t)r * cstride);
         if (r) lds_barrier();           // pass 0's last exchange was wave-local, but pass 1's first write crosses waves
         FwdChain2<B, 0>::run(tid, x, y, lds, lds + W, twf, lc);
