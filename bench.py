@@ -186,6 +186,8 @@ def main():
         ntt["device_copy"] = {"bytes_read_plus_written": cb, "median_us": ts[len(ts) // 2] * 1e6, "GBps": cb / ts[len(ts) // 2] / 1e9,
                               "frac_of_hbm_peak": cb / ts[len(ts) // 2] / HBM_PEAK,
                               "note": "torch copy_ of 2 GiB: the practical HBM ceiling the NTT's fraction should be read against"}
+        for name, _ in fns:
+            ntt[name]["frac_of_device_copy"] = ntt[name]["GBps"] / ntt["device_copy"]["GBps"]
         return ntt
 
 
