@@ -559,3 +559,46 @@ def test_hoisted_rotation_is_a_valid_key_switch_oracle():
     assert max(abs(centre((a - b) % Q)) for a, b in zip(got, want)) < (1 << 24)
     plain = orc_e.keyswitch_hybrid(Oracle.from_params(p).apply_galois(ct1, g), key_g, 2)
     assert not np.array_equal(plain.reshape(hoisted.shape), hoisted)      # a different, equally valid decomposition
+
+
+def _fold_primes(n, count):
+    """`count` primes 2^60 - d (d < 2^24: the fold-reduction kernels), q = 1 mod 2n, largest first."""
+    out, q = [], (1 << 60) - ((1 << 60) - 1) % (2 * n)
+    while len(out) < count:
+        if po.is_prime(q):
+            out.append(q)
+        q -= 2 * n
+    assert (1 << 60) - out[-1] < (1 << 24)
+    return tuple(out)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("log2n,limbs", [(10, 5), (10, 6), (11, 7), (12, 8)])
+def test_key_switch_with_shared_digit_transforms_bit_exact(log2n, limbs):
+    """relin_shared_kernel (N <= 4096, 4..7 digits): every remainder path after the first four digits - none (4), one (5), two (6),
+    two + one (7) - for the RNS-digit relinearisation (digits = limbs, when <= 7) and for the hybrid forms (digits = limbs - 1)."""
+    from deeppowers_amd.evaluator import Ciphertext, Context, Evaluator, to_device, to_host
+    n = 1 << log2n
+    qs = _fold_primes(n, limbs)
+    pe = FheParams(log2n, qs, tuple(po.min_primitive_2n_root(n, q) for q in qs))
+    orc = Oracle.from_params(pe)
+    ctx = Context(pe, 0)
+    assert ctx.uses_fold
+    ev = Evaluator(ctx)
+    L, Ld, batch = limbs, limbs - 1, 3
+    if L <= 7:
+        ct3 = orc.fill(batch * 3, 191).reshape(batch, 3, L, n)
+        ct3[0, 2] = (np.array(pe.moduli, np.uint64) - np.uint64(1))[:, None]
+        evk = orc.fill(L * 2, 192).reshape(L, 2, L, n)
+        evk[0, 0] = (np.array(pe.moduli, np.uint64) - np.uint64(1))[:, None]
+        got = to_host(ev.relinearize(Ciphertext(to_device(ct3, ctx.device)), to_device(evk, ctx.device)).data)
+        assert np.array_equal(got, orc.relinearize(ct3, evk, threads=0))
+    data = Oracle(pe.log2_n, pe.moduli[:-1], pe.psi[:-1])
+    key = orc.fill(Ld * 2, 193).reshape(Ld, 2, L, n)
+    for comps in (3, 2):
+        ct = data.fill(batch * comps, 194 + comps).reshape(batch, comps, Ld, n)
+        ct[0, comps - 1] = (np.array(pe.moduli[:-1], np.uint64) - np.uint64(1))[:, None]
+        want = orc.keyswitch_hybrid(ct, key, comps, threads=0)
+        got = to_host(ev.keyswitch_hybrid(Ciphertext(to_device(ct, ctx.device)), to_device(key, ctx.device)).data)
+        assert np.array_equal(got, want), comps
+    ctx.close()
