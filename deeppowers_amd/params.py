@@ -85,3 +85,61 @@ class FheParams:
     def n8192_l6() -> "FheParams":
         """configs[4] sizes: N=8192, 6 x 60-bit limbs."""
         return FheParams(13, tuple(p[0] for p in PRIMES_60), tuple(p[2] for p in PRIMES_60))
+
+
+# ---- building other parameter sets ---------------------------------------------------------------------------------
+def is_prime(n: int) -> bool:
+    """Deterministic Miller-Rabin for n < 3.3e24 (the first 13 primes as witnesses)."""
+    if n < 2:
+        return False
+    small = (2, 3, 5, 7, 11, 13, 17, 19, 23, 29, 31, 37, 41)
+    for p in small:
+        if n % p == 0:
+            return n == p
+    d, r = n - 1, 0
+    while d % 2 == 0:
+        d //= 2
+        r += 1
+    for a in small:
+        x = pow(a, d, n)
+        if x in (1, n - 1):
+            continue
+        for _ in range(r - 1):
+            x = x * x % n
+            if x == n - 1:
+                break
+        else:
+            return False
+    return True
+
+
+def min_primitive_2n_root(n: int, q: int) -> int:
+    """Smallest psi with psi^n = -1 (mod q), i.e. of order exactly 2n (n a power of two, q = 1 mod 2n prime) - Appendix A's rule."""
+    if (q - 1) % (2 * n):
+        raise ValueError("q is not 1 mod 2N")
+    roots, g = set(), 2
+    while len(roots) < 64:                      # a handful of candidates psi = g^((q-1)/2n) of full order, then all their odd powers
+        w = pow(g, (q - 1) // (2 * n), q)
+        if pow(w, n, q) == q - 1:
+            x, w2, best = w, w * w % q, w
+            for _ in range(n):                  # the 2N-th roots of full order are the odd powers of any one of them
+                if x < best:
+                    best = x
+                x = x * w2 % q
+            return best
+        g += 1
+    raise ValueError("no primitive 2N-th root found")
+
+
+def ntt_primes(log2_n: int, count: int, bits: int = 60) -> "FheParams":
+    """`count` largest primes below 2^bits with q = 1 (mod 2N) and their smallest primitive 2N-th roots.  For bits = 60 these are of the
+    form 2^60 - d with small d, the shape the library's fold-reduction kernels take (dpfhe_ctx_uses_fold)."""
+    n = 1 << log2_n
+    qs, q = [], (1 << bits) - ((1 << bits) - 1) % (2 * n)
+    while len(qs) < count:
+        if q < 3:
+            raise ValueError("not enough primes")
+        if is_prime(q):
+            qs.append(q)
+        q -= 2 * n
+    return FheParams(log2_n, tuple(qs), tuple(min_primitive_2n_root(n, v) for v in qs))

@@ -49,3 +49,21 @@ def test_params_validation():
         FheParams(12, ((1 << 61) + 1,), (3,))  # too wide
     p = FheParams.n4096_l4()
     assert p.n == 4096 and p.n_limbs == 4 and p.words_per_ct(2) * 8 == 256 * 1024 and p.words_per_ct(3) * 8 == 384 * 1024
+
+
+def test_parameter_search_reproduces_the_pinned_table_and_the_oracle():
+    """deeppowers_amd.params.ntt_primes / is_prime / min_primitive_2n_root (product-side helpers for other parameter sets) against
+    Appendix A's pinned constants and against the oracle's independent implementations."""
+    from deeppowers_amd.params import PRIMES_60, is_prime, min_primitive_2n_root, ntt_primes
+    from oracle import pyoracle as po
+    p13 = ntt_primes(13, 6)
+    assert p13.moduli == tuple(x[0] for x in PRIMES_60) and p13.psi == tuple(x[2] for x in PRIMES_60)
+    p12 = ntt_primes(12, 4)
+    assert p12.moduli == tuple(x[0] for x in PRIMES_60[:4]) and p12.psi == tuple(x[1] for x in PRIMES_60[:4])
+    for log2n, bits in ((8, 60), (10, 30), (16, 60), (11, 45)):
+        p = ntt_primes(log2n, 2, bits)
+        for q, w in zip(p.moduli, p.psi):
+            assert po.is_prime(q) and is_prime(q) and q < (1 << bits) and (q - 1) % (2 << log2n) == 0
+            assert w == po.min_primitive_2n_root(1 << log2n, q) == min_primitive_2n_root(1 << log2n, q)
+    for n in (1, 4, 9, 561, 1105, 2**61 - 1, (2**31 - 1) * (2**31 - 1), 3215031751):
+        assert is_prime(n) == po.is_prime(n), n

@@ -12,24 +12,13 @@ if os.environ.get("DPFHE_AB_LIB"):
     _cabi.LIB_PATH = os.path.abspath(os.environ["DPFHE_AB_LIB"])
 from deeppowers_amd.evaluator import Context, Evaluator  # noqa: E402
 from deeppowers_amd.params import FheParams  # noqa: E402
-from oracle import pyoracle as po  # noqa: E402  (prime search only)
-
-
-def fold_primes(two_n, count):
-    out, k = [], 1
-    while len(out) < count:
-        c = (1 << 60) - (k * two_n - 1)
-        if c % two_n == 1 and po.is_prime(c):
-            out.append(c)
-        k += 1
-    return out
-
+from deeppowers_amd.params import ntt_primes  # noqa: E402
 
 for ln, polys in ((14, 6144), (15, 4096), (16, 2048)):
     n = 1 << ln
     L = 2
-    qs = fold_primes(2 * n, L)
-    p = FheParams(ln, tuple(qs), tuple(po.min_primitive_2n_root(n, q) for q in qs))
+    p = ntt_primes(ln, L)
+    qs = p.moduli
     ctx = Context(p, 0)
     ev = Evaluator(ctx)
     q = torch.tensor(qs, dtype=torch.int64, device=ctx.device).view(1, L, 1)
