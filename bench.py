@@ -147,31 +147,52 @@ def main():
     torch.cuda.synchronize()
 
     def measure_ntt():
-        # BASELINE configs[1]: NTT / INTT HBM-roofline run, batch 1024 RNS polys x 4 limbs
+        # BASELINE configs[1] as SURVEY.md 8(d) states it ("Config 2: 1024 RNS polys (4096 residue polys, 128 MiB), forward then inverse,
+        # timed separately, >= 20 iterations after 5 warm-ups, median"): ONE 128 MiB buffer transformed in place, forward then inverse
+        # (so the data round-trips and the last inverse must reproduce the input - checked).  The 128 MiB fit the chip's 256 MiB
+        # Infinity Cache; the same batch out of place (256 MiB touched) and a 1 GiB batch (nothing cached) are reported next to it.
         nb = 1024
         x = torch.randint(0, 2**62, (nb, L, N), generator=g, dtype=torch.int64, device=dev) % q.view(1, L, 1)
+        x0 = x.clone()
         y = torch.empty_like(x)
-        ntt = {}
-        fns = (("fwd", ev.ntt_forward), ("inv", ev.ntt_inverse))
-        for _ in range(5):
-            for _, fn in fns:
-                fn(x, out=y)
-        # 30 launches of each direction, interleaved (the clocks drift by ~10 % within a second of sustained load, so
-        # measuring one direction after the other would penalise the second), enqueued back to back, each bracketed by
-        # its own pair of HIP events; one host sync at the end (a host sync after every launch reads 10-15 % slower)
-        evs = {name: [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(30)] for name, _ in fns}
-        for i in range(30):
-            for name, fn in fns:
-                s_, e_ = evs[name][i]
-                s_.record(); fn(x, out=y); e_.record()
-        torch.cuda.synchronize()
-        for name, _ in fns:
-            ts = sorted(s_.elapsed_time(e_) * 1e-3 for s_, e_ in evs[name])
+
+        def timed_pair(fwd, inv, reps, warm):
+            # `reps` launches of each direction, interleaved (the clocks drift by ~10 % within a second of sustained load, so
+            # measuring one direction after the other would penalise the second), enqueued back to back, each bracketed by its
+            # own pair of HIP events; one host sync at the end (a host sync after every launch reads 10-15 % slower)
+            fns = (("fwd", fwd), ("inv", inv))
+            for _ in range(warm):
+                for _, fn in fns:
+                    fn()
+            evs = {name: [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)] for name, _ in fns}
+            for i in range(reps):
+                for name, fn in fns:
+                    s_, e_ = evs[name][i]
+                    s_.record(); fn(); e_.record()
+            torch.cuda.synchronize()
+            return {name: sorted(s_.elapsed_time(e_) * 1e-3 for s_, e_ in evs[name]) for name, _ in fns}
+
+        def entry(ts, nbytes):
             med = ts[len(ts) // 2]
-            nbytes = 2 * N * 8 * nb * L
-            ntt[name] = {"median_us": med * 1e6, "min_us": ts[0] * 1e6, "GBps": nbytes / med / 1e9, "frac_of_hbm_peak": nbytes / med / HBM_PEAK}
-        ntt["algorithmic_bytes"] = 2 * N * 8 * nb * L
-        ntt["workload"] = "BASELINE configs[1]: batch=1024 RNS polys x 4 limbs, N=4096, out-of-place"
+            return {"median_us": med * 1e6, "min_us": ts[0] * 1e6, "GBps": nbytes / med / 1e9, "frac_of_hbm_peak": nbytes / med / HBM_PEAK}
+
+        nbytes = 2 * N * 8 * nb * L
+        ntt = {}
+        t_in = timed_pair(lambda: ev.ntt_forward_(x), lambda: ev.ntt_inverse_(x), 30, 5)
+        ntt["round_trip_exact"] = bool(torch.equal(x, x0))
+        for name in ("fwd", "inv"):
+            ntt[name] = entry(t_in[name], nbytes)
+        t_out = timed_pair(lambda: ev.ntt_forward(x, out=y), lambda: ev.ntt_inverse(x, out=y), 30, 5)
+        ntt["out_of_place"] = {name: entry(t_out[name], nbytes) for name in ("fwd", "inv")}
+        ntt["algorithmic_bytes"] = nbytes
+        ntt["workload"] = ("BASELINE configs[1]: batch=1024 RNS polys x 4 limbs, N=4096 (4096 residue polynomials, 128 MiB), in place, forward then "
+                           "inverse interleaved, median of 30; `out_of_place`: the same batch into a second buffer; `steady_state`: 8192 RNS polys (1 GiB) out of place")
+        nb2 = 8192
+        x2 = a.data.view(-1)[: nb2 * L * N].view(nb2, L, N)        # canonical residues already resident (the multiply's operand)
+        y2 = outs[0].view(-1)[: nb2 * L * N].view(nb2, L, N)
+        t_big = timed_pair(lambda: ev.ntt_forward(x2, out=y2), lambda: ev.ntt_inverse(x2, out=y2), 20, 3)
+        ntt["steady_state"] = {name: entry(t_big[name], 2 * N * 8 * nb2 * L) for name in ("fwd", "inv")}
+        fns = (("fwd", None), ("inv", None))
         # "also report a measured device-copy bandwidth as the practical ceiling" - a plain device-to-device copy of
         # the multiply's 2 GiB operand (far beyond the 256 MiB Infinity Cache) into its output buffer, same event bracketing
         src, dst = a.data.view(-1), outs[0].view(-1)[: a.data.numel()]
@@ -187,7 +208,8 @@ def main():
                               "frac_of_hbm_peak": cb / ts[len(ts) // 2] / HBM_PEAK,
                               "note": "torch copy_ of 2 GiB: the practical HBM ceiling the NTT's fraction should be read against"}
         for name, _ in fns:
-            ntt[name]["frac_of_device_copy"] = ntt[name]["GBps"] / ntt["device_copy"]["GBps"]
+            for blk in (ntt, ntt["out_of_place"], ntt["steady_state"]):
+                blk[name]["frac_of_device_copy"] = blk[name]["GBps"] / ntt["device_copy"]["GBps"]
         return ntt
 
 

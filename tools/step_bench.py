@@ -91,6 +91,9 @@ def step(i):
         return step_chunked(i)
     k = i & 1
     main.wait_event(red_done[k])
+    if mode == "mulonly1":      # one output buffer instead of two alternating ones (footprint / TLB reach)
+        ev.multiply(a, b, out=outs[0], stream=main)
+        return
     c = ev.multiply(a, b, out=outs[k], stream=main)
     if mode == "mulonly":
         return
