@@ -33,7 +33,7 @@ def build_example(name="encrypted_multiply"):
 
 
 def test_example_compiles():
-    assert all(os.path.exists(build_example(e)) for e in ("encrypted_multiply", "bench_ct_mul", "encrypted_linear", "encrypted_gpt2_linear", "encrypted_gpt2_ffn", "sharded_ct_mul"))
+    assert all(os.path.exists(build_example(e)) for e in ("encrypted_multiply", "bench_ct_mul", "encrypted_linear", "encrypted_gpt2_linear", "encrypted_gpt2_ffn", "sharded_ct_mul", "sharded_ffn"))
 
 
 @pytest.mark.gpu
@@ -105,3 +105,21 @@ def test_example_encrypted_ffn_block_chained_on_the_device():
     application.  The program checks the hand-over slot by slot and the result against x + W_down (W_up x) mod t."""
     out = subprocess.run([build_example("encrypted_gpt2_ffn"), "4", "1"], capture_output=True, text=True, timeout=900)
     assert out.returncode == 0 and "OK" in out.stdout and "MISMATCH" not in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+
+
+@pytest.mark.gpu
+def test_example_tensor_parallel_encrypted_ffn():
+    """configs[4]'s shape: the encrypted FFN linear path sharded over the inner dimension, one process per GPU, partial ciphertexts
+    all-gathered over the library's communicator and summed.  World size 1 runs the real multi-process program (fork, id through a
+    file, RCCL); world sizes 2, 4 and 8 are played by one process on this box's single GPU (`emulate`: real slices, real hand-over
+    between the two packed layers - a different one for each slice width -, real sum; the gather is a host copy).  Every run decrypts to
+    W_down (W_up x) mod t and all of them print the same checksum."""
+    import json
+    sums = set()
+    for args in (["1", "1"], ["2", "1", "0", "emulate"], ["4", "1", "0", "emulate"], ["8", "1", "0", "emulate"]):
+        out = subprocess.run([build_example("sharded_ffn")] + args, capture_output=True, text=True, timeout=900)
+        assert out.returncode == 0 and "OK" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+        line = json.loads(next(l for l in out.stdout.splitlines() if l.startswith("{")))
+        assert line["correct"] and line["world"] == int(args[0])
+        sums.add(line["result_checksum"])
+    assert len(sums) == 1
