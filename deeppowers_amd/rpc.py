@@ -18,6 +18,7 @@ so the descriptors are built here at run time; tests/test_rpc.py keeps the two i
 """
 from __future__ import annotations
 
+import collections
 import threading
 import time
 import uuid
@@ -167,14 +168,15 @@ class _Metrics:
 class EncryptedInferenceServer:
     """gRPC front of one Context.  `ctx` may be None for a transport-only server (host_only models)."""
 
-    def __init__(self, ctx, params: FheParams | None = None, max_workers: int = 4):
+    def __init__(self, ctx, params: FheParams | None = None, max_workers: int = 4, max_sessions: int = 64):
         self.ctx = ctx
         self.params = params if params is not None else ctx.params
         self.ev = None
         if ctx is not None:
             from .evaluator import Evaluator
             self.ev = Evaluator(ctx)
-        self.models, self.sessions = {}, {}
+        # evaluation keys are MBs of device memory per session: least-recently-used sessions are dropped beyond `max_sessions`
+        self.models, self.sessions, self.max_sessions = {}, collections.OrderedDict(), max_sessions
         self.metrics = _Metrics()
         self._gpu_lock = threading.Lock()   # one evaluation at a time per context: requests queue here, kernels fill the chip anyway
         self._server, self._workers = None, max_workers
@@ -216,6 +218,8 @@ class EncryptedInferenceServer:
                     a = self._to_device(request.ciphertext)
                     b = self._to_device(request.ciphertext_b) if request.ciphertext_b else None
                     keys = self.sessions.get(request.session_id)
+                    if keys is not None:
+                        self.sessions.move_to_end(request.session_id)
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     s = torch.cuda.current_stream(self.ctx.device)
                     e0.record(s)
@@ -247,10 +251,15 @@ class EncryptedInferenceServer:
             self.metrics.error(True)
             context.abort(grpc.StatusCode.INVALID_ARGUMENT, str(ex))
         if self.ctx is None:
-            self.sessions[request.session_id] = words
+            keys = words
         else:
             from .evaluator import to_device
-            self.sessions[request.session_id] = to_device(words, self.ctx.device)
+            keys = to_device(words, self.ctx.device)
+        with self._gpu_lock:
+            self.sessions[request.session_id] = keys
+            self.sessions.move_to_end(request.session_id)
+            while len(self.sessions) > self.max_sessions:
+                self.sessions.popitem(last=False)
         return pb["RegisterKeysResponse"](ok=True)
 
     def _get_metrics(self, request, context):

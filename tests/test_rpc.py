@@ -85,6 +85,13 @@ def test_transport_echo_errors_and_metrics():
             client.register_relin_keys(_canonical(rng, p, 2, 2))
         assert e.value.code() == grpc.StatusCode.INVALID_ARGUMENT
         assert client.register_relin_keys(_canonical(rng, p, p.n_limbs, 2))
+        # sessions are bounded: the least recently used one is dropped
+        server.max_sessions = 2
+        for sid in ("s1", "s2", "s3"):
+            c2 = rpc.EncryptedClient(f"127.0.0.1:{port}", p, session_id=sid)
+            assert c2.register_relin_keys(_canonical(rng, p, p.n_limbs, 2))
+            c2.close()
+        assert list(server.sessions) == ["s2", "s3"]
         m = client.metrics()
         assert m.total_requests == 6 and m.errors.total_errors == 5 and m.errors.internal_errors == 1 and m.errors.invalid_argument_errors == 4
         assert m.latency.p50_ms > 0 and m.throughput.ciphertexts_per_second > 0
