@@ -481,14 +481,11 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE), 2) void ct_mul_dual_kernel(u64*
             }
         }
     }
-#ifndef DPFHE_CTMUL_DUAL_INV
-#define DPFHE_CTMUL_DUAL_INV 1
-#endif
     if (OUT_NTT) {
         B::store_bot(tid, D0, dst);
         B::store_bot(tid, D1, dst + cstride);
         B::store_bot(tid, D2, dst + 2 * cstride);
-    } else if (DPFHE_CTMUL_DUAL_INV) {
+    } else {
         // c0 | c1 side by side, then c2.  Before the single chain: its wave-local writes go to buffer 0, which other waves read
         // in the pair's last exchange
         asm volatile("" : "+v"(tid));
@@ -502,18 +499,6 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE), 2) void ct_mul_dual_kernel(u64*
         InvChain<B, B::NPH - 1, kInvIn>::run(tid, D2, lds, twi, last, lc);
         B::inv_canon(D2, lc);
         B::template store_top<true>(tid, D2, dst + 2 * cstride);
-    } else {
-#pragma unroll 1
-        for (int c = 0; c < 3; ++c) {
-            asm volatile("" : "+v"(tid));
-            // buffers alternate: the chain's own barrier (after its last exchange) orders inverse c+2's writes after every
-            // wave's reads of inverse c; the forward chains' last exchanges were wave-local
-            InvChain<B, B::NPH - 1, kInvIn>::run(tid, D0, lds + (c & 1) * W, twi, last, lc);
-            B::inv_canon(D0, lc);
-            B::template store_top<true>(tid, D0, dst + (size_t)c * cstride);
-#pragma unroll
-            for (int k = 0; k < E; ++k) { D0[k] = D1[k]; D1[k] = D2[k]; }
-        }
     }
 }
 
