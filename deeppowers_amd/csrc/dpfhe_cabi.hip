@@ -556,7 +556,8 @@ extern "C" int dpfhe_matvec_plain(dpfhe_ctx* c, uint64_t* d_y, const uint64_t* d
     const int n = 1 << c->log2n;
     const int chunks = (n + 511) / 512;
     constexpr int RT = 4;
-    const size_t blocks = ((rows + RT - 1) / RT) * c->n_limbs * (size_t)chunks;
+    const size_t slabs = c->n_limbs * (size_t)chunks;
+    const size_t blocks = ((slabs + 7) / 8) * 8 * ((rows + RT - 1) / RT);   // block ids laid out per XCD: kernels_misc.h matvec_kernel
     if (blocks > kMaxGrid) return fail(DPFHE_INVALID_ARGUMENT, "dpfhe_matvec_plain", "too many rows for one launch");
     DPFHE_ON_DEVICE(c, "dpfhe_matvec_plain");
     hipStream_t s = static_cast<hipStream_t>(stream);
@@ -578,30 +579,31 @@ extern "C" int dpfhe_matvec_plain_multi(dpfhe_ctx* c, uint64_t* d_y, const uint6
     const size_t poly = (size_t)c->n_limbs << c->log2n;
     hipStream_t s = static_cast<hipStream_t>(stream);
     DPFHE_ON_DEVICE(c, what);
-    // groups of 2 (or 1) right-hand sides per launch, 4 rows per workgroup: 32 128-bit accumulators per thread.  Every group re-reads W
-    // once and every row tile re-reads the group's x (L2 / Infinity Cache hits).  Measured on the 32 x 32 x 1024-diagonal matvec of
-    // a packed GPT-2 layer, per token: 86 us single, 104 us with 2 x 4 or 4 x 2 tiles un-pipelined, 75 us with 2 x 4 pipelined.  x / y are [cols | rows][n_rhs][2][L][N]: a group is a strided slice, so the kernels take the full stride.
-    size_t t = 0;
-    while (t < n_rhs) {
-#ifndef DPFHE_MATVEC_GROUP4
-#define DPFHE_MATVEC_GROUP4 0   // A/B switch: 4 right-hand sides x 2 rows per workgroup instead of 2 x 4
-#endif
-        const size_t g = (DPFHE_MATVEC_GROUP4 && n_rhs - t >= 4) ? 4 : (n_rhs - t >= 2 ? 2 : 1);
-        const uint64_t* xs = d_x + t * 2 * poly;
-        uint64_t* ys = d_y + t * 2 * poly;
-#define MV_LAUNCH(ARITH, RT, C, LC)                                                                                                                      \
-        {                                                                                                                                                \
-            const size_t blocks = ((rows + RT - 1) / RT) * c->n_limbs * (size_t)chunks;                                                                  \
-            if (blocks > kMaxGrid) return fail(DPFHE_INVALID_ARGUMENT, what, "too many rows for one launch");                                         \
-            hipLaunchKernelGGL((matvec_multi_kernel<ARITH, RT, C>), dim3((unsigned)blocks), dim3(256), 0, s, ys, d_W, xs, LC, (int)c->n_limbs, n, chunks, rows, cols, \
-                               n_rhs * 2);                                                                                                               \
-        }
-        if (c->fold) { if (g == 4) MV_LAUNCH(FoldArith, 2, 8, c->foldt.lc) else if (g == 2) MV_LAUNCH(FoldArith, 4, 4, c->foldt.lc) else MV_LAUNCH(FoldArith, 4, 2, c->foldt.lc) }
-        else { if (g == 4) MV_LAUNCH(ShoupArith, 2, 8, c->shoup.lc) else if (g == 2) MV_LAUNCH(ShoupArith, 4, 4, c->shoup.lc) else MV_LAUNCH(ShoupArith, 4, 2, c->shoup.lc) }
-#undef MV_LAUNCH
-        if (int e = check_launch("matvec_multi kernel launch")) return e;
-        t += g;
+    // 2 right-hand sides x 4 rows per workgroup (32 128-bit accumulators per thread); all groups of 2 in ONE launch whose block ids put
+    // the groups of a W tile on the same XCD (kernels_misc.h), an odd last right-hand side in a second launch.  x / y are
+    // [cols | rows][n_rhs][2][L][N]: a group is a strided slice, so the kernels take the full stride.  Measured on the 32 x 32 x
+    // 1024-diagonal matvec of a packed GPT-2 layer, per token: 86 us single; 8 tokens: 75 us with one launch per group (W re-read from
+    // HBM by every group), see DESIGN.md for the XCD-grouped launch.
+    const size_t pairs = n_rhs / 2;
+#define MV_LAUNCH(ARITH, RT, C, LC, GROUPS, XS, YS)                                                                                                      \
+    {                                                                                                                                                    \
+        const size_t slabs = c->n_limbs * (size_t)chunks, rtiles = (rows + RT - 1) / RT, tiles = rtiles * slabs;                                         \
+        const size_t blocks = ((slabs + 7) / 8) * 8 * rtiles * (GROUPS);                                                                                 \
+        if (blocks > kMaxGrid) return fail(DPFHE_INVALID_ARGUMENT, what, "too many rows for one launch");                                             \
+        hipLaunchKernelGGL((matvec_multi_kernel<ARITH, RT, C>), dim3((unsigned)blocks), dim3(256), 0, s, YS, d_W, XS, LC, (int)c->n_limbs, n, chunks, rows, cols, \
+                           n_rhs * 2, (unsigned)(GROUPS), (unsigned)tiles);                                                                              \
     }
+    if (pairs) {
+        if (c->fold) MV_LAUNCH(FoldArith, 4, 4, c->foldt.lc, pairs, d_x, d_y) else MV_LAUNCH(ShoupArith, 4, 4, c->shoup.lc, pairs, d_x, d_y)
+        if (int e = check_launch("matvec_multi kernel launch")) return e;
+    }
+    if (n_rhs & 1) {
+        const uint64_t* xs = d_x + (n_rhs - 1) * 2 * poly;
+        uint64_t* ys = d_y + (n_rhs - 1) * 2 * poly;
+        if (c->fold) MV_LAUNCH(FoldArith, 4, 2, c->foldt.lc, 1, xs, ys) else MV_LAUNCH(ShoupArith, 4, 2, c->shoup.lc, 1, xs, ys)
+        if (int e = check_launch("matvec_multi kernel launch")) return e;
+    }
+#undef MV_LAUNCH
     return DPFHE_SUCCESS;
 }
 

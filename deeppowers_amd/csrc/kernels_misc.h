@@ -146,9 +146,14 @@ template <class Arith, int RT>
 __global__ __launch_bounds__(256) void matvec_kernel(u64* y, const u64* W, const u64* x, const LimbConst* lcs, int n_limbs, int n,
                                                      int chunks, size_t rows, size_t cols) {
     const size_t L = (size_t)n_limbs;
-    const int chunk = (int)(blockIdx.x % chunks);
-    const int limb = (int)((blockIdx.x / chunks) % L);
-    const size_t row0 = (blockIdx.x / chunks / L) * RT;
+    // XCD-aware block ids (see matvec_multi_kernel): slab p = (limb, chunk) on XCD p mod 8, its row tiles adjacent there - the x tile of
+    // a slab is fetched from HBM once and re-read from that XCD's L2 by the other row tiles
+    const unsigned n_slabs = (unsigned)L * (unsigned)chunks, R = (unsigned)((rows + RT - 1) / RT);
+    const unsigned id = blockIdx.x, q = id >> 3, slab = (q / R) * 8u + (id & 7u);
+    if (slab >= n_slabs) return;
+    const int chunk = (int)(slab % chunks);
+    const int limb = (int)(slab / chunks);
+    const size_t row0 = (size_t)(q % R) * RT;
     const int w0 = chunk * 512 + threadIdx.x * 2;
     if (w0 >= n) return;
     const LimbConst lc = lcs[limb];
@@ -216,13 +221,24 @@ __global__ __launch_bounds__(256) void matvec_kernel(u64* y, const u64* W, const
 // tokens: the W stream (the 335 MB of diagonals of a packed GPT-2 layer) is read once per launch instead of once per token.
 template <class Arith, int RT, int C>
 __global__ __launch_bounds__(256) void matvec_multi_kernel(u64* y, const u64* W, const u64* x, const LimbConst* lcs, int n_limbs, int n,
-                                                           int chunks, size_t rows, size_t cols, size_t polys_per_col /* >= C: the full [n_rhs][2] extent */) {
+                                                           int chunks, size_t rows, size_t cols, size_t polys_per_col /* >= C: the full [n_rhs][2] extent */,
+                                                           unsigned n_groups, unsigned n_tiles) {
+    // `n_groups` groups of C / 2 right-hand sides and all row tiles in ONE launch, block ids laid out for the 8 XCDs (workgroups are
+    // dealt to them round-robin by id): slab p = (limb, chunk of 512 words) lives on XCD p mod 8, and its row tiles x groups are
+    // adjacent ids on that XCD - id = ((p / 8) * R * G + r * G + g) * 8 + p % 8.  The G workgroups of a row tile read the same W tile and
+    // the R workgroups of a group the same x tile at about the same time: each is fetched from HBM once, the rest are L2 hits.
     const size_t L = (size_t)n_limbs;
-    const int chunk = (int)(blockIdx.x % chunks);
-    const int limb = (int)((blockIdx.x / chunks) % L);
-    const size_t row0 = (blockIdx.x / chunks / L) * RT;
+    const unsigned n_slabs = (unsigned)L * (unsigned)chunks, R = n_tiles / n_slabs;   // n_tiles = row tiles * slabs
+    const unsigned id = blockIdx.x, lane = id & 7u, q = id >> 3;
+    const unsigned group = q % n_groups, rt = (q / n_groups) % R, slab = (q / (n_groups * R)) * 8u + lane;
+    if (slab >= n_slabs) return;
+    const int chunk = (int)(slab % chunks);
+    const int limb = (int)(slab / chunks);
+    const size_t row0 = (size_t)rt * RT;
     const int w0 = chunk * 512 + threadIdx.x * 2;
     if (w0 >= n) return;
+    x += (size_t)group * C * L * n;
+    y += (size_t)group * C * L * n;
     const LimbConst lc = lcs[limb];
     const u64 two64 = lc.two64;
     const size_t wstride = L * n, xstride = polys_per_col * L * n, rstride = cols * L * n;
