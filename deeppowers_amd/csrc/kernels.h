@@ -570,15 +570,26 @@ __device__ __forceinline__ u64 canon_any(u64 v, const LimbConst& lc) {  // any v
 template <class Arith, int LOGN, int LOGE, int MODE>
 __global__ __launch_bounds__(1 << (LOGN - LOGE), (Arith::kFold ? 2 : 1)) void relin_kernel(u64* __restrict__ out2, const u64* __restrict__ in3,
                                                                        const u64* __restrict__ evk, size_t key_stride, unsigned key_group,
-                                                                       DevTables<Arith> tb) {
+                                                                       unsigned n_outer, DevTables<Arith> tb) {
     typedef NttBody<Arith, LOGN, LOGE> B;
     static_assert(LOGE == kFusedLoge, "the fused kernels read the fused twiddle layout (DevTables::fwd4 / inv4)");
     constexpr int E = B::E, N = B::G::N;
     __shared__ __attribute__((aligned(16))) u64 lds[B::G::lds_words()];
     int tid = threadIdx.x;
     const int L = tb.n_limbs;
-    const size_t bi = blockIdx.x / (unsigned)L;
-    const int limb = (int)(blockIdx.x % (unsigned)L);
+    size_t bi;
+    int limb;
+    if (n_outer) {
+        // `key_group` consecutive items share a key (the giant steps of several tokens): their workgroups for one limb get ids that are
+        // equal modulo 8 and adjacent above that, i.e. the same XCD at the same time - the key tiles come from HBM once per group
+        const unsigned q = blockIdx.x >> 3, inner = q % key_group, outer = (q / key_group) * 8u + (blockIdx.x & 7u);
+        if (outer >= n_outer) return;
+        limb = (int)(outer % (unsigned)L);
+        bi = (size_t)(outer / (unsigned)L) * key_group + inner;
+    } else {
+        bi = blockIdx.x / (unsigned)L;
+        limb = (int)(blockIdx.x % (unsigned)L);
+    }
     const LimbConst lc = tb.lc[limb];
     const InvLast<typename B::Tw> last = tb.last[limb];
     constexpr int kInComps = (MODE == 0 || MODE == 2) ? 3 : 2;
@@ -664,15 +675,26 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE), (Arith::kFold ? 2 : 1)) void re
 template <class Arith, int LOGN, int LOGE, int MODE>
 __global__ __launch_bounds__(1 << (LOGN - LOGE), 2) void relin_shared_kernel(u64* __restrict__ out2, const u64* __restrict__ in3,
                                                                            const u64* __restrict__ evk, size_t key_stride, unsigned key_group,
-                                                                           DevTables<Arith> tb) {
+                                                                           unsigned n_outer, DevTables<Arith> tb) {
     typedef NttBody<Arith, LOGN, LOGE> B;
     static_assert(Arith::kFold && LOGE == kFusedLoge, "FoldArith, fused twiddle layout");
     constexpr int E = B::E, N = B::G::N, W = B::G::lds_words();
     __shared__ __attribute__((aligned(16))) u64 lds[2 * W];
     int tid = threadIdx.x;
     const int L = tb.n_limbs;
-    const size_t bi = blockIdx.x / (unsigned)L;
-    const int limb = (int)(blockIdx.x % (unsigned)L);
+    size_t bi;
+    int limb;
+    if (n_outer) {
+        // `key_group` consecutive items share a key (the giant steps of several tokens): their workgroups for one limb get ids that are
+        // equal modulo 8 and adjacent above that, i.e. the same XCD at the same time - the key tiles come from HBM once per group
+        const unsigned q = blockIdx.x >> 3, inner = q % key_group, outer = (q / key_group) * 8u + (blockIdx.x & 7u);
+        if (outer >= n_outer) return;
+        limb = (int)(outer % (unsigned)L);
+        bi = (size_t)(outer / (unsigned)L) * key_group + inner;
+    } else {
+        bi = blockIdx.x / (unsigned)L;
+        limb = (int)(blockIdx.x % (unsigned)L);
+    }
     const LimbConst lc = tb.lc[limb];
     const InvLast<typename B::Tw> last = tb.last[limb];
     constexpr int kInComps = (MODE == 0 || MODE == 2) ? 3 : 2;
@@ -760,7 +782,7 @@ struct GaloisElts { unsigned v[kMaxGaloisBatch]; };
 template <class Arith, int LOGN, int LOGE>
 __global__ __launch_bounds__(1 << (LOGN - LOGE), (Arith::kFold ? 2 : 1)) void hoisted_ks_kernel(u64* __restrict__ work, const u64* __restrict__ digits,
                                                                                            const u64* __restrict__ keys, size_t key_stride, GaloisElts elts,
-                                                                                           unsigned n_items, DevTables<Arith> tb) {
+                                                                                           unsigned n_items, unsigned n_tiles, DevTables<Arith> tb) {
     typedef NttBody<Arith, LOGN, LOGE> B;
     static_assert(LOGE == kFusedLoge, "the fused kernels read the fused twiddle layout (DevTables::fwd4 / inv4)");
     constexpr int E = B::E, N = B::G::N;
@@ -771,7 +793,10 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE), (Arith::kFold ? 2 : 1)) void ho
     // chain each - the k rotations of one token would otherwise fill a fraction of the chip with long-running workgroups
     // Several input ciphertexts (tokens) share the rotations: block = ((rotation * L + limb) * 2 + comp) * n_items + token, so
     // that the workgroups reading one key tile are neighbours in time (the tile is fetched once into L2 / Infinity Cache).
-    const unsigned token = blockIdx.x % n_items, tile = blockIdx.x / n_items;
+    // ... and on the same XCD: ids are dealt to the 8 XCDs round-robin, so id = ((tile / 8) * n_items + token) * 8 + tile % 8 keeps the
+    // n_items workgroups of a tile on XCD tile % 8, adjacent in time - the key tile comes from HBM once, the other tokens hit that L2
+    const unsigned q = blockIdx.x >> 3, token = q % n_items, tile = (q / n_items) * 8u + (blockIdx.x & 7u);
+    if (tile >= n_tiles) return;
     const int comp = (int)(tile & 1u);
     const size_t rot = (tile >> 1) / (unsigned)L;
     const int limb = (int)((tile >> 1) % (unsigned)L);

@@ -101,16 +101,19 @@ int launch_relin(int log2n, int mode, u64* out2, const u64* in3, const u64* evk,
     // 4..7 digits at N <= 4096: digit transforms side by side (relin_shared_kernel: -10 % on relinearize at N=4096, L=4; at N=8192,
     // where one workgroup owns the CU and the key tiles are what it streams, the same form measured -1 %: not instantiated)
     const int n_digits = mode >= 2 ? tb.n_limbs - 1 : tb.n_limbs;
+    // items that share a key (key_group > 1) are laid out per XCD: kernels.h relin_kernel
+    const unsigned kg = key_group ? key_group : 1u;
+    const unsigned n_outer = (kg > 1 && blocks % ((size_t)kg * tb.n_limbs) == 0) ? (unsigned)(blocks / kg) : 0u;   // whole groups only
+    const unsigned grid = n_outer ? ((n_outer + 7u) / 8u) * 8u * kg : (unsigned)blocks;
 #define RL_ONE(LN, M)                                                                                                                                    \
-    if constexpr (DPFHE_RELIN_SHARED && Arith::kFold && LN >= 10 && LN <= 12) {                                                                                   \
+    if constexpr (DPFHE_RELIN_SHARED && Arith::kFold && LN >= 10 && LN <= 12) {                                                                          \
         if (n_digits >= 4 && n_digits <= 7) {                                                                                                            \
-            hipLaunchKernelGGL((relin_shared_kernel<Arith, LN, kFusedLoge, M>), dim3((unsigned)blocks), dim3(Geo<LN, kFusedLoge>::T), 0, s, out2, in3, evk, \
-                               key_stride, key_group ? key_group : 1u, tb);                                                                            \
+            hipLaunchKernelGGL((relin_shared_kernel<Arith, LN, kFusedLoge, M>), dim3(grid), dim3(Geo<LN, kFusedLoge>::T), 0, s, out2, in3, evk,          \
+                               key_stride, kg, n_outer, tb);                                                                                             \
             break;                                                                                                                                       \
         }                                                                                                                                                \
     }                                                                                                                                                    \
-    hipLaunchKernelGGL((relin_kernel<Arith, LN, kFusedLoge, M>), dim3((unsigned)blocks), dim3(Geo<LN, kFusedLoge>::T), 0, s, out2, in3, evk, key_stride, \
-                       key_group ? key_group : 1u, tb)
+    hipLaunchKernelGGL((relin_kernel<Arith, LN, kFusedLoge, M>), dim3(grid), dim3(Geo<LN, kFusedLoge>::T), 0, s, out2, in3, evk, key_stride, kg, n_outer, tb)
 #define RL_CASE(LN, LE)                \
     if (mode == 0) { RL_ONE(LN, 0); }      \
     else if (mode == 1) { RL_ONE(LN, 1); } \
@@ -127,9 +130,10 @@ int launch_hoisted_ks(int log2n, u64* work, const u64* digits, const u64* keys, 
                       size_t n_items, const DevTables<Arith>& tb, hipStream_t s) {
     GaloisElts ge{};
     for (size_t i = 0; i < count && i < (size_t)kMaxGaloisBatch; ++i) ge.v[i] = elts[i];
-    const unsigned blocks = (unsigned)(count * (size_t)tb.n_limbs * 2 * n_items);   // (rotation, limb, key component, token)
+    const unsigned tiles = (unsigned)(count * (size_t)tb.n_limbs * 2);              // (rotation, limb, key component)
+    const unsigned blocks = ((tiles + 7u) / 8u) * 8u * (unsigned)n_items;           // x token, ids laid out per XCD (kernels.h)
 #define HK_CASE(LN, LE) \
-    hipLaunchKernelGGL((hoisted_ks_kernel<Arith, LN, kFusedLoge>), dim3(blocks), dim3(Geo<LN, kFusedLoge>::T), 0, s, work, digits, keys, key_stride, ge, (unsigned)n_items, tb)
+    hipLaunchKernelGGL((hoisted_ks_kernel<Arith, LN, kFusedLoge>), dim3(blocks), dim3(Geo<LN, kFusedLoge>::T), 0, s, work, digits, keys, key_stride, ge, (unsigned)n_items, tiles, tb)
     DPFHE_GEO_SWITCH(log2n, HK_CASE)
 #undef HK_CASE
     return 0;
