@@ -23,7 +23,11 @@ a = Ciphertext(torch.randint(0, 2**62, (B, 2, L, N), dtype=torch.int64, device=d
 b = Ciphertext(torch.randint(0, 2**62, (B, 2, L, N), dtype=torch.int64, device=dev) % q)
 outs = [ctx.empty(B, components=3) for _ in range(2)]
 parts = [ctx.empty(components=3) for _ in range(2)]
-main = torch.cuda.current_stream(); side = torch.cuda.Stream(device=dev)
+prio = os.environ.get("STEP_PRIO")   # "hi_main": the multiply on a high-priority stream, the reduce on a normal one
+main = torch.cuda.Stream(device=dev, priority=-1) if prio == "hi_main" else torch.cuda.current_stream()
+side = torch.cuda.Stream(device=dev)
+if prio == "hi_main":
+    torch.cuda.set_stream(main)
 mul_done = [torch.cuda.Event() for _ in range(2)]; red_done = [torch.cuda.Event() for _ in range(2)]
 
 
