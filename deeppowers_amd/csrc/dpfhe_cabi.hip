@@ -637,7 +637,10 @@ extern "C" int dpfhe_reduce_sum(dpfhe_ctx* c, uint64_t* d_out, const uint64_t* d
     const LimbConst* lc = c->fold ? c->foldt.lc : c->shoup.lc;
     const int chunks = (n + 511) / 512;
     const size_t words_per_item = components * c->n_limbs * (size_t)n;
-    const unsigned splits = (unsigned)(count < (size_t)kReduceSplits ? count : (size_t)kReduceSplits);
+    // batch splits (their partial sums are combined with atomics): 15 for the large batches of the sharded multiply; a short batch (the
+    // 32 rotated terms of a packed layer) keeps at least 8 items per split, so that every work item has 4 independent loads in flight
+    const size_t want = count / 8 ? count / 8 : 1;
+    const unsigned splits = (unsigned)(want < (size_t)kReduceSplits ? want : (size_t)kReduceSplits);
     hipStream_t s = static_cast<hipStream_t>(stream);
     HIP_TRY(hipMemsetAsync(d_out, 0, words_per_item * sizeof(u64), s));
     if (blocks * (size_t)chunks * splits > kMaxGrid) return fail(DPFHE_INVALID_ARGUMENT, "dpfhe_reduce_sum", "too many components for one launch");
@@ -645,7 +648,7 @@ extern "C" int dpfhe_reduce_sum(dpfhe_ctx* c, uint64_t* d_out, const uint64_t* d
     // two workgroups per CU walk the work items: as fast as an uncapped launch when alone (537 vs 551 us for 8192 x 3
     // components at N=4096) and 2 % faster for the multiply it overlaps with in bench.py
     unsigned grid = poly_chunks * splits;
-    if (grid > 2u * (unsigned)c->n_cu) grid = 2u * (unsigned)c->n_cu;
+    if (count > 512 && grid > 2u * (unsigned)c->n_cu) grid = 2u * (unsigned)c->n_cu;   // short batches are latency-bound: no cap
     hipLaunchKernelGGL(reduce_partial_kernel, dim3(grid), dim3(256), 0, s, d_out, d_in, lc, (int)c->n_limbs, n, chunks, count, words_per_item,
                        poly_chunks, splits);
     if (int e = check_launch("reduce_sum partial kernel launch")) return e;
