@@ -2,6 +2,9 @@
 import os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import deeppowers_amd._cabi as _cabi
+if os.environ.get("DPFHE_AB_LIB"):
+    _cabi.LIB_PATH = os.path.abspath(os.environ["DPFHE_AB_LIB"])
 from deeppowers_amd.evaluator import Ciphertext, Context, Evaluator, Plaintext
 from deeppowers_amd.params import FheParams
 from tools.ntt_bench import timeit
