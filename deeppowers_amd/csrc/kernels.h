@@ -861,4 +861,74 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE), (Arith::kFold ? 2 : 1)) void ho
     B::store_top(tid, acc, work + ((item * 2 + comp) * L + limb) * N);
 }
 
+// Both key components in one workgroup (used when the grid is large enough without the split: several tokens): the permuted digit
+// words are gathered ONCE for the two inner products and the two inverse transforms run side by side (InvChain2, two LDS buffers).
+// One workgroup per (rotation, limb, token); same XCD-aware id layout (tile = (rotation, limb)).
+template <class Arith, int LOGN, int LOGE>
+__global__ __launch_bounds__(1 << (LOGN - LOGE), 2) void hoisted_ks2_kernel(u64* __restrict__ work, const u64* __restrict__ digits,
+                                                                           const u64* __restrict__ keys, size_t key_stride, GaloisElts elts,
+                                                                           unsigned n_items, unsigned n_tiles, DevTables<Arith> tb) {
+    typedef NttBody<Arith, LOGN, LOGE> B;
+    static_assert(Arith::kFold && LOGE == kFusedLoge, "FoldArith, fused twiddle layout");
+    constexpr int E = B::E, N = B::G::N, W = B::G::lds_words();
+    __shared__ __attribute__((aligned(16))) u64 lds[2 * W];
+    const int tid = threadIdx.x;
+    const int L = tb.n_limbs, Ld = L - 1;
+    const unsigned q = blockIdx.x >> 3, token = q % n_items, tile = (q / n_items) * 8u + (blockIdx.x & 7u);
+    if (tile >= n_tiles) return;
+    const size_t rot = tile / (unsigned)L;
+    const int limb = (int)(tile % (unsigned)L);
+    const size_t item = rot * n_items + token;
+    digits += (size_t)token * (size_t)(L - 1) * L * N;
+    const LimbConst lc = tb.lc[limb];
+    const InvLast<typename B::Tw> last = tb.last[limb];
+    const unsigned g = elts.v[rot];
+    const u64* evk = keys + rot * key_stride;
+    unsigned src[E];
+#pragma unroll
+    for (int kk = 0; kk < E; ++kk) {
+        const unsigned p = (unsigned)tid * E + kk;
+        const unsigned e = 2u * (__brev(p) >> (32 - LOGN)) + 1u;
+        const unsigned e2 = (g * e) & (2u * N - 1u);
+        src[kk] = __brev((e2 - 1u) >> 1) >> (32 - LOGN);
+    }
+    u64 acc0[E], acc1[E], x[E], e[E];
+#pragma unroll
+    for (int k = 0; k < E; ++k) acc0[k] = acc1[k] = 0;
+    static_assert(7 * kMulB + kRedB <= kWord, "up to seven lazily added products fit a 64-bit word");
+    B::load_bot(tid, e, evk + ((size_t)0 * L + limb) * N);
+    {
+        const u64* d = digits + (size_t)limb * N;
+#pragma unroll
+        for (int k = 0; k < E; ++k) x[k] = d[src[k]];
+    }
+#pragma unroll 1
+    for (int j = 0; j < Ld; ++j) {
+        // pipeline: the second component's tile is requested before the first component's products, the next digit's words and
+        // first tile before the second component's products
+        u64 e1[E], xn[E];
+        B::load_bot(tid, e1, evk + (((size_t)j * 2 + 1) * L + limb) * N);
+#pragma unroll
+        for (int k = 0; k < E; ++k) acc0[k] += FoldArith::mul60(x[k], e[k], (u32)lc.d);
+        const int jn = j + 1 < Ld ? j + 1 : j;
+        B::load_bot(tid, e, evk + (((size_t)jn * 2 + 0) * L + limb) * N);
+        {
+            const u64* d = digits + ((size_t)jn * L + limb) * N;
+#pragma unroll
+            for (int k = 0; k < E; ++k) xn[k] = d[src[k]];
+        }
+#pragma unroll
+        for (int k = 0; k < E; ++k) acc1[k] += FoldArith::mul60(x[k], e1[k], (u32)lc.d);
+#pragma unroll
+        for (int k = 0; k < E; ++k) x[k] = xn[k];
+    }
+#pragma unroll
+    for (int k = 0; k < E; ++k) { acc0[k] = FoldArith::reduce(acc0[k], lc); acc1[k] = FoldArith::reduce(acc1[k], lc); }
+    InvChain2<B, B::NPH - 1, 2 * kMulB>::run(tid, acc0, acc1, lds, lds + W, tb.inv4 + (size_t)limb * N, last, lc);
+    B::inv_canon(acc0, lc);
+    B::store_top(tid, acc0, work + ((item * 2 + 0) * L + limb) * N);
+    B::inv_canon(acc1, lc);
+    B::store_top(tid, acc1, work + ((item * 2 + 1) * L + limb) * N);
+}
+
 }  // namespace dpfhe

@@ -130,9 +130,24 @@ int launch_hoisted_ks(int log2n, u64* work, const u64* digits, const u64* keys, 
                       size_t n_items, const DevTables<Arith>& tb, hipStream_t s) {
     GaloisElts ge{};
     for (size_t i = 0; i < count && i < (size_t)kMaxGaloisBatch; ++i) ge.v[i] = elts[i];
-    const unsigned tiles = (unsigned)(count * (size_t)tb.n_limbs * 2);              // (rotation, limb, key component)
+    // few workgroups (one token): one per (rotation, limb, key component), half the serial chain each; many (several tokens, Ld <= 7 so
+    // that the lazy sums fit): one per (rotation, limb) doing both components - the digit words are gathered once and the two inverse
+    // transforms share their twiddles (kernels.h hoisted_ks2_kernel)
+#ifndef DPFHE_HOISTED_MERGE_MIN
+#define DPFHE_HOISTED_MERGE_MIN 512
+#endif
+    const unsigned tiles1 = (unsigned)(count * (size_t)tb.n_limbs);                 // (rotation, limb)
+    const bool merged = Arith::kFold && tb.n_limbs - 1 <= 7 && (size_t)tiles1 * n_items >= (size_t)DPFHE_HOISTED_MERGE_MIN;
+    const unsigned tiles = merged ? tiles1 : tiles1 * 2u;                           // ... x key component when split
     const unsigned blocks = ((tiles + 7u) / 8u) * 8u * (unsigned)n_items;           // x token, ids laid out per XCD (kernels.h)
-#define HK_CASE(LN, LE) \
+#define HK_CASE(LN, LE)                                                                                                                                  \
+    if constexpr (Arith::kFold) {                                                                                                                        \
+        if (merged) {                                                                                                                                    \
+            hipLaunchKernelGGL((hoisted_ks2_kernel<Arith, LN, kFusedLoge>), dim3(blocks), dim3(Geo<LN, kFusedLoge>::T), 0, s, work, digits, keys, key_stride, ge, \
+                               (unsigned)n_items, tiles, tb);                                                                                            \
+            break;                                                                                                                                       \
+        }                                                                                                                                                \
+    }                                                                                                                                                    \
     hipLaunchKernelGGL((hoisted_ks_kernel<Arith, LN, kFusedLoge>), dim3(blocks), dim3(Geo<LN, kFusedLoge>::T), 0, s, work, digits, keys, key_stride, ge, (unsigned)n_items, tiles, tb)
     DPFHE_GEO_SWITCH(log2n, HK_CASE)
 #undef HK_CASE
