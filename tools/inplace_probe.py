@@ -1,5 +1,7 @@
+"""NTT at BASELINE configs[1] in place (one 128 MiB buffer, what SURVEY.md 8(d) specifies) against out of place (a second buffer, 256 MiB
+touched = the size of the Infinity Cache), and at a 1 GiB batch where nothing is cached (tool)."""
 import os, sys, torch
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from deeppowers_amd.evaluator import Context, Evaluator
 from deeppowers_amd.params import FheParams
 p = FheParams.n4096_l4(); ctx = Context(p, 0); ev = Evaluator(ctx)
