@@ -31,6 +31,10 @@ SYMBOLS = {
     "dpfhe_rotate_hybrid_batch": ([C.c_void_p, _U64P, _U64P, C.c_size_t, C.POINTER(C.c_uint32), _U64P, _U64P, _U64P, C.c_size_t, C.c_void_p], C.c_int),
     "dpfhe_rotate_hybrid_hoisted": ([C.c_void_p, _U64P, _U64P, C.c_size_t, C.POINTER(C.c_uint32), _U64P, _U64P, _U64P, _U64P, C.c_size_t, C.c_void_p], C.c_int),
     "dpfhe_rotate_hybrid_grouped": ([C.c_void_p, _U64P, _U64P, C.POINTER(C.c_uint32), C.c_size_t, C.c_size_t, _U64P, _U64P, _U64P, C.c_void_p], C.c_int),
+    "dpfhe_rotate_hoisted_qp": ([C.c_void_p, _U64P, _U64P, C.c_size_t, C.POINTER(C.c_uint32), _U64P, _U64P, _U64P, C.c_size_t, C.c_void_p], C.c_int),
+    "dpfhe_ntt_inv_galois": ([C.c_void_p, _U64P, _U64P, C.c_size_t, C.POINTER(C.c_uint32), C.c_size_t, C.c_void_p], C.c_int),
+    "dpfhe_switch_key_qp": ([C.c_void_p, _U64P, _U64P, _U64P, C.c_size_t, C.c_size_t, C.c_void_p], C.c_int),
+    "dpfhe_rescale_bsgs": ([C.c_void_p, _U64P, _U64P, _U64P, C.c_size_t, C.c_size_t, C.c_void_p], C.c_int),
     "dpfhe_matvec_plain_multi": ([C.c_void_p, _U64P, _U64P, _U64P, C.c_size_t, C.c_size_t, C.c_size_t, C.c_void_p], C.c_int),
     "dpfhe_rescale": ([C.c_void_p, _U64P, _U64P, C.c_size_t, C.c_void_p], C.c_int),
     "dpfhe_apply_galois": ([C.c_void_p, _U64P, _U64P, C.c_size_t, C.c_uint32, C.c_void_p], C.c_int),
@@ -38,6 +42,7 @@ SYMBOLS = {
     "dpfhe_matvec_plain": ([C.c_void_p, _U64P, _U64P, _U64P, C.c_size_t, C.c_size_t, C.c_void_p], C.c_int),
     "dpfhe_matvec_scalar": ([C.c_void_p, _U64P, _U64P, _U64P, C.c_size_t, C.c_size_t, C.c_void_p], C.c_int),
     "dpfhe_reduce_sum": ([C.c_void_p, _U64P, _U64P, C.c_size_t, C.c_size_t, C.c_void_p], C.c_int),
+    "dpfhe_copy": ([C.c_void_p, _U64P, _U64P, C.c_size_t, C.c_void_p], C.c_int),
     "dpfhe_comm_unique_id": ([C.POINTER(C.c_uint8)], C.c_int),
     "dpfhe_comm_create": ([C.POINTER(C.c_void_p), C.POINTER(C.c_uint8), C.c_int, C.c_int, C.c_int], C.c_int),
     "dpfhe_comm_destroy": ([C.c_void_p], C.c_int),

@@ -68,6 +68,7 @@ struct dpfhe_ctx {
     int device = 0;
     bool fold = false;
     int n_cu = 256;          // compute units of the device (launch-size caps of the streaming kernels)
+    uint64_t p_special = 0;  // the LAST modulus (the special prime of hybrid key switching when this is an extended context)
     void* d_blob = nullptr;  // one allocation: LimbConst[L] | fwd | inv | last | RescaleConst[L]  (both arithmetic layouts share it)
     const RescaleConst* d_rescale = nullptr;
     DevTables<ShoupArith> shoup{};
@@ -100,7 +101,7 @@ extern "C" int dpfhe_ctx_create(dpfhe_ctx** out, uint32_t log2_n, uint32_t n_lim
 
     dpfhe_ctx* c = new (std::nothrow) dpfhe_ctx;
     if (!c) return fail(DPFHE_OUT_OF_MEMORY, "dpfhe_ctx_create", "host allocation");
-    c->log2n = log2_n; c->n_limbs = n_limbs; c->device = device_id; c->fold = fold;
+    c->log2n = log2_n; c->n_limbs = n_limbs; c->device = device_id; c->fold = fold; c->p_special = moduli[L - 1];
     { int cus = 0; if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device_id) == hipSuccess && cus > 0) c->n_cu = cus; }
 
     // blob layout (all 256-byte aligned sections).  One twiddle table pair per kernel geometry in use: slot 0 = the
@@ -211,6 +212,13 @@ extern "C" uint32_t dpfhe_ctx_limbs(const dpfhe_ctx* c) { return c ? c->n_limbs 
 extern "C" int dpfhe_ctx_uses_fold(const dpfhe_ctx* c) { return c && c->fold ? 1 : 0; }
 
 // ------------------------------------------------------------------------------------------------
+// words per thread of the FoldArith matvec kernels: 2 right-hand-side polynomials per workgroup / 4 (kernels_misc.h matvec_fold_kernel)
+#ifndef DPFHE_MATVEC_WPT2
+#define DPFHE_MATVEC_WPT2 2
+#endif
+#ifndef DPFHE_MATVEC_WPT4
+#define DPFHE_MATVEC_WPT4 1
+#endif
 static inline bool misaligned(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) != 0; }
 static const size_t kMaxGrid = 0x7fffffff;
 
@@ -527,6 +535,138 @@ extern "C" int dpfhe_rotate_hybrid_hoisted(dpfhe_ctx* c, uint64_t* d_out2, const
     return check_launch("hoisted rescale launch");
 }
 
+// ------------------------------------------------------------------------------------------------
+// N3, round 3: baby-step / giant-step sums with the division by P DEFERRED (the rotated terms stay in the NTT domain over Q P)
+// ------------------------------------------------------------------------------------------------
+extern "C" int dpfhe_rotate_hoisted_qp(dpfhe_ctx* c, uint64_t* d_out_qp, const uint64_t* d_in2, size_t n_items, const uint32_t* galois_elts, const uint64_t* d_keys,
+                                       uint64_t* d_in_ntt, uint64_t* d_digits, size_t batch, void* stream) {
+    const char* what = "dpfhe_rotate_hoisted_qp";
+    if (!c) return fail(DPFHE_INVALID_ARGUMENT, what, "null context");
+    if (c->n_limbs < 2) return fail(DPFHE_INVALID_STATE, what, "the extended context needs at least one data limb and the special prime");
+    if (c->log2n > (uint32_t)kMaxFusedLog2N) return fail(DPFHE_INVALID_STATE, what, "no fused kernel geometry for this log2_n");
+    if (n_items == 0) return DPFHE_SUCCESS;
+    if (!d_out_qp || !d_in2 || (batch && (!galois_elts || !d_keys)) || !d_in_ntt || !d_digits || misaligned(d_out_qp) || misaligned(d_in2) || misaligned(d_keys) ||
+        misaligned(d_in_ntt) || misaligned(d_digits))
+        return fail(DPFHE_INVALID_ARGUMENT, what, "null or misaligned buffer");
+    const size_t L = c->n_limbs, Ld = L - 1, T = n_items;
+    const int n = 1 << c->log2n;
+    const unsigned two_n = 2u << c->log2n;
+    for (size_t i = 0; i < batch; ++i)
+        if (!(galois_elts[i] & 1u) || galois_elts[i] >= two_n) return fail(DPFHE_INVALID_ARGUMENT, what, "galois elements must be odd and < 2N");
+    const size_t in_words = T * 2 * Ld * (size_t)n, out_words = (batch + 1) * T * 2 * L * n, dig_words = T * Ld * L * (size_t)n;
+    if (overlaps(d_out_qp, out_words, d_in2, in_words) || overlaps(d_out_qp, out_words, d_in_ntt, in_words) || overlaps(d_out_qp, out_words, d_digits, dig_words) ||
+        overlaps(d_digits, dig_words, d_in2, in_words) || overlaps(d_digits, dig_words, d_in_ntt, in_words) || overlaps(d_in_ntt, in_words, d_in2, in_words))
+        return fail(DPFHE_INVALID_ARGUMENT, what, "buffers must not overlap");
+    const size_t key_words = Ld * 2 * L * (size_t)n;
+    const int chunks = (n + 511) / 512;
+    if ((batch + 1) * T * L * 8 > kMaxGrid || T * Ld * L * (size_t)chunks > kMaxGrid || T * 2 * L * (size_t)chunks > kMaxGrid)
+        return fail(DPFHE_INVALID_ARGUMENT, what, "batch too large for one launch");
+    const LimbConst* lc = c->fold ? c->foldt.lc : c->shoup.lc;
+    const u64 p_special = c->p_special;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    DPFHE_ON_DEVICE(c, what);
+    // 1. NTT of the inputs on the data limbs (the same tables, seen as an Ld-limb context)
+    {
+        int rc;
+        if (c->fold) { DevTables<FoldArith> td = c->foldt; td.n_limbs = (int)Ld; rc = launch_ntt<FoldArith>((int)c->log2n, false, d_in_ntt, d_in2, T * 2 * Ld, td, s); }
+        else { DevTables<ShoupArith> td = c->shoup; td.n_limbs = (int)Ld; rc = launch_ntt<ShoupArith>((int)c->log2n, false, d_in_ntt, d_in2, T * 2 * Ld, td, s); }
+        if (rc) return fail(DPFHE_INVALID_STATE, what, "no kernel geometry for this log2_n");
+        if (int e = check_launch("input NTT launch")) return e;
+    }
+    // 2. digits of every item's c1, lifted to every limb and transformed
+    const unsigned lift_grid = (unsigned)(T * Ld * L * (size_t)chunks);
+    if (c->fold) hipLaunchKernelGGL((lift_digits_kernel<FoldArith>), dim3(lift_grid), dim3(256), 0, s, d_digits, d_in2 + Ld * (size_t)n, 2 * Ld * (size_t)n, lc, (int)L, n, chunks);
+    else hipLaunchKernelGGL((lift_digits_kernel<ShoupArith>), dim3(lift_grid), dim3(256), 0, s, d_digits, d_in2 + Ld * (size_t)n, 2 * Ld * (size_t)n, lc, (int)L, n, chunks);
+    if (int e = check_launch("lift_digits kernel launch")) return e;
+    {
+        const int rc = c->fold ? launch_ntt<FoldArith>((int)c->log2n, false, d_digits, d_digits, T * Ld * L, c->foldt, s)
+                               : launch_ntt<ShoupArith>((int)c->log2n, false, d_digits, d_digits, T * Ld * L, c->shoup, s);
+        if (rc) return fail(DPFHE_INVALID_STATE, what, "no kernel geometry for this log2_n");
+        if (int e = check_launch("digit NTT launch")) return e;
+    }
+    // 3. item block 0: the inputs themselves as P * ct over the extended basis
+    const unsigned idg = (unsigned)(T * 2 * L * (size_t)chunks);
+    if (c->fold) hipLaunchKernelGGL((lift_qp_kernel<FoldArith>), dim3(idg), dim3(256), 0, s, d_out_qp, d_in_ntt, lc, p_special, (int)L, n, chunks);
+    else hipLaunchKernelGGL((lift_qp_kernel<ShoupArith>), dim3(idg), dim3(256), 0, s, d_out_qp, d_in_ntt, lc, p_special, (int)L, n, chunks);
+    if (int e = check_launch("lift_qp kernel launch")) return e;
+    // 4. the rotations: gather + key inner products, 64 rotations per launch
+    for (size_t first = 0; first < batch; first += kMaxGaloisBatch) {
+        const size_t cnt = batch - first < (size_t)kMaxGaloisBatch ? batch - first : (size_t)kMaxGaloisBatch;
+        uint64_t* dst = d_out_qp + (1 + first) * T * 2 * L * n;
+        const int rc = c->fold ? launch_hoisted_qp<FoldArith>((int)c->log2n, dst, d_digits, d_in_ntt, d_keys + first * key_words, key_words, galois_elts + first, cnt, T, p_special, c->foldt, s)
+                               : launch_hoisted_qp<ShoupArith>((int)c->log2n, dst, d_digits, d_in_ntt, d_keys + first * key_words, key_words, galois_elts + first, cnt, T, p_special, c->shoup, s);
+        if (rc) return fail(DPFHE_INVALID_STATE, what, "no kernel geometry for this log2_n");
+        if (int e = check_launch("hoisted_qp kernel launch")) return e;
+    }
+    return DPFHE_SUCCESS;
+}
+
+extern "C" int dpfhe_ntt_inv_galois(dpfhe_ctx* c, uint64_t* d_out, const uint64_t* d_in, size_t rns_polys_per_elt, const uint32_t* galois_elts, size_t n_elts, void* stream) {
+    const char* what = "dpfhe_ntt_inv_galois";
+    if (!c) return fail(DPFHE_INVALID_ARGUMENT, what, "null context");
+    if (n_elts == 0 || rns_polys_per_elt == 0) return DPFHE_SUCCESS;
+    if (!d_out || !d_in || !galois_elts || misaligned(d_out) || misaligned(d_in)) return fail(DPFHE_INVALID_ARGUMENT, what, "null or misaligned buffer");
+    const unsigned two_n = 2u << c->log2n;
+    for (size_t i = 0; i < n_elts; ++i)
+        if (!(galois_elts[i] & 1u) || galois_elts[i] >= two_n) return fail(DPFHE_INVALID_ARGUMENT, what, "galois elements must be odd and < 2N");
+    const size_t per_elt = rns_polys_per_elt * c->n_limbs, words = n_elts * per_elt << c->log2n;
+    if (d_out != d_in && overlaps(d_out, words, d_in, words)) return fail(DPFHE_INVALID_ARGUMENT, what, "output must be the input buffer or disjoint from it");
+    if (per_elt * (n_elts < (size_t)kMaxGaloisBatch ? n_elts : (size_t)kMaxGaloisBatch) > kMaxGrid) return fail(DPFHE_INVALID_ARGUMENT, what, "batch too large for one launch");
+    DPFHE_ON_DEVICE(c, what);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    for (size_t first = 0; first < n_elts; first += kMaxGaloisBatch) {
+        const size_t cnt = n_elts - first < (size_t)kMaxGaloisBatch ? n_elts - first : (size_t)kMaxGaloisBatch;
+        const size_t off = first * per_elt << c->log2n;
+        const int rc = c->fold ? launch_ntt_inv_galois<FoldArith>((int)c->log2n, d_out + off, d_in + off, galois_elts + first, cnt, per_elt, c->foldt, s)
+                               : launch_ntt_inv_galois<ShoupArith>((int)c->log2n, d_out + off, d_in + off, galois_elts + first, cnt, per_elt, c->shoup, s);
+        if (rc) return fail(DPFHE_INVALID_STATE, what, "no single-kernel transform for this log2_n");
+        if (int e = check_launch("ntt_inv_galois kernel launch")) return e;
+    }
+    return DPFHE_SUCCESS;
+}
+
+extern "C" int dpfhe_switch_key_qp(dpfhe_ctx* c, uint64_t* d_out_qp, const uint64_t* d_in2, const uint64_t* d_keys, size_t n_keys, size_t group, void* stream) {
+    const char* what = "dpfhe_switch_key_qp";
+    if (!c) return fail(DPFHE_INVALID_ARGUMENT, what, "null context");
+    if (c->n_limbs < 2) return fail(DPFHE_INVALID_STATE, what, "the extended context needs at least one data limb and the special prime");
+    const size_t batch = n_keys * group;
+    if (batch == 0) return DPFHE_SUCCESS;
+    if (!d_out_qp || !d_in2 || !d_keys || misaligned(d_out_qp) || misaligned(d_in2) || misaligned(d_keys)) return fail(DPFHE_INVALID_ARGUMENT, what, "null or misaligned buffer");
+    const size_t L = c->n_limbs, Ld = L - 1;
+    const int n = 1 << c->log2n;
+    if (overlaps(d_out_qp, batch * 2 * L * n, d_in2, batch * 2 * Ld * n)) return fail(DPFHE_INVALID_ARGUMENT, what, "output overlaps the input");
+    const size_t blocks = batch * L;
+    if ((blocks / 8 + 1) * 8 + 8 * group > kMaxGrid) return fail(DPFHE_INVALID_ARGUMENT, what, "batch too large for one launch");
+    DPFHE_ON_DEVICE(c, what);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const size_t key_words = Ld * 2 * L * (size_t)n;
+    const int rc = c->fold ? launch_relin<FoldArith>((int)c->log2n, 4, d_out_qp, d_in2, d_keys, key_words, (unsigned)group, blocks, c->foldt, s)
+                           : launch_relin<ShoupArith>((int)c->log2n, 4, d_out_qp, d_in2, d_keys, key_words, (unsigned)group, blocks, c->shoup, s);
+    if (rc) return fail(DPFHE_INVALID_STATE, what, "no kernel geometry for this log2_n");
+    return check_launch("switch_key_qp kernel launch");
+}
+
+extern "C" int dpfhe_rescale_bsgs(dpfhe_ctx* c, uint64_t* d_out2, const uint64_t* d_in_qp, const uint64_t* d_addends, size_t n_add, size_t batch, void* stream) {
+    const char* what = "dpfhe_rescale_bsgs";
+    if (!c) return fail(DPFHE_INVALID_ARGUMENT, what, "null context");
+    if (c->n_limbs < 2) return fail(DPFHE_INVALID_STATE, what, "no limb left to drop");
+    if (batch == 0) return DPFHE_SUCCESS;
+    if (!d_out2 || !d_in_qp || (n_add && !d_addends) || misaligned(d_out2) || misaligned(d_in_qp) || misaligned(d_addends))
+        return fail(DPFHE_INVALID_ARGUMENT, what, "null or misaligned buffer");
+    const size_t L = c->n_limbs, Ld = L - 1;
+    const int n = 1 << c->log2n;
+    const int chunks = (n + 511) / 512;
+    if (overlaps(d_out2, batch * 2 * Ld * n, d_in_qp, batch * 2 * L * n) || (n_add && overlaps(d_out2, batch * 2 * Ld * n, d_addends, n_add * batch * 2 * Ld * n)))
+        return fail(DPFHE_INVALID_ARGUMENT, what, "output overlaps an input");
+    const size_t blocks = batch * 2 * Ld * (size_t)chunks;
+    if (blocks > kMaxGrid) return fail(DPFHE_INVALID_ARGUMENT, what, "batch too large for one launch");
+    DPFHE_ON_DEVICE(c, what);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (c->fold) hipLaunchKernelGGL((rescale_bsgs_kernel<FoldArith>), dim3((unsigned)blocks), dim3(256), 0, s, d_out2, d_in_qp, d_addends, n_add, batch, c->foldt.lc, c->d_rescale, (int)L, n, chunks);
+    else hipLaunchKernelGGL((rescale_bsgs_kernel<ShoupArith>), dim3((unsigned)blocks), dim3(256), 0, s, d_out2, d_in_qp, d_addends, n_add, batch, c->shoup.lc, c->d_rescale, (int)L, n, chunks);
+    return check_launch("rescale_bsgs kernel launch");
+}
+
 extern "C" int dpfhe_apply_galois(dpfhe_ctx* c, uint64_t* d_out, const uint64_t* d_in, size_t n_rns_polys, uint32_t galois_elt, void* stream) {
     if (!c) return fail(DPFHE_INVALID_ARGUMENT, "dpfhe_apply_galois", "null context");
     const unsigned two_n = 2u << c->log2n;
@@ -554,15 +694,24 @@ extern "C" int dpfhe_matvec_plain(dpfhe_ctx* c, uint64_t* d_y, const uint64_t* d
     if (!d_y || !d_W || !d_x || misaligned(d_y) || misaligned(d_W) || misaligned(d_x))
         return fail(DPFHE_INVALID_ARGUMENT, "dpfhe_matvec_plain", "null or misaligned buffer");
     const int n = 1 << c->log2n;
-    const int chunks = (n + 511) / 512;
     constexpr int RT = 4;
+    DPFHE_ON_DEVICE(c, "dpfhe_matvec_plain");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (c->fold) {   // column accumulators split at bit 30 (kernels_misc.h matvec_fold_kernel): 4 multiply-adds per term
+        constexpr int WPT = DPFHE_MATVEC_WPT2;
+        const int chunks = (n + 256 * WPT - 1) / (256 * WPT);
+        const size_t slabs = c->n_limbs * (size_t)chunks, rtiles = (rows + RT - 1) / RT;
+        const size_t blocks = ((slabs + 7) / 8) * 8 * rtiles;
+        if (blocks > kMaxGrid) return fail(DPFHE_INVALID_ARGUMENT, "dpfhe_matvec_plain", "too many rows for one launch");
+        hipLaunchKernelGGL((matvec_fold_kernel<RT, 2, WPT>), dim3((unsigned)blocks), dim3(256), 0, s, d_y, d_W, d_x, c->foldt.lc, (int)c->n_limbs, n, chunks, rows, cols,
+                           (size_t)2, 1u, (unsigned)(rtiles * slabs));
+        return check_launch("matvec kernel launch");
+    }
+    const int chunks = (n + 511) / 512;
     const size_t slabs = c->n_limbs * (size_t)chunks;
     const size_t blocks = ((slabs + 7) / 8) * 8 * ((rows + RT - 1) / RT);   // block ids laid out per XCD: kernels_misc.h matvec_kernel
     if (blocks > kMaxGrid) return fail(DPFHE_INVALID_ARGUMENT, "dpfhe_matvec_plain", "too many rows for one launch");
-    DPFHE_ON_DEVICE(c, "dpfhe_matvec_plain");
-    hipStream_t s = static_cast<hipStream_t>(stream);
-    if (c->fold) hipLaunchKernelGGL((matvec_kernel<FoldArith, RT>), dim3((unsigned)blocks), dim3(256), 0, s, d_y, d_W, d_x, c->foldt.lc, (int)c->n_limbs, n, chunks, rows, cols);
-    else hipLaunchKernelGGL((matvec_kernel<ShoupArith, RT>), dim3((unsigned)blocks), dim3(256), 0, s, d_y, d_W, d_x, c->shoup.lc, (int)c->n_limbs, n, chunks, rows, cols);
+    hipLaunchKernelGGL((matvec_kernel<ShoupArith, RT>), dim3((unsigned)blocks), dim3(256), 0, s, d_y, d_W, d_x, c->shoup.lc, (int)c->n_limbs, n, chunks, rows, cols);
     return check_launch("matvec kernel launch");
 }
 
@@ -585,6 +734,29 @@ extern "C" int dpfhe_matvec_plain_multi(dpfhe_ctx* c, uint64_t* d_y, const uint6
     // 1024-diagonal matvec of a packed GPT-2 layer, per token: 86 us single; 8 tokens: 75 us with one launch per group (W re-read from
     // HBM by every group), see DESIGN.md for the XCD-grouped launch.
     const size_t pairs = n_rhs / 2;
+    if (c->fold) {   // split-at-bit-30 column accumulators (kernels_misc.h matvec_fold_kernel), same grouping and block-id layout
+#define MVF_LAUNCH(RT, C, WPT, GROUPS, XS, YS)                                                                                                          \
+    {                                                                                                                                                    \
+        const int chunks = (n + 256 * (WPT) - 1) / (256 * (WPT));                                                                                        \
+        const size_t slabs = c->n_limbs * (size_t)chunks, rtiles = (rows + RT - 1) / RT, tiles = rtiles * slabs;                                         \
+        const size_t blocks = ((slabs + 7) / 8) * 8 * rtiles * (GROUPS);                                                                                 \
+        if (blocks > kMaxGrid) return fail(DPFHE_INVALID_ARGUMENT, what, "too many rows for one launch");                                             \
+        hipLaunchKernelGGL((matvec_fold_kernel<RT, C, WPT>), dim3((unsigned)blocks), dim3(256), 0, s, YS, d_W, XS, c->foldt.lc, (int)c->n_limbs, n, chunks, rows, cols, \
+                           n_rhs * 2, (unsigned)(GROUPS), (unsigned)tiles);                                                                              \
+    }
+        if (pairs) {
+            MVF_LAUNCH(4, 4, DPFHE_MATVEC_WPT4, pairs, d_x, d_y)
+            if (int e = check_launch("matvec_multi kernel launch")) return e;
+        }
+        if (n_rhs & 1) {
+            const uint64_t* xs = d_x + (n_rhs - 1) * 2 * poly;
+            uint64_t* ys = d_y + (n_rhs - 1) * 2 * poly;
+            MVF_LAUNCH(4, 2, DPFHE_MATVEC_WPT2, 1, xs, ys)
+            if (int e = check_launch("matvec_multi kernel launch")) return e;
+        }
+#undef MVF_LAUNCH
+        return DPFHE_SUCCESS;
+    }
 #define MV_LAUNCH(ARITH, RT, C, LC, GROUPS, XS, YS)                                                                                                      \
     {                                                                                                                                                    \
         const size_t slabs = c->n_limbs * (size_t)chunks, rtiles = (rows + RT - 1) / RT, tiles = rtiles * slabs;                                         \
@@ -594,13 +766,13 @@ extern "C" int dpfhe_matvec_plain_multi(dpfhe_ctx* c, uint64_t* d_y, const uint6
                            n_rhs * 2, (unsigned)(GROUPS), (unsigned)tiles);                                                                              \
     }
     if (pairs) {
-        if (c->fold) MV_LAUNCH(FoldArith, 4, 4, c->foldt.lc, pairs, d_x, d_y) else MV_LAUNCH(ShoupArith, 4, 4, c->shoup.lc, pairs, d_x, d_y)
+        MV_LAUNCH(ShoupArith, 4, 4, c->shoup.lc, pairs, d_x, d_y)
         if (int e = check_launch("matvec_multi kernel launch")) return e;
     }
     if (n_rhs & 1) {
         const uint64_t* xs = d_x + (n_rhs - 1) * 2 * poly;
         uint64_t* ys = d_y + (n_rhs - 1) * 2 * poly;
-        if (c->fold) MV_LAUNCH(FoldArith, 4, 2, c->foldt.lc, 1, xs, ys) else MV_LAUNCH(ShoupArith, 4, 2, c->shoup.lc, 1, xs, ys)
+        MV_LAUNCH(ShoupArith, 4, 2, c->shoup.lc, 1, xs, ys)
         if (int e = check_launch("matvec_multi kernel launch")) return e;
     }
 #undef MV_LAUNCH
@@ -654,6 +826,19 @@ extern "C" int dpfhe_reduce_sum(dpfhe_ctx* c, uint64_t* d_out, const uint64_t* d
     if (int e = check_launch("reduce_sum partial kernel launch")) return e;
     hipLaunchKernelGGL(reduce_final_kernel, dim3((unsigned)(blocks * chunks)), dim3(256), 0, s, d_out, lc, (int)c->n_limbs, n, chunks);
     return check_launch("reduce_sum kernel launch");
+}
+
+extern "C" int dpfhe_copy(dpfhe_ctx* c, uint64_t* d_dst, const uint64_t* d_src, size_t n_words, void* stream) {
+    if (!c) return fail(DPFHE_INVALID_ARGUMENT, "dpfhe_copy", "null context");
+    if (n_words == 0) return DPFHE_SUCCESS;
+    if (!d_dst || !d_src || misaligned(d_dst) || misaligned(d_src) || (n_words & 1)) return fail(DPFHE_INVALID_ARGUMENT, "dpfhe_copy", "null or misaligned buffer, or an odd word count");
+    if (overlaps(d_dst, n_words, d_src, n_words)) return fail(DPFHE_INVALID_ARGUMENT, "dpfhe_copy", "buffers overlap");
+    const size_t n_vec = n_words / 2, blocks = (n_vec + 2047) / 2048;
+    if (blocks > kMaxGrid) return fail(DPFHE_INVALID_ARGUMENT, "dpfhe_copy", "too many words for one launch");
+    DPFHE_ON_DEVICE(c, "dpfhe_copy");
+    hipLaunchKernelGGL(copy_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), reinterpret_cast<U64x2*>(d_dst),
+                       reinterpret_cast<const U64x2*>(d_src), n_vec);
+    return check_launch("copy kernel launch");
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -8,6 +8,7 @@
 
 #include <cerrno>
 #include <cstdio>
+#include <algorithm>
 #include <cstring>
 #include <istream>
 #include <ostream>
@@ -913,6 +914,35 @@ void Decryptor::decrypt_exact(const Ciphertext& ct, uint64_t t, uint64_t* out) {
     });
 }
 
+double Decryptor::noise_budget_bits(const Ciphertext& ct, uint64_t t) {
+    if (ct.is_ntt()) throw Exception(ErrorCode::INVALID_STATE, "noise_budget_bits: ciphertext must be in the coefficient domain");
+    if (t < 2 || t >> 32) throw Exception(ErrorCode::INVALID_ARGUMENT, "noise_budget_bits: plaintext modulus must be in [2, 2^32)");
+    const FheParams& p = impl_->ctx->params();
+    const size_t L = p.n_limbs();
+    auto bits = [](const Big& a) {
+        for (size_t i = a.size(); i-- > 0;)
+            if (a[i]) return (double)(i * 64) + (double)(64 - __builtin_clzll(a[i]));
+        return 0.0;
+    };
+    double worst = 0.0;   // most noise bits seen
+    for_each_phase(*impl_->ctx, *impl_->sk, impl_->garner_inv, ct, [&](size_t, size_t, const std::vector<uint64_t>& digit) {
+        // m = round(t x / Q) from the mixed-radix digits (exact: the noise is far below the long double's resolution of 1/2), then the
+        // noise  e = t x - m Q  in exact integers
+        long double f = 0.0L;
+        for (size_t i = 0; i < L; ++i) f = ((long double)digit[i] + f) / (long double)p.moduli[i];
+        const uint64_t m = (uint64_t)(f * (long double)t + 0.5L);
+        Big x{0};
+        for (size_t i = L; i-- > 0;) { big_mul_small(x, p.moduli[i]); big_add(x, Big{digit[i]}); }
+        big_mul_small(x, t);
+        Big mq(impl_->Q);
+        big_mul_small(mq, m);
+        const Big e = big_cmp(x, mq) >= 0 ? big_sub(x, mq) : big_sub(mq, x);
+        const double b = bits(e);
+        if (b > worst) worst = b;
+    });
+    return bits(impl_->Q) - 1.0 - worst;
+}
+
 // ---- HybridKeySwitcher ---------------------------------------------------------------------------------------------------
 class HybridKeySwitcher::Impl {
 public:
@@ -925,9 +955,10 @@ public:
     std::unique_ptr<PolyBuffer> scratch_work;      // batched rotations: reused across calls (one caller at a time per switcher)
     std::unique_ptr<Ciphertext> scratch_rotated;
     std::unique_ptr<PolyBuffer> scratch_digits;    // hoisted rotations: NTT of the lifted digits, [Ld][L][N]
+    std::unique_ptr<Ciphertext> scratch_in_ntt;    // rotate_hoisted_qp: NTT of the inputs on the data limbs
     void init(const Context& data_ctx, const SecretKey& sk, uint64_t special_prime, uint64_t special_psi);
     // the keys of an element list, packed back to back once and cached
-    const PolyBuffer* packed_keys(const std::vector<uint32_t>& elts) {
+    const PolyBuffer* packed_keys(const std::vector<uint32_t>& elts, Stream* s = nullptr) {
         for (auto& kv : packed) if (kv.first == elts) return kv.second.get();
         const FheParams& pe = ext->params();
         const size_t L = pe.n_limbs(), Ld = L - 1, key_words = Ld * 2 * L * pe.n();
@@ -936,7 +967,9 @@ public:
             const PolyBuffer* key = nullptr;
             for (auto& kv : galois) if (kv.first == elts[i]) key = kv.second.get();
             if (!key) throw Exception(ErrorCode::INVALID_STATE, "HybridKeySwitcher: no key for an element (add_galois_element first)");
-            hip_check(hipMemcpy(buf->data() + i * key_words, key->data(), key_words * sizeof(uint64_t), hipMemcpyDeviceToDevice), "hipMemcpy D2D");
+            // on the caller's stream: a blocking null-stream copy would not order against work on a non-blocking stream
+            hip_check(hipMemcpyAsync(buf->data() + i * key_words, key->data(), key_words * sizeof(uint64_t), hipMemcpyDeviceToDevice, static_cast<hipStream_t>(s)),
+                      "hipMemcpyAsync D2D");
         }
         packed.emplace_back(elts, std::move(buf));
         return packed.back().second.get();
@@ -1050,7 +1083,7 @@ void HybridKeySwitcher::apply_galois_range(const Ciphertext& in2, size_t in_firs
         throw Exception(ErrorCode::INVALID_ARGUMENT, "HybridKeySwitcher::apply_galois_range: input range of 1 (broadcast) or k items, output with room for k items");
     const FheParams& pe = impl_->ext->params();
     const size_t L = pe.n_limbs(), Ld = L - 1, n = pe.n(), ct_words = 2 * Ld * n;
-    const PolyBuffer* keys = impl_->packed_keys(elts);
+    const PolyBuffer* keys = impl_->packed_keys(elts, s);
     impl_->ensure_scratch(k);   // kept for the next call: no allocation and no host synchronisation on the steady path
     check(dpfhe_rotate_hybrid_batch(static_cast<dpfhe_ctx*>(impl_->ext->handle()), out2.data() + out_first * ct_words, in2.data() + in_first * ct_words,
                                     broadcast ? 1 : k, elts.data(), keys->data(), impl_->scratch_work->data(), impl_->scratch_rotated->data(), k, s),
@@ -1066,7 +1099,7 @@ void HybridKeySwitcher::apply_galois_hoisted(const Ciphertext& in2, size_t in_fi
         throw Exception(ErrorCode::INVALID_ARGUMENT, "HybridKeySwitcher::apply_galois_hoisted: n_items input items, output with room for k * n_items items");
     const FheParams& pe = impl_->ext->params();
     const size_t L = pe.n_limbs(), Ld = L - 1, n = pe.n(), ct_words = 2 * Ld * n;
-    const PolyBuffer* keys = impl_->packed_keys(elts);
+    const PolyBuffer* keys = impl_->packed_keys(elts, s);
     impl_->ensure_scratch(k * n_items);
     if (!impl_->scratch_digits || impl_->scratch_digits->batch() < n_items * Ld) impl_->scratch_digits.reset(new PolyBuffer(*impl_->ext, n_items * Ld, 1, true));
     check(dpfhe_rotate_hybrid_hoisted(static_cast<dpfhe_ctx*>(impl_->ext->handle()), out2.data() + out_first * ct_words, in2.data() + in_first * ct_words, n_items,
@@ -1083,12 +1116,48 @@ void HybridKeySwitcher::apply_galois_grouped(const Ciphertext& in2, size_t in_fi
         throw Exception(ErrorCode::INVALID_ARGUMENT, "HybridKeySwitcher::apply_galois_grouped: k * group items in and out");
     const FheParams& pe = impl_->ext->params();
     const size_t Ld = pe.n_limbs() - 1, n = pe.n(), ct_words = 2 * Ld * n;
-    const PolyBuffer* keys = impl_->packed_keys(elts);
+    const PolyBuffer* keys = impl_->packed_keys(elts, s);
     impl_->ensure_scratch(batch);
     check(dpfhe_rotate_hybrid_grouped(static_cast<dpfhe_ctx*>(impl_->ext->handle()), out2.data() + out_first * ct_words, in2.data() + in_first * ct_words, elts.data(), k,
                                       group, keys->data(), impl_->scratch_work->data(), impl_->scratch_rotated->data(), s),
           "dpfhe_rotate_hybrid_grouped");
     out2.set_ntt(false);
+}
+
+const Context& HybridKeySwitcher::extended_context() const { return *impl_->ext; }
+
+void HybridKeySwitcher::rotate_hoisted_qp(const Ciphertext& in2, size_t in_first, size_t n_items, const std::vector<uint32_t>& elts, PolyBuffer& out_qp,
+                                          size_t out_first, Stream* s) const {
+    const size_t k = elts.size();
+    if (n_items == 0) return;
+    const FheParams& pe = impl_->ext->params();
+    const size_t L = pe.n_limbs(), Ld = L - 1, n = pe.n();
+    if (in2.is_ntt() || in2.size() != 2 || out_qp.size() != 2 || in_first + n_items > in2.batch() || out_first + (k + 1) * n_items > out_qp.batch() ||
+        out_qp.words() != out_qp.batch() * 2 * L * n)
+        throw Exception(ErrorCode::INVALID_ARGUMENT, "HybridKeySwitcher::rotate_hoisted_qp: n_items coefficient-domain inputs, (k + 1) * n_items items on the extended context out");
+    const PolyBuffer* keys = k ? impl_->packed_keys(elts, s) : nullptr;
+    if (!impl_->scratch_digits || impl_->scratch_digits->batch() < n_items * Ld) impl_->scratch_digits.reset(new PolyBuffer(*impl_->ext, n_items * Ld, 1, true));
+    if (!impl_->scratch_in_ntt || impl_->scratch_in_ntt->batch() < n_items) impl_->scratch_in_ntt.reset(new Ciphertext(*impl_->data_ctx, 2, n_items, true));
+    check(dpfhe_rotate_hoisted_qp(static_cast<dpfhe_ctx*>(impl_->ext->handle()), out_qp.data() + out_first * 2 * L * n, in2.data() + in_first * 2 * Ld * n, n_items,
+                                  elts.data(), keys ? keys->data() : nullptr, impl_->scratch_in_ntt->data(), impl_->scratch_digits->data(), k, s),
+          "dpfhe_rotate_hoisted_qp");
+    out_qp.set_ntt(true);
+}
+
+void HybridKeySwitcher::switch_key_qp(const Ciphertext& in2, size_t in_first, const std::vector<uint32_t>& elts, size_t group, PolyBuffer& out_qp,
+                                      size_t out_first, Stream* s) const {
+    const size_t k = elts.size(), batch = k * group;
+    if (batch == 0) return;
+    const FheParams& pe = impl_->ext->params();
+    const size_t L = pe.n_limbs(), Ld = L - 1, n = pe.n();
+    if (in2.is_ntt() || in2.size() != 2 || out_qp.size() != 2 || in_first + batch > in2.batch() || out_first + batch > out_qp.batch() ||
+        out_qp.words() != out_qp.batch() * 2 * L * n)
+        throw Exception(ErrorCode::INVALID_ARGUMENT, "HybridKeySwitcher::switch_key_qp: k * group coefficient-domain items in, as many items on the extended context out");
+    const PolyBuffer* keys = impl_->packed_keys(elts, s);
+    check(dpfhe_switch_key_qp(static_cast<dpfhe_ctx*>(impl_->ext->handle()), out_qp.data() + out_first * 2 * L * n, in2.data() + in_first * 2 * Ld * n, keys->data(), k,
+                              group, s),
+          "dpfhe_switch_key_qp");
+    out_qp.set_ntt(true);
 }
 
 // ---- N3: slot packing --------------------------------------------------------------------------------------------------------
@@ -1201,13 +1270,21 @@ public:
     size_t n1 = 0, n2 = 0;
     std::unique_ptr<Plaintext> diag;   // [passes][n2][n1] pre-rotated diagonals, NTT domain
     std::vector<uint32_t> baby_elts, giant_elts, fold_elts;
-    std::unique_ptr<Ciphertext> babies, inner, rotated, fold;   // per-layer scratch, reused by every apply() (one caller at a time)
+    // per-layer scratch, reused by every apply() (one caller at a time).  Terms over Q P live on the key switcher's extended context.
+    std::unique_ptr<PolyBuffer> babies_qp, inner_qp, terms_qp, ksum_qp;
+    std::unique_ptr<Ciphertext> rot, fold;
+    std::vector<uint32_t> inner_elts;                            // element of inner sum (pass, i): 1 for i = 0, the giant step's otherwise
     size_t tokens = 0;                                           // scratch capacity in tokens
     void ensure_tokens(size_t T) {
         if (T <= tokens) return;
-        babies.reset(new Ciphertext(*ctx, 2, n1 * T));                              // [n1][T]
-        inner.reset(new Ciphertext(*ctx, 2, passes * n2 * T, /*is_ntt=*/true));     // [passes * n2][T]
-        if (n2 > 1) rotated.reset(new Ciphertext(*ctx, 2, passes * n2 * T));
+        const Context& ext = ks->extended_context();
+        babies_qp.reset(new PolyBuffer(ext, n1 * T, 2, true));                      // [n1][T]: P rot_j(x_t) + key-switching terms, NTT domain
+        inner_qp.reset(new PolyBuffer(ext, passes * n2 * T, 2, true));              // [passes * n2][T]
+        rot.reset(new Ciphertext(*ctx, 2, passes * n2 * T));                        // the inner sums, rotated by their giant step, divided by P
+        if (n2 > 1) {
+            terms_qp.reset(new PolyBuffer(ext, (n2 - 1) * T, 2, true));             // key inner products of one output ciphertext's giant steps
+            ksum_qp.reset(new PolyBuffer(ext, T, 2, true));
+        }
         if (!fold_elts.empty()) fold.reset(new Ciphertext(*ctx, 2, 2 * T));         // [2][T]: running sums | their rotation
         tokens = T;
     }
@@ -1259,8 +1336,15 @@ PackedLinear::PackedLinear(const Context& ctx, const BatchEncoder& enc, HybridKe
 
     // Pre-rotated diagonals.  The product of giant step i lands on output slot r = r' - i n1 (row rotation), so position r' of
     // diagonal (i, j) carries the weight of the output row that slot r holds and of input index (r + k) mod n, k = i n1 + j.
-    I.diag.reset(new Plaintext(ctx, I.passes * I.n2 * n1, /*is_ntt=*/false));
-    std::vector<uint64_t> slots(N), host(n1 * L * N);
+    // They are multiplied with terms over Q P (the division by P comes after the sum), so they are encoded over all limbs of the
+    // key switcher's extended context.
+    const Context& ext = ks.extended_context();
+    const FheParams& pe = ext.params();
+    if (pe.log2_n != p.log2_n || pe.n_limbs() != L + 1 || !std::equal(p.moduli.begin(), p.moduli.end(), pe.moduli.begin()))
+        throw Exception(ErrorCode::INVALID_ARGUMENT, "PackedLinear: the key switcher was built for another context");
+    const size_t Le = L + 1;
+    I.diag.reset(new Plaintext(ext, I.passes * I.n2 * n1, /*is_ntt=*/false));
+    std::vector<uint64_t> slots(N), host(n1 * Le * N);
     std::vector<int64_t> coeffs(N);
     for (size_t pass = 0; pass < I.passes; ++pass) {
         for (size_t i = 0; i < I.n2; ++i) {
@@ -1273,16 +1357,20 @@ PackedLinear::PackedLinear(const Context& ctx, const BatchEncoder& enc, HybridKe
                         slots[rho * row + rp] = (R != (size_t)-1 && col < in_dim) ? W[R * in_dim + col] : 0;
                     }
                 enc.encode(slots.data(), coeffs.data());
-                for (size_t l = 0; l < L; ++l)
-                    for (size_t c = 0; c < N; ++c) host[(j * L + l) * N + c] = lift_signed(coeffs[c], p.moduli[l]);
+                for (size_t l = 0; l < Le; ++l)
+                    for (size_t c = 0; c < N; ++c) host[(j * Le + l) * N + c] = lift_signed(coeffs[c], pe.moduli[l]);
             }
-            hip_check(hipMemcpy(I.diag->data() + ((pass * I.n2 + i) * n1) * L * N, host.data(), host.size() * sizeof(uint64_t), hipMemcpyHostToDevice), "hipMemcpy H2D");
+            hip_check(hipMemcpy(I.diag->data() + ((pass * I.n2 + i) * n1) * Le * N, host.data(), host.size() * sizeof(uint64_t), hipMemcpyHostToDevice), "hipMemcpy H2D");
         }
     }
-    Evaluator ev(ctx);
+    Evaluator ev(ext);
     ev.transform_to_ntt_inplace(*I.diag);
+    for (size_t pass = 0; pass < I.passes; ++pass) {
+        I.inner_elts.push_back(1u);
+        I.inner_elts.insert(I.inner_elts.end(), I.giant_elts.begin(), I.giant_elts.end());
+    }
     I.ensure_tokens(1);
-    ctx.synchronize();
+    ext.synchronize();
 }
 PackedLinear::~PackedLinear() = default;
 size_t PackedLinear::dim() const { return impl_->m; }
@@ -1324,34 +1412,32 @@ void PackedLinear::apply(const Ciphertext& x, Ciphertext& y, Stream* s) const {
     const size_t ct_words = 2 * p.n_limbs() * p.n(), n1 = I.n1, n2 = I.n2;
     hipStream_t hs = static_cast<hipStream_t>(s);
     dpfhe_ctx* h = static_cast<dpfhe_ctx*>(ctx.handle());
-    Evaluator ev(ctx);
+    dpfhe_ctx* he = static_cast<dpfhe_ctx*>(I.ks->extended_context().handle());
     // Layout of every intermediate: [rotation or diagonal index][token][component] - the token index sits where the plaintext
     // matvec sees "more components", so keys and diagonals are read once for all tokens.
-    // baby steps: rot_j(x_t), j < n1, for all tokens in ONE hoisted rotation pass, then transformed together
-    Ciphertext& babies = *I.babies;
-    Ciphertext& inner = *I.inner;
-    babies.set_ntt(false);
-    hip_check(hipMemcpyAsync(babies.data(), x.data(), T * ct_words * sizeof(uint64_t), hipMemcpyDeviceToDevice, hs), "hipMemcpyAsync");
-    I.ks->apply_galois_hoisted(x, 0, T, I.baby_elts, babies, /*out_first=*/T, s);   // one digit decomposition + NTT per token for all n1 - 1 rotations
-    // (babies/inner may be larger than n1 * T / passes * n2 * T items after a bigger batch: only the leading items are used)
-    check(dpfhe_ntt_fwd(h, babies.data(), n1 * T * 2, s), "dpfhe_ntt_fwd");
+    // baby steps: P rot_j(x_t) + key-switching term, j < n1, all tokens, ONE hoisted pass; they stay in the NTT domain over Q P
+    I.ks->rotate_hoisted_qp(x, 0, T, I.baby_elts, *I.babies_qp, 0, s);
     // inner sums of all giant steps of all output ciphertexts of all tokens: ONE matrix-vector product over the pre-rotated diagonals
-    check(dpfhe_matvec_plain_multi(h, inner.data(), I.diag->data(), babies.data(), I.passes * n2, n1, T, s), "dpfhe_matvec_plain_multi");
-    check(dpfhe_ntt_inv(h, inner.data(), I.passes * n2 * T * 2, s), "dpfhe_ntt_inv");
-    // giant steps: inner sum (pass, i, t) rotated by i*n1 (one grouped rotation pass per output ciphertext), then the sum over i
+    check(dpfhe_matvec_plain_multi(he, I.inner_qp->data(), I.diag->data(), I.babies_qp->data(), I.passes * n2, n1, T, s), "dpfhe_matvec_plain_multi");
+    // back to the coefficient domain, the giant step's automorphism applied by the transform's loads; then the ONE division by P
+    // the baby steps and the plaintext products share
+    check(dpfhe_ntt_inv_galois(he, I.inner_qp->data(), I.inner_qp->data(), T * 2, I.inner_elts.data(), I.passes * n2, s), "dpfhe_ntt_inv_galois");
+    Ciphertext& rot = *I.rot;
+    check(dpfhe_rescale(he, rot.data(), I.inner_qp->data(), I.passes * n2 * T * 2, s), "dpfhe_rescale");
+    rot.set_ntt(false);
+    // giant steps: key inner products of the rotated inner sums (i >= 1), summed over Q P; one inverse transform and one
+    // division by P per output ciphertext, which also adds the c0 parts and the un-rotated inner sum
     uint64_t* sums = I.fold_elts.empty() ? y.data() : I.fold->data();   // wide-input layer: the block sum is folded below before it becomes y
     if (n2 > 1) {
-        Ciphertext& rotated = *I.rotated;
         for (size_t pass = 0; pass < I.passes; ++pass) {
             const size_t base = pass * n2 * T;
-            hip_check(hipMemcpyAsync(rotated.data() + base * ct_words, inner.data() + base * ct_words, T * ct_words * sizeof(uint64_t), hipMemcpyDeviceToDevice, hs),
-                      "hipMemcpyAsync");
-            inner.set_ntt(false);
-            I.ks->apply_galois_grouped(inner, base + T, I.giant_elts, T, rotated, base + T, s);
-            check(dpfhe_reduce_sum(h, sums + pass * T * ct_words, rotated.data() + base * ct_words, n2, 2 * T, s), "dpfhe_reduce_sum");
+            I.ks->switch_key_qp(rot, base + T, I.giant_elts, T, *I.terms_qp, 0, s);
+            check(dpfhe_reduce_sum(he, I.ksum_qp->data(), I.terms_qp->data(), n2 - 1, 2 * T, s), "dpfhe_reduce_sum");
+            check(dpfhe_ntt_inv(he, I.ksum_qp->data(), T * 2, s), "dpfhe_ntt_inv");
+            check(dpfhe_rescale_bsgs(he, sums + pass * T * ct_words, I.ksum_qp->data(), rot.data() + base * ct_words, n2, T, s), "dpfhe_rescale_bsgs");
         }
     } else {
-        hip_check(hipMemcpyAsync(sums, inner.data(), I.passes * T * ct_words * sizeof(uint64_t), hipMemcpyDeviceToDevice, hs), "hipMemcpyAsync");
+        hip_check(hipMemcpyAsync(sums, rot.data(), I.passes * T * ct_words * sizeof(uint64_t), hipMemcpyDeviceToDevice, hs), "hipMemcpyAsync");
     }
     // wide input (m < n): slot r holds the partial sum over input indices congruent to r + k; fold the n/m windows together
     if (!I.fold_elts.empty()) {
@@ -1366,6 +1452,161 @@ void PackedLinear::apply(const Ciphertext& x, Ciphertext& y, Stream* s) const {
     }
     y.set_ntt(false);
     // enqueue only: the scratch belongs to the layer, the caller synchronises (Context::synchronize) before reading y
+}
+
+// ---- N3: hand-over between packed layers and the transformer block's linear skeleton ------------------------------------------
+class PackedSelect::Impl {
+public:
+    const Context* ctx = nullptr;
+    HybridKeySwitcher* ks = nullptr;
+    size_t offset = 0;
+    uint32_t shift_elt = 0, swap_elt = 0;
+    std::vector<uint32_t> spread_elts;          // right rotations by period, 2 period, ... up to half a slot row
+    std::unique_ptr<Plaintext> mask;            // NTT domain: 1 on slots [0, length) of row 0, 0 elsewhere
+    std::unique_ptr<Ciphertext> a, b;           // scratch, T items each
+    size_t tokens = 0;
+    void ensure(size_t T) {
+        if (T <= tokens) return;
+        a.reset(new Ciphertext(*ctx, 2, T));
+        b.reset(new Ciphertext(*ctx, 2, T));
+        tokens = T;
+    }
+};
+
+PackedSelect::PackedSelect(const Context& ctx, const BatchEncoder& enc, HybridKeySwitcher& ks, size_t offset, size_t length, size_t period) : impl_(new Impl) {
+    const FheParams& p = ctx.params();
+    const size_t N = p.n(), row = N / 2, L = p.n_limbs();
+    if (enc.slot_count() != N || length == 0 || period < length || (period & (period - 1)) || period > row || offset + length > row)
+        throw Exception(ErrorCode::INVALID_ARGUMENT, "PackedSelect: slice of slot row 0, period a power of two in [length, N/2]");
+    Impl& I = *impl_;
+    I.ctx = &ctx; I.ks = &ks; I.offset = offset;
+    if (offset) { I.shift_elt = enc.galois_element((int)offset); ks.add_galois_element(I.shift_elt); }
+    for (size_t sft = period; sft < row; sft <<= 1) { I.spread_elts.push_back(enc.galois_element(-(int)sft)); ks.add_galois_element(I.spread_elts.back()); }
+    I.swap_elt = (uint32_t)(2 * N - 1);
+    ks.add_galois_element(I.swap_elt);
+    std::vector<uint64_t> slots(N, 0), host(L * N);
+    std::vector<int64_t> coeffs(N);
+    for (size_t i = 0; i < length; ++i) slots[i] = 1;
+    enc.encode(slots.data(), coeffs.data());
+    for (size_t l = 0; l < L; ++l)
+        for (size_t c = 0; c < N; ++c) host[l * N + c] = lift_signed(coeffs[c], p.moduli[l]);
+    I.mask.reset(new Plaintext(ctx, 1, false));
+    I.mask->copy_from_host(host.data());
+    Evaluator ev(ctx);
+    ev.transform_to_ntt_inplace(*I.mask);
+    I.ensure(1);
+    ctx.synchronize();
+}
+PackedSelect::~PackedSelect() = default;
+size_t PackedSelect::key_switches_per_apply() const { return (impl_->offset ? 1 : 0) + impl_->spread_elts.size() + 1; }
+
+void PackedSelect::apply(const Ciphertext& x, Ciphertext& y, Stream* s) const {
+    Impl& I = *impl_;
+    const size_t T = x.batch();
+    if (x.is_ntt() || x.size() != 2 || y.size() != 2 || y.batch() != T || T == 0)
+        throw Exception(ErrorCode::INVALID_ARGUMENT, "PackedSelect::apply: T 2-component coefficient-domain ciphertexts in and out");
+    I.ensure(T);
+    dpfhe_ctx* h = static_cast<dpfhe_ctx*>(I.ctx->handle());
+    const FheParams& p = I.ctx->params();
+    const size_t poly = p.n_limbs() * p.n();
+    Ciphertext &a = *I.a, &b = *I.b;
+    const Ciphertext* cur = &x;
+    if (I.offset) {   // slot offset + i -> slot i
+        I.ks->apply_galois_grouped(x, 0, std::vector<uint32_t>(1, I.shift_elt), T, a, 0, s);
+        cur = &a;
+    }
+    // mask: NTT, one dyadic product per polynomial with the (broadcast) mask, back
+    check(dpfhe_ntt_fwd_oop(h, b.data(), cur->data(), T * 2, s), "dpfhe_ntt_fwd_oop");
+    for (size_t i = 0; i < T * 2; ++i) check(dpfhe_dyadic_mul(h, b.data() + i * poly, b.data() + i * poly, I.mask->data(), 1, s), "dpfhe_dyadic_mul");
+    check(dpfhe_ntt_inv(h, b.data(), T * 2, s), "dpfhe_ntt_inv");
+    b.set_ntt(false);
+    // spread along the row: b += rot(b, -period), then -2 period, ...; then the other row
+    Ciphertext* have = &b;
+    Ciphertext* tmp = &a;
+    auto rotate_add = [&](uint32_t g, Ciphertext& out) {
+        I.ks->apply_galois_grouped(*have, 0, std::vector<uint32_t>(1, g), T, *tmp, 0, s);
+        check(dpfhe_add(h, out.data(), have->data(), tmp->data(), T * 2, s), "dpfhe_add");
+        out.set_ntt(false);
+    };
+    for (uint32_t g : I.spread_elts) rotate_add(g, *have);
+    rotate_add(I.swap_elt, y);
+}
+
+class PackedTransformerBlock::Impl {
+public:
+    const Context* ctx = nullptr;
+    HybridKeySwitcher* ks = nullptr;
+    size_t d = 0, h = 0;
+    std::unique_ptr<PackedLinear> qkv, proj, up, down;
+    std::unique_ptr<PackedSelect> take_v;
+    std::unique_ptr<Ciphertext> st[5], o, u, us, dn;   // stages + scratch, T items each
+    size_t tokens = 0;
+    void ensure(size_t T) {
+        if (T <= tokens) return;
+        for (auto& c : st) c.reset(new Ciphertext(*ctx, 2, T));
+        o.reset(new Ciphertext(*ctx, 2, T)); u.reset(new Ciphertext(*ctx, 2, T)); us.reset(new Ciphertext(*ctx, 2, T)); dn.reset(new Ciphertext(*ctx, 2, T));
+        tokens = T;
+    }
+};
+
+PackedTransformerBlock::PackedTransformerBlock(const Context& ctx, const BatchEncoder& enc, HybridKeySwitcher& ks, const uint64_t* W_qkv, const uint64_t* W_o,
+                                               const uint64_t* W_up, const uint64_t* W_down, size_t d, size_t h) : impl_(new Impl) {
+    if (!W_qkv || !W_o || !W_up || !W_down || d == 0 || h == 0) throw Exception(ErrorCode::INVALID_ARGUMENT, "PackedTransformerBlock: null or empty matrix");
+    Impl& I = *impl_;
+    I.ctx = &ctx; I.ks = &ks; I.d = d; I.h = h;
+    I.qkv.reset(new PackedLinear(ctx, enc, ks, W_qkv, 3 * d, d));
+    I.proj.reset(new PackedLinear(ctx, enc, ks, W_o, d, d));
+    I.up.reset(new PackedLinear(ctx, enc, ks, W_up, h, d));
+    I.down.reset(new PackedLinear(ctx, enc, ks, W_down, d, h));
+    const size_t row = ctx.params().n() / 2;
+    // the hand-overs below rely on: one output ciphertext per layer, outputs of the wide layers at slot r of row 0 (out >= period),
+    // and W_down consuming a vector that fills a whole slot row
+    if (I.qkv->output_ciphertexts() != 1 || I.up->output_ciphertexts() != 1 || I.down->output_ciphertexts() != 1 || I.proj->output_ciphertexts() != 1 ||
+        3 * d < I.qkv->input_period() || 3 * d > row || h < I.up->input_period() || I.down->input_period() != row || I.proj->input_period() != I.qkv->input_period())
+        throw Exception(ErrorCode::INVALID_ARGUMENT, "PackedTransformerBlock: needs 3 d <= N/2, h >= the padded d and the padded h = N/2 (GPT-2 small at N = 8192: d = 768, h = 3072)");
+    I.take_v.reset(new PackedSelect(ctx, enc, ks, 2 * d, d, I.proj->input_period()));
+    ks.add_galois_element((uint32_t)(2 * ctx.params().n() - 1));
+    I.ensure(1);
+}
+PackedTransformerBlock::~PackedTransformerBlock() = default;
+size_t PackedTransformerBlock::hidden() const { return impl_->d; }
+size_t PackedTransformerBlock::inner() const { return impl_->h; }
+size_t PackedTransformerBlock::key_switches_per_token() const {
+    const Impl& I = *impl_;
+    return I.qkv->key_switches_per_apply() + I.take_v->key_switches_per_apply() + I.proj->key_switches_per_apply() + I.up->key_switches_per_apply() + 1 +
+           I.down->key_switches_per_apply();
+}
+void PackedTransformerBlock::pack_input(const uint64_t* x, uint64_t* slots) const { impl_->qkv->pack_input(x, slots); }
+void PackedTransformerBlock::unpack_output(const uint64_t* slots, uint64_t* y) const { impl_->down->unpack_output(slots, y); }
+const Ciphertext& PackedTransformerBlock::stage(int index) const {
+    if (index < 0 || index > 4 || !impl_->st[index]) throw Exception(ErrorCode::INVALID_ARGUMENT, "PackedTransformerBlock::stage: index in [0, 4]");
+    return *impl_->st[index];
+}
+
+void PackedTransformerBlock::apply(const Ciphertext& x, Ciphertext& y, Stream* s) const {
+    Impl& I = *impl_;
+    const size_t T = x.batch();
+    if (x.is_ntt() || x.size() != 2 || y.size() != 2 || y.batch() != T || T == 0)
+        throw Exception(ErrorCode::INVALID_ARGUMENT, "PackedTransformerBlock::apply: T 2-component coefficient-domain ciphertexts in and out");
+    I.ensure(T);
+    dpfhe_ctx* h = static_cast<dpfhe_ctx*>(I.ctx->handle());
+    const FheParams& p = I.ctx->params();
+    const size_t words = T * 2 * p.n_limbs() * p.n();
+    Ciphertext &qkv = *I.st[0], &a = *I.st[1], &h1 = *I.st[2], &u2 = *I.st[3], &h2 = *I.st[4];
+    I.qkv->apply(x, qkv, s);                                   // q | k | v at slots 0 .. 3d-1 of row 0 (gpt_model.cpp:793)
+    I.take_v->apply(qkv, a, s);                                // attention over one position: the output is v; re-packed as a layer input
+    I.proj->apply(a, *I.o, s);                                 // attention-output projection
+    check(dpfhe_add(h, h1.data(), x.data(), I.o->data(), T * 2, s), "dpfhe_add");   // residual
+    h1.set_ntt(false);
+    I.up->apply(h1, *I.u, s);                                  // FFN up (gpt_model.cpp:848): outputs at slot r of row 0
+    I.ks->apply_galois_grouped(*I.u, 0, std::vector<uint32_t>(1, (uint32_t)(2 * p.n() - 1)), T, *I.us, 0, s);   // row swap
+    check(dpfhe_add(h, u2.data(), I.u->data(), I.us->data(), T * 2, s), "dpfhe_add");                          // both rows: W_down's input packing
+    u2.set_ntt(false);
+    I.down->apply(u2, *I.dn, s);                               // FFN down
+    check(dpfhe_add(h, h2.data(), h1.data(), I.dn->data(), T * 2, s), "dpfhe_add");   // residual
+    h2.set_ntt(false);
+    hip_check(hipMemcpyAsync(y.data(), h2.data(), words * sizeof(uint64_t), hipMemcpyDeviceToDevice, static_cast<hipStream_t>(s)), "hipMemcpyAsync");
+    y.set_ntt(false);
 }
 
 }  // namespace fhe

@@ -310,6 +310,46 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE)) void ntt_inv_kernel(u64* __rest
     B::store_top(tid, x, out + p * B::G::N);
 }
 
+// N3: inverse NTT of sigma_g applied in the NTT domain.  In forward-output order position p carries the evaluation at
+// psi^(2 brv(p) + 1) and sigma_g: a(X) -> a(X^g) only permutes evaluation points, NTT(sigma_g a)[p] = NTT(a)[p'] with
+// 2 brv(p') + 1 = g (2 brv(p) + 1) mod 2N: the kernel gathers its input words through that permutation (8-byte gathers inside one
+// 2^LOGN-word polynomial: L2 hits after the first touch of a line) and runs the ordinary inverse transform, so
+// out = sigma_g(INTT(in)) with no separate automorphism pass.  `polys_per_elt` consecutive residue polynomials share element
+// elts.v[blockIdx.x / polys_per_elt].  In place is safe: every load of the workgroup precedes the transform's workgroup barrier,
+// every store follows it.
+struct GaloisElts { unsigned v[kMaxGaloisBatch]; };
+
+template <class Arith, int LOGN, int LOGE>
+__global__ __launch_bounds__(1 << (LOGN - LOGE)) void ntt_inv_galois_kernel(u64* __restrict__ out, const u64* __restrict__ in, GaloisElts elts,
+                                                                             unsigned polys_per_elt, DevTables<Arith> tb) {
+    typedef NttBody<Arith, LOGN, LOGE> B;
+    constexpr int E = B::E, N = B::G::N;
+    static_assert(B::G::highest_cross_wave_exchange() >= 0 || B::G::T <= 64, "in-place safety relies on the transform's workgroup barrier");
+    __shared__ __attribute__((aligned(16))) u64 lds[B::G::lds_words()];
+    const int tid = threadIdx.x;
+    const size_t p = blockIdx.x;
+    const int limb = (int)(p % (size_t)tb.n_limbs);
+    const unsigned g = elts.v[blockIdx.x / polys_per_elt];
+    const LimbConst lc = tb.lc[limb];
+    const typename B::Tw* tw = tb.inv + (size_t)limb * N;
+    const InvLast<typename B::Tw> last = tb.last[limb];
+    typename B::TwRegs tw_first;
+    B::template load_tw<B::NPH - 1, false>(tid, tw, tw_first);
+    const u64* src = in + p * N;
+    u64 x[E];
+#pragma unroll
+    for (int kk = 0; kk < E; ++kk) {
+        const unsigned pos = (unsigned)tid * E + kk;
+        const unsigned e = 2u * (__brev(pos) >> (32 - LOGN)) + 1u;
+        const unsigned e2 = (g * e) & (2u * N - 1u);
+        x[kk] = src[__brev((e2 - 1u) >> 1) >> (32 - LOGN)];
+    }
+    if constexpr (B::G::T <= 64) __syncthreads();   // single-wave geometries have no barrier inside the transform
+    InvChain<B, B::NPH - 1, kUnit>::run_with(tid, x, lds, tw, last, lc, tw_first);
+    B::inv_canon(x, lc);
+    B::store_top(tid, x, out + p * N);
+}
+
 // ------------------------------------------------------------------------------------------------
 // A6: fused ciphertext x ciphertext multiply.  One workgroup per (ciphertext pair, limb).
 //   4 forward NTTs -> register-resident dyadic tensor product -> 3 inverse NTTs, as three rounds of
@@ -563,6 +603,9 @@ __device__ __forceinline__ u64 canon_any(u64 v, const LimbConst& lc) {  // any v
 // MODE 0: relinearisation - input has 3 components, digits come from c2, both c0 and c1 are added back.
 // MODE 1: key switch after a Galois automorphism (N3) - input has 2 components, digits come from c1, only c0 is added:
 //         (c0', c1') = (c0 + sum_j d_j b_j, sum_j d_j a_j).
+// MODE 4: MODE 3 with the result LEFT IN THE NTT DOMAIN over Q P (no inverse transforms, nothing added): the giant steps of a packed
+//         matrix-vector product sum these over the rotations and pay ONE inverse transform + divide-by-P for the whole sum
+//         (dpfhe_switch_key_qp).  Ld transforms per workgroup instead of Ld + 2.
 // MODE 2 / 3: the inner product of HYBRID key switching (one special prime P = the context's LAST limb).  The data
 //         lives on the first Ld = L - 1 limbs; the kernel runs for all L limbs (including P), takes the Ld digits from
 //         c2 (MODE 2, 3-component input) or c1 (MODE 3, 2-component input) and writes t = sum_j d_j (.) key_j to a work
@@ -642,6 +685,15 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE), (Arith::kFold ? 2 : 1)) void re
     if (Arith::kFold) {
 #pragma unroll
         for (int k = 0; k < E; ++k) { acc0[k] = FoldArith::reduce(acc0[k], lc); acc1[k] = FoldArith::reduce(acc1[k], lc); }
+    }
+    if constexpr (MODE == 4) {   // the inner products stay in the NTT domain over Q P: canonical words, forward-output order
+        if (Arith::kFold) {
+#pragma unroll
+            for (int k = 0; k < E; ++k) { acc0[k] = FoldArith::canon_small(acc0[k], lc); acc1[k] = FoldArith::canon_small(acc1[k], lc); }
+        }
+        B::store_bot(tid, acc0, out2 + ((bi * 2 + 0) * L + limb) * N);
+        B::store_bot(tid, acc1, out2 + ((bi * 2 + 1) * L + limb) * N);
+        return;
     }
     constexpr int kInvIn = Arith::kFold ? 2 * kMulB : kUnit;
 #pragma unroll 1
@@ -746,6 +798,13 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE), 2) void relin_shared_kernel(u64
     }
 #pragma unroll
     for (int k = 0; k < E; ++k) { acc0[k] = FoldArith::reduce(acc0[k], lc); acc1[k] = FoldArith::reduce(acc1[k], lc); }
+    if constexpr (MODE == 4) {
+#pragma unroll
+        for (int k = 0; k < E; ++k) { acc0[k] = FoldArith::canon_small(acc0[k], lc); acc1[k] = FoldArith::canon_small(acc1[k], lc); }
+        B::store_bot(tid, acc0, out2 + ((bi * 2 + 0) * L + limb) * N);
+        B::store_bot(tid, acc1, out2 + ((bi * 2 + 1) * L + limb) * N);
+        return;
+    }
     asm volatile("" : "+v"(tid));
     InvChain2<B, B::NPH - 1, 2 * kMulB>::run(tid, acc0, acc1, lds, lds + W, tb.inv4 + (size_t)limb * N, last, lc);
     B::inv_canon(acc0, lc);
@@ -777,8 +836,6 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE), 2) void relin_shared_kernel(u64
 // 69 us against 86 us for the un-hoisted pass; replacing the gather by coalesced loads changes nothing - what bounds one
 // token is each CU streaming its 320 KB of key tiles at ~10 B/clk, i.e. the 122 MB of keys spread over few workgroups.)
 // ------------------------------------------------------------------------------------------------
-struct GaloisElts { unsigned v[kMaxGaloisBatch]; };
-
 template <class Arith, int LOGN, int LOGE>
 __global__ __launch_bounds__(1 << (LOGN - LOGE), (Arith::kFold ? 2 : 1)) void hoisted_ks_kernel(u64* __restrict__ work, const u64* __restrict__ digits,
                                                                                            const u64* __restrict__ keys, size_t key_stride, GaloisElts elts,
@@ -929,6 +986,100 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE), 2) void hoisted_ks2_kernel(u64*
     B::store_top(tid, acc0, work + ((item * 2 + 0) * L + limb) * N);
     B::inv_canon(acc1, lc);
     B::store_top(tid, acc1, work + ((item * 2 + 1) * L + limb) * N);
+}
+
+// ------------------------------------------------------------------------------------------------
+// N3, round 3: hoisted rotations whose results STAY in the NTT domain over the extended basis Q P ("double hoisting", Bossuat et
+// al. 2021): item (rotation r, token t) =
+//     ( sum_j perm_g(digit_j) (.) key_{g,j,0}  +  P perm_g(NTT(c0)),   sum_j perm_g(digit_j) (.) key_{g,j,1} )      over all L limbs
+// (the P c0 term vanishes on the special limb), i.e. P sigma_g(ct) + key-switching noise before the division by P.  The plaintext
+// products of a packed matrix-vector product are taken on these, and ONE inverse transform + divide-by-P is paid per inner SUM
+// instead of one per rotation: the kernel is a gather + multiply-accumulate stream - no transform, no LDS.  One workgroup per
+// (rotation, limb, token), both key components; same XCD-aware id layout as hoisted_ks2_kernel.
+// `xntt`: NTT of the input ciphertexts on the data limbs, [token][2][Ld][N].  Output canonical, forward-output order.
+// ------------------------------------------------------------------------------------------------
+template <class Arith, int LOGN, int LOGE>
+__global__ __launch_bounds__(1 << (LOGN - LOGE), (Arith::kFold ? 2 : 1)) void hoisted_qp_kernel(u64* __restrict__ out, const u64* __restrict__ digits,
+                                                                                           const u64* __restrict__ xntt, const u64* __restrict__ keys,
+                                                                                           size_t key_stride, GaloisElts elts, unsigned n_items, unsigned n_tiles,
+                                                                                           u64 p_special, DevTables<Arith> tb) {
+    typedef NttBody<Arith, LOGN, LOGE> B;
+    constexpr int E = B::E, N = B::G::N;
+    const int tid = threadIdx.x;
+    const int L = tb.n_limbs, Ld = L - 1;
+    const unsigned q = blockIdx.x >> 3, token = q % n_items, tile = (q / n_items) * 8u + (blockIdx.x & 7u);
+    if (tile >= n_tiles) return;
+    const size_t rot = tile / (unsigned)L;
+    const int limb = (int)(tile % (unsigned)L);
+    const size_t item = rot * n_items + token;
+    digits += (size_t)token * (size_t)Ld * L * N;
+    const LimbConst lc = tb.lc[limb];
+    const unsigned g = elts.v[rot];
+    const u64* evk = keys + rot * key_stride;
+    unsigned src[E];
+#pragma unroll
+    for (int kk = 0; kk < E; ++kk) {
+        const unsigned p = (unsigned)tid * E + kk;
+        const unsigned e = 2u * (__brev(p) >> (32 - LOGN)) + 1u;
+        const unsigned e2 = (g * e) & (2u * N - 1u);
+        src[kk] = __brev((e2 - 1u) >> 1) >> (32 - LOGN);
+    }
+    u64 acc0[E], acc1[E], x[E], e[E];
+    // first term of component 0: P perm_g(NTT(c0)) on the data limbs (one lazily added product like the others)
+    const u64 pmod = canon_any<Arith>(p_special, lc);
+    if (limb < Ld) {
+        const u64* c0 = xntt + ((size_t)token * 2 * Ld + limb) * N;
+#pragma unroll
+        for (int k = 0; k < E; ++k) {
+            const u64 v = c0[src[k]];
+            acc0[k] = Arith::kFold ? FoldArith::mul60(v, pmod, (u32)lc.d) : ShoupArith::mul_var(v, pmod, lc);
+            acc1[k] = 0;
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < E; ++k) acc0[k] = acc1[k] = 0;
+    }
+    B::load_bot(tid, e, evk + ((size_t)0 * L + limb) * N);
+    {
+        const u64* d = digits + (size_t)limb * N;
+#pragma unroll
+        for (int k = 0; k < E; ++k) x[k] = d[src[k]];
+    }
+    int lazy_terms = 1;
+#pragma unroll 1
+    for (int j = 0; j < Ld; ++j) {
+        u64 e1[E], xn[E];
+        B::load_bot(tid, e1, evk + (((size_t)j * 2 + 1) * L + limb) * N);
+        if (Arith::kFold) {
+            if (lazy_terms == 13) {
+#pragma unroll
+                for (int k = 0; k < E; ++k) { acc0[k] = FoldArith::reduce(acc0[k], lc); acc1[k] = FoldArith::reduce(acc1[k], lc); }
+                lazy_terms = 1;
+            }
+            ++lazy_terms;
+        }
+#pragma unroll
+        for (int k = 0; k < E; ++k)
+            acc0[k] = Arith::kFold ? acc0[k] + FoldArith::mul60(x[k], e[k], (u32)lc.d) : add_mod(acc0[k], ShoupArith::mul_var(x[k], e[k], lc), lc.q);
+        const int jn = j + 1 < Ld ? j + 1 : j;
+        B::load_bot(tid, e, evk + (((size_t)jn * 2 + 0) * L + limb) * N);
+        {
+            const u64* d = digits + ((size_t)jn * L + limb) * N;
+#pragma unroll
+            for (int k = 0; k < E; ++k) xn[k] = d[src[k]];
+        }
+#pragma unroll
+        for (int k = 0; k < E; ++k)
+            acc1[k] = Arith::kFold ? acc1[k] + FoldArith::mul60(x[k], e1[k], (u32)lc.d) : add_mod(acc1[k], ShoupArith::mul_var(x[k], e1[k], lc), lc.q);
+#pragma unroll
+        for (int k = 0; k < E; ++k) x[k] = xn[k];
+    }
+    if (Arith::kFold) {
+#pragma unroll
+        for (int k = 0; k < E; ++k) { acc0[k] = FoldArith::canon(acc0[k], lc); acc1[k] = FoldArith::canon(acc1[k], lc); }
+    }
+    B::store_bot(tid, acc0, out + ((item * 2 + 0) * L + limb) * N);
+    B::store_bot(tid, acc1, out + ((item * 2 + 1) * L + limb) * N);
 }
 
 }  // namespace dpfhe

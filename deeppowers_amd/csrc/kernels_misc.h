@@ -60,6 +60,22 @@ __global__ __launch_bounds__(256) void dyadic_kernel(u64* out, const u64* a, con
     }
 }
 
+// The practical HBM ceiling the transforms are read against ("also report a measured device-copy bandwidth"):
+// a plain copy with the streaming kernels' access shape - 16 bytes per lane, 4 KiB-contiguous per wave instruction, eight
+// independent loads in flight per thread, one 32 KiB tile (a residue polynomial at N = 4096) per workgroup.
+__global__ __launch_bounds__(256) void copy_kernel(U64x2* __restrict__ dst, const U64x2* __restrict__ src, size_t n_vec) {
+    const size_t base = (size_t)blockIdx.x * 2048 + threadIdx.x;
+    if ((size_t)blockIdx.x * 2048 + 2048 <= n_vec) {   // whole tile (workgroup-uniform)
+        U64x2 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = src[base + u * 256];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) dst[base + u * 256] = v[u];
+    } else {
+        for (size_t i = base; i < n_vec; i += 256) dst[i] = src[i];
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // A8: out[c][l][:] = sum_i in[i][c][l][:]  (HBM-bound: one read per term).
 // grid (residue-poly chunks, splits): each workgroup reduces its share of the batch to a canonical partial
@@ -294,6 +310,106 @@ __global__ __launch_bounds__(256) void matvec_multi_kernel(u64* y, const u64* W,
     }
 }
 
+// A7 for FoldArith contexts (round 3): the same product with the split-at-bit-30 column accumulators of modarith.h
+// (FoldArith::dot30_mac: FOUR multiply-adds per term instead of the 21 instructions of a 128-bit accumulate; one 18-instruction
+// fold per 8 columns).  W tile (RT rows) and x tile (C polynomials) of a column are split once and used RT x C times.  Same
+// XCD-aware block ids, same software pipeline; WPT words per thread (chunks of 256 WPT words).  Serves dpfhe_matvec_plain
+// (C = 2, one group) and dpfhe_matvec_plain_multi.
+template <int WPT> struct WordVec;
+template <> struct WordVec<1> { u64 v[1]; };
+template <> struct __attribute__((aligned(16))) WordVec<2> { u64 v[2]; };
+template <int WPT>
+__device__ __forceinline__ WordVec<WPT> load_words(const u64* p, bool in_range) {   // rows beyond the matrix read as zero
+    WordVec<WPT> r;
+    if (in_range) r = *reinterpret_cast<const WordVec<WPT>*>(p);
+    else {
+#pragma unroll
+        for (int k = 0; k < WPT; ++k) r.v[k] = 0;
+    }
+    return r;
+}
+
+template <int RT, int C, int WPT>
+__global__ __launch_bounds__(256) void matvec_fold_kernel(u64* y, const u64* W, const u64* x, const LimbConst* lcs, int n_limbs, int n,
+                                                          int chunks, size_t rows, size_t cols, size_t polys_per_col, unsigned n_groups,
+                                                          unsigned n_tiles) {
+    typedef WordVec<WPT> V;
+    typedef FoldArith::Half30 H;
+    const size_t L = (size_t)n_limbs;
+    const unsigned n_slabs = (unsigned)L * (unsigned)chunks, R = n_tiles / n_slabs;
+    const unsigned id = blockIdx.x, lane = id & 7u, q = id >> 3;
+    const unsigned group = q % n_groups, rt = (q / n_groups) % R, slab = (q / (n_groups * R)) * 8u + lane;
+    if (slab >= n_slabs) return;
+    const int chunk = (int)(slab % chunks);
+    const int limb = (int)(slab / chunks);
+    const size_t row0 = (size_t)rt * RT;
+    const int w0 = chunk * 256 * WPT + threadIdx.x * WPT;
+    if (w0 >= n) return;
+    x += (size_t)group * C * L * n;
+    y += (size_t)group * C * L * n;
+    const LimbConst lc = lcs[limb];
+    const size_t wstride = L * n, xstride = polys_per_col * L * n, rstride = cols * L * n;
+    FoldArith::Dot30 acc[RT][C][WPT];   // the folded running word rides in column 0 of the fresh accumulator (8 products + 1 word < 10 * 2^60)
+#pragma unroll
+    for (int r = 0; r < RT; ++r)
+#pragma unroll
+        for (int c = 0; c < C; ++c)
+#pragma unroll
+            for (int k = 0; k < WPT; ++k) acc[r][c][k] = FoldArith::Dot30{0, 0, 0};
+    const u64* wp = W + (row0 * cols * L + limb) * n + w0;
+    const u64* xp = x + (size_t)limb * n + w0;
+    V w[RT], xv[C];
+#pragma unroll
+    for (int r = 0; r < RT; ++r) w[r] = load_words<WPT>(wp + r * rstride, row0 + r < rows);
+#pragma unroll
+    for (int c = 0; c < C; ++c) xv[c] = *reinterpret_cast<const V*>(xp + (size_t)c * L * n);
+    int since = 0;
+    for (size_t j = 0; j < cols; ++j) {
+        const size_t jn = j + 1 < cols ? j + 1 : j;
+        V wn[RT], xn[C];
+#pragma unroll
+        for (int r = 0; r < RT; ++r) wn[r] = load_words<WPT>(wp + r * rstride + jn * wstride, row0 + r < rows);
+#pragma unroll
+        for (int c = 0; c < C; ++c) xn[c] = *reinterpret_cast<const V*>(xp + jn * xstride + (size_t)c * L * n);
+#pragma unroll
+        for (int k = 0; k < WPT; ++k) {
+            H wh[RT], xh[C];
+#pragma unroll
+            for (int r = 0; r < RT; ++r) wh[r] = FoldArith::split30(w[r].v[k]);
+#pragma unroll
+            for (int c = 0; c < C; ++c) xh[c] = FoldArith::split30(xv[c].v[k]);
+#pragma unroll
+            for (int c = 0; c < C; ++c)
+#pragma unroll
+                for (int r = 0; r < RT; ++r) FoldArith::dot30_mac(acc[r][c][k], wh[r], xh[c]);
+        }
+#pragma unroll
+        for (int r = 0; r < RT; ++r) w[r] = wn[r];
+#pragma unroll
+        for (int c = 0; c < C; ++c) xv[c] = xn[c];
+        if (++since == FoldArith::kDot30Period) {
+#pragma unroll
+            for (int r = 0; r < RT; ++r)
+#pragma unroll
+                for (int c = 0; c < C; ++c)
+#pragma unroll
+                    for (int k = 0; k < WPT; ++k) acc[r][c][k] = FoldArith::Dot30{FoldArith::dot30_fold(acc[r][c][k], 0, lc), 0, 0};
+            since = 0;
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < RT; ++r) {
+        if (row0 + r >= rows) break;
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            V o;
+#pragma unroll
+            for (int k = 0; k < WPT; ++k) o.v[k] = FoldArith::canon_small(since ? FoldArith::dot30_fold(acc[r][c][k], 0, lc) : acc[r][c][k].s0, lc);
+            *reinterpret_cast<V*>(y + (((row0 + r) * polys_per_col + c) * L + limb) * n + w0) = o;
+        }
+    }
+}
+
 // A7, scalar weights (SURVEY.md section 8a A7 "cheap special case"): W_ij are residues in Z_q (one word per limb),
 // y_i = sum_j w_ij * x_j.  The weights of a row tile are workgroup-uniform (scalar loads -> SGPR multiplier operands),
 // x_j is loaded once per column and used for RT rows: RT*4 multiply-accumulates per 32 bytes loaded - ALU-bound.
@@ -391,6 +507,74 @@ __global__ __launch_bounds__(256) void rescale_kernel(u64* out, const u64* in, c
         r.b = add_mod(r.b, ad.b, lc.q);
     }
     *reinterpret_cast<U64x2*>(out + (poly * Lo + limb) * n + w0) = r;
+}
+
+// N3 (round 3, deferred divide-by-P): the last step of a baby-step / giant-step sum whose key-switched terms were summed over Q P.
+//   out[b][comp][i] = round(in[b][comp] / P)_i  +  sum_{a < n_add} addends[a][b][0][i]   (comp 0)
+//                                               +  addends[0][b][1][i]                    (comp 1)
+// in: [batch][2][L][N] (coefficient domain, Q P), addends: [n_add][batch][2][Ld][N] (the rotated inner sums: item 0 is the
+// un-rotated one and keeps both components, of the others only c0 survives - their c1 went through the key switch), out:
+// [batch][2][Ld][N].  One pass; the rounding is orc_rescale's.
+template <class Arith>
+__global__ __launch_bounds__(256) void rescale_bsgs_kernel(u64* out, const u64* in, const u64* addends, size_t n_add, size_t batch, const LimbConst* lcs,
+                                                           const RescaleConst* rcs, int n_limbs, int n, int chunks) {
+    const int Lo = n_limbs - 1;
+    const int chunk = (int)(blockIdx.x % chunks);
+    const int limb = (int)((blockIdx.x / chunks) % Lo);
+    const size_t poly = blockIdx.x / chunks / Lo;   // = b * 2 + comp
+    const int w0 = chunk * 512 + threadIdx.x * 2;
+    if (w0 >= n) return;
+    const LimbConst lc = lcs[limb];
+    const RescaleConst rc = rcs[limb];
+    const U64x2 x = *reinterpret_cast<const U64x2*>(in + (poly * n_limbs + limb) * n + w0);
+    const U64x2 last = *reinterpret_cast<const U64x2*>(in + (poly * n_limbs + Lo) * n + w0);
+    U64x2 r;
+    {
+        const u64 t = csub(last.a + rc.h, rc.q_last);
+        const u64 tm = Arith::kFold ? FoldArith::canon(t, lc) : ShoupArith::mul_var(t, 1, lc);
+        r.a = Arith::mul_var(sub_mod(add_mod(x.a, rc.h_mod, lc.q), tm, lc.q), rc.inv, lc);
+    }
+    {
+        const u64 t = csub(last.b + rc.h, rc.q_last);
+        const u64 tm = Arith::kFold ? FoldArith::canon(t, lc) : ShoupArith::mul_var(t, 1, lc);
+        r.b = Arith::mul_var(sub_mod(add_mod(x.b, rc.h_mod, lc.q), tm, lc.q), rc.inv, lc);
+    }
+    const size_t terms = (poly & 1) ? (n_add ? 1 : 0) : n_add;
+    const u64* ap = addends + (poly * Lo + limb) * n + w0;
+    const size_t astride = batch * 2 * Lo * (size_t)n;
+    size_t a = 0;
+    for (; a + 4 <= terms; a += 4) {
+        U64x2 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const U64x2*>(ap + (a + u) * astride);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { r.a = add_mod(r.a, v[u].a, lc.q); r.b = add_mod(r.b, v[u].b, lc.q); }
+    }
+    for (; a < terms; ++a) {
+        const U64x2 v = *reinterpret_cast<const U64x2*>(ap + a * astride);
+        r.a = add_mod(r.a, v.a, lc.q); r.b = add_mod(r.b, v.b, lc.q);
+    }
+    *reinterpret_cast<U64x2*>(out + (poly * Lo + limb) * n + w0) = r;
+}
+
+// N3 (round 3): a ciphertext in the NTT domain on the data limbs, lifted to the extended basis as P * ct: word * (P mod q_i) on the
+// data limbs, 0 on the special limb (P = 0 mod P).  in: [n_polys][Ld][N] -> out: [n_polys][L][N].  The un-rotated baby step.
+template <class Arith>
+__global__ __launch_bounds__(256) void lift_qp_kernel(u64* out, const u64* in, const LimbConst* lcs, u64 p_special, int n_limbs, int n, int chunks) {
+    const int chunk = (int)(blockIdx.x % chunks);
+    const int limb = (int)((blockIdx.x / chunks) % n_limbs);
+    const size_t poly = blockIdx.x / chunks / n_limbs;
+    const int w0 = chunk * 512 + threadIdx.x * 2;
+    if (w0 >= n) return;
+    U64x2 r{0, 0};
+    if (limb < n_limbs - 1) {
+        const LimbConst lc = lcs[limb];
+        const u64 pmod = Arith::kFold ? FoldArith::canon(p_special, lc) : ShoupArith::mul_var(p_special, 1, lc);
+        const U64x2 v = *reinterpret_cast<const U64x2*>(in + (poly * (n_limbs - 1) + limb) * n + w0);
+        r.a = Arith::mul_var(v.a, pmod, lc);
+        r.b = Arith::mul_var(v.b, pmod, lc);
+    }
+    *reinterpret_cast<U64x2*>(out + (poly * n_limbs + limb) * n + w0) = r;
 }
 
 // N3, hoisted rotations: digit j of the key-switched component (limb j of c1, coefficient domain, values < q_j) lifted to every

@@ -100,6 +100,7 @@ int launch_relin(int log2n, int mode, u64* out2, const u64* in3, const u64* evk,
 #endif
     // 4..7 digits at N <= 4096: digit transforms side by side (relin_shared_kernel: -10 % on relinearize at N=4096, L=4; at N=8192,
     // where one workgroup owns the CU and the key tiles are what it streams, the same form measured -1 %: not instantiated)
+    if (mode < 0 || mode > 4) return -1;
     const int n_digits = mode >= 2 ? tb.n_limbs - 1 : tb.n_limbs;
     // items that share a key (key_group > 1) are laid out per XCD: kernels.h relin_kernel
     const unsigned kg = key_group ? key_group : 1u;
@@ -118,7 +119,8 @@ int launch_relin(int log2n, int mode, u64* out2, const u64* in3, const u64* evk,
     if (mode == 0) { RL_ONE(LN, 0); }      \
     else if (mode == 1) { RL_ONE(LN, 1); } \
     else if (mode == 2) { RL_ONE(LN, 2); } \
-    else { RL_ONE(LN, 3); }
+    else if (mode == 3) { RL_ONE(LN, 3); } \
+    else { RL_ONE(LN, 4); }
     DPFHE_GEO_SWITCH(log2n, RL_CASE)
 #undef RL_CASE
 #undef RL_ONE
@@ -151,6 +153,34 @@ int launch_hoisted_ks(int log2n, u64* work, const u64* digits, const u64* keys, 
     hipLaunchKernelGGL((hoisted_ks_kernel<Arith, LN, kFusedLoge>), dim3(blocks), dim3(Geo<LN, kFusedLoge>::T), 0, s, work, digits, keys, key_stride, ge, (unsigned)n_items, tiles, tb)
     DPFHE_GEO_SWITCH(log2n, HK_CASE)
 #undef HK_CASE
+    return 0;
+}
+
+template <class Arith>
+int launch_hoisted_qp(int log2n, u64* out, const u64* digits, const u64* xntt, const u64* keys, size_t key_stride, const unsigned* elts, size_t count,
+                      size_t n_items, u64 p_special, const DevTables<Arith>& tb, hipStream_t s) {
+    GaloisElts ge{};
+    for (size_t i = 0; i < count && i < (size_t)kMaxGaloisBatch; ++i) ge.v[i] = elts[i];
+    const unsigned tiles = (unsigned)(count * (size_t)tb.n_limbs);                  // (rotation, limb)
+    const unsigned blocks = ((tiles + 7u) / 8u) * 8u * (unsigned)n_items;           // x token, ids laid out per XCD (kernels.h)
+#define HQ_CASE(LN, LE)                                                                                                                                  \
+    hipLaunchKernelGGL((hoisted_qp_kernel<Arith, LN, kFusedLoge>), dim3(blocks), dim3(Geo<LN, kFusedLoge>::T), 0, s, out, digits, xntt, keys, key_stride, ge, \
+                       (unsigned)n_items, tiles, p_special, tb)
+    DPFHE_GEO_SWITCH(log2n, HQ_CASE)
+#undef HQ_CASE
+    return 0;
+}
+
+template <class Arith>
+int launch_ntt_inv_galois(int log2n, u64* out, const u64* in, const unsigned* elts, size_t n_elts, size_t polys_per_elt, const DevTables<Arith>& tb, hipStream_t s) {
+    if (tb.n_sub != 1) return -1;   // split transforms (N > 16384) have no gather form
+    GaloisElts ge{};
+    for (size_t i = 0; i < n_elts && i < (size_t)kMaxGaloisBatch; ++i) ge.v[i] = elts[i];
+    const unsigned grid = (unsigned)(n_elts * polys_per_elt);
+#define NG_CASE(LN, LE) \
+    hipLaunchKernelGGL((ntt_inv_galois_kernel<Arith, LN, LE>), dim3(grid), dim3(Geo<LN, LE>::T), 0, s, out, in, ge, (unsigned)polys_per_elt, tb)
+    DPFHE_NTT_GEO_SWITCH(log2n, NG_CASE)
+#undef NG_CASE
     return 0;
 }
 

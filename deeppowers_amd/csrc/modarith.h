@@ -200,6 +200,41 @@ struct FoldArith {
     static DPF_HD u64 canon(u64 x, const LimbConst& c) { return canon_small(reduce(x, c), c); }
     // a*b mod q, canonical; a < 2^64, b < 2^60
     static DPF_HD u64 mul_var(u64 a, u64 b, const LimbConst& c) { return csub(mul60(a, b, (u32)c.d), c.q); }
+
+    // ---- lazy dot products of CANONICAL residues (the plaintext matrix-vector products, kernels_misc.h) -------------------
+    // Both factors are split at bit 30 (a = a0 + a1 2^30, all four halves < 2^30), so every partial product is < 2^60 and
+    // the three columns  S0 = sum a0 b0,  S1 = sum (a0 b1 + a1 b0),  S2 = sum a1 b1  are plain 64-bit multiply-add chains:
+    // FOUR v_mad_u64_u32 per multiply-accumulate and nothing else (the 128-bit accumulators this replaces cost 21 VALU
+    // instructions per term: 4 multiply-adds, 2 multiplies, 7 moves, 4 64-bit adds, compare/select/add3).  After at most
+    // kDot30Period terms (S1 < 16 * 2^60) the columns are folded into one reduced word:
+    //   S0 + S1 2^30 + S2 2^60  ==  S0 + (S1 mod 2^30) 2^30 + (S2 + (S1 >> 30)) d        (2^60 == d)
+    // 18 instructions per fold (4 multiply-adds), i.e. 2.25 per term.
+    struct Half30 { u32 lo, hi; };
+    struct Dot30 { u64 s0, s1, s2; };
+    static constexpr int kDot30Period = 8;
+    static DPF_HD Half30 split30(u64 v) {
+        DPFHE_EMU_ASSERT(v < (1ull << 60));
+        return Half30{(u32)v & 0x3fffffffu, (u32)(v >> 30)};
+    }
+    static DPF_HD void dot30_mac(Dot30& s, const Half30& a, const Half30& b) {
+        DPFHE_EMU_ASSERT(s.s0 < (15ull << 60) && s.s1 < (14ull << 60) && s.s2 < (15ull << 60));
+        s.s0 = mad32(a.lo, b.lo, s.s0);
+        s.s1 = mad32(a.hi, b.lo, mad32(a.lo, b.hi, s.s1));
+        s.s2 = mad32(a.hi, b.hi, s.s2);
+    }
+    // folds the columns and a running reduced word r (< 2^60 + 2^29) into a new running word < 2^60 + 16 d
+    static DPF_HD u64 dot30_fold(const Dot30& s, u64 r, const LimbConst& c) {
+        DPFHE_EMU_ASSERT(r < (1ull << 60) + (1ull << 29));
+        const u32 d = (u32)c.d;
+        const u64 r0 = reduce(s.s0, c);                                         // < 2^60 + 16 d
+        const u64 U = s.s2 + (s.s1 >> 30);                                      // < 2^63 + 2^34
+        const u64 V = r0 + r + ((u64)((u32)s.s1 & 0x3fffffffu) << 30);          // < 3 * 2^60 + 2^30
+        const u64 T = mad32((u32)(U >> 32), d, 0);                              // U.hi d < 2^56;  U.hi d 2^32 = (T mod 2^28) 2^32 + (T >> 28) 2^60
+        u64 A = mad32((u32)U, d, V);                                            // < 3 * 2^60 + 2^57
+        A = mad32((u32)(T >> 28), d, A);                                        // + < 2^52
+        A += (u64)((u32)T & 0x0fffffffu) << 32;                                 // + < 2^60: A < 2^63
+        return reduce(A, c);
+    }
 };
 
 // canonical add / sub / negate (inputs canonical)

@@ -369,6 +369,74 @@ class Evaluator:
                                                           rotated.data_ptr(), self._sp(stream)), "dpfhe_rotate_hybrid_grouped")
         return Ciphertext(out, False)
 
+    def device_copy(self, dst: torch.Tensor, src: torch.Tensor, stream=None) -> torch.Tensor:
+        """Plain device-to-device copy through the library's streaming access shape (dpfhe_copy): the practical HBM ceiling."""
+        if dst.numel() != src.numel() or dst.dtype != torch.int64 or src.dtype != torch.int64 or not dst.is_contiguous() or not src.is_contiguous():
+            raise _cabi.DpfheError(2000, "device_copy: two contiguous int64 tensors of the same size")
+        _cabi.check(self._lib.dpfhe_copy(self.ctx.handle, dst.data_ptr(), src.data_ptr(), src.numel(), self._sp(stream)), "dpfhe_copy")
+        return dst
+
+    # ---- N3, round 3: baby-step / giant-step with the division by P deferred (include/dpfhe.h) ---------------------------
+    def rotate_hoisted_qp(self, ct: Ciphertext, galois_elts, keys: torch.Tensor, stream=None) -> torch.Tensor:
+        """[T][2][L-1][N] coefficient-domain inputs on the extended context -> [1 + k][T][2][L][N], NTT domain over Q P:
+        block 0 = P * ct, block 1 + r = P * sigma_{g_r}(ct) + its key-switching term (not yet divided by P)."""
+        p = self.ctx.params
+        L, Ld, n = p.n_limbs, p.n_limbs - 1, p.n
+        d = ct.data
+        k = len(galois_elts)
+        if ct.is_ntt or ct.size != 2 or d.dim() != 4 or d.shape[-2] != Ld or d.shape[-1] != n or d.dtype != torch.int64 or not d.is_contiguous():
+            raise _cabi.DpfheError(2000, "rotate_hoisted_qp: coefficient-domain [T][2][L-1][N] ciphertexts on the extended context")
+        T = d.shape[0]
+        if k and (tuple(keys.shape) != (k, Ld, 2, L, n) or keys.dtype != torch.int64 or not keys.is_contiguous()):
+            raise _cabi.DpfheError(2000, "keys must be [k][L-1][2][L][N]")
+        out = self._empty((k + 1, T, 2, L, n), stream)
+        in_ntt = self._empty((T, 2, Ld, n), stream)
+        digits = self._empty((T, Ld, L, n), stream)
+        elts = (C.c_uint32 * max(k, 1))(*[int(g) for g in galois_elts])
+        _cabi.check(self._lib.dpfhe_rotate_hoisted_qp(self.ctx.handle, out.data_ptr(), d.data_ptr(), T, elts, keys.data_ptr() if k else None, in_ntt.data_ptr(),
+                                                      digits.data_ptr(), k, self._sp(stream)), "dpfhe_rotate_hoisted_qp")
+        return out
+
+    def ntt_inverse_galois(self, t: torch.Tensor, galois_elts, out: torch.Tensor | None = None, stream=None) -> torch.Tensor:
+        """t: [len(elts)][...][L][N] NTT domain -> sigma_{g_e}(INTT(t[e])) (the automorphism as a gather in the NTT domain)."""
+        self._chk(t)
+        k = len(galois_elts)
+        if t.shape[0] != k:
+            raise _cabi.DpfheError(2000, "ntt_inverse_galois: leading dimension = number of elements")
+        out = self._empty_like(t, stream) if out is None else out
+        elts = (C.c_uint32 * k)(*[int(g) for g in galois_elts])
+        _cabi.check(self._lib.dpfhe_ntt_inv_galois(self.ctx.handle, out.data_ptr(), t.data_ptr(), self._npolys(t) // k, elts, k, self._sp(stream)), "dpfhe_ntt_inv_galois")
+        return out
+
+    def switch_key_qp(self, ct: Ciphertext, keys: torch.Tensor, group: int, stream=None) -> torch.Tensor:
+        """[k * group][2][L-1][N] coefficient-domain items (item i with key i // group) -> [k * group][2][L][N]: the key inner
+        products sum_j NTT(lift([c1]_{q_j})) (.) key_j in the NTT domain over Q P, nothing added, not divided by P."""
+        p = self.ctx.params
+        L, Ld, n = p.n_limbs, p.n_limbs - 1, p.n
+        d = ct.data
+        k = keys.shape[0]
+        if ct.is_ntt or ct.size != 2 or d.dim() != 4 or d.shape[0] != k * group or d.shape[-2] != Ld or d.shape[-1] != n or d.dtype != torch.int64 or not d.is_contiguous():
+            raise _cabi.DpfheError(2000, "switch_key_qp: coefficient-domain [k * group][2][L-1][N] ciphertexts on the extended context")
+        if tuple(keys.shape) != (k, Ld, 2, L, n) or keys.dtype != torch.int64 or not keys.is_contiguous():
+            raise _cabi.DpfheError(2000, "keys must be [k][L-1][2][L][N]")
+        out = self._empty((k * group, 2, L, n), stream)
+        _cabi.check(self._lib.dpfhe_switch_key_qp(self.ctx.handle, out.data_ptr(), d.data_ptr(), keys.data_ptr(), k, group, self._sp(stream)), "dpfhe_switch_key_qp")
+        return out
+
+    def rescale_bsgs(self, t_qp: torch.Tensor, addends: torch.Tensor, stream=None) -> torch.Tensor:
+        """t_qp: [batch][2][L][N] (coefficient domain over Q P), addends: [n_add][batch][2][L-1][N] -> [batch][2][L-1][N] =
+        round(t / P) + (sum over ALL addends of component 0, component 1 of addend 0)."""
+        self._chk(t_qp)
+        p = self.ctx.params
+        L, Ld, n = p.n_limbs, p.n_limbs - 1, p.n
+        batch = t_qp.shape[0]
+        if t_qp.dim() != 4 or t_qp.shape[1] != 2 or addends.dim() != 5 or tuple(addends.shape[1:]) != (batch, 2, Ld, n) or not addends.is_contiguous():
+            raise _cabi.DpfheError(2000, "rescale_bsgs: t [batch][2][L][N], addends [n_add][batch][2][L-1][N]")
+        out = self._empty((batch, 2, Ld, n), stream)
+        _cabi.check(self._lib.dpfhe_rescale_bsgs(self.ctx.handle, out.data_ptr(), t_qp.data_ptr(), addends.data_ptr(), addends.shape[0], batch, self._sp(stream)),
+                    "dpfhe_rescale_bsgs")
+        return out
+
     def matvec_plain_multi(self, W: Plaintext, x: torch.Tensor, n_rhs: int, stream=None) -> torch.Tensor:
         """y[i][t] = sum_j W[i][j] (.) x[j][t].  W.data: [rows][cols][L][N] (NTT), x: [cols][n_rhs][2][L][N] (NTT) -> [rows][n_rhs][2][L][N]."""
         self._chk(W.data, x)

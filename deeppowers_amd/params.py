@@ -117,8 +117,7 @@ def min_primitive_2n_root(n: int, q: int) -> int:
     """Smallest psi with psi^n = -1 (mod q), i.e. of order exactly 2n (n a power of two, q = 1 mod 2n prime) - Appendix A's rule."""
     if (q - 1) % (2 * n):
         raise ValueError("q is not 1 mod 2N")
-    roots, g = set(), 2
-    while len(roots) < 64:                      # a handful of candidates psi = g^((q-1)/2n) of full order, then all their odd powers
+    for g in range(2, 2 + 4096):                # g^((q-1)/2n) has full order for half of all g: the search ends after a few candidates
         w = pow(g, (q - 1) // (2 * n), q)
         if pow(w, n, q) == q - 1:
             x, w2, best = w, w * w % q, w
@@ -127,8 +126,7 @@ def min_primitive_2n_root(n: int, q: int) -> int:
                     best = x
                 x = x * w2 % q
             return best
-        g += 1
-    raise ValueError("no primitive 2N-th root found")
+    raise ValueError("no primitive 2N-th root found (q not prime?)")
 
 
 def ntt_primes(log2_n: int, count: int, bits: int = 60) -> "FheParams":

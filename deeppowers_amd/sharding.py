@@ -57,13 +57,20 @@ class NativeComm:
         return bytes(uid)
 
     @classmethod
-    def from_process_group(cls, device_id: int, group=None) -> "NativeComm":
-        """Rendezvous over an existing torch.distributed group (any backend): rank 0's id is broadcast as 128 bytes."""
+    def rendezvous(cls, group=None) -> tuple[int, int, bytes]:
+        """(rank, world, id): rank 0 creates the RCCL id, every rank of the torch.distributed group (any backend) receives its 128
+        bytes.  No device needed: tests/test_sharding_gloo.py runs it at world size 2 over gloo."""
         rank, world = (dist.get_rank(group), dist.get_world_size(group)) if dist.is_initialized() else (0, 1)
         box = [cls.new_unique_id() if rank == 0 else None]
         if dist.is_initialized() and world > 1:
             dist.broadcast_object_list(box, src=0, group=group)
-        return cls(rank, world, device_id, box[0])
+        return rank, world, box[0]
+
+    @classmethod
+    def from_process_group(cls, device_id: int, group=None) -> "NativeComm":
+        """Rendezvous over an existing torch.distributed group (any backend), then dpfhe_comm_create on `device_id`."""
+        rank, world, uid = cls.rendezvous(group)
+        return cls(rank, world, device_id, uid)
 
     def allgather(self, partial: torch.Tensor, out: torch.Tensor | None = None, stream=None) -> torch.Tensor:
         """[...] int64 CUDA tensor -> [world, ...], enqueued on `stream` (default: the current stream of the tensor's device)."""

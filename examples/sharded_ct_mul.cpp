@@ -8,7 +8,8 @@
 // through a file in a private temporary directory (rank 0 writes it, the others wait for it) - the "host program's own
 // rendezvous" the C ABI asks for.  Pair i of the GLOBAL batch is generated from i alone, so the global result does not depend on
 // <world>: every rank prints the SHA-free checksum (xor-rotate of all words) of the final sum and the parent checks that all ranks
-// agree and, with world == 1, that it equals a serial recomputation.  Stands in for the reference's all-gather call site,
+// agree AND that the sum equals a world-size-1 recomputation of the same global batch by one more child on the first device
+// (run_reference: no communicator at all).  Stands in for the reference's all-gather call site,
 // /root/reference/src/core/distributed/distributed_context.cpp:97-122.
 //
 //   g++ -O2 -std=c++17 -Iinclude -I/opt/rocm/include examples/sharded_ct_mul.cpp -o examples/sharded_ct_mul \
@@ -124,6 +125,40 @@ static int run_rank(int rank, int world, size_t pairs, int steps, int device, co
     }
 }
 
+// World-size-1 recomputation of the SAME global batch (world * pairs pairs) on one device, without any communicator: shard after
+// shard -> its partial, partials summed locally.  Agreement between ranks is not correctness; equality with this is.
+static int run_reference(int world, size_t pairs, int device, const std::string& dir) {
+    try {
+        const FheParams p = FheParams::n4096_l4();
+        const size_t n = p.n(), L = p.n_limbs();
+        Context ctx(p, device);
+        Evaluator ev(ctx);
+        std::vector<uint64_t> ha(pairs * 2 * L * n), hb(pairs * 2 * L * n);
+        Ciphertext a(ctx, 2, pairs), b(ctx, 2, pairs), c(ctx, 3, pairs), partials(ctx, 3, (size_t)world), total(ctx, 3, 1), one(ctx, 3, 1);
+        const size_t ct3 = 3 * L * n;
+        for (int r = 0; r < world; ++r) {
+            for (size_t i = 0; i < pairs; ++i) {
+                fill_pair(p, (uint64_t)r * pairs + i, 0, &ha[i * 2 * L * n]);
+                fill_pair(p, (uint64_t)r * pairs + i, 1, &hb[i * 2 * L * n]);
+            }
+            a.copy_from_host(ha.data());
+            b.copy_from_host(hb.data());
+            ev.multiply(a, b, c);
+            ev.reduce_sum(c, one);
+            ctx.synchronize();
+            if (hipMemcpy(partials.data() + (size_t)r * ct3, one.data(), ct3 * sizeof(uint64_t), hipMemcpyDeviceToDevice) != hipSuccess) return 4;
+        }
+        ev.reduce_sum(partials, total);
+        std::vector<uint64_t> ht(total.words());
+        total.copy_to_host(ht.data());
+        std::ofstream(dir + "/ref") << checksum(ht) << "\n";
+        return 0;
+    } catch (const Exception& e) {
+        std::fprintf(stderr, "reference: deeppowers::fhe error %d: %s\n", (int)e.code(), e.what());
+        return 2;
+    }
+}
+
 int main(int argc, char** argv) {
     const int world = argc > 1 ? std::atoi(argv[1]) : 1;
     const size_t pairs = argc > 2 ? (size_t)std::atol(argv[2]) : 256;
@@ -156,11 +191,25 @@ int main(int argc, char** argv) {
         if (r == 0) ref = sum; else if (sum != ref) { std::fprintf(stderr, "rank %d holds a different global sum\n", r); ++bad; }
         rate += per_s;
     }
+    bool matches_world1 = false;
+    if (!bad) {   // one more child: the whole global batch at world size 1 on the first device
+        const pid_t pid = fork();
+        if (pid < 0) { std::perror("fork"); return 1; }
+        if (pid == 0) _exit(run_reference(world, pairs, first_device, dir));
+        int st = 0;
+        waitpid(pid, &st, 0);
+        uint64_t want = 0;
+        std::ifstream f(dir + "/ref");
+        if (!WIFEXITED(st) || WEXITSTATUS(st) != 0 || !(f >> want)) { std::fprintf(stderr, "the world-size-1 recomputation failed\n"); ++bad; }
+        else if (want != ref) { std::fprintf(stderr, "the sharded global sum differs from the world-size-1 recomputation of the same batch\n"); ++bad; }
+        else matches_world1 = true;
+        std::remove((dir + "/ref").c_str());
+    }
     for (int r = 0; r < world; ++r) std::remove((dir + "/r" + std::to_string(r)).c_str());
     std::remove((dir + "/rccl_id").c_str());
     rmdir(dir.c_str());
     if (bad) { std::printf("FAILED\n"); return 1; }
-    std::printf("{\"host\": \"c++\", \"world\": %d, \"pairs_per_rank\": %zu, \"steps\": %d, \"global_sum_checksum\": \"%016llx\", \"ct_mul_per_s\": %.1f}\nOK\n",
-                world, pairs, steps, (unsigned long long)ref, rate);
+    std::printf("{\"host\": \"c++\", \"world\": %d, \"pairs_per_rank\": %zu, \"steps\": %d, \"global_sum_checksum\": \"%016llx\", \"matches_world1_recomputation\": %s, \"ct_mul_per_s\": %.1f}\nOK\n",
+                world, pairs, steps, (unsigned long long)ref, matches_world1 ? "true" : "false", rate);
     return 0;
 }

@@ -294,6 +294,10 @@ public:
     void decrypt(const Ciphertext& ct, unsigned log2_scale, int64_t* messages_out);
     // inverse of encrypt_exact: messages_out[k] = round(t * phase_k / Q) mod t, in [0, t)
     void decrypt_exact(const Ciphertext& ct, uint64_t plain_modulus, uint64_t* messages_out);
+    // Remaining noise budget of encrypt_exact-style ciphertexts in bits (the smallest over all items and coefficients):
+    // log2(Q / 2) - log2 |t * phase - Q * round(t * phase / Q)|, exact big-integer arithmetic.  Decryption is correct while it is > 0;
+    // a fresh ciphertext at N = 8192 with five 60-bit limbs and t = 65537 has ~ 270 bits.  Host-side (whoever holds the secret key).
+    double noise_budget_bits(const Ciphertext& ct, uint64_t plain_modulus);
 
 private:
     class Impl;
@@ -335,6 +339,22 @@ public:
     void apply_galois_grouped(const Ciphertext& in2, size_t in_first, const std::vector<uint32_t>& galois_elts, size_t group, Ciphertext& out2,
                               size_t out_first, Stream* stream = nullptr) const;
 
+    // ---- division by P deferred ("double hoisting"; include/dpfhe.h "N3, round 3") -------------------------------------
+    // The context of the data moduli + the special prime: buffers holding terms over Q P live on it.
+    const Context& extended_context() const;
+    // n_items inputs (in2 items in_first ...) -> out_qp items out_first + r * n_items + t, r = 0 .. elts.size(): r = 0 is P * ct_t, r >= 1 is
+    // P * sigma_{elts[r-1]}(ct_t) + its key-switching term; NTT domain over Q P, NOT divided by P (dpfhe_rotate_hoisted_qp).
+    // `out_qp`: 2-component buffer on extended_context().
+    void rotate_hoisted_qp(const Ciphertext& in2, size_t in_first, size_t n_items, const std::vector<uint32_t>& galois_elts, PolyBuffer& out_qp,
+                           size_t out_first, Stream* stream = nullptr) const;
+    // elts.size() * group items (in2 items in_first ...), item i with the key of elts[i / group]: out_qp item out_first + i = the key
+    // inner product of item i's c1 alone, NTT domain over Q P (dpfhe_switch_key_qp); the caller sums such terms, transforms back
+    // once and finishes with dpfhe_rescale_bsgs.  The items must already carry the automorphism (coefficient domain).
+    void switch_key_qp(const Ciphertext& in2, size_t in_first, const std::vector<uint32_t>& galois_elts, size_t group, PolyBuffer& out_qp,
+                       size_t out_first, Stream* stream = nullptr) const;
+    // One HybridKeySwitcher serves ONE stream at a time: its scratch buffers and its cache of packed keys are shared by every call
+    // (and by every PackedLinear built on it); calls on different streams must be ordered by the caller.
+
 private:
     class Impl;
     std::unique_ptr<Impl> impl_;
@@ -375,9 +395,12 @@ private:
 //     n / m partial sums are folded with log2(n / m) more rotations; the result repeats with period m (it is a valid input
 //     of the next layer);
 //   * one block (out_dim <= m = n): every window computes the same block, the result repeats with period n.
-// Per application: ONE hoisted rotation pass for the baby steps (digits of c1 extended and transformed once, `hoisted_ks_kernel`), one
-// batched forward NTT, ONE dpfhe_matvec_plain over all pre-transformed diagonals of all output ciphertexts, one batched inverse
-// NTT, one batched rotation pass + one reduce_sum per output ciphertext.
+// Per application (round 3: the division by P is deferred - "double hoisting"): ONE hoisted rotation pass for the baby steps whose
+// results stay in the NTT domain over Q P (dpfhe_rotate_hoisted_qp: gathers + key inner products, no transform), ONE
+// dpfhe_matvec_plain_multi over all pre-transformed diagonals (encoded over Q P) of all output ciphertexts, one inverse transform
+// that applies the giant-step automorphisms as it loads (dpfhe_ntt_inv_galois) + one divide-by-P pass over the inner sums, then per
+// output ciphertext the giant steps' key inner products (dpfhe_switch_key_qp: Ld transforms each instead of Ld + 2), their sum,
+// ONE inverse transform and ONE divide-by-P + add (dpfhe_rescale_bsgs).
 class PackedLinear {
 public:
     // W: out_dim * in_dim values < t, row-major.  The needed Galois keys are added to `ks`.
@@ -405,6 +428,61 @@ public:
     // synchronisation; the scratch belongs to the layer and grows only when a larger T than ever before arrives, so one apply()
     // at a time per object); synchronise before reading y on the host.
     void apply(const Ciphertext& x, Ciphertext& y, Stream* stream = nullptr) const;
+
+private:
+    class Impl;
+    std::unique_ptr<Impl> impl_;
+};
+
+// PackedSelect: `length` consecutive slots of slot row 0 of a packed ciphertext, starting at `offset`, re-packed as a vector that
+// repeats with period `period` (a power of two >= length dividing N/2) along BOTH slot rows - the input packing of a PackedLinear.
+// The on-device hand-over between two packed layers when the next layer consumes a SLICE of the previous one's output (the V third of
+// a fused QKV product feeding the attention-output projection): one rotation by `offset`, one plaintext mask product (it zeroes
+// everything else; costs one multiplicative level of noise, like a layer), log2(N/2 / period) rotate-and-add steps, one row swap.
+class PackedSelect {
+public:
+    PackedSelect(const Context& data_ctx, const BatchEncoder& enc, HybridKeySwitcher& ks, size_t offset, size_t length, size_t period);
+    ~PackedSelect();
+    PackedSelect(const PackedSelect&) = delete;
+    PackedSelect& operator=(const PackedSelect&) = delete;
+    size_t key_switches_per_apply() const;
+    // x, y: T items, 2 components, coefficient domain; enqueues on `stream` (scratch belongs to the object: one apply() at a time)
+    void apply(const Ciphertext& x, Ciphertext& y, Stream* stream = nullptr) const;
+
+private:
+    class Impl;
+    std::unique_ptr<Impl> impl_;
+};
+
+// PackedTransformerBlock: the LINEAR SKELETON of one GPT-2 block on encrypted, slot-packed hidden states - every dense site of
+// /root/reference/src/core/execution/models/gpt_model.cpp:786-859 chained on the device for T tokens:
+//     qkv = W_qkv x                      (:793, d -> 3 d, one fused product)
+//     a   = v                            attention over ONE position: softmax over a single key is 1, so the attention output IS v
+//     h1  = x + W_o a                    attention-output projection + residual
+//     h2  = h1 + W_down (W_up h1)        (:848, d -> h -> d) + residual
+// over Z_t.  LayerNorm, GELU and the softmax over longer contexts are the non-linear parts an FHE forward cannot take as is
+// (SURVEY.md section 7): they are the identity here.  Five multiplicative levels (four matrices + the mask of the v hand-over); the
+// caller can watch the budget with Decryptor::noise_budget_bits.  Tokens are independent: a multi-rank driver gives each rank its own
+// tokens and needs no collective before the final gather (examples/encrypted_gpt2_block.cpp).
+class PackedTransformerBlock {
+public:
+    // row-major weights with entries < t: W_qkv (3 d x d, rows [q | k | v]), W_o (d x d), W_up (h x d), W_down (d x h)
+    PackedTransformerBlock(const Context& data_ctx, const BatchEncoder& enc, HybridKeySwitcher& ks, const uint64_t* W_qkv, const uint64_t* W_o,
+                           const uint64_t* W_up, const uint64_t* W_down, size_t d, size_t h);
+    ~PackedTransformerBlock();
+    PackedTransformerBlock(const PackedTransformerBlock&) = delete;
+    PackedTransformerBlock& operator=(const PackedTransformerBlock&) = delete;
+    size_t hidden() const;
+    size_t inner() const;
+    size_t key_switches_per_token() const;
+    void pack_input(const uint64_t* x /* d values */, uint64_t* slots /* N */) const;
+    void unpack_output(const uint64_t* slots /* N */, uint64_t* y /* d values */) const;
+    // x, y: T items (tokens), 2 components, coefficient domain, packed as pack_input packs; y is packed the same way (it can enter the
+    // next block as it is).  Enqueues on `stream`; one apply() at a time per object.
+    void apply(const Ciphertext& x, Ciphertext& y, Stream* stream = nullptr) const;
+    // intermediate results of the LAST apply() (T items each; valid until the next one): 0 = qkv (slot r of row 0 = output r), 1 = a = v in
+    // the input packing, 2 = h1, 3 = W_up h1 in the input packing of W_down, 4 = h2 (= y)
+    const Ciphertext& stage(int index) const;
 
 private:
     class Impl;

@@ -136,6 +136,33 @@ int dpfhe_rotate_hybrid_hoisted(dpfhe_ctx* ctx_ext, uint64_t* d_out2, const uint
 int dpfhe_rotate_hybrid_grouped(dpfhe_ctx* ctx_ext, uint64_t* d_out2, const uint64_t* d_in2, const uint32_t* galois_elts, size_t n_elts, size_t group,
                                 const uint64_t* d_keys, uint64_t* d_work, uint64_t* d_rotated, void* stream);
 
+/* -- N3, round 3: baby-step / giant-step sums with the division by P DEFERRED ("double hoisting", Bossuat-Mouchet-Troncoso-Pastoriza-
+ * Hubaux 2021).  A rotated term is kept in the NTT domain over the extended basis Q P as  P sigma_g(ct) + key-switching noise;
+ * plaintext products and sums are taken there, and one inverse transform + divide-by-P is paid per SUM, not per rotation.
+ * Stages (ctx_ext = data moduli + special prime P as its last limb; QP buffers are [..][2][L][N], data buffers [..][2][Ld][N]):
+ *
+ * dpfhe_rotate_hoisted_qp: n_items coefficient-domain inputs d_in2 [n_items][2][Ld][N] -> d_out_qp [(1 + batch)][n_items][2][L][N], NTT
+ *   domain (forward-output order), canonical:  block 0 = (P c0, P c1) (the input itself);  block 1 + r, r < batch =
+ *     ( sum_j NTT(sigma_g lift([c1]_{q_j})) (.) key_{g,j,0} + P NTT(sigma_g c0),  sum_j NTT(sigma_g lift([c1]_{q_j})) (.) key_{g,j,1} ),  g = galois_elts[r]
+ *   (the P c0 term is 0 on the special limb).  Keys as for dpfhe_rotate_hybrid_hoisted.  Scratch: d_in_ntt n_items * 2 * Ld * N words,
+ *   d_digits n_items * Ld * L * N words.  round(block / P) after an inverse transform equals dpfhe_rotate_hybrid_hoisted's output.
+ * dpfhe_ntt_inv_galois (any context): block e of rns_polys_per_elt RNS polynomials:  d_out = sigma_{galois_elts[e]}(INTT(d_in)), the
+ *   automorphism applied as a gather in the NTT domain (no separate pass).  d_out == d_in allowed.  log2_n <= 14.
+ * dpfhe_switch_key_qp: batch = n_keys * group coefficient-domain items d_in2 [batch][2][Ld][N], item i with key i / group ->
+ *   d_out_qp [batch][2][L][N] = sum_j NTT(lift([c1]_{q_j})) (.) key_j, NTT domain, nothing added, no division: the giant steps'
+ *   terms, to be summed (dpfhe_reduce_sum on ctx_ext), inverse-transformed once and finished by
+ * dpfhe_rescale_bsgs: d_in_qp [batch][2][L][N] (coefficient domain) -> d_out2 [batch][2][Ld][N] = round(in / P) + addends, where
+ *   d_addends is [n_add][batch][2][Ld][N]: component 0 adds component 0 of ALL n_add items, component 1 adds component 1 of item 0
+ *   only (the rotated inner sums of a baby-step / giant-step product: item 0 is not rotated; the c1 of the others went into
+ *   dpfhe_switch_key_qp). */
+int dpfhe_rotate_hoisted_qp(dpfhe_ctx* ctx_ext, uint64_t* d_out_qp, const uint64_t* d_in2, size_t n_items, const uint32_t* galois_elts,
+                            const uint64_t* d_keys, uint64_t* d_in_ntt, uint64_t* d_digits, size_t batch, void* stream);
+int dpfhe_ntt_inv_galois(dpfhe_ctx* ctx, uint64_t* d_out, const uint64_t* d_in, size_t rns_polys_per_elt, const uint32_t* galois_elts, size_t n_elts,
+                         void* stream);
+int dpfhe_switch_key_qp(dpfhe_ctx* ctx_ext, uint64_t* d_out_qp, const uint64_t* d_in2, const uint64_t* d_keys, size_t n_keys, size_t group, void* stream);
+int dpfhe_rescale_bsgs(dpfhe_ctx* ctx_ext, uint64_t* d_out2, const uint64_t* d_in_qp, const uint64_t* d_addends, size_t n_add, size_t batch,
+                       void* stream);
+
 /* -- N3: Galois automorphism a(X) -> a(X^galois_elt) (galois_elt odd, < 2N), coefficient domain, d_out != d_in;
  *        and the key switch that follows it:  (c0', c1') = (c0 + sum_j [c1]_{q_j} (.) key_j[0], sum_j [c1]_{q_j} (.) key_j[1]),
  *        key_j = (-(a_j s) + e_j + g_j sigma(s), a_j) in the NTT domain, layout [L][2][L][N] like the relinearisation keys. */
@@ -149,7 +176,7 @@ int dpfhe_matvec_plain(dpfhe_ctx* ctx, uint64_t* d_y, const uint64_t* d_W, const
                        size_t cols, void* stream);
 
 /* -- A7 with n_rhs right-hand sides (tokens): x is [cols][n_rhs][2][L][N], y is [rows][n_rhs][2][L][N] (the token index sits between
- *    the column / row and the component); y[i][t] = sum_j W[i][j] (.) x[j][t].  W is streamed once per group of 4 right-hand sides. */
+ *    the column / row and the component); y[i][t] = sum_j W[i][j] (.) x[j][t].  W is streamed from HBM once: 2 right-hand sides (4 polynomials) x 4 rows per workgroup, the groups of a W tile adjacent on one XCD. */
 int dpfhe_matvec_plain_multi(dpfhe_ctx* ctx, uint64_t* d_y, const uint64_t* d_W, const uint64_t* d_x, size_t rows, size_t cols, size_t n_rhs,
                              void* stream);
 
@@ -161,6 +188,11 @@ int dpfhe_matvec_scalar(dpfhe_ctx* ctx, uint64_t* d_y, const uint64_t* d_w, cons
 /* -- A8: modular sum of `count` ciphertexts of `components` RNS polys each into one ------------------
  * d_in: [count][components][L][N] -> d_out: [components][L][N].  (shard-local reduce before the all-gather) */
 int dpfhe_reduce_sum(dpfhe_ctx* ctx, uint64_t* d_out, const uint64_t* d_in, size_t count, size_t components, void* stream);
+
+/* -- measurement aid (SURVEY.md 8(d) "also report a measured device-copy bandwidth as the practical ceiling"): a plain device-to-device
+ * copy of n_words (even) u64 words with the access shape of the library's streaming kernels (16 bytes per lane, eight loads in
+ * flight per thread).  bench.py reads the transforms' HBM rates against it. */
+int dpfhe_copy(dpfhe_ctx* ctx, uint64_t* d_dst, const uint64_t* d_src, size_t n_words, void* stream);
 
 /* -- (e): the one collective - RCCL all-gather of one partial ciphertext per rank over xGMI ----------
  * One process per GPU.  Rank 0 calls dpfhe_comm_unique_id, ships the 128 bytes to the other ranks by any

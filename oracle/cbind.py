@@ -42,6 +42,10 @@ def _load():
     lib.orc_keyswitch_hybrid.argtypes = [C.c_void_p, _U64P, _U64P, _U64P, C.c_size_t, C.c_int, C.c_int]
     lib.orc_rotate_hoisted.argtypes = [C.c_void_p, _U64P, _U64P, C.POINTER(C.c_uint32), _U64P, C.c_size_t, C.c_int]
     lib.orc_rotate_hoisted.restype = None
+    lib.orc_rotate_hoisted_qp.argtypes = [C.c_void_p, _U64P, _U64P, C.POINTER(C.c_uint32), _U64P, C.c_size_t, C.c_int]
+    lib.orc_rotate_hoisted_qp.restype = None
+    lib.orc_switch_key_qp.argtypes = [C.c_void_p, _U64P, _U64P, _U64P, C.c_size_t, C.c_int]
+    lib.orc_switch_key_qp.restype = None
     lib.orc_rescale.argtypes = [C.c_void_p, _U64P, _U64P, C.c_size_t]
     lib.orc_apply_galois.argtypes = [C.c_void_p, _U64P, _U64P, C.c_size_t, C.c_uint32]
     lib.orc_switch_key.argtypes = [C.c_void_p, _U64P, _U64P, _U64P, C.c_size_t, C.c_int]
@@ -168,6 +172,24 @@ class Oracle:
         e = (C.c_uint32 * k)(*[int(g) for g in elts])
         lib().orc_rotate_hoisted(self._h, _p(out), _p(np.ascontiguousarray(ct2)), e, _p(np.ascontiguousarray(keys)), k, threads)
         return out.reshape(k, 2, self.L - 1, self.n)
+
+    def rotate_hoisted_qp(self, ct2, elts, keys, threads=1):
+        """self is the EXTENDED context; ct2: [2][L-1][N] (one item) -> [1 + k][2][L][N], NTT domain over Q P, not divided by P:
+        block 0 = P ct, block 1 + r = P sigma_g(ct) + the key-switching term of rotation r."""
+        k = len(elts)
+        out = np.empty((k + 1) * 2 * self.L * self.n, np.uint64)
+        e = (C.c_uint32 * max(k, 1))(*[int(g) for g in elts])
+        kk = np.ascontiguousarray(keys) if k else np.zeros(1, np.uint64)
+        lib().orc_rotate_hoisted_qp(self._h, _p(out), _p(np.ascontiguousarray(ct2)), e, _p(kk), k, threads)
+        return out.reshape(k + 1, 2, self.L, self.n)
+
+    def switch_key_qp(self, ct2, key, threads=1):
+        """self is the EXTENDED context; ct2: [batch][2][L-1][N] -> [batch][2][L][N]: sum_j NTT(lift([c1]_j)) (.) key_j, NTT domain."""
+        ct2 = np.ascontiguousarray(ct2)
+        batch = ct2.size // (2 * (self.L - 1) * self.n)
+        out = np.empty(batch * 2 * self.L * self.n, np.uint64)
+        lib().orc_switch_key_qp(self._h, _p(out), _p(ct2), _p(np.ascontiguousarray(key)), batch, threads)
+        return out.reshape(batch, 2, self.L, self.n)
 
     def rescale(self, x):
         x = np.ascontiguousarray(x)

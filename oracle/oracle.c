@@ -554,6 +554,95 @@ void orc_rotate_hoisted(const orc_ctx* c, uint64_t* out2, const uint64_t* in2, c
     }
 }
 
+/* N3, round 3 ("double hoisting", Bossuat et al. 2021): the hoisted rotations BEFORE the division by P, left in the NTT domain
+ * over the extended basis.  Definition form (automorphism in the coefficient domain, then the transform - the GPU permutes in the
+ * NTT domain instead):  block 0 = (P c0, P c1);  block 1 + r =
+ *   ( sum_j NTT(sigma_g lift([c1]_{q_j})) (.) key_{g,j,0} + P NTT(sigma_g c0),  sum_j NTT(sigma_g lift([c1]_{q_j})) (.) key_{g,j,1} ),
+ * the P-multiples vanishing on the special limb.  c = EXTENDED context; in2: [2][Ld][N] (one item, coefficient domain);
+ * keys: [k][Ld][2][L][N]; out: [1 + k][2][L][N]. */
+void orc_rotate_hoisted_qp(const orc_ctx* c, uint64_t* out, const uint64_t* in2, const uint32_t* elts, const uint64_t* keys, size_t k_rot, int threads) {
+    const size_t n = 1ull << c->log2n, L = c->n_limbs, Ld = L - 1;
+    const uint64_t P = c->limb[Ld].q;
+    threads = clamp_threads(threads);
+#pragma omp parallel num_threads(threads)
+    {
+        uint64_t* d = malloc(2 * n * sizeof(uint64_t));
+        uint64_t* dg = d + n;
+#pragma omp for schedule(static)
+        for (long long it = -1; it < (long long)k_rot; ++it) {
+            const uint32_t g = it < 0 ? 1u : elts[it];
+            const uint64_t* key = it < 0 ? NULL : keys + (size_t)it * Ld * 2 * L * n;
+            uint64_t* o = out + (size_t)(it + 1) * 2 * L * n;
+            for (size_t i = 0; i < L; ++i) {
+                const orc_limb* T = &c->limb[i];
+                const uint64_t q = T->q, pm = P % q;
+                uint64_t *acc0 = o + (0 * L + i) * n, *acc1 = o + (1 * L + i) * n;
+                memset(acc0, 0, n * sizeof(uint64_t)); memset(acc1, 0, n * sizeof(uint64_t));
+                for (int comp = 0; comp < 2 && i < Ld; ++comp) {          /* P sigma_g(c_comp): comp 1 only for the identity block */
+                    if (comp == 1 && it >= 0) break;
+                    for (size_t x = 0; x < n; ++x) {
+                        const size_t idx = (x * (size_t)g) & (2 * n - 1);
+                        const uint64_t v = in2[(comp * Ld + i) * n + x];
+                        if (idx < n) dg[idx] = v; else dg[idx - n] = v ? q - v : 0;
+                    }
+                    ntt_fwd_poly(T, dg);
+                    uint64_t* a = comp ? acc1 : acc0;
+                    for (size_t x = 0; x < n; ++x) a[x] = mulmod_slow(dg[x], pm, q);
+                }
+                if (it < 0) continue;
+                for (size_t j = 0; j < Ld; ++j) {
+                    for (size_t x = 0; x < n; ++x) d[x] = in2[(Ld + j) * n + x] % q;          /* lift */
+                    for (size_t x = 0; x < n; ++x) {                                          /* then rotate, mod q_i */
+                        const size_t idx = (x * (size_t)g) & (2 * n - 1);
+                        if (idx < n) dg[idx] = d[x]; else dg[idx - n] = d[x] ? q - d[x] : 0;
+                    }
+                    ntt_fwd_poly(T, dg);
+                    const uint64_t* k0 = key + ((j * 2 + 0) * L + i) * n;
+                    const uint64_t* k1 = key + ((j * 2 + 1) * L + i) * n;
+                    for (size_t x = 0; x < n; ++x) {
+                        uint64_t s0 = acc0[x] + mulmod_barrett(dg[x], k0[x], T); acc0[x] = s0 - ((s0 >= q) ? q : 0);
+                        uint64_t s1 = acc1[x] + mulmod_barrett(dg[x], k1[x], T); acc1[x] = s1 - ((s1 >= q) ? q : 0);
+                    }
+                }
+            }
+        }
+        free(d);
+    }
+}
+
+/* N3, round 3: the key inner product of hybrid key switching alone, left in the NTT domain over Q P (the giant steps' terms):
+ * out[b][comp][i] = sum_j NTT_i(lift_i([c1]_{q_j})) (.) key_{j,comp,i}.  in2: [batch][2][Ld][N] coefficient domain, key: [Ld][2][L][N],
+ * out: [batch][2][L][N].  Same inner loop as orc_keyswitch_hybrid, without its inverse transforms and its division. */
+void orc_switch_key_qp(const orc_ctx* c, uint64_t* out, const uint64_t* in2, const uint64_t* key, size_t batch, int threads) {
+    const size_t n = 1ull << c->log2n, L = c->n_limbs, Ld = L - 1;
+    threads = clamp_threads(threads);
+#pragma omp parallel num_threads(threads)
+    {
+        uint64_t* d = malloc(n * sizeof(uint64_t));
+#pragma omp for schedule(static)
+        for (long long bi = 0; bi < (long long)batch; ++bi) {
+            const uint64_t* digits = in2 + (((size_t)bi * 2 + 1) * Ld) * n;
+            for (size_t i = 0; i < L; ++i) {
+                const orc_limb* T = &c->limb[i];
+                const uint64_t q = T->q;
+                uint64_t *acc0 = out + (((size_t)bi * 2 + 0) * L + i) * n, *acc1 = out + (((size_t)bi * 2 + 1) * L + i) * n;
+                memset(acc0, 0, n * sizeof(uint64_t)); memset(acc1, 0, n * sizeof(uint64_t));
+                for (size_t j = 0; j < Ld; ++j) {
+                    for (size_t k = 0; k < n; ++k) d[k] = digits[j * n + k] % q;
+                    ntt_fwd_poly(T, d);
+                    const uint64_t* k0 = key + ((j * 2 + 0) * L + i) * n;
+                    const uint64_t* k1 = key + ((j * 2 + 1) * L + i) * n;
+                    for (size_t k = 0; k < n; ++k) {
+                        uint64_t s0 = acc0[k] + mulmod_barrett(d[k], k0[k], T); acc0[k] = s0 - ((s0 >= q) ? q : 0);
+                        uint64_t s1 = acc1[k] + mulmod_barrett(d[k], k1[k], T); acc1[k] = s1 - ((s1 >= q) ? q : 0);
+                    }
+                }
+            }
+        }
+        free(d);
+    }
+}
+
 void orc_apply_galois(const orc_ctx* c, uint64_t* out, const uint64_t* in, size_t n_rns_polys, uint32_t g) {
     const size_t n = 1ull << c->log2n, L = c->n_limbs;
     for (size_t p = 0; p < n_rns_polys * L; ++p) {

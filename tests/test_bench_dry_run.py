@@ -1,0 +1,48 @@
+"""CPU: bench.py's multi-rank host path at world size 2 over gloo (`--dry-run`: kernels stood in by host arithmetic).  Walks the
+rendezvous, the native communicator's id shipping, the barriers, the all-gather of one partial per rank, the MAX / MIN reductions
+and the rank-0 report - what the driver's 1/2/4/8-GPU scaling run exercises (reference collective:
+/root/reference/src/core/distributed/distributed_context.cpp:97-122)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _line(out):
+    lines = [l for l in out.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out
+    return json.loads(lines[0])
+
+
+@pytest.mark.parametrize("world", [1, 2])
+def test_bench_dry_run_walks_every_collective(world):
+    cmd = [sys.executable]
+    if world > 1:
+        cmd += ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1", "--master-port", str(_free_port())]
+    cmd += [os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "3", "--warmup", "1", "--dry-run", "--native-comm"]
+    run = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert run.returncode == 0, run.stdout + run.stderr
+    r = _line(run.stdout)
+    assert r["dry_run"] is True and r["n_gpus"] == world and r["steps"] == 3 and r["warmup"] == 1 and r["scaling"] == "weak"
+    assert r["reduce_consistent"] is True and r["global_sum_matches_world1"] is True and r["native_comm_id_shipped"] is True
+    assert r["per_rank_ct_mul_per_s"]["ranks"] == world and 0 < r["per_rank_ct_mul_per_s"]["min"] <= r["per_rank_ct_mul_per_s"]["max"]
+    assert r["allgather_us"]["min"] <= r["allgather_us"]["median"] <= r["allgather_us"]["max"]
+    assert r["config"]["global_batch"] == world * r["config"]["batch_per_gpu"]
+    # value is the whole-job aggregate: all ranks' pairs over the MAX-over-ranks time
+    assert abs(r["value"] - r["config"]["global_batch"] * r["steps"] / (r["ms_per_step"] * 1e-3 * r["steps"])) < 1e-6 * r["value"]
+
+
+def test_bench_refuses_a_world_size_mismatch():
+    run = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run"], capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert run.returncode != 0 and "torch.distributed.run" in (run.stdout + run.stderr)

@@ -126,3 +126,23 @@ def test_emulated_split_transform_matches_oracle(emu, ln, arith):
             rc = emu.emu_ntt_split(arith, ln, inv, q, psi, a.ctypes.data_as(U), out.ctypes.data_as(U))
             assert rc == 0 and np.array_equal(out, ref(a))
     assert emu.emu_overflows() == before, "lazy arithmetic wrapped around 2^64"
+
+
+def test_dot30_column_accumulators_match_128_bit_arithmetic(emu):
+    """The FoldArith matvec kernels accumulate products of canonical residues in three 64-bit columns (operands split at bit 30)
+    and fold every 8 terms: same result as exact integer arithmetic, no 64-bit wrap, for random and worst-case operands."""
+    emu.emu_dot30.argtypes = [C.c_uint64, U, U, C.c_size_t]
+    emu.emu_dot30.restype = C.c_uint64
+    rng = np.random.default_rng(5)
+    before = emu.emu_overflows()
+    for q, _, _ in PRIMES_60[:6]:
+        for n in (1, 7, 8, 9, 16, 31, 32, 64, 127, 1000):
+            cases = [(rng.integers(0, q, n, dtype=np.uint64), rng.integers(0, q, n, dtype=np.uint64)),
+                     (np.full(n, q - 1, np.uint64), np.full(n, q - 1, np.uint64)),
+                     (np.full(n, (1 << 30) - 1, np.uint64), np.full(n, q - 1, np.uint64)),
+                     (np.full(n, q - 1, np.uint64), np.full(n, ((1 << 30) - 1) << 30, np.uint64) % np.uint64(q))]
+            for a, b in cases:
+                a, b = np.ascontiguousarray(a), np.ascontiguousarray(b)
+                want = sum(int(x) * int(y) for x, y in zip(a, b)) % q
+                assert emu.emu_dot30(q, a.ctypes.data_as(U), b.ctypes.data_as(U), n) == want
+    assert emu.emu_overflows() == before

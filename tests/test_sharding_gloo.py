@@ -76,3 +76,24 @@ def test_world2_allgather_reduce_matches_single_process(tmp_path, total):
 def test_allgather_without_process_group_is_identity():
     t = torch.arange(12, dtype=torch.int64).reshape(3, 4)
     assert torch.equal(allgather_partials(t), t.unsqueeze(0))
+
+
+def _rendezvous_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from deeppowers_amd.sharding import NativeComm
+    r, w, uid = NativeComm.rendezvous()
+    assert (r, w) == (rank, world) and isinstance(uid, bytes) and len(uid) == 128
+    with open(os.path.join(out_dir, f"id{rank}"), "wb") as f:
+        f.write(uid)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_native_comm_rendezvous_ships_rank0s_rccl_id_at_world2(tmp_path):
+    """The id-shipping half of the library's own communicator (dpfhe_comm_unique_id on rank 0 -> 128 bytes to every rank) at world
+    size 2: needs no device, so it runs here; dpfhe_comm_create / dpfhe_comm_allgather are exercised on the GPU box."""
+    world = 2
+    mp.spawn(_rendezvous_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    ids = [open(os.path.join(tmp_path, f"id{r}"), "rb").read() for r in range(world)]
+    assert ids[0] == ids[1] and len(ids[0]) == 128 and any(ids[0])

@@ -302,3 +302,17 @@ extern "C" int emu_lds_words(int log2n, int loge) {
     if (log2n == 10 && loge == 4) return Geo<10, 4>::lds_words();
     return -1;
 }
+
+// FoldArith::dot30_* (the plaintext matvec's column accumulators): dot product of canonical residues through the very code
+// the kernel runs (fold every kDot30Period terms, the running word riding in column 0), against 128-bit arithmetic.
+extern "C" u64 emu_dot30(u64 q, const u64* a, const u64* b, size_t n) {
+    LimbConst lc{};
+    lc.q = q; lc.d = (1ull << 60) - q;
+    FoldArith::Dot30 acc{0, 0, 0};
+    int since = 0;
+    for (size_t i = 0; i < n; ++i) {
+        FoldArith::dot30_mac(acc, FoldArith::split30(a[i]), FoldArith::split30(b[i]));
+        if (++since == FoldArith::kDot30Period) { acc = FoldArith::Dot30{FoldArith::dot30_fold(acc, 0, lc), 0, 0}; since = 0; }
+    }
+    return FoldArith::canon_small(since ? FoldArith::dot30_fold(acc, 0, lc) : acc.s0, lc);
+}
