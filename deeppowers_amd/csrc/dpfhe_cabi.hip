@@ -383,7 +383,9 @@ static int hybrid_entry(dpfhe_ctx* c, const char* what, int in_comps, uint64_t* 
             return fail(DPFHE_INVALID_ARGUMENT, what, "output, input and work buffers must not overlap");
     }
     const size_t blocks = batch * L;
-    if (blocks > kMaxGrid) return fail(DPFHE_INVALID_ARGUMENT, what, "batch too large for one launch");
+    // the grouped launch pads the grid to whole XCD rounds (launch_impl.h launch_relin): ceil(blocks / group / 8) * 8 * group workgroups
+    const size_t kg = key_group ? key_group : 1, padded = ((blocks / kg + 7) / 8) * 8 * kg;
+    if (blocks > kMaxGrid || padded > kMaxGrid) return fail(DPFHE_INVALID_ARGUMENT, what, "batch too large for one launch");
     DPFHE_ON_DEVICE(c, "hybrid key switch");
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int mode = in_comps == 3 ? 2 : 3;
@@ -494,7 +496,8 @@ extern "C" int dpfhe_rotate_hybrid_hoisted(dpfhe_ctx* c, uint64_t* d_out2, const
         return fail(DPFHE_INVALID_ARGUMENT, what, "buffers must not overlap");
     const size_t key_words = Ld * 2 * L * (size_t)n;
     const int chunks = (n + 511) / 512;
-    if (total * 2 * Ld * (size_t)chunks > kMaxGrid || total * L * 2 > kMaxGrid || T * Ld * L * (size_t)chunks > kMaxGrid)
+    // (the key-switch launch pads its (rotation, limb[, component]) tiles to a multiple of 8 per token: launch_impl.h launch_hoisted_ks)
+    if (total * 2 * Ld * (size_t)chunks > kMaxGrid || (total * L * 2 + 8 * T) > kMaxGrid || T * Ld * L * (size_t)chunks > kMaxGrid)
         return fail(DPFHE_INVALID_ARGUMENT, what, "batch too large for one launch");
     const LimbConst* lc = c->fold ? c->foldt.lc : c->shoup.lc;
     hipStream_t s = static_cast<hipStream_t>(stream);
@@ -814,8 +817,8 @@ extern "C" int dpfhe_reduce_sum(dpfhe_ctx* c, uint64_t* d_out, const uint64_t* d
     const size_t want = count / 8 ? count / 8 : 1;
     const unsigned splits = (unsigned)(want < (size_t)kReduceSplits ? want : (size_t)kReduceSplits);
     hipStream_t s = static_cast<hipStream_t>(stream);
-    HIP_TRY(hipMemsetAsync(d_out, 0, words_per_item * sizeof(u64), s));
     if (blocks * (size_t)chunks * splits > kMaxGrid) return fail(DPFHE_INVALID_ARGUMENT, "dpfhe_reduce_sum", "too many components for one launch");
+    HIP_TRY(hipMemsetAsync(d_out, 0, words_per_item * sizeof(u64), s));   // after every validation: a rejected call leaves d_out untouched
     const unsigned poly_chunks = (unsigned)(blocks * chunks);
     // two workgroups per CU walk the work items: as fast as an uncapped launch when alone (537 vs 551 us for 8192 x 3
     // components at N=4096) and 2 % faster for the multiply it overlaps with in bench.py

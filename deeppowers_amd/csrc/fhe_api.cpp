@@ -9,6 +9,7 @@
 #include <cerrno>
 #include <cstdio>
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <istream>
 #include <ostream>
@@ -1255,6 +1256,8 @@ uint32_t BatchEncoder::galois_element(int left_rotation) const {
 }
 
 // ---- N3: packed matrix-vector product (diagonal method, baby-step / giant-step) -------------------------------------------
+constexpr int kBabyShiftDefault = 1;
+
 class PackedLinear::Impl {
 public:
     const Context* ctx = nullptr;
@@ -1323,6 +1326,13 @@ PackedLinear::PackedLinear(const Context& ctx, const BatchEncoder& enc, HybridKe
     I.passes = I.replicate ? 1 : (I.blocks + I.copies - 1) / I.copies;
     size_t n1 = 1;
     while (n1 * n1 < I.m) n1 <<= 1;
+    // A hoisted baby step (gathers + key inner products, no transform) costs about a third of a giant step (Ld transforms per limb + its
+    // share of the inverse transform and the division by P), so the split leans towards baby steps: n1 = 2 sqrt(m) when m allows.
+    // DPFHE_BSGS_BABY_SHIFT overrides the exponent (experiments).
+    int shift = kBabyShiftDefault;
+    if (const char* e = std::getenv("DPFHE_BSGS_BABY_SHIFT")) shift = std::atoi(e);
+    for (; shift > 0 && n1 * 2 < I.m; --shift) n1 <<= 1;
+    for (; shift < 0 && n1 > 2; ++shift) n1 >>= 1;
     I.n1 = n1; I.n2 = I.m / n1;
     const uint64_t t = enc.plain_modulus();
     for (size_t j = 1; j < I.n1; ++j) I.baby_elts.push_back(enc.galois_element((int)j));

@@ -337,12 +337,20 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE)) void ntt_inv_galois_kernel(u64*
     B::template load_tw<B::NPH - 1, false>(tid, tw, tw_first);
     const u64* src = in + p * N;
     u64 x[E];
+    if constexpr (B::kLdsIO) {   // coalesced 16-byte loads of the wave's source region, permuted through its LDS rows (ntt_core.h stage_gather)
+        unsigned addr[E];
+        const long shift = B::gather_plan(tid, g, addr);
+        u64 v[E];
+        B::stage_load(tid, v, src + shift);
+        B::stage_gather(tid, x, v, lds, addr);
+    } else {
 #pragma unroll
-    for (int kk = 0; kk < E; ++kk) {
-        const unsigned pos = (unsigned)tid * E + kk;
-        const unsigned e = 2u * (__brev(pos) >> (32 - LOGN)) + 1u;
-        const unsigned e2 = (g * e) & (2u * N - 1u);
-        x[kk] = src[__brev((e2 - 1u) >> 1) >> (32 - LOGN)];
+        for (int kk = 0; kk < E; ++kk) {
+            const unsigned pos = (unsigned)tid * E + kk;
+            const unsigned e = 2u * (__brev(pos) >> (32 - LOGN)) + 1u;
+            const unsigned e2 = (g * e) & (2u * N - 1u);
+            x[kk] = src[__brev((e2 - 1u) >> 1) >> (32 - LOGN)];
+        }
     }
     if constexpr (B::G::T <= 64) __syncthreads();   // single-wave geometries have no barrier inside the transform
     InvChain<B, B::NPH - 1, kUnit>::run_with(tid, x, lds, tw, last, lc, tw_first);
@@ -1005,6 +1013,11 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE), (Arith::kFold ? 2 : 1)) void ho
                                                                                            u64 p_special, DevTables<Arith> tb) {
     typedef NttBody<Arith, LOGN, LOGE> B;
     constexpr int E = B::E, N = B::G::N;
+    // Every operand tile goes through the wave's private LDS rows (ntt_core.h stage_*): key tiles row by row, the permuted digit
+    // words and c0 by stage_gather - coalesced 16-byte global loads only, no register transposition (80 VALU instructions per tile)
+    // and no 8-byte gathers.  Geometries without the row layout (N < 1024) keep register transposes and global gathers.
+    constexpr bool kStage = B::kLdsIO && Arith::kFold;   // (the generic-prime path keeps its registers for the 128-bit Barrett products)
+    __shared__ __attribute__((aligned(16))) u64 lds[kStage ? B::G::lds_words() : 16];
     const int tid = threadIdx.x;
     const int L = tb.n_limbs, Ld = L - 1;
     const unsigned q = blockIdx.x >> 3, token = q % n_items, tile = (q / n_items) * 8u + (blockIdx.x & 7u);
@@ -1016,40 +1029,17 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE), (Arith::kFold ? 2 : 1)) void ho
     const LimbConst lc = tb.lc[limb];
     const unsigned g = elts.v[rot];
     const u64* evk = keys + rot * key_stride;
-    unsigned src[E];
-#pragma unroll
-    for (int kk = 0; kk < E; ++kk) {
-        const unsigned p = (unsigned)tid * E + kk;
-        const unsigned e = 2u * (__brev(p) >> (32 - LOGN)) + 1u;
-        const unsigned e2 = (g * e) & (2u * N - 1u);
-        src[kk] = __brev((e2 - 1u) >> 1) >> (32 - LOGN);
-    }
-    u64 acc0[E], acc1[E], x[E], e[E];
-    // first term of component 0: P perm_g(NTT(c0)) on the data limbs (one lazily added product like the others)
     const u64 pmod = canon_any<Arith>(p_special, lc);
-    if (limb < Ld) {
-        const u64* c0 = xntt + ((size_t)token * 2 * Ld + limb) * N;
+    u64 acc0[E], acc1[E], x[E], e[E];
+    auto mac = [&](u64 (&acc)[E], bool first) {
 #pragma unroll
         for (int k = 0; k < E; ++k) {
-            const u64 v = c0[src[k]];
-            acc0[k] = Arith::kFold ? FoldArith::mul60(v, pmod, (u32)lc.d) : ShoupArith::mul_var(v, pmod, lc);
-            acc1[k] = 0;
+            if (Arith::kFold) acc[k] = (first ? 0 : acc[k]) + FoldArith::mul60(x[k], e[k], (u32)lc.d);
+            else acc[k] = first ? ShoupArith::mul_var(x[k], e[k], lc) : add_mod(acc[k], ShoupArith::mul_var(x[k], e[k], lc), lc.q);
         }
-    } else {
-#pragma unroll
-        for (int k = 0; k < E; ++k) acc0[k] = acc1[k] = 0;
-    }
-    B::load_bot(tid, e, evk + ((size_t)0 * L + limb) * N);
-    {
-        const u64* d = digits + (size_t)limb * N;
-#pragma unroll
-        for (int k = 0; k < E; ++k) x[k] = d[src[k]];
-    }
-    int lazy_terms = 1;
-#pragma unroll 1
-    for (int j = 0; j < Ld; ++j) {
-        u64 e1[E], xn[E];
-        B::load_bot(tid, e1, evk + (((size_t)j * 2 + 1) * L + limb) * N);
+    };
+    int lazy_terms = 0;
+    auto lazy_guard = [&]() {   // 13 lazily added products + one reduced word stay below 15 q
         if (Arith::kFold) {
             if (lazy_terms == 13) {
 #pragma unroll
@@ -1058,28 +1048,86 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE), (Arith::kFold ? 2 : 1)) void ho
             }
             ++lazy_terms;
         }
+    };
+    if constexpr (kStage) {
+        unsigned addr[E];
+        const long shift = B::gather_plan(tid, g, addr);
+        u64 ve[E], vx[E];   // two tiles in flight (a third prefetch buffer spills at 2 waves per SIMD)
+        // component 0 starts with P perm_g(NTT(c0)) on the data limbs
+        if (limb < Ld) {
+            B::stage_load(tid, vx, xntt + ((size_t)token * 2 * Ld + limb) * N + shift);
+            B::stage_gather(tid, x, vx, lds, addr);
 #pragma unroll
-        for (int k = 0; k < E; ++k)
-            acc0[k] = Arith::kFold ? acc0[k] + FoldArith::mul60(x[k], e[k], (u32)lc.d) : add_mod(acc0[k], ShoupArith::mul_var(x[k], e[k], lc), lc.q);
-        const int jn = j + 1 < Ld ? j + 1 : j;
-        B::load_bot(tid, e, evk + (((size_t)jn * 2 + 0) * L + limb) * N);
-        {
-            const u64* d = digits + ((size_t)jn * L + limb) * N;
+            for (int k = 0; k < E; ++k) {
+                acc0[k] = Arith::kFold ? FoldArith::mul60(x[k], pmod, (u32)lc.d) : ShoupArith::mul_var(x[k], pmod, lc);
+                acc1[k] = 0;
+            }
+            lazy_terms = 1;
+        } else {
 #pragma unroll
-            for (int k = 0; k < E; ++k) xn[k] = d[src[k]];
+            for (int k = 0; k < E; ++k) acc0[k] = acc1[k] = 0;
         }
+        B::stage_load(tid, ve, evk + ((size_t)0 * L + limb) * N);
+        B::stage_load(tid, vx, digits + (size_t)limb * N + shift);
+#pragma unroll 1
+        for (int j = 0; j < Ld; ++j) {
+            B::stage_rows(tid, e, ve, lds);
+            B::stage_gather(tid, x, vx, lds, addr);
+            const int jn = j + 1 < Ld ? j + 1 : j;   // the last iteration re-requests its own tiles (cache hits) instead of branching
+            B::stage_load(tid, ve, evk + (((size_t)j * 2 + 1) * L + limb) * N);       // in flight during the first component's products
+            B::stage_load(tid, vx, digits + ((size_t)jn * L + limb) * N + shift);
+            lazy_guard();
+            mac(acc0, false);
+            B::stage_rows(tid, e, ve, lds);
+            B::stage_load(tid, ve, evk + (((size_t)jn * 2 + 0) * L + limb) * N);      // ... during the second component's
+            mac(acc1, false);
+        }
+    } else {
+        unsigned src[E];
 #pragma unroll
-        for (int k = 0; k < E; ++k)
-            acc1[k] = Arith::kFold ? acc1[k] + FoldArith::mul60(x[k], e1[k], (u32)lc.d) : add_mod(acc1[k], ShoupArith::mul_var(x[k], e1[k], lc), lc.q);
+        for (int kk = 0; kk < E; ++kk) {
+            const unsigned p = (unsigned)tid * E + kk;
+            const unsigned ee = 2u * (__brev(p) >> (32 - LOGN)) + 1u;
+            const unsigned e2 = (g * ee) & (2u * N - 1u);
+            src[kk] = __brev((e2 - 1u) >> 1) >> (32 - LOGN);
+        }
+        if (limb < Ld) {
+            const u64* c0 = xntt + ((size_t)token * 2 * Ld + limb) * N;
 #pragma unroll
-        for (int k = 0; k < E; ++k) x[k] = xn[k];
+            for (int k = 0; k < E; ++k) {
+                const u64 v = c0[src[k]];
+                acc0[k] = Arith::kFold ? FoldArith::mul60(v, pmod, (u32)lc.d) : ShoupArith::mul_var(v, pmod, lc);
+                acc1[k] = 0;
+            }
+            lazy_terms = 1;
+        } else {
+#pragma unroll
+            for (int k = 0; k < E; ++k) acc0[k] = acc1[k] = 0;
+        }
+#pragma unroll 1
+        for (int j = 0; j < Ld; ++j) {
+            const u64* d = digits + ((size_t)j * L + limb) * N;
+#pragma unroll
+            for (int k = 0; k < E; ++k) x[k] = d[src[k]];
+            B::load_bot(tid, e, evk + (((size_t)j * 2 + 0) * L + limb) * N);
+            lazy_guard();
+            mac(acc0, false);
+            B::load_bot(tid, e, evk + (((size_t)j * 2 + 1) * L + limb) * N);
+            mac(acc1, false);
+        }
     }
     if (Arith::kFold) {
 #pragma unroll
         for (int k = 0; k < E; ++k) { acc0[k] = FoldArith::canon(acc0[k], lc); acc1[k] = FoldArith::canon(acc1[k], lc); }
     }
-    B::store_bot(tid, acc0, out + ((item * 2 + 0) * L + limb) * N);
-    B::store_bot(tid, acc1, out + ((item * 2 + 1) * L + limb) * N);
+    if constexpr (kStage) {
+        B::store_bot_lds(tid, acc0, out + ((item * 2 + 0) * L + limb) * N, lds);
+        wave_sync();
+        B::store_bot_lds(tid, acc1, out + ((item * 2 + 1) * L + limb) * N, lds);
+    } else {
+        B::store_bot(tid, acc0, out + ((item * 2 + 0) * L + limb) * N);
+        B::store_bot(tid, acc1, out + ((item * 2 + 1) * L + limb) * N);
+    }
 }
 
 }  // namespace dpfhe

@@ -335,6 +335,7 @@ __global__ __launch_bounds__(256) void matvec_fold_kernel(u64* y, const u64* W, 
                                                           unsigned n_tiles) {
     typedef WordVec<WPT> V;
     typedef FoldArith::Half30 H;
+    constexpr int P = FoldArith::kDot30Period;
     const size_t L = (size_t)n_limbs;
     const unsigned n_slabs = (unsigned)L * (unsigned)chunks, R = n_tiles / n_slabs;
     const unsigned id = blockIdx.x, lane = id & 7u, q = id >> 3;
@@ -343,59 +344,72 @@ __global__ __launch_bounds__(256) void matvec_fold_kernel(u64* y, const u64* W, 
     const int chunk = (int)(slab % chunks);
     const int limb = (int)(slab / chunks);
     const size_t row0 = (size_t)rt * RT;
-    const int w0 = chunk * 256 * WPT + threadIdx.x * WPT;
-    if (w0 >= n) return;
+    const unsigned w0 = (unsigned)(chunk * 256 * WPT + (int)threadIdx.x * WPT);   // the ONLY per-thread part of every address
+    if ((int)w0 >= n) return;
     x += (size_t)group * C * L * n;
     y += (size_t)group * C * L * n;
     const LimbConst lc = lcs[limb];
     const size_t wstride = L * n, xstride = polys_per_col * L * n, rstride = cols * L * n;
-    FoldArith::Dot30 acc[RT][C][WPT];   // the folded running word rides in column 0 of the fresh accumulator (8 products + 1 word < 10 * 2^60)
+    // uniform bases (scalar registers, scalar adds) + one 32-bit lane offset: no per-lane 64-bit address arithmetic
+    const u64* const wu = W + (row0 * cols * L + limb) * n;
+    const u64* const xu = x + (size_t)limb * n;
+    auto ld_w = [&](int r, size_t j) { return load_words<WPT>(&(wu + (r * rstride + j * wstride))[w0], row0 + r < rows); };
+    auto ld_x = [&](int c, size_t j) { return *reinterpret_cast<const V*>(&(xu + (j * xstride + (size_t)c * L * n))[w0]); };
+    u64 run[RT][C][WPT];   // folded running words (reduced); the first products of every period chain onto them
 #pragma unroll
     for (int r = 0; r < RT; ++r)
 #pragma unroll
         for (int c = 0; c < C; ++c)
 #pragma unroll
-            for (int k = 0; k < WPT; ++k) acc[r][c][k] = FoldArith::Dot30{0, 0, 0};
-    const u64* wp = W + (row0 * cols * L + limb) * n + w0;
-    const u64* xp = x + (size_t)limb * n + w0;
+            for (int k = 0; k < WPT; ++k) run[r][c][k] = 0;
     V w[RT], xv[C];
 #pragma unroll
-    for (int r = 0; r < RT; ++r) w[r] = load_words<WPT>(wp + r * rstride, row0 + r < rows);
+    for (int r = 0; r < RT; ++r) w[r] = ld_w(r, 0);
 #pragma unroll
-    for (int c = 0; c < C; ++c) xv[c] = *reinterpret_cast<const V*>(xp + (size_t)c * L * n);
-    int since = 0;
-    for (size_t j = 0; j < cols; ++j) {
-        const size_t jn = j + 1 < cols ? j + 1 : j;
-        V wn[RT], xn[C];
+    for (int c = 0; c < C; ++c) xv[c] = ld_x(c, 0);
+    // Periods of P columns, unrolled: the accumulators of a period start from {running word, 0, 0} as multiply-add addends (no
+    // zeroing moves), the operands of column j + 1 are requested before the RT x C products of column j, one fold ends the period.
+    for (size_t j0 = 0; j0 < cols; j0 += P) {
+        FoldArith::Dot30 acc[RT][C][WPT];
 #pragma unroll
-        for (int r = 0; r < RT; ++r) wn[r] = load_words<WPT>(wp + r * rstride + jn * wstride, row0 + r < rows);
+        for (int u = 0; u < P; ++u) {
+            const size_t j = j0 + u;
+            if (j >= cols) {   // ragged last period: nothing to add (uniform branch)
+                if (u == 0) break;
+                continue;
+            }
+            const size_t jn = j + 1 < cols ? j + 1 : j;
+            V wn[RT], xn[C];
 #pragma unroll
-        for (int c = 0; c < C; ++c) xn[c] = *reinterpret_cast<const V*>(xp + jn * xstride + (size_t)c * L * n);
+            for (int r = 0; r < RT; ++r) wn[r] = ld_w(r, jn);
 #pragma unroll
-        for (int k = 0; k < WPT; ++k) {
-            H wh[RT], xh[C];
+            for (int c = 0; c < C; ++c) xn[c] = ld_x(c, jn);
 #pragma unroll
-            for (int r = 0; r < RT; ++r) wh[r] = FoldArith::split30(w[r].v[k]);
+            for (int k = 0; k < WPT; ++k) {
+                H wh[RT], xh[C];
 #pragma unroll
-            for (int c = 0; c < C; ++c) xh[c] = FoldArith::split30(xv[c].v[k]);
+                for (int r = 0; r < RT; ++r) wh[r] = FoldArith::split30(w[r].v[k]);
 #pragma unroll
-            for (int c = 0; c < C; ++c)
-#pragma unroll
-                for (int r = 0; r < RT; ++r) FoldArith::dot30_mac(acc[r][c][k], wh[r], xh[c]);
-        }
-#pragma unroll
-        for (int r = 0; r < RT; ++r) w[r] = wn[r];
-#pragma unroll
-        for (int c = 0; c < C; ++c) xv[c] = xn[c];
-        if (++since == FoldArith::kDot30Period) {
-#pragma unroll
-            for (int r = 0; r < RT; ++r)
+                for (int c = 0; c < C; ++c) xh[c] = FoldArith::split30(xv[c].v[k]);
 #pragma unroll
                 for (int c = 0; c < C; ++c)
 #pragma unroll
-                    for (int k = 0; k < WPT; ++k) acc[r][c][k] = FoldArith::Dot30{FoldArith::dot30_fold(acc[r][c][k], 0, lc), 0, 0};
-            since = 0;
+                    for (int r = 0; r < RT; ++r) {
+                        if (u == 0) acc[r][c][k] = FoldArith::Dot30{run[r][c][k], 0, 0};
+                        FoldArith::dot30_mac(acc[r][c][k], wh[r], xh[c]);
+                    }
+            }
+#pragma unroll
+            for (int r = 0; r < RT; ++r) w[r] = wn[r];
+#pragma unroll
+            for (int c = 0; c < C; ++c) xv[c] = xn[c];
         }
+#pragma unroll
+        for (int r = 0; r < RT; ++r)
+#pragma unroll
+            for (int c = 0; c < C; ++c)
+#pragma unroll
+                for (int k = 0; k < WPT; ++k) run[r][c][k] = FoldArith::dot30_fold(acc[r][c][k], 0, lc);
     }
 #pragma unroll
     for (int r = 0; r < RT; ++r) {
@@ -404,8 +418,8 @@ __global__ __launch_bounds__(256) void matvec_fold_kernel(u64* y, const u64* W, 
         for (int c = 0; c < C; ++c) {
             V o;
 #pragma unroll
-            for (int k = 0; k < WPT; ++k) o.v[k] = FoldArith::canon_small(since ? FoldArith::dot30_fold(acc[r][c][k], 0, lc) : acc[r][c][k].s0, lc);
-            *reinterpret_cast<V*>(y + (((row0 + r) * polys_per_col + c) * L + limb) * n + w0) = o;
+            for (int k = 0; k < WPT; ++k) o.v[k] = FoldArith::canon_small(run[r][c][k], lc);
+            *reinterpret_cast<V*>(&(y + (((row0 + r) * polys_per_col + c) * L + limb) * n)[w0]) = o;
         }
     }
 }

@@ -5,6 +5,14 @@
 
 namespace dpfhe {
 
+// gfx950 ONLY: the paired / quad fused kernels (ct_mul_dual_kernel, ct_mul_quad_kernel, relin_shared_kernel, hoisted_ks2_kernel) hold
+// TWO padded LDS images of a polynomial per workgroup - 76 KiB at N = 4096, 152 KiB at N = 8192 of CDNA4's 160 KiB per CU (gfx942
+// has 64 KiB: this library does not build for it, by design - no dual paths).  A padding change that breaks the budget fails here,
+// not at launch time.
+constexpr size_t kLdsBytesPerCu = 160 * 1024;
+static_assert(2 * sizeof(u64) * Geo<13, kFusedLoge>::lds_words() <= kLdsBytesPerCu, "two LDS images of an N = 8192 polynomial must fit one CU's 160 KiB");
+static_assert(sizeof(u64) * Geo<14, 4>::lds_words() <= kLdsBytesPerCu, "the N = 16384 transform's LDS image must fit one CU's 160 KiB");
+
 // (log2n -> LOGE) pairs proven by tests/test_emulated_kernels.py
 #define DPFHE_GEO_SWITCH(log2n, MACRO) \
     switch (log2n) {                   \
@@ -70,8 +78,11 @@ static int launch_ct_mul_dom(int log2n, u64* out3, const u64* a2, const u64* b2,
 #ifndef DPFHE_CTMUL_QUAD
 #define DPFHE_CTMUL_QUAD 1
 #endif
+#ifndef DPFHE_CTMUL_QUAD_MAXLOGN
+#define DPFHE_CTMUL_QUAD_MAXLOGN 12   // tools/ab_variant.sh quad13 -DDPFHE_CTMUL_QUAD_MAXLOGN=13 builds the N = 8192 form for A/B runs
+#endif
 #define CT_CASE(LN, LE)                                                                                                                              \
-    if constexpr (DPFHE_CTMUL_QUAD && Arith::kFold && !IN_NTT && !OUT_NTT && LN <= 12)                                                           \
+    if constexpr (DPFHE_CTMUL_QUAD && Arith::kFold && !IN_NTT && !OUT_NTT && LN <= DPFHE_CTMUL_QUAD_MAXLOGN)                                                           \
         hipLaunchKernelGGL((ct_mul_quad_kernel<Arith, LN, kFusedLoge>), dim3((unsigned)blocks), dim3(Geo<LN, kFusedLoge>::T), 0, s, out3, a2, b2, tb); \
     else if constexpr (DPFHE_CTMUL_DUAL && Arith::kFold && !IN_NTT && LN <= DPFHE_CTMUL_DUAL_MAXLOGN)                                                                                          \
         hipLaunchKernelGGL((ct_mul_dual_kernel<Arith, LN, kFusedLoge, OUT_NTT>), dim3((unsigned)blocks), dim3(Geo<LN, kFusedLoge>::T), 0, s, out3, a2, b2, tb); \

@@ -76,6 +76,17 @@ DPF_HD u64 csub(u64 x, u64 m) {
     return x >= m ? t : x;
 }
 
+// a + x 2^32 when the sum is known not to carry out of 64 bits: one 32-bit add into the high word
+DPF_HD u64 add_hi32(u64 a, u32 x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    u32 hi = (u32)(a >> 32);
+    asm("v_add_u32 %0, %1, %2" : "=v"(hi) : "v"(hi), "v"(x));
+    return ((u64)hi << 32) | (u32)a;
+#else
+    return a + ((u64)x << 32);
+#endif
+}
+
 // -------------------------------------------------------------------------------------------------
 struct alignas(16) TwShoup {
     u64 w, wsh;
@@ -219,20 +230,30 @@ struct FoldArith {
     static DPF_HD void dot30_mac(Dot30& s, const Half30& a, const Half30& b) {
         DPFHE_EMU_ASSERT(s.s0 < (15ull << 60) && s.s1 < (14ull << 60) && s.s2 < (15ull << 60));
         s.s0 = mad32(a.lo, b.lo, s.s0);
-        s.s1 = mad32(a.hi, b.lo, mad32(a.lo, b.hi, s.s1));
+        u64 m = mad32(a.lo, b.hi, s.s1);
+#if defined(__HIP_DEVICE_COMPILE__)
+        asm("" : "+v"(m));   // keep the chain as written: hipcc otherwise sums the two cross products first and spends a 64-bit add on s1
+#endif
+        s.s1 = mad32(a.hi, b.lo, m);
         s.s2 = mad32(a.hi, b.hi, s.s2);
     }
-    // folds the columns and a running reduced word r (< 2^60 + 2^29) into a new running word < 2^60 + 16 d
+    // folds the columns and a running reduced word r (< 2^60 + 2^29) into a new running word < 2^60 + 16 d.  Written on 32-bit halves so
+    // that every step is ONE instruction: the shifted addends are built by multiply-adds with 2^30 and by an add into the high word
+    // (left as 64-bit shifts hipcc materialises {0, x} register pairs: 23 instructions instead of 16).
     static DPF_HD u64 dot30_fold(const Dot30& s, u64 r, const LimbConst& c) {
         DPFHE_EMU_ASSERT(r < (1ull << 60) + (1ull << 29));
         const u32 d = (u32)c.d;
-        const u64 r0 = reduce(s.s0, c);                                         // < 2^60 + 16 d
+        u32 two30 = 1u << 30;
+#if defined(__HIP_DEVICE_COMPILE__)
+        asm("s_mov_b32 %0, 0x40000000" : "=s"(two30));                         // opaque: x * 2^30 + y stays one v_mad_u64_u32
+#endif
+        const u64 r0 = reduce(s.s0, c) + r;                                     // < 2^61 + 2^30            (r is 0 in the matvec kernels: folded away)
         const u64 U = s.s2 + (s.s1 >> 30);                                      // < 2^63 + 2^34
-        const u64 V = r0 + r + ((u64)((u32)s.s1 & 0x3fffffffu) << 30);          // < 3 * 2^60 + 2^30
+        const u64 V = mad32((u32)s.s1 & 0x3fffffffu, two30, r0);                // + (S1 mod 2^30) 2^30:  < 3 * 2^60 + 2^30
         const u64 T = mad32((u32)(U >> 32), d, 0);                              // U.hi d < 2^56;  U.hi d 2^32 = (T mod 2^28) 2^32 + (T >> 28) 2^60
         u64 A = mad32((u32)U, d, V);                                            // < 3 * 2^60 + 2^57
         A = mad32((u32)(T >> 28), d, A);                                        // + < 2^52
-        A += (u64)((u32)T & 0x0fffffffu) << 32;                                 // + < 2^60: A < 2^63
+        A = add_hi32(A, (u32)T & 0x0fffffffu);                                  // + (T mod 2^28) 2^32 < 2^60: A < 2^63, no carry out of the high word
         return reduce(A, c);
     }
 };

@@ -371,11 +371,14 @@ struct NttBody {
     // exchange, so no workgroup barrier is needed around it - only before a LATER all-to-all exchange overwrites the rows.
     // Lane L moves, in slice r, piece (L/8 + L%8) % 8 of thread 8r + L%8: the skew keeps 16 consecutive lanes on 16
     // different 16-byte slots.
+    // Both results are a per-thread base (slice 0) plus a compile-time multiple of r - written that way so that ONE address register
+    // and immediate offsets serve all eight slices (left as lds_row(thread of slice r) the compiler rebuilds every address with
+    // bit-field arithmetic: ~30 VALU instructions per transform).
     static __device__ __forceinline__ void lds_slice(int tid, int r, unsigned& lds_word, unsigned& piece) {
         const unsigned lane = (unsigned)tid & 63u, wave_thread0 = (unsigned)tid & ~63u, i = lane & 7u, pc = ((lane >> 3) + i) & 7u;
-        const unsigned t = wave_thread0 + ((unsigned)r << 3) + i;
-        lds_word = (unsigned)G::lds_row((int)t) + pc * 2;
-        piece = t * PC + pc;
+        const unsigned base_w = (unsigned)G::lds_row((int)(wave_thread0 + i)) + pc * 2, base_p = (wave_thread0 + i) * PC + pc;   // thread 8 r + i of the wave, r = 0
+        lds_word = base_w + (unsigned)r * (8u * (E + 2));
+        piece = base_p + (unsigned)r * (8u * PC);
     }
     static __device__ __forceinline__ void load_bot_lds(int tid, u64 (&x)[E], const u64* g, u64* lds) {
         const V2* p = reinterpret_cast<const V2*>(g);
@@ -388,6 +391,60 @@ struct NttBody {
 #pragma clang loop unroll(full)
         for (int k = 0; k < PC; ++k) { V2 t = row[k]; x[2 * k] = t.a; x[2 * k + 1] = t.b; }
     }
+    // The same staging in two halves, for callers that want the global loads in flight while they compute: stage_load requests the
+    // wave's 64 E-word region (lane-contiguous 16-byte pieces), stage_rows / stage_gather put it through the wave's LDS rows.
+    // stage_gather reads word k of the thread from LDS word addr[k] instead of its own row: the Galois permutation in the NTT domain
+    // maps every aligned 2^s-word block ONTO an aligned 2^s-word block (high bits of the bit-reversed index depend on high bits only),
+    // so a thread's E source words sit in ONE row and a wave's sources in ONE 64 E-word region - `g` is then the polynomial shifted
+    // by (source region - own region) * 64 E words, and no 8-byte global gather is left.  Rows are wave-private: wavefront-scope
+    // ordering only (the LDS runs one wave's DS instructions in order); the caller fences before reusing the rows.
+    static __device__ __forceinline__ void stage_load(int tid, u64 (&v)[E], const u64* g) {   // plain words: struct arrays carried around a loop stay in scratch
+        const V2* p = reinterpret_cast<const V2*>(g);
+#pragma clang loop unroll(full)
+        for (int r = 0; r < PC; ++r) { unsigned w, pc; lds_slice(tid, r, w, pc); const V2 t = p[pc]; v[2 * r] = t.a; v[2 * r + 1] = t.b; }
+    }
+    static __device__ __forceinline__ void stage_write(int tid, const u64 (&v)[E], u64* lds) {
+#pragma clang loop unroll(full)
+        for (int r = 0; r < PC; ++r) { unsigned w, pc; lds_slice(tid, r, w, pc); *reinterpret_cast<V2*>(lds + w) = V2{v[2 * r], v[2 * r + 1]}; }
+    }
+    static __device__ __forceinline__ void stage_rows(int tid, u64 (&x)[E], const u64 (&v)[E], u64* lds) {
+        stage_write(tid, v, lds);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const V2* row = reinterpret_cast<const V2*>(lds + (unsigned)G::lds_row(tid));
+#pragma clang loop unroll(full)
+        for (int k = 0; k < PC; ++k) { V2 t = row[k]; x[2 * k] = t.a; x[2 * k + 1] = t.b; }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+    static __device__ __forceinline__ void stage_gather(int tid, u64 (&x)[E], const u64 (&v)[E], u64* lds, const unsigned (&addr)[E]) {
+        stage_write(tid, v, lds);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma clang loop unroll(full)
+        for (int k = 0; k < E; ++k) x[k] = lds[addr[k]];
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+    // source addressing of stage_gather for the thread's E output positions tid E + k under sigma_g: LDS word addresses of the
+    // source words, and the region shift (in words) to add to the polynomial's base
+    static __device__ __forceinline__ long gather_plan(int tid, unsigned g, unsigned (&addr)[E]) {
+        unsigned src0 = 0;
+#pragma clang loop unroll(full)
+        for (int k = 0; k < E; ++k) {
+            const unsigned p = (unsigned)tid * E + k;
+            const unsigned e = 2u * (__brev(p) >> (32 - LOGN)) + 1u;
+            const unsigned e2 = (g * e) & (2u * G::N - 1u);
+            const unsigned sp = __brev((e2 - 1u) >> 1) >> (32 - LOGN);
+            if (k == 0) src0 = sp;
+            addr[k] = sp & (E - 1);
+        }
+        const unsigned row = (unsigned)G::lds_row((int)(((unsigned)tid & ~63u) + ((src0 >> LOGE) & 63u)));
+#pragma clang loop unroll(full)
+        for (int k = 0; k < E; ++k) addr[k] += row;
+        const int region = __builtin_amdgcn_readfirstlane((int)(src0 >> (6 + LOGE)));     // wave-uniform
+        return ((long)region - (long)(tid >> 6)) * (long)(64 * E);
+    }
     static __device__ __forceinline__ void store_bot_lds(int tid, const u64 (&x)[E], u64* g, u64* lds) {
         V2* row = reinterpret_cast<V2*>(lds + (unsigned)G::lds_row(tid));
 #pragma clang loop unroll(full)
@@ -398,6 +455,10 @@ struct NttBody {
     }
 #endif
 #if !defined(__HIP_DEVICE_COMPILE__)
+    static void stage_load(int, u64 (&)[E], const u64*) {}
+    static void stage_rows(int, u64 (&)[E], const u64 (&)[E], u64*) {}
+    static void stage_gather(int, u64 (&)[E], const u64 (&)[E], u64*, const unsigned (&)[E]) {}
+    static long gather_plan(int, unsigned, unsigned (&)[E]) { return 0; }
     static void load_bot_lds(int, u64 (&)[E], const u64*, u64*) {}   // device-only paths: never called on the host
     static void store_bot_lds(int, const u64 (&)[E], u64*, u64*) {}
 #endif

@@ -53,8 +53,15 @@ MESSAGES = [
 METHODS = [("EncryptedGenerate", "EncryptedGenerateRequest", "EncryptedGenerateResponse"),
            ("RegisterKeys", "RegisterKeysRequest", "RegisterKeysResponse"),
            ("GetMetrics", "MetricsRequest", "MetricsResponse")]
-# ciphertext batches are MBs (256 KiB per ciphertext at N=4096, L=4): lift gRPC's 4 MiB default
+# ciphertext batches are MBs (256 KiB per ciphertext at N=4096, L=4): gRPC's 4 MiB default is lifted - to a BOUND derived from the
+# parameters and a maximum batch on the server (one oversized request must not be able to exhaust the host or the GPU), without a
+# bound on the client's side of the channel
 CHANNEL_OPTIONS = [("grpc.max_receive_message_length", -1), ("grpc.max_send_message_length", -1)]
+
+
+def message_limit(params: FheParams, max_batch: int) -> int:
+    """bytes of the largest legal message: `max_batch` three-component ciphertexts + the wire header + protobuf framing slack"""
+    return max_batch * 3 * params.n_limbs * params.n * 8 + 4096 + 8 * params.n_limbs
 
 
 def _build_messages():
@@ -168,9 +175,10 @@ class _Metrics:
 class EncryptedInferenceServer:
     """gRPC front of one Context.  `ctx` may be None for a transport-only server (host_only models)."""
 
-    def __init__(self, ctx, params: FheParams | None = None, max_workers: int = 4, max_sessions: int = 64):
+    def __init__(self, ctx, params: FheParams | None = None, max_workers: int = 4, max_sessions: int = 64, max_batch: int = 1024):
         self.ctx = ctx
         self.params = params if params is not None else ctx.params
+        self.max_batch = max_batch   # ciphertexts per request: bounds the message size (start()) and what _to_device may upload
         self.ev = None
         if ctx is not None:
             from .evaluator import Evaluator
@@ -188,6 +196,8 @@ class EncryptedInferenceServer:
     def _to_device(self, blob):
         from .evaluator import Ciphertext, to_device
         words, is_ntt = wire.loads(blob, self.params)
+        if words.shape[0] > self.max_batch:
+            raise ValueError(f"batch of {words.shape[0]} ciphertexts exceeds this server's limit of {self.max_batch}")
         return Ciphertext(to_device(words, self.ctx.device), is_ntt)
 
     def _generate(self, request, context):
@@ -256,6 +266,11 @@ class EncryptedInferenceServer:
             from .evaluator import to_device
             keys = to_device(words, self.ctx.device)
         with self._gpu_lock:
+            # The session id is the bearer token of its keys (clients draw 128 random bits, EncryptedClient): a second registration
+            # under an existing id - another tenant guessing or replaying it - must not replace the keys its owner's requests rely on.
+            if request.session_id in self.sessions:
+                self.metrics.error(True)
+                context.abort(grpc.StatusCode.ALREADY_EXISTS, "session already holds keys: register under a fresh session id")
             self.sessions[request.session_id] = keys
             self.sessions.move_to_end(request.session_id)
             while len(self.sessions) > self.max_sessions:
@@ -270,14 +285,16 @@ class EncryptedInferenceServer:
                                      total_requests=m["total"])
 
     # -- lifecycle ---------------------------------------------------------------------------------------------
-    def start(self, address: str = "127.0.0.1:0") -> int:
+    def start(self, address: str = "127.0.0.1:0", credentials=None) -> int:
+        """`credentials`: grpc.ssl_server_credentials(...) for TLS (the reference's optional init_ssl, grpc_server.cpp); None = plain TCP"""
         impl = {"EncryptedGenerate": self._generate, "RegisterKeys": self._register_keys, "GetMetrics": self._get_metrics}
         handlers = {name: grpc.unary_unary_rpc_method_handler(impl[name], request_deserializer=pb[req].FromString, response_serializer=pb[resp].SerializeToString)
                     for name, req, resp in METHODS}
-        self._server = grpc.server(futures.ThreadPoolExecutor(max_workers=self._workers), options=CHANNEL_OPTIONS)
+        limit = message_limit(self.params, self.max_batch)
+        self._server = grpc.server(futures.ThreadPoolExecutor(max_workers=self._workers),
+                                   options=[("grpc.max_receive_message_length", limit), ("grpc.max_send_message_length", limit)])
         self._server.add_generic_rpc_handlers((grpc.method_handlers_generic_handler(f"{PACKAGE}.{SERVICE}", handlers),))
-        # plain TCP: the reference's optional TLS (grpc_server.cpp init_ssl) maps to add_secure_port with the deployment's credentials
-        port = self._server.add_insecure_port(address)
+        port = self._server.add_secure_port(address, credentials) if credentials is not None else self._server.add_insecure_port(address)
         if port == 0:
             raise RuntimeError(f"could not bind {address}")
         self._server.start()

@@ -92,8 +92,16 @@ def test_transport_echo_errors_and_metrics():
             assert c2.register_relin_keys(_canonical(rng, p, p.n_limbs, 2))
             c2.close()
         assert list(server.sessions) == ["s2", "s3"]
+        # a session id is the bearer token of its keys: nobody can replace the keys registered under an existing id
+        thief = rpc.EncryptedClient(f"127.0.0.1:{port}", p, session_id="s3")
+        with pytest.raises(grpc.RpcError) as e:
+            thief.register_relin_keys(_canonical(rng, p, p.n_limbs, 2))
+        assert e.value.code() == grpc.StatusCode.ALREADY_EXISTS
+        thief.close()
+        # message sizes are bounded by the parameters and the server's maximum batch
+        assert rpc.message_limit(p, server.max_batch) < 2**31 and rpc.message_limit(p, 1) > 3 * p.n_limbs * p.n * 8
         m = client.metrics()
-        assert m.total_requests == 6 and m.errors.total_errors == 5 and m.errors.internal_errors == 1 and m.errors.invalid_argument_errors == 4
+        assert m.total_requests == 7 and m.errors.total_errors == 6 and m.errors.internal_errors == 1 and m.errors.invalid_argument_errors == 5
         assert m.latency.p50_ms > 0 and m.throughput.ciphertexts_per_second > 0
     finally:
         client.close()
