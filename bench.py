@@ -183,6 +183,7 @@ def main():
     ap.add_argument("--native-comm", action="store_true",
                     help="all-gather through the library's own communicator (dpfhe_comm_*, RCCL behind the C ABI) instead of torch.distributed")
     ap.add_argument("--sustained-seconds", type=float, default=2.0, help="length of each sustained NTT / copy window (0 = skip the block)")
+    ap.add_argument("--skip-other", action="store_true", help="skip the other_configs block (profiling runs: every launch is serialised under rocprofv3)")
     ap.add_argument("--dry-run", action="store_true", help="CPU + gloo: walk the multi-rank host path (collectives, barriers, report) without kernels")
     args = ap.parse_args()
     if args.dry_run:
@@ -399,14 +400,14 @@ def main():
         return res
 
     def measure_packed_kernels(alu_peak):
-        """N3 roofline: the stages of one packed GPT-2 layer application (QKV 768 -> 2304: 32 baby x 32 giant steps, one output
+        """N3 roofline: the stages of one packed GPT-2 layer application (QKV 768 -> 2304: 64 baby x 16 giant steps, one output
         ciphertext) at N=8192, 5 data limbs + special prime, 8 tokens, on synthetic operands, each stage timed alone (median of 5) against its
         ALGORITHMIC bytes (keys + operands + results, every buffer counted once) and, where it transforms, its butterflies."""
         from deeppowers_amd.evaluator import Plaintext
         pe = FheParams.n8192_l6()
         cx = Context(pe, local_rank)
         evx = Evaluator(cx)
-        Lx, Ld, Nx, T, n1, n2 = pe.n_limbs, pe.n_limbs - 1, pe.n, 8, 32, 32
+        Lx, Ld, Nx, T, n1, n2 = pe.n_limbs, pe.n_limbs - 1, pe.n, 8, 64, 16   # PackedLinear's split of the 1024 diagonals (baby-heavy: fhe_api.cpp kBabyShiftDefault)
         qx = torch.tensor(pe.moduli, dtype=torch.int64, device=dev)
 
         def rnd(*shape, limbs):
@@ -439,12 +440,12 @@ def main():
         t = timed(lambda: evx.rotate_hoisted_qp(xin, elts, keys))
         stage("baby steps (dpfhe_rotate_hoisted_qp)", "ntt_fwd (inputs, digits) + lift_digits + lift_qp + hoisted_qp_kernel", t,
               ((n1 - 1) * Ld * 2 * Lx + T * 2 * Ld + T * Ld * Lx + n1 * T * 2 * Lx) * W, T * (2 * Ld + Ld * Lx),
-              "keys [31][5][2][6] + inputs + lifted digits (gathered 31 times from L2, counted once) + 32 x 8 results over Q P; no inverse transform, no division by P")
+              f"keys [{n1 - 1}][5][2][6] + inputs + lifted digits (permuted {n1 - 1} times out of L2, counted once) + {n1} x 8 results over Q P; no inverse transform, no division by P")
         inner = evx.matvec_plain_multi(diag, babies, T)
         t = timed(lambda: evx.matvec_plain_multi(diag, babies, T))
         stage("plaintext products (dpfhe_matvec_plain_multi)", "matvec_fold_kernel<4,4,1>", t, (n2 * n1 * Lx + n1 * T * 2 * Lx + n2 * T * 2 * Lx) * W, 0,
               "1024 diagonals over Q P (W, streamed once) + baby steps + inner sums; 4 multiply-adds per term (operands split at bit 30)")
-        ielts = [1] + [pow(3, 32 * i, 2 * Nx) for i in range(1, n2)]
+        ielts = [1] + [pow(3, n1 * i, 2 * Nx) for i in range(1, n2)]
         t = timed(lambda: evx.ntt_inverse_galois(inner, ielts, out=inner))
         stage("inverse transform + giant-step automorphism (dpfhe_ntt_inv_galois)", "ntt_inv_galois_kernel", t, 2 * n2 * T * 2 * Lx * W, n2 * T * 2 * Lx,
               "in place; the automorphism is the gather pattern of the loads")
@@ -456,7 +457,7 @@ def main():
         terms = evx.switch_key_qp(gin, gkeys, T)
         t = timed(lambda: evx.switch_key_qp(gin, gkeys, T))
         stage("giant-step key inner products (dpfhe_switch_key_qp)", "relin_kernel<MODE 4>", t, ((n2 - 1) * Ld * 2 * Lx + (n2 - 1) * T * Ld + (n2 - 1) * T * 2 * Lx) * W,
-              (n2 - 1) * T * Ld * Lx, "keys [31][5][2][6] + the c1 digits + 31 x 8 terms over Q P; Ld transforms per (item, limb) instead of Ld + 2")
+              (n2 - 1) * T * Ld * Lx, f"keys [{n2 - 1}][5][2][6] + the c1 digits + {n2 - 1} x 8 terms over Q P; Ld transforms per (item, limb) instead of Ld + 2")
         ksum = torch.empty((T, 2, Lx, Nx), dtype=torch.int64, device=dev)
 
         def tail():
@@ -467,7 +468,7 @@ def main():
         t = timed(tail)
         stage("sum of the terms + ONE inverse transform + ONE division by P (dpfhe_reduce_sum, dpfhe_ntt_inv, dpfhe_rescale_bsgs)",
               "reduce_partial/final + ntt_inv_kernel + rescale_bsgs_kernel", t, ((n2 - 1) * T * 2 * Lx + 3 * T * 2 * Lx + n2 * T * Ld + T * Ld + T * 2 * Ld) * W, T * 2 * Lx,
-              "reads the 31 x 8 terms once, adds the c0 parts of the 32 rotated inner sums")
+              f"reads the {n2 - 1} x 8 terms once, adds the c0 parts of the {n2} rotated inner sums")
         total = sum(e["median_us"] for e in stages)
         worst = min((e for e in stages if e["median_us"] > 0.05 * total), key=lambda e: max(e["frac_of_hbm_peak"], e.get("frac_of_butterfly_ceiling") or 0))
         out = {"workload": "one application of the packed QKV layer (768 -> 2304) to 8 tokens, stage by stage, synthetic operands; N=8192, 5 x 60-bit data limbs + special prime",
@@ -602,7 +603,7 @@ def main():
     # before the long multiply loop heats the chip into lower clocks; every rank measures (same thermal history on every GPU),
     # rank 0 reports
     ntt_result = measure_ntt()
-    other_result = measure_other_configs() if world == 1 else None
+    other_result = measure_other_configs() if (world == 1 and not args.skip_other) else None
     if other_result is not None:
         try:
             other_result.setdefault("packed_linear", {})["kernels"] = measure_packed_kernels(alu_result[0])
