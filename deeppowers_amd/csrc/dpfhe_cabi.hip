@@ -219,6 +219,9 @@ extern "C" int dpfhe_ctx_uses_fold(const dpfhe_ctx* c) { return c && c->fold ? 1
 #ifndef DPFHE_MATVEC_WPT4
 #define DPFHE_MATVEC_WPT4 1
 #endif
+#ifndef DPFHE_MATVEC_RT4
+#define DPFHE_MATVEC_RT4 4    // rows per workgroup of the 4-polynomial (2-token) kernel; tools/ab_variant.sh mvrt8 -DDPFHE_MATVEC_RT4=8 for A/B runs
+#endif
 static inline bool misaligned(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) != 0; }
 static const size_t kMaxGrid = 0x7fffffff;
 
@@ -748,7 +751,7 @@ extern "C" int dpfhe_matvec_plain_multi(dpfhe_ctx* c, uint64_t* d_y, const uint6
                            n_rhs * 2, (unsigned)(GROUPS), (unsigned)tiles);                                                                              \
     }
         if (pairs) {
-            MVF_LAUNCH(4, 4, DPFHE_MATVEC_WPT4, pairs, d_x, d_y)
+            MVF_LAUNCH(DPFHE_MATVEC_RT4, 4, DPFHE_MATVEC_WPT4, pairs, d_x, d_y)
             if (int e = check_launch("matvec_multi kernel launch")) return e;
         }
         if (n_rhs & 1) {
@@ -839,8 +842,13 @@ extern "C" int dpfhe_copy(dpfhe_ctx* c, uint64_t* d_dst, const uint64_t* d_src, 
     const size_t n_vec = n_words / 2, blocks = (n_vec + 2047) / 2048;
     if (blocks > kMaxGrid) return fail(DPFHE_INVALID_ARGUMENT, "dpfhe_copy", "too many words for one launch");
     DPFHE_ON_DEVICE(c, "dpfhe_copy");
-    hipLaunchKernelGGL(copy_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), reinterpret_cast<U64x2*>(d_dst),
-                       reinterpret_cast<const U64x2*>(d_src), n_vec);
+    // streams that cannot live in the 256 MiB Infinity Cache (source + destination) go around it
+    if (n_words * 16 > (size_t)256 << 20)
+        hipLaunchKernelGGL(copy_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), reinterpret_cast<U64x2*>(d_dst),
+                           reinterpret_cast<const U64x2*>(d_src), n_vec);
+    else
+        hipLaunchKernelGGL(copy_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), reinterpret_cast<U64x2*>(d_dst),
+                           reinterpret_cast<const U64x2*>(d_src), n_vec);
     return check_launch("copy kernel launch");
 }
 

@@ -265,7 +265,10 @@ struct InvChain3 {
 // dispatcher keeps the generations de-phased - persistent workgroups with prefetch, up-front twiddle fetch and
 // staggered starts were all measured slower).
 // ------------------------------------------------------------------------------------------------
-template <class Arith, int LOGN, int LOGE>
+// NT: non-temporal global accesses, chosen by the launcher for batches whose input + output exceed the 256 MiB Infinity Cache (a
+// stream that cannot stay there gains from not allocating in it - the plain copy kernel goes from 5.7 to 6.25 TB/s -, while
+// configs[1]'s 128 MiB, which DO stay, measured 6 % slower with them: DESIGN.md section 5).
+template <class Arith, int LOGN, int LOGE, bool NT = false>
 __global__ __launch_bounds__(1 << (LOGN - LOGE)) void ntt_fwd_kernel(u64* __restrict__ out, const u64* __restrict__ in,
                                                                       DevTables<Arith> tb) {
     typedef NttBody<Arith, LOGN, LOGE> B;
@@ -277,14 +280,14 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE)) void ntt_fwd_kernel(u64* __rest
     const LimbConst lc = tb.lc[limb];
     const typename B::Tw* tw = tb.fwd + ((size_t)limb * tb.n_sub + sub) * B::G::N;
     u64 x[B::E];
-    B::load_top(tid, x, in + p * B::G::N);
+    B::template load_top<NT>(tid, x, in + p * B::G::N);
     FwdChain<B, 0>::run(tid, x, lds, tw, lc);
     B::fwd_canon(x, lc);
-    if constexpr (B::kLdsIO) B::store_bot_lds(tid, x, out + p * B::G::N, lds);   // rows == what this wave read in the last exchange
+    if constexpr (B::kLdsIO) B::template store_bot_lds<NT>(tid, x, out + p * B::G::N, lds);   // rows == what this wave read in the last exchange
     else B::store_bot(tid, x, out + p * B::G::N);
 }
 
-template <class Arith, int LOGN, int LOGE>
+template <class Arith, int LOGN, int LOGE, bool NT = false>
 __global__ __launch_bounds__(1 << (LOGN - LOGE)) void ntt_inv_kernel(u64* __restrict__ out, const u64* __restrict__ in,
                                                                       DevTables<Arith> tb) {
     typedef NttBody<Arith, LOGN, LOGE> B;
@@ -300,14 +303,14 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE)) void ntt_inv_kernel(u64* __rest
     B::template load_tw<B::NPH - 1, false>(tid, tw, tw_first);
     u64 x[B::E];
     if constexpr (B::kLdsIO) {
-        B::load_bot_lds(tid, x, in + p * B::G::N, lds);
+        B::template load_bot_lds<NT>(tid, x, in + p * B::G::N, lds);
         InvChain<B, B::NPH - 1, kUnit>::run_with(tid, x, lds, tw, last, lc, tw_first);   // the staged rows are the wave's own
     } else {
         B::load_bot(tid, x, in + p * B::G::N);
         InvChain<B, B::NPH - 1, kUnit>::run_with(tid, x, lds, tw, last, lc, tw_first);
     }
     B::inv_canon(x, lc);
-    B::store_top(tid, x, out + p * B::G::N);
+    B::template store_top<NT>(tid, x, out + p * B::G::N);
 }
 
 // N3: inverse NTT of sigma_g applied in the NTT domain.  In forward-output order position p carries the evaluation at

@@ -63,14 +63,21 @@ __global__ __launch_bounds__(256) void dyadic_kernel(u64* out, const u64* a, con
 // The practical HBM ceiling the transforms are read against ("also report a measured device-copy bandwidth"):
 // a plain copy with the streaming kernels' access shape - 16 bytes per lane, 4 KiB-contiguous per wave instruction, eight
 // independent loads in flight per thread, one 32 KiB tile (a residue polynomial at N = 4096) per workgroup.
+template <bool NT>   // NT: non-temporal loads and stores (a stream far beyond the 256 MiB Infinity Cache gains from not allocating there)
 __global__ __launch_bounds__(256) void copy_kernel(U64x2* __restrict__ dst, const U64x2* __restrict__ src, size_t n_vec) {
     const size_t base = (size_t)blockIdx.x * 2048 + threadIdx.x;
     if ((size_t)blockIdx.x * 2048 + 2048 <= n_vec) {   // whole tile (workgroup-uniform)
         U64x2 v[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = src[base + u * 256];
+        for (int u = 0; u < 8; ++u) {
+            if (NT) { v[u].a = __builtin_nontemporal_load(&src[base + u * 256].a); v[u].b = __builtin_nontemporal_load(&src[base + u * 256].b); }
+            else v[u] = src[base + u * 256];
+        }
 #pragma unroll
-        for (int u = 0; u < 8; ++u) dst[base + u * 256] = v[u];
+        for (int u = 0; u < 8; ++u) {
+            if (NT) { __builtin_nontemporal_store(v[u].a, &dst[base + u * 256].a); __builtin_nontemporal_store(v[u].b, &dst[base + u * 256].b); }
+            else dst[base + u * 256] = v[u];
+        }
     } else {
         for (size_t i = base; i < n_vec; i += 256) dst[i] = src[i];
     }

@@ -55,7 +55,17 @@ template <class Arith>
 int launch_ntt(int log2n, bool inverse, u64* out, const u64* in, size_t npolys, const DevTables<Arith>& tb, hipStream_t s) {
     if (log2n == 15) { launch_ntt_split<Arith, 3>(inverse, out, in, npolys, tb, s); return 0; }
     if (log2n == 16) { launch_ntt_split<Arith, 4>(inverse, out, in, npolys, tb, s); return 0; }
+    // batches whose input + output cannot stay in the 256 MiB Infinity Cache stream around it (FoldArith, the two production ring degrees)
+    const size_t touched = (npolys << log2n) * sizeof(u64) * (out == in ? 1 : 2);
+    const bool nt = Arith::kFold && (log2n == 12 || log2n == 13) && touched > ((size_t)256 << 20);
 #define NTT_CASE(LN, LE)                                                                                                              \
+    if constexpr (Arith::kFold && (LN == 12 || LN == 13)) {                                                                           \
+        if (nt) {                                                                                                                     \
+            if (inverse) hipLaunchKernelGGL((ntt_inv_kernel<Arith, LN, LE, true>), dim3((unsigned)npolys), dim3(Geo<LN, LE>::T), 0, s, out, in, tb); \
+            else hipLaunchKernelGGL((ntt_fwd_kernel<Arith, LN, LE, true>), dim3((unsigned)npolys), dim3(Geo<LN, LE>::T), 0, s, out, in, tb);         \
+            break;                                                                                                                    \
+        }                                                                                                                             \
+    }                                                                                                                                 \
     if (inverse) hipLaunchKernelGGL((ntt_inv_kernel<Arith, LN, LE>), dim3((unsigned)npolys), dim3(Geo<LN, LE>::T), 0, s, out, in, tb); \
     else hipLaunchKernelGGL((ntt_fwd_kernel<Arith, LN, LE>), dim3((unsigned)npolys), dim3(Geo<LN, LE>::T), 0, s, out, in, tb)
     DPFHE_NTT_GEO_SWITCH(log2n, NTT_CASE)

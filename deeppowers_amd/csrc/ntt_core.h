@@ -380,11 +380,16 @@ struct NttBody {
         lds_word = base_w + (unsigned)r * (8u * (E + 2));
         piece = base_p + (unsigned)r * (8u * PC);
     }
+    template <bool NT = false>
     static __device__ __forceinline__ void load_bot_lds(int tid, u64 (&x)[E], const u64* g, u64* lds) {
         const V2* p = reinterpret_cast<const V2*>(g);
         V2 v[PC];
 #pragma clang loop unroll(full)
-        for (int r = 0; r < PC; ++r) { unsigned w, pc; lds_slice(tid, r, w, pc); v[r] = p[pc]; }
+        for (int r = 0; r < PC; ++r) {
+            unsigned w, pc; lds_slice(tid, r, w, pc);
+            if (NT) { v[r].a = __builtin_nontemporal_load(&p[pc].a); v[r].b = __builtin_nontemporal_load(&p[pc].b); }
+            else v[r] = p[pc];
+        }
 #pragma clang loop unroll(full)
         for (int r = 0; r < PC; ++r) { unsigned w, pc; lds_slice(tid, r, w, pc); *reinterpret_cast<V2*>(lds + w) = v[r]; }
         const V2* row = reinterpret_cast<const V2*>(lds + (unsigned)G::lds_row(tid));   // same wave wrote it: program order + lgkmcnt
@@ -445,13 +450,19 @@ struct NttBody {
         const int region = __builtin_amdgcn_readfirstlane((int)(src0 >> (6 + LOGE)));     // wave-uniform
         return ((long)region - (long)(tid >> 6)) * (long)(64 * E);
     }
+    template <bool NT = false>
     static __device__ __forceinline__ void store_bot_lds(int tid, const u64 (&x)[E], u64* g, u64* lds) {
         V2* row = reinterpret_cast<V2*>(lds + (unsigned)G::lds_row(tid));
 #pragma clang loop unroll(full)
         for (int k = 0; k < PC; ++k) row[k] = V2{x[2 * k], x[2 * k + 1]};
         V2* p = reinterpret_cast<V2*>(g);
 #pragma clang loop unroll(full)
-        for (int r = 0; r < PC; ++r) { unsigned w, pc; lds_slice(tid, r, w, pc); p[pc] = *reinterpret_cast<const V2*>(lds + w); }
+        for (int r = 0; r < PC; ++r) {
+            unsigned w, pc; lds_slice(tid, r, w, pc);
+            const V2 t = *reinterpret_cast<const V2*>(lds + w);
+            if (NT) { __builtin_nontemporal_store(t.a, &p[pc].a); __builtin_nontemporal_store(t.b, &p[pc].b); }
+            else p[pc] = t;
+        }
     }
 #endif
 #if !defined(__HIP_DEVICE_COMPILE__)
@@ -459,8 +470,8 @@ struct NttBody {
     static void stage_rows(int, u64 (&)[E], const u64 (&)[E], u64*) {}
     static void stage_gather(int, u64 (&)[E], const u64 (&)[E], u64*, const unsigned (&)[E]) {}
     static long gather_plan(int, unsigned, unsigned (&)[E]) { return 0; }
-    static void load_bot_lds(int, u64 (&)[E], const u64*, u64*) {}   // device-only paths: never called on the host
-    static void store_bot_lds(int, const u64 (&)[E], u64*, u64*) {}
+    template <bool NT = false> static DPF_HD void load_bot_lds(int, u64 (&)[E], const u64*, u64*) {}   // device-only paths: never called on the host
+    template <bool NT = false> static DPF_HD void store_bot_lds(int, const u64 (&)[E], u64*, u64*) {}
 #endif
     static DPF_HD void load_bot(int tid, u64 (&x)[E], const u64* g) {
         const V2* p = reinterpret_cast<const V2*>(g);

@@ -147,3 +147,14 @@ def test_example_transformer_block_skeleton(ranks):
     b = line["noise_budget_bits"]
     assert b["fresh"] > b["qkv"] > b["v_handover"] > b["h1"] > b["ffn_up_handover"] > b["h2"] > 0, b
     assert line["key_switches_per_token"] >= 62 * 4
+
+
+@pytest.mark.gpu
+def test_example_two_transformer_blocks_fit_the_five_limb_budget():
+    """Two chained blocks (ten multiplicative levels, 510 key switches per token) still decrypt to the plaintext result at N=8192 with
+    five 60-bit data limbs: the remaining budget is small but positive - the honest depth of this parameter set."""
+    import json
+    out = subprocess.run([build_example("encrypted_gpt2_block"), "2", "1", "json", "0", "2"], capture_output=True, text=True, timeout=1500)
+    assert out.returncode == 0 and "OK" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+    line = json.loads(next(l for l in out.stdout.splitlines() if l.startswith("{")))
+    assert line["correct"] and line["layers"] == 2 and 0 < line["noise_budget_bits"]["gathered_output"] < 60
