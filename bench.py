@@ -299,13 +299,13 @@ def main():
         ntt["per_launch_events"] = {name: entry(t_in[name], nbytes) for name in ("fwd", "inv")}
         ntt["per_launch_events"]["note"] = ("one HIP event pair around EVERY launch, forward and inverse interleaved (rounds 1-2's figure): a lone ~60 us launch between two "
                                             "event records also pays its own dispatch latency, which back-to-back launches hide")
-        ntt["fwd"] = entry(timed_runs(lambda: ev.ntt_forward_(x), 30, 8, 5), nbytes)
-        ntt["inv"] = entry(timed_runs(lambda: ev.ntt_inverse_(x), 30, 8, 5), nbytes)
-        t_out = {"fwd": timed_runs(lambda: ev.ntt_forward(x, out=y), 30, 8, 5), "inv": timed_runs(lambda: ev.ntt_inverse(x, out=y), 30, 8, 5)}
+        ntt["fwd"] = entry(timed_runs(lambda: ev.ntt_forward_(x), 30, 32, 5), nbytes)
+        ntt["inv"] = entry(timed_runs(lambda: ev.ntt_inverse_(x), 30, 32, 5), nbytes)
+        t_out = {"fwd": timed_runs(lambda: ev.ntt_forward(x, out=y), 30, 32, 5), "inv": timed_runs(lambda: ev.ntt_inverse(x, out=y), 30, 32, 5)}
         ntt["out_of_place"] = {name: entry(t_out[name], nbytes) for name in ("fwd", "inv")}
         ntt["algorithmic_bytes"] = nbytes
         ntt["workload"] = ("BASELINE configs[1]: batch=1024 RNS polys x 4 limbs, N=4096 (4096 residue polynomials, 128 MiB), in place; forward and inverse timed "
-                           "separately, 5 warm-ups, median of 30 samples of 8 back-to-back launches each (one HIP event pair per sample); `out_of_place`: the same batch into "
+                           "separately, 5 warm-ups, median of 30 samples of 32 back-to-back launches each (one HIP event pair per sample: the pair costs ~15 us of exposed dispatch latency, 0.5 us per launch at this sample size); `out_of_place`: the same batch into "
                            "a second buffer; `steady_state`: 8192 RNS polys (1 GiB) out of place; `per_launch_events`: the interleaved one-event-pair-per-launch figure")
         nb2 = 8192
         if a.data.numel() >= nb2 * L * N:
