@@ -424,9 +424,10 @@ public:
     void unpack_output(const uint64_t* slots, uint64_t* y) const;
     // x: T items (T tokens, each packed with pack_input), y: output_ciphertexts() * T items, output ciphertext o of token t at item
     // o * T + t; 2 components, coefficient domain.  All tokens share ONE pass over the rotation keys and the diagonals (hoisted
-    // baby steps per token, one multi-right-hand-side matvec, grouped giant steps).  Enqueues on `stream` and returns (no host
-    // synchronisation; the scratch belongs to the layer and grows only when a larger T than ever before arrives, so one apply()
-    // at a time per object); synchronise before reading y on the host.
+    // baby steps per token, one multi-right-hand-side matvec, the giant steps' key inner products summed before ONE division by P).
+    // Enqueues on `stream` and returns (no host synchronisation).  Scratch: the layer's own buffers (they grow only when a larger T
+    // than ever before arrives) AND the key switcher's (digit images, packed keys) - so one apply() at a time per LAYER, and all layers
+    // built on one HybridKeySwitcher share ONE stream at a time; synchronise before reading y on the host.
     void apply(const Ciphertext& x, Ciphertext& y, Stream* stream = nullptr) const;
 
 private:
