@@ -588,13 +588,16 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE), 2) void ct_mul_quad_kernel(u64*
         y[k] = FoldArith::mul60(a0, b1, (u32)lc.d) + FoldArith::mul60(a1, b0, (u32)lc.d);
         z[k] = FoldArith::mul60(a1, b1, (u32)lc.d);
     }
+#ifndef DPFHE_CTMUL_NT_STORE
+#define DPFHE_CTMUL_NT_STORE 1
+#endif
     InvChain3<B, B::NPH - 1, kInvIn>::run(tid, x, y, z, lds, lds + W, tb.inv4 + (size_t)limb * N, last, lc);
     B::inv_canon(x, lc);
-    B::template store_top<true>(tid, x, dst);
+    B::template store_top<DPFHE_CTMUL_NT_STORE != 0>(tid, x, dst);
     B::inv_canon(y, lc);
-    B::template store_top<true>(tid, y, dst + cstride);
+    B::template store_top<DPFHE_CTMUL_NT_STORE != 0>(tid, y, dst + cstride);
     B::inv_canon(z, lc);
-    B::template store_top<true>(tid, z, dst + 2 * cstride);
+    B::template store_top<DPFHE_CTMUL_NT_STORE != 0>(tid, z, dst + 2 * cstride);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -91,6 +91,9 @@ __global__ __launch_bounds__(256) void copy_kernel(U64x2* __restrict__ dst, cons
 // No workspace, no per-call allocation.
 // ------------------------------------------------------------------------------------------------
 constexpr int kReduceSplits = 15;
+#ifndef DPFHE_REDUCE_NT
+#define DPFHE_REDUCE_NT 0
+#endif
 
 // Work item = (512-word chunk of a residue polynomial, batch split); a workgroup walks the items with stride gridDim.x,
 // so the launch size caps how much of the chip (and of the HBM bandwidth) the reduction takes at once.
@@ -110,7 +113,14 @@ __global__ __launch_bounds__(256) void reduce_partial_kernel(u64* out, const u64
         for (; it + 4 <= hi; it += 4) {
             U64x2 v[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const U64x2*>(src + (it + u) * words_per_item);
+            for (int u = 0; u < 4; ++u) {
+#if DPFHE_REDUCE_NT
+                const u64* pp = src + (it + u) * words_per_item;   // read once, far beyond the Infinity Cache: do not allocate there
+                v[u].a = __builtin_nontemporal_load(pp); v[u].b = __builtin_nontemporal_load(pp + 1);
+#else
+                v[u] = *reinterpret_cast<const U64x2*>(src + (it + u) * words_per_item);
+#endif
+            }
 #pragma unroll
             for (int u = 0; u < 4; ++u) { s0 = csub(s0 + v[u].a, q); s1 = csub(s1 + v[u].b, q); }
         }
