@@ -602,3 +602,61 @@ def test_key_switch_with_shared_digit_transforms_bit_exact(log2n, limbs):
         got = to_host(ev.keyswitch_hybrid(Ciphertext(to_device(ct, ctx.device)), to_device(key, ctx.device)).data)
         assert np.array_equal(got, want), comps
     ctx.close()
+
+
+# ---- round 3: the deferred division by P ("double hoisting") - the new oracle restatements pinned on the CPU ----------------------
+def test_qp_restatements_agree_with_the_divided_forms_oracle():
+    """orc_rotate_hoisted_qp / orc_switch_key_qp are the hoisted rotation and the hybrid key switch BEFORE the division by P, in the NTT
+    domain over Q P.  Dividing them must give the restatements validated above, word for word:
+      round(INTT(block r) / P) == orc_rotate_hoisted,   round(INTT(block 0) / P) == the ciphertext itself,
+      c0 + round(INTT(switch_key_qp) / P) == orc_keyswitch_hybrid   (round((t + P c0) / P) = c0 + round(t / P) exactly)."""
+    for pe in (FheParams(12, tuple(x[0] for x in PRIMES_60[:3]), tuple(x[1] for x in PRIMES_60[:3])),
+               ext_params(small_params(8, 3))):
+        orc = Oracle.from_params(pe)
+        L, Ld, n = pe.n_limbs, pe.n_limbs - 1, pe.n
+        data = Oracle(pe.log2_n, pe.moduli[:-1], pe.psi[:-1])
+        k = 3
+        elts = [pow(3, i + 1, 2 * n) for i in range(k)]
+        elts[-1] = 2 * n - 1
+        keys = orc.fill(k * Ld * 2, 701).reshape(k, Ld, 2, L, n)
+        ct = data.fill(2, 702).reshape(2, Ld, n)
+        ct[1, 0] = np.uint64(pe.moduli[0] - 1)                       # worst-case digit
+        qp = orc.rotate_hoisted_qp(ct, elts, keys, threads=0)
+        assert np.array_equal(orc.rescale(orc.ntt_inv(qp[1:])), orc.rotate_hoisted(ct, elts, keys, threads=0))
+        assert np.array_equal(orc.rescale(orc.ntt_inv(qp[0:1]))[0], ct)
+        ks = orc.rescale(orc.ntt_inv(orc.switch_key_qp(ct[None], keys[0], threads=0)))[0]
+        want = orc.keyswitch_hybrid(ct[None], keys[0], 2)[0]
+        assert np.array_equal(data.dyadic("add", ks[0:1].copy(), ct[0:1].copy())[0], want[0]) and np.array_equal(ks[1], want[1])
+
+
+def test_deferred_giant_step_sum_is_a_valid_key_switched_sum_oracle():
+    """Semantics on the toy scheme (big integers): the sum of rotated ciphertexts with ONE division by P for all key-switching terms
+        rot_0 + sum_i (c0_i, 0) + round(INTT(sum_i switch_key_qp(sigma_i(ct_i))) / P)
+    has the phase  sum_i sigma_i(phase(ct_i))  up to the switching noise - what dpfhe_switch_key_qp + dpfhe_rescale_bsgs compute."""
+    p = small_params()
+    pe = ext_params(p)
+    rng = np.random.default_rng(91)
+    s = rng.integers(-1, 2, p.n)
+    orc_e, orc_d = Oracle.from_params(pe), Oracle.from_params(p)
+    L, Ld, n = pe.n_limbs, p.n_limbs, p.n
+    gs = [1, pow(3, 3, 2 * n), pow(3, 17, 2 * n), 2 * n - 1]
+    cts, phases = [], []
+    for i in range(len(gs)):
+        ct, _ = encrypt(rng, p, s, rng.integers(0, 1000, n), 1 << 30)
+        cts.append(ct)
+        phases.append(phase(p, ct, s)[0])
+    Q = phase(p, cts[0], s)[1]
+    want = [0] * n
+    for ph, g in zip(phases, gs):
+        want = [(a + b) % Q for a, b in zip(want, galois_int(ph, g, Q))]
+    acc = np.zeros((1, 2, L, n), np.uint64)
+    total = cts[0].copy()                                              # the un-rotated term keeps both components
+    for ct, g in zip(cts[1:], gs[1:]):
+        rot = orc_d.apply_galois(ct, g)
+        key_g = keygen_hybrid(rng, p, pe, s, galois_int([int(v) for v in s], g))
+        acc = orc_e.dyadic("add", acc, orc_e.switch_key_qp(rot[None], np.ascontiguousarray(key_g), threads=1))
+        total[0] = orc_d.dyadic("add", total[0][None].copy(), np.ascontiguousarray(rot[0])[None])[0]      # c0 parts
+    total = orc_d.dyadic("add", np.ascontiguousarray(total), orc_e.rescale(orc_e.ntt_inv(acc))[0])
+    got, _ = phase(p, total.reshape(np.asarray(cts[0]).shape), s)
+    centre = lambda v: v - Q if v > Q // 2 else v
+    assert max(abs(centre((a - b) % Q)) for a, b in zip(got, want)) < (1 << 26)
