@@ -13,7 +13,10 @@ namespace dpfhe {
 // 16 everywhere keeps one twiddle layout per context)
 // N = 16384 (128 KiB of LDS per polynomial): 1024 threads, one workgroup per CU (16 words per thread measured 5 % faster
 // than 32 on the forward transform); the fused kernels stop at N = 8192.
-constexpr int ntt_loge(int log2n) { return (void)log2n, 4; }
+#ifndef DPFHE_NTT12_LOGE
+#define DPFHE_NTT12_LOGE 4   // tools/ab_variant.sh ntt12e5 -DDPFHE_NTT12_LOGE=5: 32 words per thread at N = 4096 (A/B only)
+#endif
+constexpr int ntt_loge(int log2n) { return log2n == 12 ? DPFHE_NTT12_LOGE : 4; }
 constexpr int kMaxLog2N = 16, kMaxFusedLog2N = 13;
 // N > 16384: split transform - log2(N1) top stages in ntt_top_kernel, then N1 transforms of N2 = 4096 points each
 constexpr int kSplitLog2N2 = 12;

@@ -31,12 +31,12 @@ static_assert(sizeof(u64) * Geo<14, 4>::lds_words() <= kLdsBytesPerCu, "the N = 
         case 9: MACRO(9, 4); break;         \
         case 10: MACRO(10, 4); break;       \
         case 11: MACRO(11, 4); break;       \
-        case 12: MACRO(12, 4); break;       \
+        case 12: MACRO(12, DPFHE_NTT12_LOGE); break; \
         case 13: MACRO(13, 4); break;       \
         case 14: MACRO(14, 4); break;       \
         default: return -1;                 \
     }
-static_assert(ntt_loge(12) == 4 && ntt_loge(13) == 4 && ntt_loge(8) == 4 && ntt_loge(14) == 4, "launch.h ntt_loge must match DPFHE_NTT_GEO_SWITCH");
+static_assert(ntt_loge(12) == DPFHE_NTT12_LOGE && ntt_loge(13) == 4 && ntt_loge(8) == 4 && ntt_loge(14) == 4, "launch.h ntt_loge must match DPFHE_NTT_GEO_SWITCH");
 
 template <class Arith, int LOG_N1>
 static void launch_ntt_split(bool inverse, u64* out, const u64* in, size_t npolys, const DevTables<Arith>& tb, hipStream_t s) {
