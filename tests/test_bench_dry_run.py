@@ -39,6 +39,12 @@ def test_bench_dry_run_walks_every_collective(world):
     assert r["per_rank_ct_mul_per_s"]["ranks"] == world and 0 < r["per_rank_ct_mul_per_s"]["min"] <= r["per_rank_ct_mul_per_s"]["max"]
     assert r["allgather_us"]["min"] <= r["allgather_us"]["median"] <= r["allgather_us"]["max"]
     assert r["config"]["global_batch"] == world * r["config"]["batch_per_gpu"]
+    if world > 1:   # rank 0's C++ multi-process programs (stood in here) while the other ranks wait on the store, not in a collective
+        progs = r["multi_gpu_programs"]
+        assert progs["configs3_cpp_host"]["world"] == world and progs["configs3_cpp_host"]["matches_world1_recomputation"] is True
+        assert progs["configs4_token_sharded_block"]["ranks"] == world and progs["configs4_token_sharded_block"]["tokens"] == 8 * world
+    else:
+        assert "multi_gpu_programs" not in r
     # value is the whole-job aggregate: all ranks' pairs over the MAX-over-ranks time
     assert abs(r["value"] - r["config"]["global_batch"] * r["steps"] / (r["ms_per_step"] * 1e-3 * r["steps"])) < 1e-6 * r["value"]
 

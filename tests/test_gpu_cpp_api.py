@@ -158,3 +158,15 @@ def test_example_two_transformer_blocks_fit_the_five_limb_budget():
     assert out.returncode == 0 and "OK" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
     line = json.loads(next(l for l in out.stdout.splitlines() if l.startswith("{")))
     assert line["correct"] and line["layers"] == 2 and 0 < line["noise_budget_bits"]["gathered_output"] < 60
+
+
+@pytest.mark.gpu
+def test_bench_multi_gpu_programs_at_world_size_one():
+    """What bench.py's rank 0 runs after the timed region at N > 1 (the C++ multi-process programs for configs[3] and configs[4]), here with
+    one rank per program: both must report their own correctness checks and parse into the bench line's entries."""
+    import bench
+    r = bench.multi_gpu_programs(1)
+    assert r["configs3_cpp_host"].get("matches_world1_recomputation") is True, r
+    assert r["configs3_cpp_host"]["world"] == 1 and r["configs3_cpp_host"]["ct_mul_per_s"] > 0
+    blk = r["configs4_token_sharded_block"]
+    assert blk.get("correct") is True and blk["ranks"] == 1 and blk["tokens"] == 8 and blk["stage_mismatches"] == [0, 0, 0, 0, 0], r
