@@ -12,11 +12,13 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <string>
 #include <vector>
 
 #include "../../include/dpfhe.h"
+#include "kernels_large.h"
 #include "kernels_misc.h"
 #include "launch.h"
 #include "ntt_core.h"
@@ -73,6 +75,10 @@ struct dpfhe_ctx {
     const RescaleConst* d_rescale = nullptr;
     DevTables<ShoupArith> shoup{};
     DevTables<FoldArith> foldt{};
+    // scratch of the composed large-ring operations: a pool of this context's own (created on first use) that keeps what it has been
+    // given until the context goes - the default pool hands its memory back at every synchronisation and pays the mapping again
+    hipMemPool_t scratch_pool = nullptr;
+    std::mutex scratch_mutex;
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -204,6 +210,7 @@ extern "C" int dpfhe_ctx_create(dpfhe_ctx** out, uint32_t log2_n, uint32_t n_lim
 extern "C" int dpfhe_ctx_destroy(dpfhe_ctx* c) {
     if (!c) return DPFHE_SUCCESS;
     if (c->d_blob) (void)hipFree(c->d_blob);
+    if (c->scratch_pool) (void)hipMemPoolDestroy(c->scratch_pool);
     delete c;
     return DPFHE_SUCCESS;
 }
@@ -238,21 +245,29 @@ const DevTables<ShoupArith>& tables_of<ShoupArith>(const dpfhe_ctx* c) { return 
 template <>
 const DevTables<FoldArith>& tables_of<FoldArith>(const dpfhe_ctx* c) { return c->foldt; }
 
+// the widest grid a batched transform of `npolys` residue polynomials launches fits one launch
+static bool ntt_grid_fits(const dpfhe_ctx* c, size_t npolys) {
+    // split transforms (N > 16384) launch npolys * N1 sub-transforms and npolys * N2 / 256 column workgroups
+    const int log_n1 = split_log_n1((int)c->log2n);
+    const size_t widest = log_n1 ? ((npolys << log_n1) > (npolys << (kSplitLog2N2 - 8)) ? (npolys << log_n1) : (npolys << (kSplitLog2N2 - 8))) : npolys;
+    return npolys <= kMaxGrid && widest <= kMaxGrid;
+}
+// arguments validated, device selected by the caller
+static int ntt_launch(dpfhe_ctx* c, bool inverse, uint64_t* out, const uint64_t* in, size_t npolys, hipStream_t s) {
+    const int rc = c->fold ? launch_ntt<FoldArith>((int)c->log2n, inverse, out, in, npolys, c->foldt, s)
+                           : launch_ntt<ShoupArith>((int)c->log2n, inverse, out, in, npolys, c->shoup, s);
+    if (rc) return fail(DPFHE_INVALID_STATE, "ntt", "no kernel geometry for this log2_n");
+    return check_launch("ntt kernel launch");
+}
+
 static int ntt_entry(dpfhe_ctx* c, bool inverse, uint64_t* out, const uint64_t* in, size_t n_rns_polys, void* stream) {
     if (!c) return fail(DPFHE_INVALID_ARGUMENT, "ntt", "null context");
     if (n_rns_polys == 0) return DPFHE_SUCCESS;
     if (!out || !in || misaligned(out) || misaligned(in)) return fail(DPFHE_INVALID_ARGUMENT, "ntt", "null or misaligned buffer");
     const size_t npolys = n_rns_polys * c->n_limbs;
-    // split transforms (N > 16384) launch npolys * N1 sub-transforms and npolys * N2 / 256 column workgroups
-    const int log_n1 = split_log_n1((int)c->log2n);
-    const size_t widest = log_n1 ? ((npolys << log_n1) > (npolys << (kSplitLog2N2 - 8)) ? (npolys << log_n1) : (npolys << (kSplitLog2N2 - 8))) : npolys;
-    if (npolys > kMaxGrid || widest > kMaxGrid) return fail(DPFHE_INVALID_ARGUMENT, "ntt", "batch too large for one launch");
+    if (!ntt_grid_fits(c, npolys)) return fail(DPFHE_INVALID_ARGUMENT, "ntt", "batch too large for one launch");
     DPFHE_ON_DEVICE(c, "ntt");
-    hipStream_t s = static_cast<hipStream_t>(stream);
-    const int rc = c->fold ? launch_ntt<FoldArith>((int)c->log2n, inverse, out, in, npolys, c->foldt, s)
-                           : launch_ntt<ShoupArith>((int)c->log2n, inverse, out, in, npolys, c->shoup, s);
-    if (rc) return fail(DPFHE_INVALID_STATE, "ntt", "no kernel geometry for this log2_n");
-    return check_launch("ntt kernel launch");
+    return ntt_launch(c, inverse, out, in, npolys, static_cast<hipStream_t>(stream));
 }
 
 extern "C" int dpfhe_ntt_fwd(dpfhe_ctx* c, uint64_t* d_io, size_t n, void* s) { return ntt_entry(c, false, d_io, d_io, n, s); }
@@ -297,6 +312,84 @@ extern "C" int dpfhe_sub(dpfhe_ctx* c, uint64_t* o, const uint64_t* a, const uin
 extern "C" int dpfhe_negate(dpfhe_ctx* c, uint64_t* o, const uint64_t* a, size_t n, void* s) { return dyadic_entry(c, DY_NEG, o, a, nullptr, n, s); }
 
 // ------------------------------------------------------------------------------------------------
+// ---- ring degrees above 8192: the fused kernels stop there (kernels_large.h); the same operations composed from the batched transforms
+// and one-pass streaming kernels.  Scratch comes from the stream-ordered allocator (hipMallocFromPoolAsync / hipFreeAsync on the caller's
+// stream: no synchronisation, the memory returns to the context's pool when the stream gets there).
+static const uint32_t kFusedMaxLog2N = 13;
+
+struct StreamScratch {
+    u64* p = nullptr;
+    dpfhe_ctx* c;
+    hipStream_t s;
+    StreamScratch(dpfhe_ctx* ctx, hipStream_t st) : c(ctx), s(st) {}
+    int alloc(size_t words, const char* what) {
+        {
+            std::lock_guard<std::mutex> lock(c->scratch_mutex);
+            if (!c->scratch_pool) {
+                hipMemPoolProps props = {};
+                props.allocType = hipMemAllocationTypePinned;
+                props.handleTypes = hipMemHandleTypeNone;
+                props.location.type = hipMemLocationTypeDevice;
+                props.location.id = c->device;
+                hipError_t e = hipMemPoolCreate(&c->scratch_pool, &props);
+                if (e != hipSuccess) { c->scratch_pool = nullptr; (void)hipGetLastError(); return fail(DPFHE_DEVICE_ERROR, what, hipGetErrorString(e)); }
+                uint64_t keep = ~0ull;
+                (void)hipMemPoolSetAttribute(c->scratch_pool, hipMemPoolAttrReleaseThreshold, &keep);
+            }
+        }
+        hipError_t e = hipMallocFromPoolAsync(reinterpret_cast<void**>(&p), words * sizeof(u64), c->scratch_pool, s);
+        if (e != hipSuccess) { p = nullptr; (void)hipGetLastError(); return fail(DPFHE_OUT_OF_MEMORY, what, hipGetErrorString(e)); }
+        return DPFHE_SUCCESS;
+    }
+    ~StreamScratch() { if (p) (void)hipFreeAsync(p, s); }
+};
+
+static int ct_mul_composed(dpfhe_ctx* c, uint64_t* d_out3, const uint64_t* d_a2, const uint64_t* d_b2, size_t batch, uint32_t flags, hipStream_t s) {
+    const size_t L = c->n_limbs, n = (size_t)1 << c->log2n, poly = L * n;
+    const int chunks = (int)(n / 512);
+    const size_t grid = batch * L * (size_t)chunks;
+    if (grid > kMaxGrid || !ntt_grid_fits(c, batch * 3 * L)) return fail(DPFHE_INVALID_ARGUMENT, "dpfhe_ct_mul", "batch too large for one launch");
+    StreamScratch ws(c, s);
+    const u64 *pa = d_a2, *pb = d_b2;
+    if (!(flags & DPFHE_IN_NTT)) {   // transformed copies of the operands: [a | b], 2 * batch * 2 * L residue polynomials
+        const bool square = d_a2 == d_b2;
+        if (int rc = ws.alloc((square ? 2 : 4) * batch * poly, "dpfhe_ct_mul (scratch for the transformed operands)")) return rc;
+        if (int rc = ntt_launch(c, false, ws.p, d_a2, batch * 2 * L, s)) return rc;
+        if (!square) if (int rc = ntt_launch(c, false, ws.p + 2 * batch * poly, d_b2, batch * 2 * L, s)) return rc;
+        pa = ws.p;
+        pb = square ? ws.p : ws.p + 2 * batch * poly;
+    }
+    const LimbConst* lc = c->fold ? c->foldt.lc : c->shoup.lc;
+    if (c->fold) hipLaunchKernelGGL((tensor3_kernel<FoldArith>), dim3((unsigned)grid), dim3(256), 0, s, d_out3, pa, pb, lc, (int)L, (int)n, chunks);
+    else hipLaunchKernelGGL((tensor3_kernel<ShoupArith>), dim3((unsigned)grid), dim3(256), 0, s, d_out3, pa, pb, lc, (int)L, (int)n, chunks);
+    if (int rc = check_launch("tensor product kernel launch")) return rc;
+    if (!(flags & DPFHE_OUT_NTT)) return ntt_launch(c, true, d_out3, d_out3, batch * 3 * L, s);
+    return DPFHE_SUCCESS;
+}
+
+// RNS-digit key switch: out2 = [mask-selected components of in] + sum_j NTT^-1( NTT([in_{last comp}]_j mod q_i) (.) evk[j] )
+static int key_switch_composed(dpfhe_ctx* c, uint64_t* d_out2, const uint64_t* d_in, int in_comps, int add_mask, const uint64_t* d_evk, size_t batch,
+                               hipStream_t s, const char* what) {
+    const size_t L = c->n_limbs, n = (size_t)1 << c->log2n;
+    const int chunks = (int)(n / 512);
+    const size_t lift_grid = batch * L * L * (size_t)chunks;
+    if (lift_grid > kMaxGrid || 2 * batch * L * (size_t)chunks > kMaxGrid || !ntt_grid_fits(c, batch * L * L)) return fail(DPFHE_INVALID_ARGUMENT, what, "batch too large for one launch");
+    StreamScratch ws(c, s);
+    if (int rc = ws.alloc(batch * L * L * n, what)) return rc;
+    const LimbConst* lc = c->fold ? c->foldt.lc : c->shoup.lc;
+    if (c->fold) hipLaunchKernelGGL((lift_rns_digits_kernel<FoldArith>), dim3((unsigned)lift_grid), dim3(256), 0, s, ws.p, d_in, in_comps, in_comps - 1, lc, (int)L, (int)n, chunks);
+    else hipLaunchKernelGGL((lift_rns_digits_kernel<ShoupArith>), dim3((unsigned)lift_grid), dim3(256), 0, s, ws.p, d_in, in_comps, in_comps - 1, lc, (int)L, (int)n, chunks);
+    if (int rc = check_launch("digit lift kernel launch")) return rc;
+    if (int rc = ntt_launch(c, false, ws.p, ws.p, batch * L * L, s)) return rc;
+    const unsigned grid = (unsigned)(batch * L * (size_t)chunks);
+    if (c->fold) hipLaunchKernelGGL((key_inner_product_kernel<FoldArith>), dim3(grid), dim3(256), 0, s, d_out2, ws.p, d_evk, lc, (int)L, (int)n, chunks);
+    else hipLaunchKernelGGL((key_inner_product_kernel<ShoupArith>), dim3(grid), dim3(256), 0, s, d_out2, ws.p, d_evk, lc, (int)L, (int)n, chunks);
+    if (int rc = check_launch("key inner product kernel launch")) return rc;
+    if (int rc = ntt_launch(c, true, d_out2, d_out2, batch * 2 * L, s)) return rc;
+    hipLaunchKernelGGL(add_back_kernel, dim3(2 * grid), dim3(256), 0, s, d_out2, d_in, in_comps, add_mask, lc, (int)L, (int)n, chunks);
+    return check_launch("add-back kernel launch");
+}
+
 extern "C" int dpfhe_ct_mul(dpfhe_ctx* c, uint64_t* d_out3, const uint64_t* d_a2, const uint64_t* d_b2, size_t batch,
                             uint32_t flags, void* stream) {
     if (!c) return fail(DPFHE_INVALID_ARGUMENT, "dpfhe_ct_mul", "null context");
@@ -313,6 +406,7 @@ extern "C" int dpfhe_ct_mul(dpfhe_ctx* c, uint64_t* d_out3, const uint64_t* d_a2
     if (blocks > kMaxGrid) return fail(DPFHE_INVALID_ARGUMENT, "dpfhe_ct_mul", "batch too large for one launch");
     DPFHE_ON_DEVICE(c, "dpfhe_ct_mul");
     hipStream_t s = static_cast<hipStream_t>(stream);
+    if (c->log2n > kFusedMaxLog2N) return ct_mul_composed(c, d_out3, d_a2, d_b2, batch, flags, s);
     const int rc = c->fold ? launch_ct_mul<FoldArith>((int)c->log2n, flags, d_out3, d_a2, d_b2, blocks, c->foldt, s)
                            : launch_ct_mul<ShoupArith>((int)c->log2n, flags, d_out3, d_a2, d_b2, blocks, c->shoup, s);
     if (rc) return fail(DPFHE_INVALID_STATE, "dpfhe_ct_mul", "no kernel geometry for this log2_n");
@@ -332,6 +426,7 @@ extern "C" int dpfhe_relinearize(dpfhe_ctx* c, uint64_t* d_out2, const uint64_t*
     if (blocks > kMaxGrid) return fail(DPFHE_INVALID_ARGUMENT, "dpfhe_relinearize", "batch too large for one launch");
     DPFHE_ON_DEVICE(c, "dpfhe_relinearize");
     hipStream_t s = static_cast<hipStream_t>(stream);
+    if (c->log2n > kFusedMaxLog2N) return key_switch_composed(c, d_out2, d_in3, 3, 3, d_evk, batch, s, "dpfhe_relinearize");
     const int rc = c->fold ? launch_relin<FoldArith>((int)c->log2n, 0, d_out2, d_in3, d_evk, 0, 1, blocks, c->foldt, s)
                            : launch_relin<ShoupArith>((int)c->log2n, 0, d_out2, d_in3, d_evk, 0, 1, blocks, c->shoup, s);
     if (rc) return fail(DPFHE_INVALID_STATE, "dpfhe_relinearize", "no kernel geometry for this log2_n");
@@ -348,6 +443,7 @@ extern "C" int dpfhe_switch_key(dpfhe_ctx* c, uint64_t* d_out2, const uint64_t* 
     if (blocks > kMaxGrid) return fail(DPFHE_INVALID_ARGUMENT, "dpfhe_switch_key", "batch too large for one launch");
     DPFHE_ON_DEVICE(c, "dpfhe_switch_key");
     hipStream_t s = static_cast<hipStream_t>(stream);
+    if (c->log2n > kFusedMaxLog2N) return key_switch_composed(c, d_out2, d_in2, 2, 1, d_key, batch, s, "dpfhe_switch_key");
     const int rc = c->fold ? launch_relin<FoldArith>((int)c->log2n, 1, d_out2, d_in2, d_key, 0, 1, blocks, c->foldt, s)
                            : launch_relin<ShoupArith>((int)c->log2n, 1, d_out2, d_in2, d_key, 0, 1, blocks, c->shoup, s);
     if (rc) return fail(DPFHE_INVALID_STATE, "dpfhe_switch_key", "no kernel geometry for this log2_n");

@@ -272,30 +272,6 @@ void Evaluator::multiply(const Ciphertext& a, const Ciphertext& b, Ciphertext& o
     Impl::same(a, b, "multiply");
     if (a.size() != 2) throw Exception(ErrorCode::INVALID_ARGUMENT, "multiply: inputs must be 2-component ciphertexts");
     if (out.size() != 3 || out.batch() != a.batch()) throw Exception(ErrorCode::INVALID_ARGUMENT, "multiply: output must be a 3-component ciphertext of the same batch");
-    const FheParams& p = impl_->ctx->params();
-    if (p.log2_n > 13) {   // no fused kernel above N = 8192: the same HIP kernels, composed (4 NTT + dyadic + 3 INTT)
-        const size_t poly = p.n_limbs() * p.n(), batch = a.batch();
-        hipStream_t hs = static_cast<hipStream_t>(s);
-        PolyBuffer fa(*impl_->ctx, batch, 2, true), fb(*impl_->ctx, batch, 2, true), t(*impl_->ctx, 1, 1, true);
-        if (a.is_ntt()) {
-            hip_check(hipMemcpyAsync(fa.data(), a.data(), batch * 2 * poly * 8, hipMemcpyDeviceToDevice, hs), "hipMemcpyAsync");
-            hip_check(hipMemcpyAsync(fb.data(), b.data(), batch * 2 * poly * 8, hipMemcpyDeviceToDevice, hs), "hipMemcpyAsync");
-        } else {
-            check(dpfhe_ntt_fwd_oop(impl_->h(), fa.data(), a.data(), batch * 2, s), "dpfhe_ntt_fwd_oop");
-            check(dpfhe_ntt_fwd_oop(impl_->h(), fb.data(), b.data(), batch * 2, s), "dpfhe_ntt_fwd_oop");
-        }
-        for (size_t i = 0; i < batch; ++i) {
-            const uint64_t *a0 = fa.data() + (i * 2) * poly, *a1 = a0 + poly, *b0 = fb.data() + (i * 2) * poly, *b1 = b0 + poly;
-            uint64_t* c = out.data() + (i * 3) * poly;
-            check(dpfhe_dyadic_mul(impl_->h(), c, a0, b0, 1, s), "dpfhe_dyadic_mul");
-            check(dpfhe_dyadic_mul(impl_->h(), c + poly, a0, b1, 1, s), "dpfhe_dyadic_mul");
-            check(dpfhe_dyadic_mul_add(impl_->h(), c + poly, a1, b0, 1, s), "dpfhe_dyadic_mul_add");
-            check(dpfhe_dyadic_mul(impl_->h(), c + 2 * poly, a1, b1, 1, s), "dpfhe_dyadic_mul");
-        }
-        if (!out.is_ntt()) check(dpfhe_ntt_inv(impl_->h(), out.data(), batch * 3, s), "dpfhe_ntt_inv");
-        hip_check(hipStreamSynchronize(hs), "hipStreamSynchronize");   // temporaries are freed on return
-        return;
-    }
     const uint32_t flags = (a.is_ntt() ? (uint32_t)DPFHE_IN_NTT : 0u) | (out.is_ntt() ? (uint32_t)DPFHE_OUT_NTT : 0u);
     check(dpfhe_ct_mul(impl_->h(), out.data(), a.data(), b.data(), a.batch(), flags, s), "dpfhe_ct_mul");
 }

@@ -238,27 +238,8 @@ class Evaluator:
         if out is None:
             out = self._empty(tuple(lead) + (3, self.ctx.params.n_limbs, self.ctx.params.n), stream)
         self._chk(out)
-        if self.ctx.params.log2_n > 13:   # no fused kernel above N = 8192: the same HIP kernels, composed (4 NTT + dyadic + 3 INTT)
-            return self._multiply_unfused(a, b, out, out_ntt, stream)
         flags = (_cabi.IN_NTT if a.is_ntt else 0) | (_cabi.OUT_NTT if out_ntt else 0)
         _cabi.check(self._lib.dpfhe_ct_mul(self.ctx.handle, out.data_ptr(), a.data.data_ptr(), b.data.data_ptr(), a.batch, flags, self._sp(stream)), "dpfhe_ct_mul")
-        return Ciphertext(out, out_ntt)
-
-    def _multiply_unfused(self, a: Ciphertext, b: Ciphertext, out: torch.Tensor, out_ntt: bool, stream=None) -> Ciphertext:
-        p = self.ctx.params
-        ad = a.data.reshape(-1, 2, p.n_limbs, p.n)
-        bd = b.data.reshape(-1, 2, p.n_limbs, p.n)
-        od = out.view(-1, 3, p.n_limbs, p.n)
-        with self._on(stream):
-            fa = ad if a.is_ntt else self.ntt_forward(ad, stream=stream)
-            fb = bd if b.is_ntt else self.ntt_forward(bd, stream=stream)
-            a0, a1, b0, b1 = (t.contiguous() for t in (fa[:, 0], fa[:, 1], fb[:, 0], fb[:, 1]))
-            c0 = self.dyadic_mul(a0, b0, stream=stream)
-            c1 = self.dyadic_mul(a0, b1, stream=stream)
-            self.dyadic_mul_add_(c1, a1, b0, stream=stream)
-            c2 = self.dyadic_mul(a1, b1, stream=stream)
-            for i, c in enumerate((c0, c1, c2)):
-                od[:, i].copy_(c if out_ntt else self.ntt_inverse_(c, stream=stream))
         return Ciphertext(out, out_ntt)
 
     def matvec_scalar(self, w: torch.Tensor, x: Ciphertext, out: torch.Tensor | None = None, stream=None) -> Ciphertext:

@@ -97,7 +97,7 @@ def rigs():
 
 
 ALL = ["config1", "n4096", "n8192", "fold8", "fold9", "fold10", "fold11", "shoup8", "shoup10", "shoup12", "shoup13"]
-NTT_ONLY = ["fold14", "shoup14", "fold15", "fold16", "shoup16"]   # N = 16384: no fused ct x ct / key-switch kernels
+NTT_ONLY = ["fold14", "shoup14", "fold15", "fold16", "shoup16"]   # N >= 16384: no fused ct x ct / key-switch kernels (composed ones: see the large-ring test)
 
 
 def test_arithmetic_policy_selection(rigs):
@@ -529,19 +529,33 @@ def test_config3_full_size_matvec_linearity_and_sampled_rows(rigs):
     del W
 
 
-@pytest.mark.parametrize("name", ["fold14", "fold16"])
-def test_large_rings_c_abi_refuses_fused_multiply_and_facade_composes(rigs, name):
-    """N > 8192 has transforms and streaming kernels only: dpfhe_ct_mul refuses (no silent fallback in the C ABI); the
-    evaluator composes the same HIP kernels (4 NTT + dyadic + 3 INTT) and matches the oracle in every domain combination"""
+@pytest.mark.parametrize("name", ["fold14", "shoup14", "fold15", "fold16"])
+def test_large_rings_multiply_and_key_switch_composed_behind_the_c_abi(rigs, name):
+    """N > 8192 has no fused kernels: dpfhe_ct_mul / dpfhe_relinearize / dpfhe_switch_key compose the batched transforms with one-pass
+    streaming kernels (kernels_large.h; scratch from the stream-ordered allocator) and match the oracle in every domain combination,
+    also for a squaring (one transformed copy) and on a side stream."""
     r = rigs(name)
     L, n = r.p.n_limbs, r.p.n
-    ah, bh = r.orc.fill(4, 1).reshape(2, 2, L, n), r.orc.fill(4, 2).reshape(2, 2, L, n)
+    ah, bh = r.orc.fill(6, 1).reshape(3, 2, L, n), r.orc.fill(6, 2).reshape(3, 2, L, n)
+    ah[0, :, :, :8] = np.array(r.p.moduli, np.uint64)[None, :, None] - np.uint64(1)   # worst-case residues
     a, b = Ciphertext(r.dev(ah)), Ciphertext(r.dev(bh))
-    out = r.ctx.empty(2, components=3)
-    rc = r.ev._lib.dpfhe_ct_mul(r.ctx.handle, out.data_ptr(), a.data.data_ptr(), b.data.data_ptr(), 2, 0, None)
-    assert rc == 2002
     want = r.orc.ct_mul(ah, bh)
     assert np.array_equal(to_host(r.ev.multiply(a, b).data), want)
     an, bn = Ciphertext(r.ev.ntt_forward(a.data), True), Ciphertext(r.ev.ntt_forward(b.data), True)
     assert np.array_equal(to_host(r.ev.multiply(an, bn, out_ntt=False).data), want)
     assert np.array_equal(to_host(r.ev.ntt_inverse(r.ev.multiply(an, bn).data)), want)
+    assert np.array_equal(to_host(r.ev.ntt_inverse(r.ev.multiply(a, b, out_ntt=True).data)), want)
+    assert np.array_equal(to_host(r.ev.multiply(a, a).data), r.orc.ct_mul(ah, ah))
+    side = torch.cuda.Stream(device=r.ctx.device)
+    side.wait_stream(torch.cuda.current_stream(r.ctx.device))
+    got = r.ev.multiply(a, b, stream=side)
+    side.synchronize()
+    assert np.array_equal(to_host(got.data), want)
+    # relinearisation and the plain key switch with RNS-digit keys (any words < q serve as a key for a bit-exactness check)
+    evk = r.orc.fill(L * 2, 7).reshape(L, 2, L, n)
+    got = r.ev.relinearize(Ciphertext(r.dev(want)), r.dev(evk))
+    assert np.array_equal(to_host(got.data), r.orc.relinearize(want, evk, threads=0))
+    got = r.ev.apply_galois(Ciphertext(r.dev(ah)), 5, r.dev(evk))   # automorphism + dpfhe_switch_key
+    assert np.array_equal(to_host(got.data), r.orc.switch_key(r.orc.apply_galois(ah, 5), evk, threads=0))
+    out = r.ctx.empty(3, components=2)
+    assert r.ev._lib.dpfhe_relinearize(r.ctx.handle, out.data_ptr(), out.data_ptr(), r.dev(evk).data_ptr(), 1, None) == 2000   # output over its input
