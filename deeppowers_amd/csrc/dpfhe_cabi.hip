@@ -382,8 +382,8 @@ static int key_switch_composed(dpfhe_ctx* c, uint64_t* d_out2, const uint64_t* d
     if (int rc = check_launch("digit lift kernel launch")) return rc;
     if (int rc = ntt_launch(c, false, ws.p, ws.p, batch * L * L, s)) return rc;
     const unsigned grid = (unsigned)(batch * L * (size_t)chunks);
-    if (c->fold) hipLaunchKernelGGL((key_inner_product_kernel<FoldArith>), dim3(grid), dim3(256), 0, s, d_out2, ws.p, d_evk, lc, (int)L, (int)n, chunks);
-    else hipLaunchKernelGGL((key_inner_product_kernel<ShoupArith>), dim3(grid), dim3(256), 0, s, d_out2, ws.p, d_evk, lc, (int)L, (int)n, chunks);
+    if (c->fold) hipLaunchKernelGGL((key_inner_product_kernel<FoldArith>), dim3(grid), dim3(256), 0, s, d_out2, ws.p, d_evk, lc, (int)L, (int)L, (int)n, chunks);
+    else hipLaunchKernelGGL((key_inner_product_kernel<ShoupArith>), dim3(grid), dim3(256), 0, s, d_out2, ws.p, d_evk, lc, (int)L, (int)L, (int)n, chunks);
     if (int rc = check_launch("key inner product kernel launch")) return rc;
     if (int rc = ntt_launch(c, true, d_out2, d_out2, batch * 2 * L, s)) return rc;
     hipLaunchKernelGGL(add_back_kernel, dim3(2 * grid), dim3(256), 0, s, d_out2, d_in, in_comps, add_mask, lc, (int)L, (int)n, chunks);
@@ -488,11 +488,32 @@ static int hybrid_entry(dpfhe_ctx* c, const char* what, int in_comps, uint64_t* 
     DPFHE_ON_DEVICE(c, "hybrid key switch");
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int mode = in_comps == 3 ? 2 : 3;
-    const int rc = c->fold ? launch_relin<FoldArith>((int)c->log2n, mode, d_work, d_in, d_key, key_stride, key_group, blocks, c->foldt, s)
-                           : launch_relin<ShoupArith>((int)c->log2n, mode, d_work, d_in, d_key, key_stride, key_group, blocks, c->shoup, s);
-    if (rc) return fail(DPFHE_INVALID_STATE, what, "no kernel geometry for this log2_n");
-    int e = check_launch("hybrid key-switch kernel launch");
-    if (e) return e;
+    if (c->log2n > kFusedMaxLog2N) {
+        // no fused kernel: digits lifted to Q P -> one batched transform -> inner products with the key -> batched inverse into `work`
+        if (key_stride != 0 || key_group > 1) return fail(DPFHE_INVALID_STATE, what, "per-item keys are not available above N = 8192");
+        const int ch = n / 512;
+        const size_t lift_grid = batch * Ld * L * (size_t)ch;
+        if (lift_grid > kMaxGrid || !ntt_grid_fits(c, batch * Ld * L)) return fail(DPFHE_INVALID_ARGUMENT, what, "batch too large for one launch");
+        StreamScratch ws(c, s);
+        if (int rc = ws.alloc(batch * Ld * L * n, what)) return rc;
+        const LimbConst* lc = c->fold ? c->foldt.lc : c->shoup.lc;
+        const u64* comp = d_in + (size_t)(in_comps - 1) * Ld * n;
+        if (c->fold) hipLaunchKernelGGL((lift_digits_kernel<FoldArith>), dim3((unsigned)lift_grid), dim3(256), 0, s, ws.p, comp, (size_t)in_comps * Ld * n, lc, (int)L, n, ch);
+        else hipLaunchKernelGGL((lift_digits_kernel<ShoupArith>), dim3((unsigned)lift_grid), dim3(256), 0, s, ws.p, comp, (size_t)in_comps * Ld * n, lc, (int)L, n, ch);
+        if (int rc = check_launch("digit lift kernel launch")) return rc;
+        if (int rc = ntt_launch(c, false, ws.p, ws.p, batch * Ld * L, s)) return rc;
+        const unsigned grid = (unsigned)(batch * L * (size_t)ch);
+        if (c->fold) hipLaunchKernelGGL((key_inner_product_kernel<FoldArith>), dim3(grid), dim3(256), 0, s, d_work, ws.p, d_key, lc, (int)Ld, (int)L, n, ch);
+        else hipLaunchKernelGGL((key_inner_product_kernel<ShoupArith>), dim3(grid), dim3(256), 0, s, d_work, ws.p, d_key, lc, (int)Ld, (int)L, n, ch);
+        if (int rc = check_launch("key inner product kernel launch")) return rc;
+        if (int rc = ntt_launch(c, true, d_work, d_work, batch * 2 * L, s)) return rc;
+    } else {
+        const int rc = c->fold ? launch_relin<FoldArith>((int)c->log2n, mode, d_work, d_in, d_key, key_stride, key_group, blocks, c->foldt, s)
+                               : launch_relin<ShoupArith>((int)c->log2n, mode, d_work, d_in, d_key, key_stride, key_group, blocks, c->shoup, s);
+        if (rc) return fail(DPFHE_INVALID_STATE, what, "no kernel geometry for this log2_n");
+        int e = check_launch("hybrid key-switch kernel launch");
+        if (e) return e;
+    }
     // divide by P with rounding and add c0 (and c1 for relinearisation): one pass over the 2*batch polynomials of `work`
     const int chunks = (n + 511) / 512;
     const size_t rblocks = batch * 2 * Ld * (size_t)chunks;

@@ -54,11 +54,12 @@ __global__ __launch_bounds__(256) void lift_rns_digits_kernel(u64* __restrict__ 
     *reinterpret_cast<U64x2*>(out + ((item * n_limbs + digit) * n_limbs + limb) * n + w0) = r;
 }
 
-// acc[item][c][i] = sum_j x[item][j][i] (.) evk[j][c][i], c = 0, 1 (NTT domain; x: [batch][L][L][N], evk: [L][2][L][N], one key for the
-// whole batch: its tiles are re-read from L2).  acc: [batch][2][L][N].
+// acc[item][c][i] = sum_{j < n_digits} x[item][j][i] (.) evk[j][c][i], c = 0, 1 (NTT domain; x: [batch][n_digits][L][N], evk: [n_digits][2][L][N],
+// one key for the whole batch: its tiles are re-read from L2).  acc: [batch][2][L][N].  n_digits = L (RNS-digit keys) or L - 1 (hybrid keys: the
+// last limb is the special prime, the sum is divided by it afterwards).
 template <class Arith>
 __global__ __launch_bounds__(256) void key_inner_product_kernel(u64* __restrict__ acc, const u64* __restrict__ x, const u64* __restrict__ evk, const LimbConst* lcs,
-                                                                int n_limbs, int n, int chunks) {
+                                                                int n_digits, int n_limbs, int n, int chunks) {
     const int chunk = (int)(blockIdx.x % chunks);
     const int limb = (int)((blockIdx.x / chunks) % n_limbs);
     const size_t item = blockIdx.x / chunks / n_limbs;
@@ -67,8 +68,8 @@ __global__ __launch_bounds__(256) void key_inner_product_kernel(u64* __restrict_
     const LimbConst lc = lcs[limb];
     U64x2 s0{0, 0}, s1{0, 0};
 #pragma unroll 2
-    for (int j = 0; j < n_limbs; ++j) {
-        const U64x2 d = *reinterpret_cast<const U64x2*>(x + ((item * n_limbs + j) * n_limbs + limb) * n + w0);
+    for (int j = 0; j < n_digits; ++j) {
+        const U64x2 d = *reinterpret_cast<const U64x2*>(x + ((item * n_digits + j) * n_limbs + limb) * n + w0);
         const U64x2 k0 = *reinterpret_cast<const U64x2*>(evk + (((size_t)j * 2 + 0) * n_limbs + limb) * n + w0);
         const U64x2 k1 = *reinterpret_cast<const U64x2*>(evk + (((size_t)j * 2 + 1) * n_limbs + limb) * n + w0);
         s0.a = add_mod(s0.a, Arith::mul_var(d.a, k0.a, lc), lc.q); s0.b = add_mod(s0.b, Arith::mul_var(d.b, k0.b, lc), lc.q);

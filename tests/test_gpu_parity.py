@@ -559,3 +559,10 @@ def test_large_rings_multiply_and_key_switch_composed_behind_the_c_abi(rigs, nam
     assert np.array_equal(to_host(got.data), r.orc.switch_key(r.orc.apply_galois(ah, 5), evk, threads=0))
     out = r.ctx.empty(3, components=2)
     assert r.ev._lib.dpfhe_relinearize(r.ctx.handle, out.data_ptr(), out.data_ptr(), r.dev(evk).data_ptr(), 1, None) == 2000   # output over its input
+    # hybrid key switching with this context read as the EXTENDED one (last limb = special prime): data on the first L - 1 limbs
+    Ld = L - 1
+    hkey = r.orc.fill(Ld * 2, 8).reshape(Ld, 2, L, n)
+    for comps in (3, 2):
+        cth = np.ascontiguousarray(r.orc.fill(3 * comps, 9 + comps).reshape(3, comps, L, n)[:, :, :Ld])
+        got = r.ev.keyswitch_hybrid(Ciphertext(r.dev(cth)), r.dev(hkey))
+        assert np.array_equal(to_host(got.data), r.orc.keyswitch_hybrid(cth, hkey, comps, threads=0))
