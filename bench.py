@@ -106,7 +106,8 @@ def multi_gpu_programs(world, run=None):
       configs[3]  examples/sharded_ct_mul: batch-sharded multiply + all-gather of one partial per rank; the global sum must equal a
                   world-size-1 recomputation of the same global batch;
       configs[4]  examples/encrypted_gpt2_block: 8 tokens per rank through one transformer block's linear skeleton (N=8192, 5+1 limbs),
-                  tokens sharded over the ranks, no collective until the all-gather of the output ciphertexts; every stage decrypted.
+                  tokens sharded over the ranks, no collective until the all-gather of the output ciphertexts; every stage decrypted;
+                  examples/sharded_ffn: ONE token, the FFN's 3072 inner features split over the ranks, all-gather of one partial each.
     A failure is reported in the entry; the headline metric does not depend on it.  `run(argv, timeout) -> (returncode, stdout)` is
     replaceable (the dry run passes a stand-in)."""
     import subprocess
@@ -119,8 +120,11 @@ def multi_gpu_programs(world, run=None):
         return r.returncode, r.stdout + r.stderr
     run = run or default_run
     out = {}
-    for key, argv in (("configs3_cpp_host", ["sharded_ct_mul", str(world), "2048", "5"]),
-                      ("configs4_token_sharded_block", ["encrypted_gpt2_block", str(8 * world), "2", "json", str(world)])):
+    programs = [("configs3_cpp_host", ["sharded_ct_mul", str(world), "2048", "5"]),
+                ("configs4_token_sharded_block", ["encrypted_gpt2_block", str(8 * world), "2", "json", str(world)])]
+    if world in (1, 2, 4, 8):   # the single-token shape of configs[4]: the FFN's inner features split over the ranks (tensor parallel)
+        programs.append(("configs4_single_token_tensor_parallel_ffn", ["sharded_ffn", str(world), "3"]))
+    for key, argv in programs:
         try:
             t0 = time.perf_counter()
             rc, text = run(argv, 420)
@@ -220,6 +224,8 @@ def dry_run(args):
         def fake(argv, timeout):
             if argv[0] == "sharded_ct_mul":
                 return 0, json.dumps({"host": "c++", "world": int(argv[1]), "matches_world1_recomputation": True, "ct_mul_per_s": 0.0, "dry_run": True}) + "\nOK\n"
+            if argv[0] == "sharded_ffn":
+                return 0, json.dumps({"block": "ffn_linear_tensor_parallel", "world": int(argv[1]), "correct": True, "dry_run": True}) + "\nOK\n"
             return 0, json.dumps({"block": "transformer_linear_skeleton", "tokens": int(argv[1]), "ranks": int(argv[4]), "correct": True, "dry_run": True}) + "\nOK\n"
         progs = on_rank0_while_others_wait(rank, lambda: multi_gpu_programs(world, fake))
         if rank == 0:

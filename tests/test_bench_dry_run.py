@@ -43,6 +43,7 @@ def test_bench_dry_run_walks_every_collective(world):
         progs = r["multi_gpu_programs"]
         assert progs["configs3_cpp_host"]["world"] == world and progs["configs3_cpp_host"]["matches_world1_recomputation"] is True
         assert progs["configs4_token_sharded_block"]["ranks"] == world and progs["configs4_token_sharded_block"]["tokens"] == 8 * world
+        assert progs["configs4_single_token_tensor_parallel_ffn"]["world"] == world
     else:
         assert "multi_gpu_programs" not in r
     # value is the whole-job aggregate: all ranks' pairs over the MAX-over-ranks time

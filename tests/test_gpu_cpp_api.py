@@ -170,3 +170,4 @@ def test_bench_multi_gpu_programs_at_world_size_one():
     assert r["configs3_cpp_host"]["world"] == 1 and r["configs3_cpp_host"]["ct_mul_per_s"] > 0
     blk = r["configs4_token_sharded_block"]
     assert blk.get("correct") is True and blk["ranks"] == 1 and blk["tokens"] == 8 and blk["stage_mismatches"] == [0, 0, 0, 0, 0], r
+    assert r["configs4_single_token_tensor_parallel_ffn"].get("correct") is True and r["configs4_single_token_tensor_parallel_ffn"]["world"] == 1, r
