@@ -24,6 +24,7 @@ SYMBOLS = {
     "dpfhe_add": ([C.c_void_p, _U64P, _U64P, _U64P, C.c_size_t, C.c_void_p], C.c_int),
     "dpfhe_sub": ([C.c_void_p, _U64P, _U64P, _U64P, C.c_size_t, C.c_void_p], C.c_int),
     "dpfhe_negate": ([C.c_void_p, _U64P, _U64P, C.c_size_t, C.c_void_p], C.c_int),
+    "dpfhe_multiply_plain": ([C.c_void_p, _U64P, _U64P, _U64P, C.c_size_t, C.c_void_p], C.c_int),
     "dpfhe_ct_mul": ([C.c_void_p, _U64P, _U64P, _U64P, C.c_size_t, C.c_uint32, C.c_void_p], C.c_int),
     "dpfhe_relinearize": ([C.c_void_p, _U64P, _U64P, _U64P, C.c_size_t, C.c_void_p], C.c_int),
     "dpfhe_relinearize_hybrid": ([C.c_void_p, _U64P, _U64P, _U64P, _U64P, C.c_size_t, C.c_void_p], C.c_int),

@@ -277,12 +277,12 @@ extern "C" int dpfhe_ntt_inv_oop(dpfhe_ctx* c, uint64_t* o, const uint64_t* i, s
 
 // ------------------------------------------------------------------------------------------------
 template <class Arith, int OP>
-static void launch_dy(dpfhe_ctx* c, u64* out, const u64* a, const u64* b, size_t npolys, hipStream_t s) {
+static void launch_dy(dpfhe_ctx* c, u64* out, const u64* a, const u64* b, size_t npolys, hipStream_t s, int b_period = 0) {
     hipLaunchKernelGGL((dyadic_kernel<Arith, OP>), dim3((unsigned)npolys), dim3(256), 0, s, out, a, b, tables_of<Arith>(c).lc,
-                       (int)c->n_limbs, 1 << c->log2n);
+                       (int)c->n_limbs, 1 << c->log2n, b_period);
 }
 
-static int dyadic_entry(dpfhe_ctx* c, int op, uint64_t* out, const uint64_t* a, const uint64_t* b, size_t n_rns_polys, void* stream) {
+static int dyadic_entry(dpfhe_ctx* c, int op, uint64_t* out, const uint64_t* a, const uint64_t* b, size_t n_rns_polys, void* stream, bool broadcast_b = false) {
     if (!c) return fail(DPFHE_INVALID_ARGUMENT, "dyadic", "null context");
     if (n_rns_polys == 0) return DPFHE_SUCCESS;
     if (!out || !a || (op != DY_NEG && !b) || misaligned(out) || misaligned(a) || misaligned(b))
@@ -292,10 +292,11 @@ static int dyadic_entry(dpfhe_ctx* c, int op, uint64_t* out, const uint64_t* a, 
     DPFHE_ON_DEVICE(c, "dyadic");
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (op == DY_NEG) b = a;
-#define DY_CASE(OP)                                                   \
-    case OP:                                                          \
-        if (c->fold) launch_dy<FoldArith, OP>(c, out, a, b, npolys, s); \
-        else launch_dy<ShoupArith, OP>(c, out, a, b, npolys, s);      \
+    const int b_period = broadcast_b ? (int)c->n_limbs : 0;
+#define DY_CASE(OP)                                                             \
+    case OP:                                                                    \
+        if (c->fold) launch_dy<FoldArith, OP>(c, out, a, b, npolys, s, b_period); \
+        else launch_dy<ShoupArith, OP>(c, out, a, b, npolys, s, b_period);      \
         break
     switch (op) {
         DY_CASE(DY_MUL); DY_CASE(DY_MUL_ADD); DY_CASE(DY_ADD); DY_CASE(DY_SUB); DY_CASE(DY_NEG);
@@ -310,6 +311,8 @@ extern "C" int dpfhe_dyadic_mul_add(dpfhe_ctx* c, uint64_t* acc, const uint64_t*
 extern "C" int dpfhe_add(dpfhe_ctx* c, uint64_t* o, const uint64_t* a, const uint64_t* b, size_t n, void* s) { return dyadic_entry(c, DY_ADD, o, a, b, n, s); }
 extern "C" int dpfhe_sub(dpfhe_ctx* c, uint64_t* o, const uint64_t* a, const uint64_t* b, size_t n, void* s) { return dyadic_entry(c, DY_SUB, o, a, b, n, s); }
 extern "C" int dpfhe_negate(dpfhe_ctx* c, uint64_t* o, const uint64_t* a, size_t n, void* s) { return dyadic_entry(c, DY_NEG, o, a, nullptr, n, s); }
+// A7: every residue polynomial of a times ONE plaintext (an RNS polynomial of L limbs), one launch for the whole batch
+extern "C" int dpfhe_multiply_plain(dpfhe_ctx* c, uint64_t* o, const uint64_t* a, const uint64_t* pt, size_t n, void* s) { return dyadic_entry(c, DY_MUL, o, a, pt, n, s, true); }
 
 // ------------------------------------------------------------------------------------------------
 // ---- ring degrees above 8192: the fused kernels stop there (kernels_large.h); the same operations composed from the batched transforms

@@ -304,9 +304,7 @@ void Evaluator::apply_galois(const Ciphertext& in2, const GaloisKeys& keys, Ciph
 void Evaluator::multiply_plain(const Ciphertext& a, const Plaintext& p, Ciphertext& out, Stream* s) const {
     if (!a.is_ntt() || !p.is_ntt()) throw Exception(ErrorCode::INVALID_STATE, "multiply_plain: operands must be in the NTT domain");
     if (p.batch() != 1 || out.words() != a.words()) throw Exception(ErrorCode::INVALID_ARGUMENT, "multiply_plain: one plaintext, output shaped like the input");
-    const size_t per_poly = p.words();  // L*N
-    for (size_t i = 0; i < a.batch() * a.size(); ++i)
-        check(dpfhe_dyadic_mul(impl_->h(), out.data() + i * per_poly, a.data() + i * per_poly, p.data(), 1, s), "dpfhe_dyadic_mul");
+    check(dpfhe_multiply_plain(impl_->h(), out.data(), a.data(), p.data(), a.batch() * a.size(), s), "dpfhe_multiply_plain");
     out.set_ntt(true);
 }
 void Evaluator::matvec_plain(const Plaintext& W, const Ciphertext& x, Ciphertext& y, Stream* s) const {
@@ -1493,17 +1491,15 @@ void PackedSelect::apply(const Ciphertext& x, Ciphertext& y, Stream* s) const {
         throw Exception(ErrorCode::INVALID_ARGUMENT, "PackedSelect::apply: T 2-component coefficient-domain ciphertexts in and out");
     I.ensure(T);
     dpfhe_ctx* h = static_cast<dpfhe_ctx*>(I.ctx->handle());
-    const FheParams& p = I.ctx->params();
-    const size_t poly = p.n_limbs() * p.n();
     Ciphertext &a = *I.a, &b = *I.b;
     const Ciphertext* cur = &x;
     if (I.offset) {   // slot offset + i -> slot i
         I.ks->apply_galois_grouped(x, 0, std::vector<uint32_t>(1, I.shift_elt), T, a, 0, s);
         cur = &a;
     }
-    // mask: NTT, one dyadic product per polynomial with the (broadcast) mask, back
+    // mask: NTT, every polynomial times the (broadcast) mask in one launch, back
     check(dpfhe_ntt_fwd_oop(h, b.data(), cur->data(), T * 2, s), "dpfhe_ntt_fwd_oop");
-    for (size_t i = 0; i < T * 2; ++i) check(dpfhe_dyadic_mul(h, b.data() + i * poly, b.data() + i * poly, I.mask->data(), 1, s), "dpfhe_dyadic_mul");
+    check(dpfhe_multiply_plain(h, b.data(), b.data(), I.mask->data(), T * 2, s), "dpfhe_multiply_plain");
     check(dpfhe_ntt_inv(h, b.data(), T * 2, s), "dpfhe_ntt_inv");
     b.set_ntt(false);
     // spread along the row: b += rot(b, -period), then -2 period, ...; then the other row

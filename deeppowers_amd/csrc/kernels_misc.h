@@ -27,12 +27,14 @@ __device__ __forceinline__ u64 dy_apply(u64 a, u64 b, u64 acc, const LimbConst& 
     return neg_mod(a, lc.q);
 }
 
+// b_period = 0: b is shaped like a; b_period = L: ONE RNS polynomial (a plaintext), broadcast over the residue polynomials of a (A7 multiply_plain:
+// its L tiles stay in L2, the launch moves two polynomials per polynomial instead of three)
 template <class Arith, int OP>
-__global__ __launch_bounds__(256) void dyadic_kernel(u64* out, const u64* a, const u64* b, const LimbConst* lcs, int n_limbs, int n) {
+__global__ __launch_bounds__(256) void dyadic_kernel(u64* out, const u64* a, const u64* b, const LimbConst* lcs, int n_limbs, int n, int b_period = 0) {
     const size_t p = blockIdx.x;
     const LimbConst lc = lcs[p % (size_t)n_limbs];
     const U64x2* pa = reinterpret_cast<const U64x2*>(a + p * n);
-    const U64x2* pb = reinterpret_cast<const U64x2*>(b + p * n);
+    const U64x2* pb = reinterpret_cast<const U64x2*>(b + (b_period ? p % (size_t)b_period : p) * n);
     U64x2* po = reinterpret_cast<U64x2*>(out + p * n);
     const int nv = n >> 1;
     constexpr int UN = 4;

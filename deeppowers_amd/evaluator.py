@@ -465,9 +465,13 @@ class Evaluator:
         """ct (.) pt, both in the NTT domain: every component times the plaintext polynomial."""
         if not (a.is_ntt and p.is_ntt):
             raise _cabi.DpfheError(2002, "multiply_plain needs NTT-domain operands")
-        with self._on(stream):   # the broadcast copy is torch work: it must run on (and belong to) the same stream
-            pt = p.data.expand(a.data.shape).contiguous()
-        return Ciphertext(self.dyadic_mul(a.data, pt, stream=stream), True)
+        pr = self.ctx.params
+        if tuple(p.data.shape[-2:]) != (pr.n_limbs, pr.n) or p.data.numel() != pr.n_limbs * pr.n:
+            raise _cabi.DpfheError(2000, "multiply_plain takes ONE plaintext ([L][N]); use dyadic_mul for per-item plaintexts")
+        self._chk(a.data, p.data)
+        out = self._empty_like(a.data, stream)
+        _cabi.check(self._lib.dpfhe_multiply_plain(self.ctx.handle, out.data_ptr(), a.data.data_ptr(), p.data.data_ptr(), self._npolys(a.data), self._sp(stream)), "dpfhe_multiply_plain")
+        return Ciphertext(out, True)
 
     def matvec_plain(self, W: Plaintext, x: Ciphertext, out: torch.Tensor | None = None, stream=None) -> Ciphertext:
         """y_i = sum_j W_ij (.) x_j.  W.data: [rows][cols][L][N] (NTT), x.data: [cols][2][L][N] (NTT)."""

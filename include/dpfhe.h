@@ -81,6 +81,10 @@ int dpfhe_dyadic_mul_add(dpfhe_ctx* ctx, uint64_t* d_acc, const uint64_t* d_a, c
 int dpfhe_add(dpfhe_ctx* ctx, uint64_t* d_out, const uint64_t* d_a, const uint64_t* d_b, size_t n_rns_polys, void* stream);
 int dpfhe_sub(dpfhe_ctx* ctx, uint64_t* d_out, const uint64_t* d_a, const uint64_t* d_b, size_t n_rns_polys, void* stream);
 int dpfhe_negate(dpfhe_ctx* ctx, uint64_t* d_out, const uint64_t* d_a, size_t n_rns_polys, void* stream);
+/* -- A7 (Evaluator::multiply_plain): d_out[i] = d_a[i] (.) d_pt for the n_rns_polys RNS polynomials of d_a (the components of a batch of
+ *    ciphertexts, NTT domain) and ONE plaintext d_pt ([L][N], NTT domain).  One launch; the plaintext's L tiles are re-read from L2.
+ *    d_out may alias d_a. */
+int dpfhe_multiply_plain(dpfhe_ctx* ctx, uint64_t* d_out, const uint64_t* d_a, const uint64_t* d_pt, size_t n_rns_polys, void* stream);
 
 /* -- A6: ciphertext x ciphertext tensor product, no relinearisation (THE METRIC OP) -----------------
  * d_a2, d_b2: [batch][2][L][N];  d_out3: [batch][3][L][N] = (a0 b0, a0 b1 + a1 b0, a1 b1) in R_q.

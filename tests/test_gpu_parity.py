@@ -307,9 +307,10 @@ def test_matvec_scalar_vs_oracle(rigs, name, rows, cols):
     assert y.is_ntt and np.array_equal(to_host(y.data), want)
 
 
-def test_multiply_plain_and_ct_add_sub_negate(rigs):
-    r = rigs("n4096")
-    L, n = 4, 4096
+@pytest.mark.parametrize("name", ["n4096", "shoup10", "n8192"])
+def test_multiply_plain_and_ct_add_sub_negate(rigs, name):
+    r = rigs(name)
+    L, n = r.p.n_limbs, r.p.n
     a = r.orc.fill(4, 51).reshape(2, 2, L, n)
     b = r.orc.fill(4, 52).reshape(2, 2, L, n)
     pt = r.orc.fill(1, 53).reshape(L, n)
@@ -320,6 +321,12 @@ def test_multiply_plain_and_ct_add_sub_negate(rigs):
     got = to_host(r.ev.multiply_plain(A, Plaintext(r.dev(pt), True)).data)
     want = r.orc.dyadic("mul", a, np.ascontiguousarray(np.broadcast_to(pt, a.shape)))
     assert np.array_equal(got, want)
+    # ONE launch for the whole batch (dpfhe_multiply_plain: the plaintext broadcast inside the kernel), also in place
+    io, ptd = r.dev(a), r.dev(pt)
+    assert r.ev._lib.dpfhe_multiply_plain(r.ctx.handle, io.data_ptr(), io.data_ptr(), ptd.data_ptr(), 4, None) == 0
+    assert np.array_equal(to_host(io), want)
+    with pytest.raises(_cabi.DpfheError):
+        r.ev.multiply_plain(A, Plaintext(r.dev(np.ascontiguousarray(np.broadcast_to(pt, a.shape))), True))   # per-item plaintexts: dyadic_mul's job
 
 
 @pytest.mark.parametrize("name,count,comps", [("n4096", 37, 3), ("config1", 5, 2), ("shoup13", 1, 3)])
