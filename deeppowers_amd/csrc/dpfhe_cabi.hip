@@ -278,8 +278,13 @@ extern "C" int dpfhe_ntt_inv_oop(dpfhe_ctx* c, uint64_t* o, const uint64_t* i, s
 // ------------------------------------------------------------------------------------------------
 template <class Arith, int OP>
 static void launch_dy(dpfhe_ctx* c, u64* out, const u64* a, const u64* b, size_t npolys, hipStream_t s, int b_period = 0) {
-    hipLaunchKernelGGL((dyadic_kernel<Arith, OP>), dim3((unsigned)npolys), dim3(256), 0, s, out, a, b, tables_of<Arith>(c).lc,
-                       (int)c->n_limbs, 1 << c->log2n, b_period);
+    // distinct streams of the launch: a, b (unless broadcast or the same buffer), the result (unless in place; read as well by mul_add)
+    const int streams = 1 + ((OP != DY_NEG && !b_period && b != a) ? 1 : 0) + ((out != a && out != b) ? 1 : 0);
+    const bool nt = (npolys << c->log2n) * sizeof(u64) * (size_t)streams > ((size_t)256 << 20);   // cannot stay in the Infinity Cache
+    if (nt) hipLaunchKernelGGL((dyadic_kernel<Arith, OP, true>), dim3((unsigned)npolys), dim3(256), 0, s, out, a, b, tables_of<Arith>(c).lc,
+                               (int)c->n_limbs, 1 << c->log2n, b_period);
+    else hipLaunchKernelGGL((dyadic_kernel<Arith, OP, false>), dim3((unsigned)npolys), dim3(256), 0, s, out, a, b, tables_of<Arith>(c).lc,
+                            (int)c->n_limbs, 1 << c->log2n, b_period);
 }
 
 static int dyadic_entry(dpfhe_ctx* c, int op, uint64_t* out, const uint64_t* a, const uint64_t* b, size_t n_rns_polys, void* stream, bool broadcast_b = false) {

@@ -211,6 +211,27 @@ def test_dyadic_ops_vs_oracle(rigs, name):
     assert np.array_equal(to_host(out), r.orc.dyadic("mul", a, b))
 
 
+@pytest.mark.parametrize("name", ["n4096", "shoup12"])
+def test_dyadic_ops_beyond_the_infinity_cache_take_the_non_temporal_path(rigs, name):
+    """A launch that touches more than the 256 MiB Infinity Cache holds runs the non-temporal variant of the dyadic kernel (dpfhe_cabi.hip
+    launch_dy): same words.  768 x L residue polynomials of 32 KiB per operand = 96 MiB (72 with three limbs) per stream."""
+    r = rigs(name)
+    L, n = r.p.n_limbs, r.p.n
+    nb = 768 if L == 4 else 1100
+    a, b, acc = (r.orc.fill(nb, seed).reshape(nb, L, n) for seed in (91, 92, 93))
+    assert 3 * a.nbytes > (256 << 20) and 2 * a.nbytes <= (256 << 20)   # three streams cross the threshold, two (negate) do not
+    A, Bd, ACC = r.dev(a), r.dev(b), r.dev(acc)
+    assert np.array_equal(to_host(r.ev.dyadic_mul(A, Bd)), r.orc.dyadic("mul", a, b, threads=0))
+    assert np.array_equal(to_host(r.ev.sub_words(A, Bd)), r.orc.dyadic("sub", a, b, threads=0))
+    assert np.array_equal(to_host(r.ev.negate_words(A)), r.orc.dyadic("negate", a, threads=0))
+    r.ev.dyadic_mul_add_(ACC, A, Bd)
+    assert np.array_equal(to_host(ACC), r.orc.dyadic("mul_add", a, b, acc=acc, threads=0))
+    pt = r.orc.fill(1, 94).reshape(L, n)
+    big = np.concatenate([a, b], 0)   # one plaintext over a 2 x 96 MiB batch: two streams + the cached plaintext
+    got = r.ev.multiply_plain(Ciphertext(r.dev(big.reshape(-1, 2, L, n)), True), Plaintext(r.dev(pt), True))
+    assert np.array_equal(to_host(got.data).reshape(big.shape), r.orc.dyadic("mul", big, np.ascontiguousarray(np.broadcast_to(pt, big.shape)), threads=0))
+
+
 # ---- ct x ct (the metric op) ---------------------------------------------------------------------------------
 @pytest.mark.parametrize("name", ALL)
 def test_ct_mul_vs_oracle_all_domains(rigs, name):

@@ -21,12 +21,12 @@ poly = L * N * 8 * nb
 for name, fn, streams in (("dyadic_mul", lambda: ev.dyadic_mul(a, b, out=o), 3), ("dyadic_mul_add", lambda: ev.dyadic_mul_add_(c, a, b), 4),
                           ("add", lambda: ev.add_words(a, b, out=o), 3), ("sub", lambda: ev.sub_words(a, b, out=o), 3), ("negate", lambda: ev.negate_words(a, out=o), 2)):
     med, mn = timeit(fn, reps=15, warm=3)
-    print(f"{name:16s} {nb} RNS polys: median {med:8.1f} us  {streams * poly / med / 1e6:7.1f} GB/s = {streams * poly / med / 8e6 * 100:5.1f}% of 8 TB/s")
+    print(f"{name:16s} {nb} RNS polys: median {med:8.1f} us  {streams * poly / med / 1e6:7.2f} TB/s = {streams * poly / med / 8e6 * 100:5.1f}% of 8 TB/s")
 del a, b, c, o
 cts = Ciphertext(rnd(8192, 3))
 out = ctx.empty(components=3)
 med, mn = timeit(lambda: ev.reduce_sum(cts, out=out), reps=15, warm=3)
-print(f"reduce_sum 8192 x 3-comp cts: median {med:8.1f} us  {8192 * 3 * L * N * 8 / med / 1e6:7.1f} GB/s = {8192 * 3 * L * N * 8 / med / 8e6 * 100:5.1f}% of 8 TB/s")
+print(f"reduce_sum 8192 x 3-comp cts: median {med:8.1f} us  {8192 * 3 * L * N * 8 / med / 1e6:7.2f} TB/s = {8192 * 3 * L * N * 8 / med / 8e6 * 100:5.1f}% of 8 TB/s")
 del cts
 rows, cols = 768, 64
 W = Plaintext(rnd(rows, cols), True)
