@@ -834,8 +834,15 @@ extern "C" int dpfhe_matvec_plain(dpfhe_ctx* c, uint64_t* d_y, const uint64_t* d
         const size_t slabs = c->n_limbs * (size_t)chunks, rtiles = (rows + RT - 1) / RT;
         const size_t blocks = ((slabs + 7) / 8) * 8 * rtiles;
         if (blocks > kMaxGrid) return fail(DPFHE_INVALID_ARGUMENT, "dpfhe_matvec_plain", "too many rows for one launch");
-        hipLaunchKernelGGL((matvec_fold_kernel<RT, 2, WPT>), dim3((unsigned)blocks), dim3(256), 0, s, d_y, d_W, d_x, c->foldt.lc, (int)c->n_limbs, n, chunks, rows, cols,
-                           (size_t)2, 1u, (unsigned)(rtiles * slabs));
+#ifndef DPFHE_MATVEC_NTW
+#define DPFHE_MATVEC_NTW 1
+#endif
+        // a W beyond the 256 MiB Infinity Cache is a read-once stream (every tile goes to exactly one workgroup here): non-temporal loads
+        const bool ntw = DPFHE_MATVEC_NTW && rows * cols * ((size_t)c->n_limbs << c->log2n) * sizeof(u64) > ((size_t)256 << 20);
+        if (ntw) hipLaunchKernelGGL((matvec_fold_kernel<RT, 2, WPT, true>), dim3((unsigned)blocks), dim3(256), 0, s, d_y, d_W, d_x, c->foldt.lc, (int)c->n_limbs, n, chunks, rows,
+                                    cols, (size_t)2, 1u, (unsigned)(rtiles * slabs));
+        else hipLaunchKernelGGL((matvec_fold_kernel<RT, 2, WPT>), dim3((unsigned)blocks), dim3(256), 0, s, d_y, d_W, d_x, c->foldt.lc, (int)c->n_limbs, n, chunks, rows, cols,
+                                (size_t)2, 1u, (unsigned)(rtiles * slabs));
         return check_launch("matvec kernel launch");
     }
     const int chunks = (n + 511) / 512;

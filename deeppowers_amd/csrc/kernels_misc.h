@@ -351,18 +351,23 @@ __global__ __launch_bounds__(256) void matvec_multi_kernel(u64* y, const u64* W,
 template <int WPT> struct WordVec;
 template <> struct WordVec<1> { u64 v[1]; };
 template <> struct __attribute__((aligned(16))) WordVec<2> { u64 v[2]; };
-template <int WPT>
+template <int WPT, bool NT = false>
 __device__ __forceinline__ WordVec<WPT> load_words(const u64* p, bool in_range) {   // rows beyond the matrix read as zero
     WordVec<WPT> r;
-    if (in_range) r = *reinterpret_cast<const WordVec<WPT>*>(p);
-    else {
+    if (in_range) {
+        if (NT) {
+#pragma unroll
+            for (int k = 0; k < WPT; ++k) r.v[k] = __builtin_nontemporal_load(p + k);
+        } else r = *reinterpret_cast<const WordVec<WPT>*>(p);
+    } else {
 #pragma unroll
         for (int k = 0; k < WPT; ++k) r.v[k] = 0;
     }
     return r;
 }
 
-template <int RT, int C, int WPT>
+// NTW: the W tiles are read once by ONE workgroup (a single group of right-hand sides) and W does not fit the Infinity Cache: non-temporal loads
+template <int RT, int C, int WPT, bool NTW = false>
 __global__ __launch_bounds__(256) void matvec_fold_kernel(u64* y, const u64* W, const u64* x, const LimbConst* lcs, int n_limbs, int n,
                                                           int chunks, size_t rows, size_t cols, size_t polys_per_col, unsigned n_groups,
                                                           unsigned n_tiles) {
@@ -386,7 +391,7 @@ __global__ __launch_bounds__(256) void matvec_fold_kernel(u64* y, const u64* W, 
     // uniform bases (scalar registers, scalar adds) + one 32-bit lane offset: no per-lane 64-bit address arithmetic
     const u64* const wu = W + (row0 * cols * L + limb) * n;
     const u64* const xu = x + (size_t)limb * n;
-    auto ld_w = [&](int r, size_t j) { return load_words<WPT>(&(wu + (r * rstride + j * wstride))[w0], row0 + r < rows); };
+    auto ld_w = [&](int r, size_t j) { return load_words<WPT, NTW>(&(wu + (r * rstride + j * wstride))[w0], row0 + r < rows); };
     auto ld_x = [&](int c, size_t j) { return *reinterpret_cast<const V*>(&(xu + (j * xstride + (size_t)c * L * n))[w0]); };
     u64 run[RT][C][WPT];   // folded running words (reduced); the first products of every period chain onto them
 #pragma unroll
