@@ -352,7 +352,7 @@ struct StreamScratch {
     ~StreamScratch() { if (p) (void)hipFreeAsync(p, s); }
 };
 
-static int ct_mul_composed(dpfhe_ctx* c, uint64_t* d_out3, const uint64_t* d_a2, const uint64_t* d_b2, size_t batch, uint32_t flags, hipStream_t s) {
+static int ct_mul_composed_slice(dpfhe_ctx* c, uint64_t* d_out3, const uint64_t* d_a2, const uint64_t* d_b2, size_t batch, uint32_t flags, hipStream_t s) {
     const size_t L = c->n_limbs, n = (size_t)1 << c->log2n, poly = L * n;
     const int chunks = (int)(n / 512);
     const size_t grid = batch * L * (size_t)chunks;
@@ -376,8 +376,8 @@ static int ct_mul_composed(dpfhe_ctx* c, uint64_t* d_out3, const uint64_t* d_a2,
 }
 
 // RNS-digit key switch: out2 = [mask-selected components of in] + sum_j NTT^-1( NTT([in_{last comp}]_j mod q_i) (.) evk[j] )
-static int key_switch_composed(dpfhe_ctx* c, uint64_t* d_out2, const uint64_t* d_in, int in_comps, int add_mask, const uint64_t* d_evk, size_t batch,
-                               hipStream_t s, const char* what) {
+static int key_switch_composed_slice(dpfhe_ctx* c, uint64_t* d_out2, const uint64_t* d_in, int in_comps, int add_mask, const uint64_t* d_evk, size_t batch,
+                                     hipStream_t s, const char* what) {
     const size_t L = c->n_limbs, n = (size_t)1 << c->log2n;
     const int chunks = (int)(n / 512);
     const size_t lift_grid = batch * L * L * (size_t)chunks;
@@ -396,6 +396,38 @@ static int key_switch_composed(dpfhe_ctx* c, uint64_t* d_out2, const uint64_t* d
     if (int rc = ntt_launch(c, true, d_out2, d_out2, batch * 2 * L, s)) return rc;
     hipLaunchKernelGGL(add_back_kernel, dim3(2 * grid), dim3(256), 0, s, d_out2, d_in, in_comps, add_mask, lc, (int)L, (int)n, chunks);
     return check_launch("add-back kernel launch");
+}
+
+// Large batches go through in slices whose scratch stays below scratch_words() (the slices run back to back on the caller's stream and reuse
+// the pool's block): the scratch of a composed operation is 4 (multiply) or L^2 / 2 (key switch) times its input.
+static size_t scratch_words() {   // 1 GiB unless DPFHE_SCRATCH_MIB says otherwise (read once)
+    static const size_t words = [] {
+        const char* e = std::getenv("DPFHE_SCRATCH_MIB");
+        const long mib = e ? std::atol(e) : 0;
+        return (size_t)(mib > 0 ? mib : 1024) << 17;
+    }();
+    return words;
+}
+static size_t slice_items(size_t batch, size_t scratch_words_per_item) {
+    const size_t fit = scratch_words() / scratch_words_per_item;
+    return fit == 0 ? 1 : (fit < batch ? fit : batch);
+}
+static int ct_mul_composed(dpfhe_ctx* c, uint64_t* d_out3, const uint64_t* d_a2, const uint64_t* d_b2, size_t batch, uint32_t flags, hipStream_t s) {
+    const size_t poly = (size_t)c->n_limbs << c->log2n, per = slice_items(batch, 4 * poly);
+    for (size_t i = 0; i < batch; i += per) {
+        const size_t m = batch - i < per ? batch - i : per;
+        if (int rc = ct_mul_composed_slice(c, d_out3 + i * 3 * poly, d_a2 + i * 2 * poly, d_b2 + i * 2 * poly, m, flags, s)) return rc;
+    }
+    return DPFHE_SUCCESS;
+}
+static int key_switch_composed(dpfhe_ctx* c, uint64_t* d_out2, const uint64_t* d_in, int in_comps, int add_mask, const uint64_t* d_evk, size_t batch,
+                               hipStream_t s, const char* what) {
+    const size_t poly = (size_t)c->n_limbs << c->log2n, per = slice_items(batch, c->n_limbs * poly);
+    for (size_t i = 0; i < batch; i += per) {
+        const size_t m = batch - i < per ? batch - i : per;
+        if (int rc = key_switch_composed_slice(c, d_out2 + i * 2 * poly, d_in + i * (size_t)in_comps * poly, in_comps, add_mask, d_evk, m, s, what)) return rc;
+    }
+    return DPFHE_SUCCESS;
 }
 
 extern "C" int dpfhe_ct_mul(dpfhe_ctx* c, uint64_t* d_out3, const uint64_t* d_a2, const uint64_t* d_b2, size_t batch,

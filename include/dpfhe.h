@@ -58,7 +58,8 @@ enum { DPFHE_IN_NTT = 1u, DPFHE_OUT_NTT = 2u };
 /* -- A0: context ----------------------------------------------------------------------------------
  * log2_n in [8, 16] (N > 16384 runs a two-kernel split transform; the fused ct x ct / key-switch kernels stop at 13: above it dpfhe_ct_mul,
  * dpfhe_relinearize and dpfhe_switch_key compose the batched transforms with one-pass streaming kernels and take their scratch from the
- * stream-ordered allocator (a memory pool of the context's own, on the caller's stream; kept until dpfhe_ctx_destroy); so do the single-key hybrid entries dpfhe_relinearize_hybrid / dpfhe_switch_key_hybrid; the batched, hoisted and grouped rotation entries return
+ * stream-ordered allocator (a memory pool of the context's own, on the caller's stream; kept until dpfhe_ctx_destroy; large batches run in slices of at most
+ * 1 GiB of scratch, or DPFHE_SCRATCH_MIB MiB when that environment variable is set); so do the single-key hybrid entries dpfhe_relinearize_hybrid / dpfhe_switch_key_hybrid; the batched, hoisted and grouped rotation entries return
  * DPFHE_INVALID_STATE there); n_limbs >= 1; moduli[i] prime < 2^60 with q = 1 (mod 2N); psi[i] a primitive
  * 2N-th root of unity mod q_i (psi^N = -1).  Builds twiddle / Shoup / Barrett tables on device_id. */
 int dpfhe_ctx_create(dpfhe_ctx** out, uint32_t log2_n, uint32_t n_limbs, const uint64_t* moduli,

@@ -594,3 +594,33 @@ def test_large_rings_multiply_and_key_switch_composed_behind_the_c_abi(rigs, nam
         cth = np.ascontiguousarray(r.orc.fill(3 * comps, 9 + comps).reshape(3, comps, L, n)[:, :, :Ld])
         got = r.ev.keyswitch_hybrid(Ciphertext(r.dev(cth)), r.dev(hkey))
         assert np.array_equal(to_host(got.data), r.orc.keyswitch_hybrid(cth, hkey, comps, threads=0))
+
+
+def test_large_ring_batches_are_sliced_to_bound_the_scratch():
+    """The composed operations above N = 8192 take their scratch in slices (1 GiB by default): with DPFHE_SCRATCH_MIB = 2 a batch of 5
+    items at N = 16384 runs as 5 (multiply: 1.5 MiB of scratch per item) and 3 (key switch: 1.1 MiB) slices - same words as the oracle.
+    The variable is read once per process, hence the child."""
+    code = r"""
+import numpy as np, torch
+from deeppowers_amd.evaluator import Ciphertext, Context, Evaluator, to_device, to_host
+from deeppowers_amd.params import PRIMES_60, FheParams
+from oracle import pyoracle as po
+from oracle.cbind import Oracle
+qs = [PRIMES_60[i][0] for i in (1, 2, 4)]
+p = FheParams(14, tuple(qs), tuple(po.min_primitive_2n_root(16384, q) for q in qs))
+ctx = Context(p, 0); ev = Evaluator(ctx); orc = Oracle.from_params(p)
+L, n = p.n_limbs, p.n
+ah, bh = orc.fill(10, 1).reshape(5, 2, L, n), orc.fill(10, 2).reshape(5, 2, L, n)
+want = orc.ct_mul(ah, bh, threads=0)
+assert np.array_equal(to_host(ev.multiply(Ciphertext(to_device(ah, ctx.device)), Ciphertext(to_device(bh, ctx.device))).data), want)
+evk = orc.fill(L * 2, 7).reshape(L, 2, L, n)
+got = ev.relinearize(Ciphertext(to_device(want, ctx.device)), to_device(evk, ctx.device))
+assert np.array_equal(to_host(got.data), orc.relinearize(want, evk, threads=0))
+print("SLICED-OK")
+"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, DPFHE_SCRATCH_MIB="2", PYTHONPATH=root)
+    run = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert run.returncode == 0 and "SLICED-OK" in run.stdout, run.stdout + run.stderr
