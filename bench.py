@@ -84,7 +84,7 @@ class PowerSampler(threading.Thread):
                 "source": "hwmon power1/freq1 of this GPU, 2 ms sampling over the timed steps"}
 
 
-def on_rank0_while_others_wait(rank, fn, key="dpfhe_bench_rank0_programs", timeout_s=900):
+def on_rank0_while_others_wait(rank, fn, key="dpfhe_bench_rank0_programs", timeout_s=600):
     """fn() on rank 0 while the other ranks wait on the HOST (a key of the process group's store), not inside a collective: a RCCL
     barrier would park a spinning kernel on every waiting GPU for as long as rank 0's programs use those GPUs."""
     import datetime
@@ -127,7 +127,7 @@ def multi_gpu_programs(world, run=None):
     for key, argv in programs:
         try:
             t0 = time.perf_counter()
-            rc, text = run(argv, 420)
+            rc, text = run(argv, 150)   # these take 5-30 s; a hung program must not hold the bench line back for long
             got = [json.loads(l) for l in text.splitlines() if l.startswith("{")]
             out[key] = dict(got[0], wall_s=round(time.perf_counter() - t0, 1)) if got and rc == 0 else {"error": text[-300:], "returncode": rc}
         except Exception as e:
