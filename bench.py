@@ -100,6 +100,24 @@ def on_rank0_while_others_wait(rank, fn, key="dpfhe_bench_rank0_programs", timeo
     return None
 
 
+def run_program(argv, timeout):
+    """(returncode, output) of examples/<argv[0]> (built by __graft_entry__.build()); the program gets its own session: it forks one process
+    per GPU, and a timeout must take the whole group down, not only the parent."""
+    import signal
+    import subprocess
+    exe = os.path.join(ROOT, "examples", argv[0])
+    if not os.path.exists(exe):
+        raise FileNotFoundError(f"{exe}: run `python -c 'import __graft_entry__ as g; g.build()'` first")
+    proc = subprocess.Popen([exe] + argv[1:], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, start_new_session=True)
+    try:
+        text, _ = proc.communicate(timeout=timeout)
+    except subprocess.TimeoutExpired:
+        os.killpg(proc.pid, signal.SIGKILL)
+        text, _ = proc.communicate()
+        return -9, (text or "") + f"\n[killed after {timeout} s]"
+    return proc.returncode, text
+
+
 def multi_gpu_programs(world, run=None):
     """N>1, rank 0 only, after the timed region: the two pure-C++ multi-process programs (one process per GPU, forked by the program itself,
     RCCL through the C ABI, no Python on the data path) over the same `world` GPUs:
@@ -110,15 +128,7 @@ def multi_gpu_programs(world, run=None):
                   examples/sharded_ffn: ONE token, the FFN's 3072 inner features split over the ranks, all-gather of one partial each.
     A failure is reported in the entry; the headline metric does not depend on it.  `run(argv, timeout) -> (returncode, stdout)` is
     replaceable (the dry run passes a stand-in)."""
-    import subprocess
-
-    def default_run(argv, timeout):
-        exe = os.path.join(ROOT, "examples", argv[0])
-        if not os.path.exists(exe):
-            raise FileNotFoundError(f"{exe}: run `python -c 'import __graft_entry__ as g; g.build()'` first")
-        r = subprocess.run([exe] + argv[1:], capture_output=True, text=True, timeout=timeout)
-        return r.returncode, r.stdout + r.stderr
-    run = run or default_run
+    run = run or run_program
     out = {}
     programs = [("configs3_cpp_host", ["sharded_ct_mul", str(world), "2048", "5"]),
                 ("configs4_token_sharded_block", ["encrypted_gpt2_block", str(8 * world), "2", "json", str(world)])]

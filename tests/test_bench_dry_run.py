@@ -53,3 +53,29 @@ def test_bench_dry_run_walks_every_collective(world):
 def test_bench_refuses_a_world_size_mismatch():
     run = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run"], capture_output=True, text=True, timeout=300, cwd=ROOT)
     assert run.returncode != 0 and "torch.distributed.run" in (run.stdout + run.stderr)
+
+
+def test_run_program_kills_the_whole_process_group_on_timeout(tmp_path):
+    """bench.run_program: the C++ multi-GPU programs fork one process per GPU; a timeout has to take the children down with the parent."""
+    import time
+
+    sys.path.insert(0, ROOT)
+    import bench
+    pidfile = tmp_path / "child.pid"
+    script = tmp_path / "forker.sh"
+    script.write_text(f"#!/bin/bash\nsleep 300 &\necho $! > {pidfile}\necho '{{\"started\": true}}'\nsleep 300\n")
+    script.chmod(0o755)
+    t0 = time.time()
+    rc, text = bench.run_program([str(script)], 1.5)   # an absolute path replaces examples/<name>
+    assert rc == -9 and "killed after" in text and '"started"' in text and time.time() - t0 < 20
+    child = int(pidfile.read_text())
+    for _ in range(50):
+        try:
+            os.kill(child, 0)
+        except ProcessLookupError:
+            break
+        time.sleep(0.1)
+    else:
+        raise AssertionError("the forked child survived the timeout")
+    rc, text = bench.run_program(["/bin/echo", "{\"ok\": 1}"], 5)
+    assert rc == 0 and text.strip() == '{"ok": 1}'
