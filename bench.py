@@ -683,7 +683,9 @@ def main():
             other_result.setdefault("packed_linear", {})["kernels"] = measure_packed_kernels(alu_result[0])
         except Exception as e:   # a secondary block must not take the headline metric down with it
             other_result.setdefault("packed_linear", {})["kernels"] = {"error": repr(e)[:300]}
-    sustained_result = measure_sustained(args.sustained_seconds) if (args.sustained_seconds > 0 and world == 1) else None
+    # every rank runs the windows whatever N is (no collective inside; rank 0 reports): the timed region below is shorter than the power
+    # manager's memory, so what ran before it decides which regime it sees - the same history for every N
+    sustained_result = measure_sustained(args.sustained_seconds) if args.sustained_seconds > 0 else None
 
     for _ in range(args.warmup):
         step()
