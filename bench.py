@@ -7,9 +7,15 @@ A "step" = one pass of the hot path over this rank's shard of synthetic cipherte
 Weak scaling: --batch-per-gpu ciphertext pairs per GPU (default 8192 = BASELINE configs[3] per-GPU
 share of 65536), inputs resident in HBM before the timed region.  `value` = ct-muls by all ranks / time.
 
-Extra objects on the JSON line:
-  roofline     - the dominant kernel of the timed region (ct_mul_quad_kernel): algorithmic bytes
+Extra objects on the JSON line (the driver's stored record keeps `config`, `roofline` and `cpu_baseline` whole and only the NAMES of
+other keys, so everything a reader of that record needs is inside those three; full detail also goes to gpurun_out/bench_detail.json):
+  roofline     - the dominant kernel of the timed region (the fused multiply, in the form config.autotune names): algorithmic bytes
                  (7*L*N*8 = 917504 B per ct-mul) / HIP-event launch duration / 8 TB/s.
+  roofline.ntt - BASELINE configs[1] (the metric's second half): forward / inverse NTT fraction of HBM peak (region-bracketed medians
+                 and the 2 s windows), against the copy kernel, with board power / cap / shader clock over the windows.
+  roofline.regime - what kind of box this is: CU count, compute / memory partition, clocks (rocm-smi), the multiply's stall share.
+  config.autotune - which form of the fused multiply ran, and every measurement behind the choice (probe at context creation,
+                 dpfhe_ctx_autotune on 8192-pair-sized scratch, three timed steps per form).
   ntt          - BASELINE configs[1] (batch = 1024 RNS polys x 4 limbs, N=4096): forward / inverse NTT
                  kernel time and fraction of HBM peak (2*N*8 algorithmic bytes per residue polynomial).
   sustained    - >= 2 s of back-to-back forward / inverse NTT launches (configs[1] in place, and 1 GiB out of place) and of the
@@ -82,6 +88,38 @@ class PowerSampler(threading.Thread):
         return {"board_w_mean": sum(ps) / len(ps), "board_w_max": max(ps), "cap_w": cap / 1e6 if cap else None,
                 "sclk_mhz_mean": sum(fs) / len(fs) if fs else None, "samples": len(ps),
                 "source": "hwmon power1/freq1 of this GPU, 2 ms sampling over the timed steps"}
+
+
+def box_regime(device_index):
+    """rank 0, outside the timed region: what rocm-smi says about this GPU (partition modes, clock levels, power cap).  The pool's
+    boxes differ in how the fused multiply runs; the record names the box it was measured on."""
+    import subprocess
+    out = {}
+    try:
+        import torch
+        p = torch.cuda.get_device_properties(device_index)
+        out.update({"name": p.name, "compute_units": p.multi_processor_count, "hbm_gib": round(p.total_memory / 2**30, 1),
+                    "l2_mib": round(getattr(p, "L2_cache_size", 0) / 2**20, 1)})
+    except Exception:
+        pass
+    try:
+        run = subprocess.run(["rocm-smi", "-d", str(device_index), "--showcomputepartition", "--showmemorypartition", "--showclocks", "--showmaxpower", "--json"],
+                             capture_output=True, text=True, timeout=20)
+        j = json.loads(run.stdout[run.stdout.index("{"):])
+        card = next(iter(j.values()))
+        for k_, v in card.items():
+            kl = k_.lower()
+            if "compute partition" in kl:
+                out["compute_partition"] = v
+            elif "memory partition" in kl:
+                out["memory_partition"] = v
+            elif "max graphics package power" in kl:
+                out["cap_w"] = v
+            elif any(c in kl for c in ("sclk clock", "mclk clock", "fclk clock", "socclk clock")) and "level" not in kl:
+                out[kl.split()[0]] = v
+    except Exception as e:
+        out["rocm_smi"] = repr(e)[:120]
+    return out
 
 
 def on_rank0_while_others_wait(rank, fn, key="dpfhe_bench_rank0_programs", timeout_s=600):
@@ -246,6 +284,39 @@ def dry_run(args):
         dist.destroy_process_group()
 
 
+def digest_other(o):
+    """other_configs in < 2 kB for the JSON line (per layer ms per token + all_correct, the stage table's fractions); the full block goes
+    to gpurun_out/bench_detail.json."""
+    r3 = lambda v: None if v is None else round(v, 4)
+    d = {}
+    for k_ in ("matvec_plain", "matvec_scalar", "relinearize"):
+        if k_ in o:
+            d[k_] = {x: r3(o[k_].get(x)) for x in ("median_us", "frac_of_hbm_peak", "per_s") if o[k_].get(x) is not None}
+    if "n8192_l6" in o:
+        c5 = o["n8192_l6"]
+        d["n8192_l6"] = {"ntt_fwd_frac": r3(c5["ntt_fwd"]["frac_of_hbm_peak"]), "ntt_inv_frac": r3(c5["ntt_inv"]["frac_of_hbm_peak"]),
+                         "ct_mul_per_s": round(c5["ct_mul"]["per_s"]), "ct_mul_frac": r3(c5["ct_mul"]["frac_of_hbm_peak"])}
+    pl = o.get("packed_linear") or {}
+    if pl:
+        e = {"all_correct": pl.get("all_correct")}
+        if pl.get("layers"):
+            e["ms_per_token"] = {f"{l.get('layer', '?')}@{l.get('tokens', '?')}": r3(l.get("ms_per_token")) for l in pl["layers"]}
+        for blk in ("ffn_block", "transformer_block", "activated_ffn"):
+            if isinstance(pl.get(blk), dict):
+                e[blk] = {x: pl[blk].get(x) for x in ("ms_per_token", "correct", "tokens", "error", "budget_bits", "levels") if pl[blk].get(x) is not None}
+        ks = pl.get("kernels") or {}
+        if ks.get("stages"):
+            e["stages"] = [{"stage": st["stage"].split(" (")[0][:40], "us": round(st["median_us"], 1), "frac_hbm": r3(st["frac_of_hbm_peak"]),
+                            "frac_bfly": r3(st.get("frac_of_butterfly_ceiling"))} for st in ks["stages"]]
+            e["sum_of_stages_ms_per_token"] = r3(ks.get("sum_of_stages_ms_per_token"))
+        elif ks.get("error"):
+            e["stages_error"] = ks["error"][:120]
+        if pl.get("error"):
+            e["error"] = pl["error"][:160]
+        d["packed_linear"] = e
+    return d
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -258,6 +329,8 @@ def main():
                     help="all-gather through the library's own communicator (dpfhe_comm_*, RCCL behind the C ABI) instead of torch.distributed")
     ap.add_argument("--sustained-seconds", type=float, default=2.0, help="length of each sustained NTT / copy window (0 = skip the block)")
     ap.add_argument("--skip-other", action="store_true", help="skip the other_configs block (profiling runs: every launch is serialised under rocprofv3)")
+    ap.add_argument("--ct-mul-form", default="auto", choices=["auto", "quad", "dual", "single"],
+                    help="form of the fused multiply: auto = measured on this box (library probe + three timed steps per form), or forced")
     ap.add_argument("--dry-run", action="store_true", help="CPU + gloo: walk the multi-rank host path (collectives, barriers, report) without kernels")
     args = ap.parse_args()
     if args.dry_run:
@@ -289,6 +362,7 @@ def main():
     ctx = Context(params, local_rank)
     ev = Evaluator(ctx)
     dev = ctx.device
+    autotune = {"at_ctx_create": ctx.tune_info()}   # dpfhe_ctx_create's own bounded probe (include/dpfhe.h "A0, continued")
 
     # synthetic inputs: uniform residues, generated on the device, resident in HBM before timing
     g = torch.Generator(device=dev).manual_seed(1000 + rank)
@@ -674,6 +748,7 @@ def main():
         return None, None, None, False
 
     alu_result = alu_ceiling()
+    regime_result = box_regime(local_rank) if rank == 0 else None
     # before the long multiply loop heats the chip into lower clocks; every rank measures (same thermal history on every GPU),
     # rank 0 reports
     ntt_result = measure_ntt()
@@ -687,6 +762,49 @@ def main():
     # manager's memory, so what ran before it decides which regime it sees - the same history for every N
     sustained_result = measure_sustained(args.sustained_seconds) if args.sustained_seconds > 0 else None
 
+    def tune_form():
+        """Which form of the fused multiply this run times.  (1) the library's own measurement repeated on scratch of the timed batch's
+        size (dpfhe_ctx_autotune over outs[1]: ~3500 synthetic pairs, 3 launches per form, twice); (2) THREE STEPS per form of the very
+        step that is timed (multiply || reduce + gather), twice in opposite orders, best pass per form - the step is what `value`
+        measures, and a form that wins alone can lose next to the reduce.  The library's pick stays unless another form's step is
+        >= 3 % faster.  Every rank measures; rank 0's pick is broadcast so that all ranks run the same code."""
+        names = ctx.variants()
+        if not names:
+            return
+        if args.ct_mul_form != "auto":
+            ctx.set_ct_mul_variant(args.ct_mul_form)
+            autotune["chosen"], autotune["how"] = args.ct_mul_form, "--ct-mul-form"
+            return
+        torch.cuda.synchronize()
+        autotune["dpfhe_ctx_autotune"] = ctx.autotune(outs[1].view(-1), reps=3, stream=main)
+        lib_pick = autotune["dpfhe_ctx_autotune"]["chosen"]
+        best = {}
+        for order in (names, names[::-1]):
+            for nm in order:
+                ctx.set_ct_mul_variant(nm)
+                step()                                   # untimed: the previous form's reduce drains behind it
+                torch.cuda.synchronize()
+                t0_ = time.perf_counter()
+                for _ in range(3):
+                    step()
+                torch.cuda.synchronize()
+                ms = (time.perf_counter() - t0_) / 3 * 1e3
+                best[nm] = min(best.get(nm, ms), ms)
+        pick = lib_pick
+        fastest = min(best, key=best.get)
+        if best[fastest] < 0.97 * best[lib_pick]:
+            pick = fastest
+        if dist.is_initialized():
+            idx = torch.tensor([names.index(pick)], device=dev)
+            dist.broadcast(idx, 0)
+            pick = names[int(idx.item())]
+        ctx.set_ct_mul_variant(pick)
+        autotune["step_probe_ms"] = {k_: round(v, 4) for k_, v in best.items()}
+        autotune["chosen"] = pick
+        autotune["how"] = ("library pick (dpfhe_ctx_autotune), confirmed by three timed steps per form" if pick == lib_pick
+                           else "three timed steps per form (>= 3 % faster than the library's pick inside the overlapped step)")
+
+    tune_form()
     for _ in range(args.warmup):
         step()
 
@@ -765,11 +883,13 @@ def main():
             "parallelism": f"batch-sharded x{world}, one process per GPU" + (", RCCL all-gather" if world > 1 else ""),
             "collective": ("dpfhe_comm_allgather (RCCL behind the C ABI)" if comm is not None else "torch.distributed all_gather_into_tensor (RCCL)") if (world > 1 or comm is not None or dist.is_initialized()) else "none (one rank)",
             "arith": "fold(2^60-d)" if ctx.uses_fold else "shoup",
+            "autotune": autotune,
         },
         # `frac` keeps the contract's meaning (algorithmic bytes / launch time / HBM peak); the kernel's real bound is VALU issue,
         # so both fractions are first-class: frac_hbm (= frac) and frac_alu (butterflies/s over the register-only ceiling).
         "roofline": {
-            "kernel": "ct_mul_quad_kernel<FoldArith,12,4>", "bound": "valu", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+            "kernel": {"quad": "ct_mul_quad_kernel<FoldArith,12,4>", "dual": "ct_mul_dual_kernel<FoldArith,12,4,false>", "single": "ct_mul_kernel<FoldArith,12,4,false,false>"}.get(autotune.get("chosen"), "ct_mul_quad_kernel<FoldArith,12,4>"),
+            "bound": "valu", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
             "frac": achieved / HBM_PEAK, "frac_hbm": achieved / HBM_PEAK, "frac_alu": (bfly_per_s / alu_peak) if alu_peak else None,
             "traffic": traffic,
             "traffic_source": (os.path.relpath(traffic_src, ROOT) + " (committed profile, NOT measured in this run: rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE in their own passes, bytes per launch)") if traffic else None,
@@ -791,12 +911,36 @@ def main():
 
     rates = [B * args.steps / e for e in per_rank_elapsed]
     result["per_rank_ct_mul_per_s"] = {"min": min(rates), "max": max(rates), "ranks": len(rates)}
+    detail = {}
     if ntt_result is not None:
-        result["ntt"] = ntt_result
+        # BASELINE.json metric, second half ("NTT HBM GB/s vs peak"), where the driver's record keeps it: configs[1] in place, the
+        # region-bracketed medians (30 samples of 32 back-to-back launches) and, when the windows ran, >= 2 s of launches with the board's
+        # power / cap / shader clock over that window and the copy kernel's rate in the same run
+        nv = {"workload": "BASELINE configs[1]: 1024 RNS polys x 4 limbs, N=4096, in place (268 435 456 algorithmic bytes per launch)",
+              "fwd_frac": ntt_result["fwd"]["frac_of_hbm_peak"], "inv_frac": ntt_result["inv"]["frac_of_hbm_peak"],
+              "fwd_us": ntt_result["fwd"]["median_us"], "inv_us": ntt_result["inv"]["median_us"],
+              "fwd_GBps": ntt_result["fwd"]["GBps"], "inv_GBps": ntt_result["inv"]["GBps"],
+              "fwd_best_us": ntt_result["fwd"]["min_us"], "inv_best_us": ntt_result["inv"]["min_us"],
+              "out_of_place_fwd_frac": ntt_result["out_of_place"]["fwd"]["frac_of_hbm_peak"], "out_of_place_inv_frac": ntt_result["out_of_place"]["inv"]["frac_of_hbm_peak"],
+              "device_copy_frac": ntt_result["device_copy"]["frac_of_hbm_peak"], "round_trip_exact": ntt_result["round_trip_exact"],
+              "method": "HIP events over regions of 32 back-to-back launches, median of 30 regions"}
+        if sustained_result is not None:
+            sf, si, sc = (sustained_result[k_] for k_ in ("ntt_fwd_configs1_in_place", "ntt_inv_configs1_in_place", "copy_1GiB"))
+            nv["sustained_2s"] = {"fwd_frac": sf["frac_of_hbm_peak"], "inv_frac": si["frac_of_hbm_peak"], "fwd_us": sf["us_per_launch"], "inv_us": si["us_per_launch"],
+                                  "fwd_frac_of_copy": sf["frac_of_copy"], "inv_frac_of_copy": si["frac_of_copy"], "copy_frac": sc["frac_of_hbm_peak"],
+                                  "board_w": sf.get("board_w_mean"), "cap_w": sf.get("cap_w"), "sclk_mhz": sf.get("sclk_mhz_mean"),
+                                  "inv_board_w": si.get("board_w_mean"), "inv_sclk_mhz": si.get("sclk_mhz_mean"), "copy_board_w": sc.get("board_w_mean"), "copy_sclk_mhz": sc.get("sclk_mhz_mean"),
+                                  "fwd_1GiB_out_of_place_frac": sustained_result["ntt_fwd_1GiB_out_of_place"]["frac_of_hbm_peak"],
+                                  "inv_1GiB_out_of_place_frac": sustained_result["ntt_inv_1GiB_out_of_place"]["frac_of_hbm_peak"]}
+        result["roofline"]["ntt"] = nv
+        detail["ntt"] = ntt_result
     if sustained_result is not None:
-        result["sustained"] = sustained_result
+        detail["sustained"] = sustained_result
+    if rank == 0:
+        result["roofline"]["regime"] = regime_result
     if other_result is not None:
-        result["other_configs"] = other_result
+        detail["other_configs"] = other_result
+        result["other_configs"] = digest_other(other_result)
     # the reduced result of the last step equals a recomputation of the same sequence on the main stream (every rank checks,
     # rank 0 reports; at N>1 the recomputation repeats the all-gather, so all ranks must take part)
     chk = ev.reduce_sum(Ciphertext(out), stream=main)
@@ -863,6 +1007,13 @@ def main():
         if rank == 0:
             result["multi_gpu_programs"] = progs
     if rank == 0:
+        try:   # the full blocks the line only digests (gpurun merges gpurun_out/ back; elsewhere this is a scratch file)
+            os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+            with open(os.path.join(ROOT, "gpurun_out", "bench_detail.json"), "w") as f:
+                json.dump(dict(result, **detail), f)
+            result["detail_file"] = "gpurun_out/bench_detail.json (ntt, sustained, other_configs in full)"
+        except Exception:
+            pass
         print(json.dumps(result))
     if dist.is_initialized():
         dist.destroy_process_group()

@@ -15,6 +15,11 @@ SYMBOLS = {
     "dpfhe_ctx_log2n": ([C.c_void_p], C.c_uint32),
     "dpfhe_ctx_limbs": ([C.c_void_p], C.c_uint32),
     "dpfhe_ctx_uses_fold": ([C.c_void_p], C.c_int),
+    "dpfhe_ctx_autotune": ([C.c_void_p, _U64P, C.c_size_t, C.c_uint32, C.c_void_p], C.c_int),
+    "dpfhe_ctx_tune_info": ([C.c_void_p, C.c_void_p], C.c_int),
+    "dpfhe_ctx_set_ct_mul_variant": ([C.c_void_p, C.c_int], C.c_int),
+    "dpfhe_ct_mul_variant_name": ([C.c_int], C.c_char_p),
+    "dpfhe_debug_ct_mul_trace": ([C.c_void_p, _U64P, _U64P, _U64P, C.c_size_t, _U64P, C.c_void_p], C.c_int),
     "dpfhe_ntt_fwd": ([C.c_void_p, _U64P, C.c_size_t, C.c_void_p], C.c_int),
     "dpfhe_ntt_inv": ([C.c_void_p, _U64P, C.c_size_t, C.c_void_p], C.c_int),
     "dpfhe_ntt_fwd_oop": ([C.c_void_p, _U64P, _U64P, C.c_size_t, C.c_void_p], C.c_int),
@@ -53,6 +58,15 @@ SYMBOLS = {
 }
 
 IN_NTT, OUT_NTT = 1, 2
+
+
+class TuneInfo(C.Structure):
+    """dpfhe_tune_info (include/dpfhe.h)"""
+    _fields_ = [("chosen", C.c_int32), ("n_variants", C.c_int32), ("source", C.c_int32), ("probe_pairs", C.c_uint32),
+                ("probe_reps", C.c_uint32), ("probe_us", C.c_float * 4)]
+
+
+TUNE_SOURCES = ("default", "probe at dpfhe_ctx_create", "dpfhe_ctx_autotune", "forced")
 
 
 class DpfheError(RuntimeError):

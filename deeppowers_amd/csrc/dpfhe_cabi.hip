@@ -9,6 +9,7 @@
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -65,6 +66,9 @@ static inline bool overlaps(const uint64_t* a, size_t na, const uint64_t* b, siz
     return a0 < b0 + nb * 8 && b0 < a0 + na * 8;
 }
 
+static inline bool misaligned(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) != 0; }
+static const size_t kMaxGrid = 0x7fffffff;
+
 struct dpfhe_ctx {
     uint32_t log2n = 0, n_limbs = 0;
     int device = 0;
@@ -79,7 +83,138 @@ struct dpfhe_ctx {
     // given until the context goes - the default pool hands its memory back at every synchronisation and pays the mapping again
     hipMemPool_t scratch_pool = nullptr;
     std::mutex scratch_mutex;
+    // which form of the fused multiply dpfhe_ct_mul(flags = 0) launches (launch.h CtMulVariant): the default of the ring degree until a
+    // probe (dpfhe_ctx_create / dpfhe_ctx_autotune), DPFHE_CTMUL_VARIANT or dpfhe_ctx_set_ct_mul_variant says otherwise.  All forms give the same words.
+    std::atomic<int> ct_mul_variant{0};
+    dpfhe_tune_info tune{};
 };
+
+
+// ------------------------------------------------------------------------------------------------
+// Variant choice of the fused multiply (the reference sketches this class of mechanism as an auto-tuner:
+// /root/reference/src/core/inference/auto_tuner.hpp:26-64).  The three forms move the same bytes and give the same words; which is
+// fastest depends on how well the box hides memory latency behind two waves per SIMD, so the choice is MEASURED:
+// `reps` back-to-back launches per form over `pairs` synthetic ciphertext pairs, two passes in opposite orders, best pass per form;
+// a non-default form is taken only when it is at least 3 % faster than the default.
+// ------------------------------------------------------------------------------------------------
+static const char* const kCtMulVariantNames[kCtMulVariants] = {"quad", "dual", "single"};
+static const float kTuneMargin = 0.97f;
+
+__global__ __launch_bounds__(256) void tune_fill_kernel(u64* __restrict__ p, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+        p[i] = ((i + 1) * 0x9E3779B97F4A7C15ull) >> 5;   // < 2^59: a canonical residue of every FoldArith prime
+}
+
+static bool ct_mul_variant_compiled(const dpfhe_ctx* c, int v) {
+    return c->fold && (c->log2n == 12 || c->log2n == 13) && v >= 0 && v < kCtMulVariants;
+}
+
+// probes on `s`; synchronises it.  us[v] < 0: not available.  Returns a hipError_t.
+static hipError_t probe_ct_mul(dpfhe_ctx* c, u64* work, size_t pairs, unsigned reps, hipStream_t s, float us[kCtMulVariants]) {
+    const size_t poly = (size_t)c->n_limbs << c->log2n, blocks = pairs * c->n_limbs;
+    u64 *a = work, *b = work + 2 * pairs * poly, *o = work + 4 * pairs * poly;
+    hipLaunchKernelGGL(tune_fill_kernel, dim3(c->n_cu * 8), dim3(256), 0, s, work, 4 * pairs * poly);
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    hipError_t err = hipEventCreate(&e0);
+    if (err == hipSuccess) err = hipEventCreate(&e1);
+    for (int v = 0; v < kCtMulVariants; ++v) us[v] = -1.0f;
+    for (int pass = 0; pass < 2 && err == hipSuccess; ++pass) {
+        for (int i = 0; i < kCtMulVariants && err == hipSuccess; ++i) {
+            const int v = pass ? kCtMulVariants - 1 - i : i;
+            if (!ct_mul_variant_compiled(c, v)) continue;
+            if (launch_ct_mul_variant<FoldArith>((int)c->log2n, v, o, a, b, blocks, c->foldt, s)) continue;    // warm-up (code object, clocks)
+            (void)hipEventRecord(e0, s);
+            for (unsigned r = 0; r < reps; ++r) (void)launch_ct_mul_variant<FoldArith>((int)c->log2n, v, o, a, b, blocks, c->foldt, s);
+            (void)hipEventRecord(e1, s);
+            err = hipEventSynchronize(e1);
+            float ms = 0;
+            if (err == hipSuccess) err = hipEventElapsedTime(&ms, e0, e1);
+            if (err == hipSuccess) { const float t = ms * 1e3f / reps; if (us[v] < 0 || t < us[v]) us[v] = t; }
+        }
+    }
+    if (err == hipSuccess) err = hipGetLastError();
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    return err;
+}
+
+static void adopt_probe(dpfhe_ctx* c, const float us[kCtMulVariants], size_t pairs, unsigned reps, int source) {
+    const int def = ct_mul_default_variant((int)c->log2n);
+    int best = def;
+    for (int v = 0; v < kCtMulVariants; ++v)
+        if (us[v] > 0 && us[def] > 0 && us[v] < kTuneMargin * us[def] && (best == def || us[v] < us[best])) best = v;
+    c->tune.n_variants = kCtMulVariants;
+    c->tune.source = source;
+    c->tune.probe_pairs = (uint32_t)pairs;
+    c->tune.probe_reps = reps;
+    for (int v = 0; v < kCtMulVariants; ++v) c->tune.probe_us[v] = us[v];
+    c->tune.chosen = best;
+    c->ct_mul_variant.store(best);
+}
+
+// at context creation: a bounded probe on transient device memory (<= 256 MiB, freed before returning; a failure keeps the default)
+static void tune_at_create(dpfhe_ctx* c) {
+    const int def = ct_mul_default_variant((int)c->log2n);
+    c->ct_mul_variant.store(def);
+    c->tune = dpfhe_tune_info{};
+    c->tune.chosen = def;
+    c->tune.n_variants = ct_mul_variant_compiled(c, def) ? kCtMulVariants : 0;
+    for (int v = 0; v < 4; ++v) c->tune.probe_us[v] = -1.0f;
+    if (!ct_mul_variant_compiled(c, def)) return;
+    if (const char* f = std::getenv("DPFHE_CTMUL_VARIANT")) {
+        for (int v = 0; v < kCtMulVariants; ++v)
+            if (!std::strcmp(f, kCtMulVariantNames[v])) { c->ct_mul_variant.store(v); c->tune.chosen = v; c->tune.source = DPFHE_TUNE_FORCED; return; }
+    }
+    const char* e = std::getenv("DPFHE_AUTOTUNE");
+    if (e && e[0] == '0') return;
+    const size_t poly = (size_t)c->n_limbs << c->log2n;
+    size_t pairs = ((size_t)256 << 20) / (7 * poly * sizeof(u64));
+    const size_t cap = (size_t)(8 * c->n_cu) / c->n_limbs;           // four generations of two workgroups per CU are plenty
+    if (pairs > cap) pairs = cap;
+    if (pairs == 0) return;
+    u64* work = nullptr;
+    if (hipMalloc(&work, 7 * pairs * poly * sizeof(u64)) != hipSuccess) { (void)hipGetLastError(); return; }
+    hipStream_t s = nullptr;
+    if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) == hipSuccess) {
+        float us[kCtMulVariants];
+        if (probe_ct_mul(c, work, pairs, 3, s, us) == hipSuccess) adopt_probe(c, us, pairs, 3, DPFHE_TUNE_AT_CREATE);
+        else (void)hipGetLastError();
+        (void)hipStreamSynchronize(s);
+        (void)hipStreamDestroy(s);
+    }
+    (void)hipFree(work);
+}
+
+extern "C" int dpfhe_ctx_autotune(dpfhe_ctx* c, uint64_t* d_work, size_t work_words, uint32_t reps, void* stream) {
+    if (!c) return fail(DPFHE_INVALID_ARGUMENT, "dpfhe_ctx_autotune", "null context");
+    if (!ct_mul_variant_compiled(c, ct_mul_default_variant((int)c->log2n))) return DPFHE_SUCCESS;   // one form only: nothing to choose
+    const size_t poly = (size_t)c->n_limbs << c->log2n, pairs = work_words / (7 * poly);
+    if (!d_work || misaligned(d_work) || pairs == 0) return fail(DPFHE_INVALID_ARGUMENT, "dpfhe_ctx_autotune", "d_work must hold at least 7 L N words (one ciphertext pair + its product)");
+    if (pairs * c->n_limbs > kMaxGrid) return fail(DPFHE_INVALID_ARGUMENT, "dpfhe_ctx_autotune", "work buffer too large for one launch");
+    if (reps == 0) reps = 3;
+    DPFHE_ON_DEVICE(c, "dpfhe_ctx_autotune");
+    float us[kCtMulVariants];
+    HIP_TRY(probe_ct_mul(c, d_work, pairs, reps, static_cast<hipStream_t>(stream), us));
+    adopt_probe(c, us, pairs, reps, DPFHE_TUNE_EXPLICIT);
+    return DPFHE_SUCCESS;
+}
+extern "C" int dpfhe_ctx_tune_info(const dpfhe_ctx* c, dpfhe_tune_info* out) {
+    if (!c || !out) return fail(DPFHE_INVALID_ARGUMENT, "dpfhe_ctx_tune_info", "null argument");
+    *out = c->tune;
+    out->chosen = c->ct_mul_variant.load();
+    return DPFHE_SUCCESS;
+}
+extern "C" int dpfhe_ctx_set_ct_mul_variant(dpfhe_ctx* c, int variant) {
+    if (!c) return fail(DPFHE_INVALID_ARGUMENT, "dpfhe_ctx_set_ct_mul_variant", "null context");
+    if (!ct_mul_variant_compiled(c, variant)) return fail(DPFHE_INVALID_ARGUMENT, "dpfhe_ctx_set_ct_mul_variant", "this context has no such form of the fused multiply");
+    c->ct_mul_variant.store(variant);
+    c->tune.chosen = variant;
+    c->tune.source = DPFHE_TUNE_FORCED;
+    return DPFHE_SUCCESS;
+}
+extern "C" const char* dpfhe_ct_mul_variant_name(int variant) {
+    return variant >= 0 && variant < kCtMulVariants ? kCtMulVariantNames[variant] : "";
+}
 
 // ------------------------------------------------------------------------------------------------
 extern "C" int dpfhe_ctx_create(dpfhe_ctx** out, uint32_t log2_n, uint32_t n_limbs, const uint64_t* moduli,
@@ -202,6 +337,7 @@ extern "C" int dpfhe_ctx_create(dpfhe_ctx** out, uint32_t log2_n, uint32_t n_lim
         c->shoup.n_sub = (int)n_sub;
         c->shoup.n_limbs = (int)n_limbs;
     }
+    tune_at_create(c);   // picks the form of the fused multiply for this box (bounded probe; DPFHE_AUTOTUNE=0 skips it)
     (void)hipSetDevice(prev);
     *out = c;
     return DPFHE_SUCCESS;
@@ -229,8 +365,6 @@ extern "C" int dpfhe_ctx_uses_fold(const dpfhe_ctx* c) { return c && c->fold ? 1
 #ifndef DPFHE_MATVEC_RT4
 #define DPFHE_MATVEC_RT4 4    // rows per workgroup of the 4-polynomial (2-token) kernel; tools/ab_variant.sh mvrt8 -DDPFHE_MATVEC_RT4=8 for A/B runs
 #endif
-static inline bool misaligned(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) != 0; }
-static const size_t kMaxGrid = 0x7fffffff;
 
 static int check_launch(const char* what) {
     hipError_t e = hipGetLastError();
@@ -447,10 +581,31 @@ extern "C" int dpfhe_ct_mul(dpfhe_ctx* c, uint64_t* d_out3, const uint64_t* d_a2
     DPFHE_ON_DEVICE(c, "dpfhe_ct_mul");
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (c->log2n > kFusedMaxLog2N) return ct_mul_composed(c, d_out3, d_a2, d_b2, batch, flags, s);
+    if (flags == 0 && c->fold) {   // coefficient domain in and out: the form chosen for this box (bit-identical results)
+        const int v = c->ct_mul_variant.load(std::memory_order_relaxed);
+        if (v != ct_mul_default_variant((int)c->log2n) && ct_mul_variant_compiled(c, v)) {
+            if (launch_ct_mul_variant<FoldArith>((int)c->log2n, v, d_out3, d_a2, d_b2, blocks, c->foldt, s)) return fail(DPFHE_INVALID_STATE, "dpfhe_ct_mul", "variant not compiled");
+            return check_launch("ct_mul kernel launch");
+        }
+    }
     const int rc = c->fold ? launch_ct_mul<FoldArith>((int)c->log2n, flags, d_out3, d_a2, d_b2, blocks, c->foldt, s)
                            : launch_ct_mul<ShoupArith>((int)c->log2n, flags, d_out3, d_a2, d_b2, blocks, c->shoup, s);
     if (rc) return fail(DPFHE_INVALID_STATE, "dpfhe_ct_mul", "no kernel geometry for this log2_n");
     return check_launch("ct_mul kernel launch");
+}
+
+// diagnostics: the quad form with per-workgroup timestamps (kernels.h ct_mul_quad_kernel<..., TRACE>); FoldArith contexts at N = 4096
+extern "C" int dpfhe_debug_ct_mul_trace(dpfhe_ctx* c, uint64_t* d_out3, const uint64_t* d_a2, const uint64_t* d_b2, size_t batch, uint64_t* d_trace, void* stream) {
+    if (!c || !d_out3 || !d_a2 || !d_b2 || !d_trace) return fail(DPFHE_INVALID_ARGUMENT, "dpfhe_debug_ct_mul_trace", "null argument");
+    if (!c->fold || c->log2n != 12) return fail(DPFHE_INVALID_STATE, "dpfhe_debug_ct_mul_trace", "FoldArith contexts at N = 4096 only");
+    const size_t blocks = batch * c->n_limbs, poly = (size_t)c->n_limbs << c->log2n;
+    if (batch == 0 || blocks > kMaxGrid) return fail(DPFHE_INVALID_ARGUMENT, "dpfhe_debug_ct_mul_trace", "bad batch");
+    if (overlaps(d_out3, batch * 3 * poly, d_a2, batch * 2 * poly) || overlaps(d_out3, batch * 3 * poly, d_b2, batch * 2 * poly))
+        return fail(DPFHE_INVALID_ARGUMENT, "dpfhe_debug_ct_mul_trace", "output overlaps an operand");
+    DPFHE_ON_DEVICE(c, "dpfhe_debug_ct_mul_trace");
+    if (launch_ct_mul_trace<FoldArith>((int)c->log2n, d_out3, d_a2, d_b2, blocks, c->foldt, d_trace, static_cast<hipStream_t>(stream)))
+        return fail(DPFHE_INVALID_STATE, "dpfhe_debug_ct_mul_trace", "not compiled");
+    return check_launch("traced ct_mul kernel launch");
 }
 
 extern "C" int dpfhe_relinearize(dpfhe_ctx* c, uint64_t* d_out2, const uint64_t* d_in3, const uint64_t* d_evk, size_t batch, void* stream) {

@@ -79,6 +79,23 @@ const FheParams& Context::params() const { return impl_->params; }
 int Context::device_id() const { return impl_->device_id; }
 bool Context::uses_fold() const { return dpfhe_ctx_uses_fold(impl_->h) != 0; }
 void* Context::handle() const { return impl_->h; }
+Context::TuneInfo Context::tune_info() const {
+    dpfhe_tune_info t{};
+    check(dpfhe_ctx_tune_info(impl_->h, &t), "dpfhe_ctx_tune_info");
+    static const char* const src[] = {"default", "probe at dpfhe_ctx_create", "dpfhe_ctx_autotune", "forced"};
+    TuneInfo r;
+    r.chosen = dpfhe_ct_mul_variant_name(t.chosen);
+    r.source = (t.source >= 0 && t.source < 4) ? src[t.source] : "?";
+    r.probe_pairs = t.probe_pairs;
+    r.probe_reps = t.probe_reps;
+    for (int v = 0; v < t.n_variants && v < 4; ++v)
+        if (t.probe_us[v] >= 0) r.probe_us.emplace_back(dpfhe_ct_mul_variant_name(v), t.probe_us[v]);
+    return r;
+}
+Context::TuneInfo Context::autotune(PolyBuffer& scratch, unsigned reps) {
+    check(dpfhe_ctx_autotune(impl_->h, scratch.data(), scratch.words(), reps, nullptr), "dpfhe_ctx_autotune");
+    return tune_info();
+}
 void Context::synchronize() const {
     hip_check(hipSetDevice(impl_->device_id), "hipSetDevice");
     hip_check(hipDeviceSynchronize(), "hipDeviceSynchronize");

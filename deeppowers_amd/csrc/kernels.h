@@ -555,14 +555,26 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE), 2) void ct_mul_dual_kernel(u64*
 
 // All four forward transforms and all three inverse transforms of the workgroup share their twiddle fetches (FwdChain4 / InvChain3
 // on two LDS buffers): 2 x 64 KiB of per-thread twiddle reads per workgroup instead of 4 x 64 KiB in ct_mul_dual_kernel.
-template <class Arith, int LOGN, int LOGE>
+// TRACE (diagnostics only, dpfhe_debug_ct_mul_trace): thread 0 of every workgroup stamps s_memrealtime (100 MHz) at the kernel's
+// milestones into trace[blockIdx.x * 8 ..]: 0 start, 1 first operand word arrived, 2 forward transforms done, 3 tensor product done,
+// 4 inverse transforms done, 5 stores issued, 6 stores drained, 7 = HW_ID | XCC_ID << 32 (where the workgroup ran).
+// The stamps stay in scalar registers until the end (the kernel has no vector register to spare); `dep` is a value the milestone must have
+// produced: as an input operand it orders the stamp after it (and makes the compiler wait for it, if it is a load).
+template <bool TRACE>
+__device__ __forceinline__ u64 trace_stamp(u64 dep) {
+    u64 t = 0;
+    if constexpr (TRACE) asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) : "v"(dep) : "memory");
+    return t;
+}
+template <class Arith, int LOGN, int LOGE, bool TRACE = false>
 __global__ __launch_bounds__(1 << (LOGN - LOGE), 2) void ct_mul_quad_kernel(u64* __restrict__ out3, const u64* __restrict__ a2,
-                                                                         const u64* __restrict__ b2, DevTables<Arith> tb) {
+                                                                         const u64* __restrict__ b2, DevTables<Arith> tb, u64* __restrict__ trace = nullptr) {
     typedef NttBody<Arith, LOGN, LOGE> B;
     static_assert(Arith::kFold && LOGE == kFusedLoge, "FoldArith, fused twiddle layout");
     constexpr int E = B::E, N = B::G::N, W = B::G::lds_words();
     __shared__ __attribute__((aligned(16))) u64 lds[2 * W];
     const int tid = threadIdx.x;
+    const u64 ts0 = trace_stamp<TRACE>((u64)tid);
     const size_t L = (size_t)tb.n_limbs;
     const size_t bi = blockIdx.x / L;
     const int limb = (int)(blockIdx.x % L);
@@ -578,9 +590,11 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE), 2) void ct_mul_quad_kernel(u64*
     B::template load_top<true>(tid, y, src_b);
     B::template load_top<true>(tid, z, src_a + cstride);
     B::template load_top<true>(tid, w, src_b + cstride);
+    const u64 ts1 = trace_stamp<TRACE>(x[0]);
     FwdChain4<B, 0>::run(tid, x, y, z, w, lds, lds + W, tb.fwd4 + (size_t)limb * N, lc);
     B::fwd_reduce_partner(y, lc);     // of every product below exactly one factor is reduced: b0, b1
     B::fwd_reduce_partner(w, lc);
+    const u64 ts2 = trace_stamp<TRACE>(w[E - 1]);
 #pragma unroll
     for (int k = 0; k < E; ++k) {
         const u64 a0 = x[k], b0 = y[k], a1 = z[k], b1 = w[k];
@@ -588,16 +602,31 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE), 2) void ct_mul_quad_kernel(u64*
         y[k] = FoldArith::mul60(a0, b1, (u32)lc.d) + FoldArith::mul60(a1, b0, (u32)lc.d);
         z[k] = FoldArith::mul60(a1, b1, (u32)lc.d);
     }
+    const u64 ts3 = trace_stamp<TRACE>(z[E - 1]);
 #ifndef DPFHE_CTMUL_NT_STORE
 #define DPFHE_CTMUL_NT_STORE 1
 #endif
     InvChain3<B, B::NPH - 1, kInvIn>::run(tid, x, y, z, lds, lds + W, tb.inv4 + (size_t)limb * N, last, lc);
+    const u64 ts4 = trace_stamp<TRACE>(z[E - 1]);
     B::inv_canon(x, lc);
     B::template store_top<DPFHE_CTMUL_NT_STORE != 0>(tid, x, dst);
     B::inv_canon(y, lc);
     B::template store_top<DPFHE_CTMUL_NT_STORE != 0>(tid, y, dst + cstride);
     B::inv_canon(z, lc);
     B::template store_top<DPFHE_CTMUL_NT_STORE != 0>(tid, z, dst + 2 * cstride);
+    if constexpr (TRACE) {
+        const u64 ts5 = trace_stamp<TRACE>((u64)tid);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const u64 ts6 = trace_stamp<TRACE>((u64)tid);
+        if (tid == 0) {
+            unsigned hw, xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            u64* t = trace + (size_t)blockIdx.x * 8;
+            t[0] = ts0; t[1] = ts1; t[2] = ts2; t[3] = ts3; t[4] = ts4; t[5] = ts5; t[6] = ts6;
+            t[7] = (u64)hw | ((u64)xcc << 32);
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------

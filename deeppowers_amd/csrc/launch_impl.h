@@ -11,6 +11,10 @@ namespace dpfhe {
 // not at launch time.
 constexpr size_t kLdsBytesPerCu = 160 * 1024;
 static_assert(2 * sizeof(u64) * Geo<13, kFusedLoge>::lds_words() <= kLdsBytesPerCu, "two LDS images of an N = 8192 polynomial must fit one CU's 160 KiB");
+// ... and today they fill it to the byte (2 x 81 920 B = 163 840 B: ct_mul_dual_kernel / hoisted_ks2_kernel at N = 8192 leave NO room for another
+// __shared__ word or a wider wave stride).  Pinned on purpose: whoever changes Geo's padding sees the exact figure change here, not a launch failure.
+static_assert(2 * sizeof(u64) * Geo<13, kFusedLoge>::lds_words() == 163840 && 2 * sizeof(u64) * Geo<12, kFusedLoge>::lds_words() == 77824,
+              "LDS footprint of the paired fused kernels changed: re-check the 160 KiB budget at N = 8192 (zero margin) and two workgroups per CU at N = 4096");
 static_assert(sizeof(u64) * Geo<14, 4>::lds_words() <= kLdsBytesPerCu, "the N = 16384 transform's LDS image must fit one CU's 160 KiB");
 
 // (log2n -> LOGE) pairs proven by tests/test_emulated_kernels.py
@@ -93,7 +97,7 @@ static int launch_ct_mul_dom(int log2n, u64* out3, const u64* a2, const u64* b2,
 #endif
 #define CT_CASE(LN, LE)                                                                                                                              \
     if constexpr (DPFHE_CTMUL_QUAD && Arith::kFold && !IN_NTT && !OUT_NTT && LN <= DPFHE_CTMUL_QUAD_MAXLOGN)                                                           \
-        hipLaunchKernelGGL((ct_mul_quad_kernel<Arith, LN, kFusedLoge>), dim3((unsigned)blocks), dim3(Geo<LN, kFusedLoge>::T), 0, s, out3, a2, b2, tb); \
+        hipLaunchKernelGGL((ct_mul_quad_kernel<Arith, LN, kFusedLoge>), dim3((unsigned)blocks), dim3(Geo<LN, kFusedLoge>::T), 0, s, out3, a2, b2, tb, (u64*)nullptr); \
     else if constexpr (DPFHE_CTMUL_DUAL && Arith::kFold && !IN_NTT && LN <= DPFHE_CTMUL_DUAL_MAXLOGN)                                                                                          \
         hipLaunchKernelGGL((ct_mul_dual_kernel<Arith, LN, kFusedLoge, OUT_NTT>), dim3((unsigned)blocks), dim3(Geo<LN, kFusedLoge>::T), 0, s, out3, a2, b2, tb); \
     else                                                                                                                                             \
@@ -110,6 +114,39 @@ int launch_ct_mul(int log2n, unsigned flags, u64* out3, const u64* a2, const u64
         case 1: return launch_ct_mul_dom<Arith, true, false>(log2n, out3, a2, b2, blocks, tb, s);
         case 2: return launch_ct_mul_dom<Arith, false, true>(log2n, out3, a2, b2, blocks, tb, s);
         default: return launch_ct_mul_dom<Arith, true, true>(log2n, out3, a2, b2, blocks, tb, s);
+    }
+}
+
+// The fused multiply in a NAMED form (coefficient domain in and out, FoldArith, N = 4096 / 8192): what dpfhe_ctx_autotune probes and
+// what a context then launches.  kCtMulQuad / kCtMulDual / kCtMulSingle differ in how many transforms share twiddle fetches and LDS
+// buffers (kernels.h), not in results (bit-identical) or HBM traffic (7 residue polynomials per limb).  -1: not compiled for this ring.
+template <class Arith>
+int launch_ct_mul_variant(int log2n, int variant, u64* out3, const u64* a2, const u64* b2, size_t blocks, const DevTables<Arith>& tb, hipStream_t s) {
+    if constexpr (!Arith::kFold) return -1;
+    else {
+#define CTV_CASE(LN)                                                                                                                                  \
+    case LN:                                                                                                                                          \
+        if (variant == kCtMulQuad) hipLaunchKernelGGL((ct_mul_quad_kernel<Arith, LN, kFusedLoge>), dim3((unsigned)blocks), dim3(Geo<LN, kFusedLoge>::T), 0, s, out3, a2, b2, tb, (u64*)nullptr); \
+        else if (variant == kCtMulDual) hipLaunchKernelGGL((ct_mul_dual_kernel<Arith, LN, kFusedLoge, false>), dim3((unsigned)blocks), dim3(Geo<LN, kFusedLoge>::T), 0, s, out3, a2, b2, tb); \
+        else if (variant == kCtMulSingle) hipLaunchKernelGGL((ct_mul_kernel<Arith, LN, kFusedLoge, false, false>), dim3((unsigned)blocks), dim3(Geo<LN, kFusedLoge>::T), 0, s, out3, a2, b2, tb); \
+        else return -1;                                                                                                                               \
+        return 0
+        switch (log2n) {
+            CTV_CASE(12);
+            CTV_CASE(13);
+            default: return -1;
+        }
+#undef CTV_CASE
+    }
+}
+// diagnostics: the quad form with per-workgroup timestamps (kernels.h trace_stamp); N = 4096 only
+template <class Arith>
+int launch_ct_mul_trace(int log2n, u64* out3, const u64* a2, const u64* b2, size_t blocks, const DevTables<Arith>& tb, u64* trace, hipStream_t s) {
+    if constexpr (!Arith::kFold) return -1;
+    else {
+        if (log2n != 12) return -1;
+        hipLaunchKernelGGL((ct_mul_quad_kernel<Arith, 12, kFusedLoge, true>), dim3((unsigned)blocks), dim3(Geo<12, kFusedLoge>::T), 0, s, out3, a2, b2, tb, trace);
+        return 0;
     }
 }
 

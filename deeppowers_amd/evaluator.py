@@ -60,6 +60,33 @@ class Context:
     def uses_fold(self) -> bool:
         return bool(self._lib.dpfhe_ctx_uses_fold(self._h))
 
+    # ---- which form of the fused multiply this context launches (include/dpfhe.h "A0, continued") ----
+    def tune_info(self) -> dict:
+        """{"chosen": name, "source": ..., "probe_us": {name: us}, "probe_pairs": n, "probe_reps": r}; forms are bit-identical."""
+        t = _cabi.TuneInfo()
+        _cabi.check(self._lib.dpfhe_ctx_tune_info(self._h, C.byref(t)), "dpfhe_ctx_tune_info")
+        name = lambda v: self._lib.dpfhe_ct_mul_variant_name(v).decode()
+        return {"chosen": name(t.chosen), "n_variants": t.n_variants, "source": _cabi.TUNE_SOURCES[t.source] if 0 <= t.source < 4 else str(t.source),
+                "probe_pairs": t.probe_pairs, "probe_reps": t.probe_reps,
+                "probe_us": {name(v): round(float(t.probe_us[v]), 2) for v in range(t.n_variants) if t.probe_us[v] >= 0}}
+
+    def autotune(self, work: torch.Tensor, reps: int = 3, stream=None) -> dict:
+        """Re-measures the forms on the caller's scratch tensor (contents are overwritten; synchronises the stream)."""
+        if work.dtype != torch.int64 or not work.is_contiguous() or work.device != self.device:
+            raise _cabi.DpfheError(2000, "autotune scratch must be a contiguous int64 tensor on the context's device")
+        s = _resolve_stream(stream, self.device)
+        _cabi.check(self._lib.dpfhe_ctx_autotune(self._h, work.data_ptr(), work.numel(), reps, s.cuda_stream), "dpfhe_ctx_autotune")
+        return self.tune_info()
+
+    def variants(self):
+        return [self._lib.dpfhe_ct_mul_variant_name(v).decode() for v in range(self.tune_info()["n_variants"])]
+
+    def set_ct_mul_variant(self, name: str):
+        names = [self._lib.dpfhe_ct_mul_variant_name(v).decode() for v in range(4)]
+        if name not in names or not name:
+            raise _cabi.DpfheError(2000, f"unknown form {name!r}")
+        _cabi.check(self._lib.dpfhe_ctx_set_ct_mul_variant(self._h, names.index(name)), "dpfhe_ctx_set_ct_mul_variant")
+
     def close(self):
         if getattr(self, "_h", None):
             self._lib.dpfhe_ctx_destroy(self._h)

@@ -20,6 +20,7 @@
 #include <memory>
 #include <stdexcept>
 #include <string>
+#include <utility>
 #include <vector>
 
 namespace deeppowers {
@@ -51,6 +52,7 @@ struct FheParams {
     static FheParams n8192_l6();    // N=8192, 6 x 60-bit limbs      (configs[4] sizes)
 };
 
+class PolyBuffer;
 class Context {
 public:
     explicit Context(const FheParams& params, int device_id = 0);
@@ -63,6 +65,15 @@ public:
     bool uses_fold() const;
     void* handle() const;  // dpfhe_ctx*
     void synchronize() const;
+    // Which form of the fused multiply Evaluator::multiply launches on this box (include/dpfhe.h "A0, continued": measured once at
+    // construction, in the spirit of the reference's AutoTuner, src/core/inference/auto_tuner.hpp:26-64).  All forms give the same words.
+    struct TuneInfo {
+        std::string chosen, source;                                // e.g. "quad", "probe at dpfhe_ctx_create"
+        std::vector<std::pair<std::string, float>> probe_us;       // microseconds per probe launch of each measured form
+        unsigned probe_pairs = 0, probe_reps = 0;
+    };
+    TuneInfo tune_info() const;
+    TuneInfo autotune(PolyBuffer& scratch, unsigned reps = 3);    // re-measure on the caller's buffer (overwritten; >= 7 RNS polynomials)
 
 private:
     class Impl;

@@ -24,9 +24,13 @@
  *     "n_rns_polys" counts RNS polynomials (L limbs x N words each); a 2-component ciphertext is 2 of them.
  *   - forward NTT: natural order in, BIT-REVERSED order out, ahat[k] = sum_j a[j] psi^((2 brv(k)+1) j);
  *     inverse NTT: bit-reversed in, natural out, including N^-1.  Outputs are canonical.
- *   - `stream` is a hipStream_t (NULL = the null stream).  Calls only enqueue work; they never allocate,
- *     never synchronise.  A dpfhe_ctx is immutable after creation: concurrent calls from different host
- *     threads on different streams are allowed.
+ *   - `stream` is a hipStream_t (NULL = the null stream).  Compute calls only enqueue work and never synchronise.  At log2_n <= 13 (every
+ *     BASELINE configuration) they never allocate either: all scratch is caller-provided (d_work / d_digits / ... arguments).  The ONE
+ *     exception is spelled out at dpfhe_ctx_create below: at log2_n >= 14 dpfhe_ct_mul, dpfhe_relinearize, dpfhe_switch_key and the two
+ *     single-key hybrid entries take their scratch from a stream-ordered pool owned by the context (no synchronisation, no host allocation;
+ *     the pool keeps its memory until dpfhe_ctx_destroy).  dpfhe_ctx_create / dpfhe_ctx_autotune / dpfhe_comm_create are set-up calls: they
+ *     allocate, run device work and synchronise.  After set-up a dpfhe_ctx is immutable: concurrent calls from different host threads on
+ *     different streams are allowed.
  *   - No C++ types and no exceptions cross this boundary.
  */
 #ifndef DPFHE_H
@@ -70,6 +74,30 @@ uint32_t dpfhe_ctx_limbs(const dpfhe_ctx* ctx);
 /* 1 if every limb is of the form 2^60 - d, d < 2^24, and the fold-reduction kernels are in use */
 int dpfhe_ctx_uses_fold(const dpfhe_ctx* ctx);
 
+/* -- A0, continued: which FORM of the fused multiply a context launches -------------------------------------------------
+ * dpfhe_ct_mul(flags = 0) has three forms at N = 4096 / 8192 on fold-reduction contexts - "quad" (all four forward and all three inverse
+ * transforms of a workgroup share twiddle fetches), "dual" (transforms in pairs), "single" (one at a time, half the LDS) - with identical
+ * results and identical HBM traffic; which is fastest depends on the box (how well two waves per SIMD hide its memory latency).
+ * dpfhe_ctx_create measures them once (three launches each, twice, on <= 256 MiB of transient device memory it frees again: the only
+ * device work and the only allocation besides the tables) and keeps the default unless another form is >= 3 % faster.
+ * Environment: DPFHE_AUTOTUNE=0 skips the probe; DPFHE_CTMUL_VARIANT=quad|dual|single forces a form.
+ * dpfhe_ctx_autotune repeats the measurement on CALLER-provided scratch (work_words >= 7 L N; pairs = work_words / (7 L N) synthetic
+ * ciphertext pairs; contents are overwritten; synchronises `stream`).  It changes the context: call it before the context is shared
+ * between threads.  Other contexts (generic primes, other ring degrees) have one form; both calls are no-ops there. */
+enum { DPFHE_TUNE_DEFAULT = 0, DPFHE_TUNE_AT_CREATE = 1, DPFHE_TUNE_EXPLICIT = 2, DPFHE_TUNE_FORCED = 3 };
+typedef struct dpfhe_tune_info {
+    int32_t chosen;        /* form in use (index for dpfhe_ct_mul_variant_name) */
+    int32_t n_variants;    /* forms this context can run (0: one form, nothing measured) */
+    int32_t source;        /* DPFHE_TUNE_* : how `chosen` was decided */
+    uint32_t probe_pairs;  /* ciphertext pairs per probe launch */
+    uint32_t probe_reps;   /* launches per form and pass */
+    float probe_us[4];     /* best-pass microseconds per launch of each form (< 0: not measured) */
+} dpfhe_tune_info;
+int dpfhe_ctx_autotune(dpfhe_ctx* ctx, uint64_t* d_work, size_t work_words, uint32_t reps, void* stream);
+int dpfhe_ctx_tune_info(const dpfhe_ctx* ctx, dpfhe_tune_info* out);
+int dpfhe_ctx_set_ct_mul_variant(dpfhe_ctx* ctx, int variant);
+const char* dpfhe_ct_mul_variant_name(int variant);
+
 /* -- A1 / A2: batched negacyclic NTT, in place and out of place -------------------------------------- */
 int dpfhe_ntt_fwd(dpfhe_ctx* ctx, uint64_t* d_io, size_t n_rns_polys, void* stream);
 int dpfhe_ntt_inv(dpfhe_ctx* ctx, uint64_t* d_io, size_t n_rns_polys, void* stream);
@@ -94,6 +122,11 @@ int dpfhe_multiply_plain(dpfhe_ctx* ctx, uint64_t* d_out, const uint64_t* d_a, c
  * not overlap either operand (DPFHE_INVALID_ARGUMENT). */
 int dpfhe_ct_mul(dpfhe_ctx* ctx, uint64_t* d_out3, const uint64_t* d_a2, const uint64_t* d_b2, size_t batch,
                  uint32_t flags, void* stream);
+
+/* diagnostics (tools/ctmul_trace.py): the "quad" form of dpfhe_ct_mul(flags = 0) with timestamps - thread 0 of workgroup w (= pair w / L, limb w % L)
+ * writes d_trace[8 w .. 8 w + 7]: s_memrealtime (100 MHz) at start / first operand word arrived / forward transforms done / tensor
+ * product done / inverse transforms done / stores issued / stores drained, then HW_ID | XCC_ID << 32.  N = 4096 fold contexts only. */
+int dpfhe_debug_ct_mul_trace(dpfhe_ctx* ctx, uint64_t* d_out3, const uint64_t* d_a2, const uint64_t* d_b2, size_t batch, uint64_t* d_trace, void* stream);
 
 /* -- N1 (first "next" row): relinearisation 3 -> 2 components with RNS-digit evaluation keys ----
  * d_in3: [batch][3][L][N], d_out2: [batch][2][L][N], both coefficient domain.
