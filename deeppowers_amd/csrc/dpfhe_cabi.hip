@@ -97,7 +97,7 @@ struct dpfhe_ctx {
 // `reps` back-to-back launches per form over `pairs` synthetic ciphertext pairs, two passes in opposite orders, best pass per form;
 // a non-default form is taken only when it is at least 3 % faster than the default.
 // ------------------------------------------------------------------------------------------------
-static const char* const kCtMulVariantNames[kCtMulVariants] = {"quad", "dual", "single"};
+static const char* const kCtMulVariantNames[kCtMulVariants] = {"quad", "dual", "single", "quadloop"};
 static const float kTuneMargin = 0.97f;
 
 __global__ __launch_bounds__(256) void tune_fill_kernel(u64* __restrict__ p, size_t n) {
@@ -907,13 +907,25 @@ extern "C" int dpfhe_rotate_hoisted_qp(dpfhe_ctx* c, uint64_t* d_out_qp, const u
     if (c->fold) hipLaunchKernelGGL((lift_qp_kernel<FoldArith>), dim3(idg), dim3(256), 0, s, d_out_qp, d_in_ntt, lc, p_special, (int)L, n, chunks);
     else hipLaunchKernelGGL((lift_qp_kernel<ShoupArith>), dim3(idg), dim3(256), 0, s, d_out_qp, d_in_ntt, lc, p_special, (int)L, n, chunks);
     if (int e = check_launch("lift_qp kernel launch")) return e;
-    // 4. the rotations: gather + key inner products, 64 rotations per launch
+    // 4. the rotations: permuted digit segments x key segments as a stream (kernels_misc.h hoisted_qp_stream_kernel), 64 rotations per launch
+    static const bool old_form = [] { const char* e = std::getenv("DPFHE_HOISTED_QP"); return e && !std::strcmp(e, "fused"); }();   // A/B only
     for (size_t first = 0; first < batch; first += kMaxGaloisBatch) {
         const size_t cnt = batch - first < (size_t)kMaxGaloisBatch ? batch - first : (size_t)kMaxGaloisBatch;
         uint64_t* dst = d_out_qp + (1 + first) * T * 2 * L * n;
-        const int rc = c->fold ? launch_hoisted_qp<FoldArith>((int)c->log2n, dst, d_digits, d_in_ntt, d_keys + first * key_words, key_words, galois_elts + first, cnt, T, p_special, c->foldt, s)
-                               : launch_hoisted_qp<ShoupArith>((int)c->log2n, dst, d_digits, d_in_ntt, d_keys + first * key_words, key_words, galois_elts + first, cnt, T, p_special, c->shoup, s);
-        if (rc) return fail(DPFHE_INVALID_STATE, what, "no kernel geometry for this log2_n");
+        if (old_form) {
+            const int rc = c->fold ? launch_hoisted_qp<FoldArith>((int)c->log2n, dst, d_digits, d_in_ntt, d_keys + first * key_words, key_words, galois_elts + first, cnt, T, p_special, c->foldt, s)
+                                   : launch_hoisted_qp<ShoupArith>((int)c->log2n, dst, d_digits, d_in_ntt, d_keys + first * key_words, key_words, galois_elts + first, cnt, T, p_special, c->shoup, s);
+            if (rc) return fail(DPFHE_INVALID_STATE, what, "no kernel geometry for this log2_n");
+        } else {
+            QpElts ge{};
+            for (size_t i = 0; i < cnt; ++i) ge.v[i] = galois_elts[first + i];
+            const size_t grid = qp_stream_grid((int)c->log2n, (int)L, cnt, T);
+            if (grid > kMaxGrid) return fail(DPFHE_INVALID_ARGUMENT, what, "batch too large for one launch");
+            if (c->fold) hipLaunchKernelGGL((hoisted_qp_stream_kernel<FoldArith, kQpPairs>), dim3((unsigned)grid), dim3(256), 0, s, dst, d_digits, d_in_ntt, d_keys + first * key_words, key_words, ge,
+                                            (unsigned)cnt, (unsigned)T, p_special, lc, (int)L, (int)c->log2n);
+            else hipLaunchKernelGGL((hoisted_qp_stream_kernel<ShoupArith, kQpPairs>), dim3((unsigned)grid), dim3(256), 0, s, dst, d_digits, d_in_ntt, d_keys + first * key_words, key_words, ge,
+                                    (unsigned)cnt, (unsigned)T, p_special, lc, (int)L, (int)c->log2n);
+        }
         if (int e = check_launch("hoisted_qp kernel launch")) return e;
     }
     return DPFHE_SUCCESS;

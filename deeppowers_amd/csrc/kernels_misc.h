@@ -629,6 +629,149 @@ __global__ __launch_bounds__(256) void lift_qp_kernel(u64* out, const u64* in, c
     *reinterpret_cast<U64x2*>(out + (poly * n_limbs + limb) * n + w0) = r;
 }
 
+// ------------------------------------------------------------------------------------------------
+// N3, round 4: the baby-step pass of the double-hoisted packed products as a STREAM (replaces kernels.h hoisted_qp_kernel, whose one
+// workgroup per (rotation, limb, token) re-read the digit images once per rotation: 2.3 x its algorithmic bytes in L2 misses).
+//   out[(r, t)] = ( sum_j perm_g(digit_{t,j}) (.) key_{r,j,0} + P perm_g(NTT(c0_t)),  sum_j perm_g(digit_{t,j}) (.) key_{r,j,1} )   over all L limbs.
+// No transform, so no NTT geometry: a workgroup is 256 threads x PP 16-byte pairs = one SEGMENT of 512 PP words of one (rotation, limb, token).
+// Keys and results are read / written in natural (forward-output) order, lane-contiguous; only the digit words are permuted, and sigma_g
+// in forward-output order maps every aligned pair ONTO an aligned pair (swapped or not) and every aligned segment onto an aligned segment:
+//   pair m -> pair m' = brv((c - 1) / 2),  c = g (2 brv(m) + 1) mod 2N reduced mod N,  words swapped iff that product is >= N
+// (brv over log2 N - 1 bits) - one 16-byte gather per pair inside ONE source segment, indices computed once per thread and reused for
+// all digits.  What makes the traffic algorithmic is WHERE workgroups run: ids are dealt to the 8 XCDs round-robin, and XCD x gets, one
+// block of 16 rotations x n_items tokens at a time, all workgroups of one (limb, SOURCE segment): the block's workgroups are resident
+// together (5 per CU), every key segment is fetched from HBM once for its n_items tokens and every digit segment once for its 16 rotations.
+// ------------------------------------------------------------------------------------------------
+constexpr int kQpPairs = 2;          // 16-byte pairs per thread: segment = 512 pairs = 1024 words
+constexpr int kQpRotGroup = 16;      // rotations that share a digit segment in one XCD block
+struct QpElts { unsigned v[kMaxGaloisBatch]; };
+
+__device__ __forceinline__ unsigned qp_brev(unsigned x, int bits) { return bits ? (__brev(x) >> (32 - bits)) : 0u; }
+
+template <class Arith, int PP>
+__global__ __launch_bounds__(256) void hoisted_qp_stream_kernel(u64* __restrict__ out, const u64* __restrict__ digits, const u64* __restrict__ xntt,
+                                                                const u64* __restrict__ keys, size_t key_stride, QpElts elts, unsigned n_rot, unsigned n_items,
+                                                                u64 p_special, const LimbConst* __restrict__ lcs, int n_limbs, int log2n) {
+    const int L = n_limbs, Ld = L - 1, n1 = log2n - 1;
+    const unsigned half = 1u << n1, n = 2u << n1, seg_pairs = 256u * PP;
+    const unsigned nseg = half > seg_pairs ? half / seg_pairs : 1u, tbits = 31u - (unsigned)__clz((int)nseg);
+    const unsigned combos = (unsigned)L * nseg, n_rg = (n_rot + kQpRotGroup - 1) / kQpRotGroup, bs = (unsigned)kQpRotGroup * n_items;
+    // id -> (XCD x, block of one (limb, source segment, rotation group), rotation in group, token)
+    const unsigned xcd = blockIdx.x & 7u, q = blockIdx.x >> 3, within = q % bs, t1 = q / bs, rg = t1 % n_rg, combo = (t1 / n_rg) * 8u + xcd;
+    const unsigned rot = rg * kQpRotGroup + within / n_items, token = within % n_items;
+    if (combo >= combos || rot >= n_rot) return;
+    const int limb = (int)(combo % (unsigned)L);
+    const unsigned sseg = combo / (unsigned)L;
+    const unsigned g = elts.v[rot];
+    // output segment whose sources are segment sseg:  2 rev(oseg) + 1 = g^-1 (2 rev(sseg) + 1)  mod 2 nseg
+    unsigned ginv = g;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) ginv *= 2u - g * ginv;                  // g^-1 mod 2^32
+    const unsigned uo = (ginv * (2u * qp_brev(sseg, (int)tbits) + 1u)) & (2u * nseg - 1u);
+    const unsigned oseg = qp_brev((uo - 1u) >> 1, (int)tbits);
+    const LimbConst lc = lcs[limb];
+    const size_t N = n;
+    unsigned ms[PP], mo[PP];
+    bool sw[PP], ok[PP];
+#pragma unroll
+    for (int c = 0; c < PP; ++c) {
+        mo[c] = oseg * seg_pairs + (unsigned)c * 256u + threadIdx.x;
+        ok[c] = mo[c] < half;
+        const unsigned cf = (g * (2u * qp_brev(mo[c], n1) + 1u)) & (2u * n - 1u);
+        sw[c] = cf >= n;
+        ms[c] = qp_brev(((cf & (n - 1u)) - 1u) >> 1, n1);
+    }
+    const size_t item = (size_t)rot * n_items + token;
+    const u64* dig = digits + ((size_t)token * Ld * L + limb) * N;      // digit j at + j L N
+    const u64* evk = keys + (size_t)rot * key_stride + (size_t)limb * N; // key (j, comp) at + (j 2 + comp) L N
+    auto gather = [&](U64x2 (&x)[PP], const u64* tile) {
+#pragma unroll
+        for (int c = 0; c < PP; ++c)
+            if (ok[c]) x[c] = reinterpret_cast<const U64x2*>(tile)[ms[c]];
+    };
+    auto unswap = [&](U64x2 (&x)[PP]) {
+#pragma unroll
+        for (int c = 0; c < PP; ++c) { const u64 a = x[c].a, b = x[c].b; x[c].a = sw[c] ? b : a; x[c].b = sw[c] ? a : b; }
+    };
+    auto stream = [&](U64x2 (&e)[PP], const u64* tile) {
+#pragma unroll
+        for (int c = 0; c < PP; ++c)
+            if (ok[c]) e[c] = reinterpret_cast<const U64x2*>(tile)[mo[c]];
+    };
+    auto mulw = [&](u64 a, u64 b) -> u64 { if constexpr (Arith::kFold) return FoldArith::mul60(a, b, (u32)lc.d); else return ShoupArith::mul_var(a, b, lc); };
+    auto accw = [&](u64 acc, u64 a, u64 b) -> u64 { if constexpr (Arith::kFold) return acc + FoldArith::mul60(a, b, (u32)lc.d); else return add_mod(acc, ShoupArith::mul_var(a, b, lc), lc.q); };
+    U64x2 acc0[PP], acc1[PP], x[PP], e0[PP], e1[PP];
+#pragma unroll
+    for (int c = 0; c < PP; ++c) { x[c] = U64x2{0, 0}; e0[c] = U64x2{0, 0}; e1[c] = U64x2{0, 0}; acc0[c] = U64x2{0, 0}; acc1[c] = U64x2{0, 0}; }
+    int lazy_terms = 0;
+    if (limb < Ld) {   // component 0 starts with P perm_g(NTT(c0)) on the data limbs (P = 0 on the special limb)
+        U64x2 c0[PP];
+#pragma unroll
+        for (int c = 0; c < PP; ++c) c0[c] = U64x2{0, 0};
+        gather(c0, xntt + ((size_t)token * 2 * Ld + limb) * N);
+        gather(x, dig);
+        stream(e0, evk);
+        stream(e1, evk + (size_t)L * N);
+        unswap(c0);
+        const u64 pmod = Arith::kFold ? FoldArith::canon(p_special, lc) : ShoupArith::mul_var(p_special, 1, lc);
+#pragma unroll
+        for (int c = 0; c < PP; ++c) { acc0[c].a = mulw(c0[c].a, pmod); acc0[c].b = mulw(c0[c].b, pmod); }
+        lazy_terms = 1;
+    } else {
+        gather(x, dig);
+        stream(e0, evk);
+        stream(e1, evk + (size_t)L * N);
+    }
+#pragma unroll 1
+    for (int j = 0; j < Ld; ++j) {
+        U64x2 xn[PP], e0n[PP], e1n[PP];
+        const int jn = j + 1 < Ld ? j + 1 : j;   // the last iteration re-requests its own segments (cache hits) instead of branching
+#pragma unroll
+        for (int c = 0; c < PP; ++c) { xn[c] = x[c]; e0n[c] = e0[c]; e1n[c] = e1[c]; }
+        gather(xn, dig + (size_t)jn * L * N);
+        stream(e0n, evk + (size_t)(jn * 2) * L * N);
+        stream(e1n, evk + (size_t)(jn * 2 + 1) * L * N);
+        unswap(x);
+        if (Arith::kFold) {
+            if (lazy_terms == 13) {   // 13 lazily added products + one reduced word stay below 15 q
+#pragma unroll
+                for (int c = 0; c < PP; ++c) {
+                    acc0[c].a = FoldArith::reduce(acc0[c].a, lc); acc0[c].b = FoldArith::reduce(acc0[c].b, lc);
+                    acc1[c].a = FoldArith::reduce(acc1[c].a, lc); acc1[c].b = FoldArith::reduce(acc1[c].b, lc);
+                }
+                lazy_terms = 1;
+            }
+            ++lazy_terms;
+        }
+#pragma unroll
+        for (int c = 0; c < PP; ++c) {
+            acc0[c].a = accw(acc0[c].a, x[c].a, e0[c].a); acc0[c].b = accw(acc0[c].b, x[c].b, e0[c].b);
+            acc1[c].a = accw(acc1[c].a, x[c].a, e1[c].a); acc1[c].b = accw(acc1[c].b, x[c].b, e1[c].b);
+        }
+#pragma unroll
+        for (int c = 0; c < PP; ++c) { x[c] = xn[c]; e0[c] = e0n[c]; e1[c] = e1n[c]; }
+    }
+    u64* o0 = out + ((item * 2 + 0) * L + limb) * N;
+    u64* o1 = out + ((item * 2 + 1) * L + limb) * N;
+#pragma unroll
+    for (int c = 0; c < PP; ++c) {
+        if (!ok[c]) continue;
+        U64x2 r0 = acc0[c], r1 = acc1[c];
+        if (Arith::kFold) {
+            r0.a = FoldArith::canon(r0.a, lc); r0.b = FoldArith::canon(r0.b, lc);
+            r1.a = FoldArith::canon(r1.a, lc); r1.b = FoldArith::canon(r1.b, lc);
+        }
+        st_vec<true>(reinterpret_cast<U64x2*>(o0) + mo[c], r0);   // written once, read by the next launch: around the caches the keys and digits live in
+        st_vec<true>(reinterpret_cast<U64x2*>(o1) + mo[c], r1);
+    }
+}
+// grid of the stream kernel (dpfhe_cabi.hip): 8 XCDs x blocks of (16 rotations x n_items) x rotation groups x ceil(L nseg / 8)
+inline size_t qp_stream_grid(int log2n, int n_limbs, size_t n_rot, size_t n_items) {
+    const size_t half = (size_t)1 << (log2n - 1), seg_pairs = 256 * kQpPairs, nseg = half > seg_pairs ? half / seg_pairs : 1;
+    const size_t combos = (size_t)n_limbs * nseg, n_rg = (n_rot + kQpRotGroup - 1) / kQpRotGroup;
+    return 8 * ((combos + 7) / 8) * n_rg * (size_t)kQpRotGroup * n_items;
+}
+
 // N3, hoisted rotations: digit j of the key-switched component (limb j of c1, coefficient domain, values < q_j) lifted to every
 // limb i of the extended basis: out[j][i][k] = c1[j][k] mod q_i (canonical).  One workgroup per (digit, limb, 512-word chunk).
 template <class Arith>

@@ -1,5 +1,7 @@
 // launch_impl.h - geometry dispatch shared by the per-policy translation units.
 #pragma once
+#include <cstdlib>
+
 #include "kernels.h"
 #include "launch.h"
 
@@ -117,6 +119,10 @@ int launch_ct_mul(int log2n, unsigned flags, u64* out3, const u64* a2, const u64
     }
 }
 
+inline unsigned loop_pairs() {   // pairs per workgroup of the looped quad form: kCtMulLoopPairs unless DPFHE_CTMUL_LOOP_PAIRS says otherwise (A/B runs)
+    static const unsigned v = [] { const char* e = std::getenv("DPFHE_CTMUL_LOOP_PAIRS"); const int n = e ? std::atoi(e) : 0; return n > 0 ? (unsigned)n : kCtMulLoopPairs; }();
+    return v;
+}
 // The fused multiply in a NAMED form (coefficient domain in and out, FoldArith, N = 4096 / 8192): what dpfhe_ctx_autotune probes and
 // what a context then launches.  kCtMulQuad / kCtMulDual / kCtMulSingle differ in how many transforms share twiddle fetches and LDS
 // buffers (kernels.h), not in results (bit-identical) or HBM traffic (7 residue polynomials per limb).  -1: not compiled for this ring.
@@ -129,6 +135,10 @@ int launch_ct_mul_variant(int log2n, int variant, u64* out3, const u64* a2, cons
         if (variant == kCtMulQuad) hipLaunchKernelGGL((ct_mul_quad_kernel<Arith, LN, kFusedLoge>), dim3((unsigned)blocks), dim3(Geo<LN, kFusedLoge>::T), 0, s, out3, a2, b2, tb, (u64*)nullptr); \
         else if (variant == kCtMulDual) hipLaunchKernelGGL((ct_mul_dual_kernel<Arith, LN, kFusedLoge, false>), dim3((unsigned)blocks), dim3(Geo<LN, kFusedLoge>::T), 0, s, out3, a2, b2, tb); \
         else if (variant == kCtMulSingle) hipLaunchKernelGGL((ct_mul_kernel<Arith, LN, kFusedLoge, false, false>), dim3((unsigned)blocks), dim3(Geo<LN, kFusedLoge>::T), 0, s, out3, a2, b2, tb); \
+        else if (variant == kCtMulQuadLoop) {                                                                                                         \
+            const unsigned batch = (unsigned)(blocks / (size_t)tb.n_limbs), per = loop_pairs(), groups = (batch + per - 1) / per;                   \
+            hipLaunchKernelGGL((ct_mul_quad_loop_kernel<Arith, LN, kFusedLoge>), dim3(groups * (unsigned)tb.n_limbs), dim3(Geo<LN, kFusedLoge>::T), 0, s, out3, a2, b2, tb, per, batch); \
+        }                                                                                                                                             \
         else return -1;                                                                                                                               \
         return 0
         switch (log2n) {
@@ -162,8 +172,17 @@ int launch_relin(int log2n, int mode, u64* out2, const u64* in3, const u64* evk,
     const int n_digits = mode >= 2 ? tb.n_limbs - 1 : tb.n_limbs;
     // items that share a key (key_group > 1) are laid out per XCD: kernels.h relin_kernel
     const unsigned kg = key_group ? key_group : 1u;
-    const unsigned n_outer = (kg > 1 && blocks % ((size_t)kg * tb.n_limbs) == 0) ? (unsigned)(blocks / kg) : 0u;   // whole groups only
-    const unsigned grid = n_outer ? ((n_outer + 7u) / 8u) * 8u * kg : (unsigned)blocks;
+    unsigned n_outer = (kg > 1 && blocks % ((size_t)kg * tb.n_limbs) == 0) ? (unsigned)(blocks / kg) : 0u;   // whole groups only
+    unsigned grid = n_outer ? ((n_outer + 7u) / 8u) * 8u * kg : (unsigned)blocks;
+#ifndef DPFHE_RELIN_KEY_MAJOR
+#define DPFHE_RELIN_KEY_MAJOR 1
+#endif
+    // eight keys or more: one key (all its limbs and items) per XCD at a time, so that the items' digits are fetched once, not once per limb
+    if (DPFHE_RELIN_KEY_MAJOR && n_outer && n_outer / (unsigned)tb.n_limbs >= 8u) {
+        const unsigned n_keys = n_outer / (unsigned)tb.n_limbs;
+        grid = ((n_keys + 7u) / 8u) * 8u * (unsigned)tb.n_limbs * kg;
+        n_outer |= kRelinRotMajor;
+    }
 #define RL_ONE(LN, M)                                                                                                                                    \
     if constexpr (DPFHE_RELIN_SHARED && Arith::kFold && LN >= 10 && LN <= 12) {                                                                          \
         if (n_digits >= 4 && n_digits <= 7) {                                                                                                            \

@@ -7,12 +7,16 @@ import time
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import deeppowers_amd._cabi as _cabi  # noqa: E402
+if os.environ.get("DPFHE_AB_LIB"):
+    _cabi.LIB_PATH = os.path.abspath(os.environ["DPFHE_AB_LIB"])
 from deeppowers_amd.evaluator import Ciphertext, Context, Evaluator  # noqa: E402
 from deeppowers_amd.params import FheParams  # noqa: E402
 from deeppowers_amd.sharding import ShardedMultiplyReduce  # noqa: E402
 
 pairs = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
-for params in (FheParams.n4096_l4(), FheParams.n8192_l6()):
+tag = os.path.basename(os.environ.get("DPFHE_AB_LIB", "HEAD")) + " loop_pairs=" + os.environ.get("DPFHE_CTMUL_LOOP_PAIRS", "default")
+for params in ((FheParams.n4096_l4(),) if len(sys.argv) > 2 and sys.argv[2] == "n4096" else (FheParams.n4096_l4(), FheParams.n8192_l6())):
     B = pairs if params.log2_n == 12 else pairs // 8
     ctx = Context(params, 0)
     ev = Evaluator(ctx)
@@ -45,6 +49,6 @@ for params in (FheParams.n4096_l4(), FheParams.n8192_l6()):
                 pipe.step(a, b)
             torch.cuda.synchronize()
             st = (time.perf_counter() - t0) / 6 * 1e3
-            print(f"pass {rnd} {form:7s} alone: median {ts[6]:7.3f} ms  min {ts[0]:7.3f} ms = {B / ts[6] / 1e3:6.3f} M ct-mul/s | in the step: {st:7.3f} ms = {B / st / 1e3:6.3f} M ct-mul/s | same words: {chk == ref}")
+            print(f"{tag} pass {rnd} {form:8s} alone: median {ts[6]:7.3f} ms  min {ts[0]:7.3f} ms = {B / ts[6] / 1e3:6.3f} M ct-mul/s | in the step: {st:7.3f} ms = {B / st / 1e3:6.3f} M ct-mul/s | same words: {chk == ref}")
     del pipe, a, b
     ctx.close()
