@@ -16,6 +16,7 @@
 #include <mutex>
 #include <new>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "../../include/dpfhe.h"
@@ -97,7 +98,7 @@ struct dpfhe_ctx {
 // `reps` back-to-back launches per form over `pairs` synthetic ciphertext pairs, two passes in opposite orders, best pass per form;
 // a non-default form is taken only when it is at least 3 % faster than the default.
 // ------------------------------------------------------------------------------------------------
-static const char* const kCtMulVariantNames[kCtMulVariants] = {"quad", "dual", "single", "quadloop"};
+static const char* const kCtMulVariantNames[kCtMulVariants] = {"quad", "dual", "single"};
 static const float kTuneMargin = 0.97f;
 
 __global__ __launch_bounds__(256) void tune_fill_kernel(u64* __restrict__ p, size_t n) {
@@ -283,12 +284,18 @@ extern "C" int dpfhe_ctx_create(dpfhe_ctx** out, uint32_t log2_n, uint32_t n_lim
                     const std::vector<u64> f = subtree_table(ht[l].rp, (int)log2_n, log_n1, r), v = subtree_table(ht[l].irp, (int)log2_n, log_n1, r);
                     pack(f, log_n2, loge_ntt, o_fwd + (l * n_sub + r) * n2 * tw_sz);
                     pack(v, log_n2, loge_ntt, o_inv + (l * n_sub + r) * n2 * tw_sz);
-                    lasts[l * n_sub + r] = InvLast<Tw>{h_make_tw<Tw>(v[1], q), h_make_tw<Tw>(1, q)};   // no N^-1 inside a block
+                    // generic primes: no N^-1 inside a block.  FoldArith: the block's last stage divides its sums by N2 exactly (FoldArith::mul_ninv),
+                    // so its differences carry N2^-1 in their twiddle; the column stage then multiplies by N1^-1 (top_last below)
+                    const u64 n2inv = std::is_same<Tw, TwFold>::value ? h_powmod((u64)n2 % q, q - 2, q) : 1;
+                    lasts[l * n_sub + r] = InvLast<Tw>{h_make_tw<Tw>(h_mulmod(v[1], n2inv, q), q), h_make_tw<Tw>(1, q)};
                 }
                 Tw* tf = reinterpret_cast<Tw*>(&blob[o_top_fwd]) + l * n_sub;
                 Tw* tv = reinterpret_cast<Tw*>(&blob[o_top_inv]) + l * n_sub;
                 for (size_t i = 1; i < n_sub; ++i) { tf[i] = h_make_tw<Tw>(ht[l].rp[i], q); tv[i] = h_make_tw<Tw>(ht[l].irp[i], q); }
-                reinterpret_cast<InvLast<Tw>*>(&blob[o_top_last])[l] = InvLast<Tw>{h_make_tw<Tw>(ht[l].w_last, q), h_make_tw<Tw>(ht[l].lc.ninv, q)};
+                // FoldArith sub-transforms divide by their own length N2 in their last stage (ntt_core.h: FoldArith::mul_ninv, exact division), so the
+                // column stage multiplies by N1^-1 = N^-1 N2 only; generic-prime sub-transforms multiply by 1 there and the column stage by N^-1
+                const u64 up = std::is_same<Tw, TwFold>::value ? (u64)n2 % q : 1;
+                reinterpret_cast<InvLast<Tw>*>(&blob[o_top_last])[l] = InvLast<Tw>{h_make_tw<Tw>(h_mulmod(ht[l].w_last, up, q), q), h_make_tw<Tw>(h_mulmod(ht[l].lc.ninv, up, q), q)};
             }
         }
     };

@@ -963,6 +963,9 @@ public:
             hip_check(hipMemcpyAsync(buf->data() + i * key_words, key->data(), key_words * sizeof(uint64_t), hipMemcpyDeviceToDevice, static_cast<hipStream_t>(s)),
                       "hipMemcpyAsync D2D");
         }
+        // The pack is cached and handed to LATER callers on ANY stream: it happens once per element list, so the copies are simply waited for
+        // here - nothing orders another stream's kernels against an asynchronous copy they never saw being enqueued.
+        hip_check(hipStreamSynchronize(static_cast<hipStream_t>(s)), "hipStreamSynchronize (key pack)");
         packed.emplace_back(elts, std::move(buf));
         return packed.back().second.get();
     }
@@ -1319,9 +1322,10 @@ PackedLinear::PackedLinear(const Context& ctx, const BatchEncoder& enc, HybridKe
     while (n1 * n1 < I.m) n1 <<= 1;
     // A hoisted baby step (gathers + key inner products, no transform) costs about a third of a giant step (Ld transforms per limb + its
     // share of the inverse transform and the division by P), so the split leans towards baby steps: n1 = 2 sqrt(m) when m allows.
-    // DPFHE_BSGS_BABY_SHIFT overrides the exponent (experiments).
     int shift = kBabyShiftDefault;
+#ifdef DPFHE_EXPERIMENTS   // split sweeps only (profiles/r03_bsgs_split_sweep.txt): a library's behaviour does not depend on its environment
     if (const char* e = std::getenv("DPFHE_BSGS_BABY_SHIFT")) shift = std::atoi(e);
+#endif
     for (; shift > 0 && n1 * 2 < I.m; --shift) n1 <<= 1;
     for (; shift < 0 && n1 > 2; ++shift) n1 >>= 1;
     I.n1 = n1; I.n2 = I.m / n1;

@@ -629,79 +629,6 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE), 2) void ct_mul_quad_kernel(u64*
     }
 }
 
-// The quad form over `per_wg` CONSECUTIVE pairs per workgroup with the next pair's operands requested ahead (round 4).  The workgroup
-// timeline of the one-pair form (tools/ctmul_trace.py) shows ~11 % of a workgroup's life spent waiting for its first operand word
-// and nothing else parked: two waves per SIMD cannot cover a whole HBM round trip.  Here a0 of pair i + 1 is requested before the
-// inverse transforms of pair i (into the registers b1 left free), b0 and a1 right after them (into the registers the inverse
-// twiddles left free), b1 at the top of the iteration: a pair after the first starts on operands that are already in registers.
-// Same words as every other form; HBM traffic unchanged (7 residue polynomials per limb).
-template <class Arith, int LOGN, int LOGE>
-__global__ __launch_bounds__(1 << (LOGN - LOGE), 2) void ct_mul_quad_loop_kernel(u64* __restrict__ out3, const u64* __restrict__ a2,
-                                                                              const u64* __restrict__ b2, DevTables<Arith> tb, unsigned per_wg, unsigned batch) {
-    typedef NttBody<Arith, LOGN, LOGE> B;
-    static_assert(Arith::kFold && LOGE == kFusedLoge, "FoldArith, fused twiddle layout");
-    constexpr int E = B::E, N = B::G::N, W = B::G::lds_words();
-    __shared__ __attribute__((aligned(16))) u64 lds[2 * W];
-    int tid = threadIdx.x;
-    const size_t L = (size_t)tb.n_limbs;
-    const int limb = (int)(blockIdx.x % L);
-    const size_t first = (size_t)(blockIdx.x / L) * per_wg;
-    const unsigned count = first + per_wg <= batch ? per_wg : (unsigned)(batch - first);
-    const LimbConst lc = tb.lc[limb];
-    const size_t cstride = L * N;
-    const InvLast<typename B::Tw> last = tb.last[limb];
-    constexpr int kInvIn = 2 * kMulB;
-    const u64* src_a = a2 + ((first * 2) * L + limb) * N;
-    const u64* src_b = b2 + ((first * 2) * L + limb) * N;
-    u64* dst = out3 + ((first * 3) * L + limb) * N;
-    u64 x[E], y[E], z[E], w[E];
-    B::template load_top<true>(tid, x, src_a);
-    B::template load_top<true>(tid, y, src_b);
-    B::template load_top<true>(tid, z, src_a + cstride);
-#pragma unroll 1
-    for (unsigned it = 0; it < count; ++it) {
-        asm volatile("" : "+v"(tid));   // keeps the twiddle fetches of consecutive iterations apart (see ct_mul_kernel)
-        B::template load_top<true>(tid, w, src_b + cstride);
-        if (it) lds_barrier();          // the previous pair's last exchange was read across waves; this pair's first one writes across them
-        FwdChain4<B, 0>::run(tid, x, y, z, w, lds, lds + W, tb.fwd4 + (size_t)limb * N, lc);
-        B::fwd_reduce_partner(y, lc);
-        B::fwd_reduce_partner(w, lc);
-#pragma unroll
-        for (int k = 0; k < E; ++k) {
-            const u64 a0 = x[k], b0 = y[k], a1 = z[k], b1 = w[k];
-            x[k] = FoldArith::mul60(a0, b0, (u32)lc.d);
-            y[k] = FoldArith::mul60(a0, b1, (u32)lc.d) + FoldArith::mul60(a1, b0, (u32)lc.d);
-            z[k] = FoldArith::mul60(a1, b1, (u32)lc.d);
-        }
-        const bool more = it + 1 < count;
-        src_a += 2 * cstride;
-        src_b += 2 * cstride;
-#ifndef DPFHE_LOOP_PREFETCH
-#define DPFHE_LOOP_PREFETCH 3
-#endif
-        u64 xn[E], yn[E], zn[E];
-        if (more && DPFHE_LOOP_PREFETCH >= 1) B::template load_top<true>(tid, xn, src_a);                 // next a0: in flight during the inverse transforms
-        asm volatile("" : "+v"(tid));
-        InvChain3<B, B::NPH - 1, kInvIn>::run(tid, x, y, z, lds, lds + W, tb.inv4 + (size_t)limb * N, last, lc);
-        if (more) {                                                           // next b0, a1: in flight during canonicalisation and stores
-            if (DPFHE_LOOP_PREFETCH < 1) B::template load_top<true>(tid, xn, src_a);
-            B::template load_top<true>(tid, yn, src_b);
-            B::template load_top<true>(tid, zn, src_a + cstride);
-        }
-        B::inv_canon(x, lc);
-        B::template store_top<DPFHE_CTMUL_NT_STORE != 0>(tid, x, dst);
-        B::inv_canon(y, lc);
-        B::template store_top<DPFHE_CTMUL_NT_STORE != 0>(tid, y, dst + cstride);
-        B::inv_canon(z, lc);
-        B::template store_top<DPFHE_CTMUL_NT_STORE != 0>(tid, z, dst + 2 * cstride);
-        dst += 3 * cstride;
-        // unconditional: after the last pair the (never requested) values are not used, and a conditional copy would keep the stored
-        // results alive next to the prefetched operands across the loop edge
-#pragma unroll
-        for (int k = 0; k < E; ++k) { x[k] = xn[k]; y[k] = yn[k]; z[k] = zn[k]; }
-    }
-}
-
 // ------------------------------------------------------------------------------------------------
 // N1: relinearisation with RNS-digit evaluation keys (no special prime).
 //   c2 = sum_j d_j g_j (mod Q) with d_j = [c2]_{q_j} (digit j = limb j of c2, coefficient domain) and g_j the CRT basis
@@ -816,8 +743,17 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE), (Arith::kFold ? 2 : 1)) void re
 #pragma unroll
             for (int k = 0; k < E; ++k) { acc0[k] = FoldArith::canon_small(acc0[k], lc); acc1[k] = FoldArith::canon_small(acc1[k], lc); }
         }
-        B::store_bot(tid, acc0, out2 + ((bi * 2 + 0) * L + limb) * N);
-        B::store_bot(tid, acc1, out2 + ((bi * 2 + 1) * L + limb) * N);
+        // through the wave's own LDS rows (what it read in the last forward exchange: no workgroup barrier), non-temporal: the terms are
+        // read once by the next launch and must not push the keys and digits out of the XCD's L2 (160 VALU instructions of register
+        // transposition less per workgroup, too)
+        if constexpr (B::kLdsIO && Arith::kFold) {
+            B::template store_bot_lds<true>(tid, acc0, out2 + ((bi * 2 + 0) * L + limb) * N, lds);
+            wave_sync();
+            B::template store_bot_lds<true>(tid, acc1, out2 + ((bi * 2 + 1) * L + limb) * N, lds);
+        } else {
+            B::store_bot(tid, acc0, out2 + ((bi * 2 + 0) * L + limb) * N);
+            B::store_bot(tid, acc1, out2 + ((bi * 2 + 1) * L + limb) * N);
+        }
         return;
     }
     constexpr int kInvIn = Arith::kFold ? 2 * kMulB : kUnit;

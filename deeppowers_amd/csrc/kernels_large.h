@@ -4,7 +4,7 @@
 // N = 8192 (one 1024-thread workgroup at N = 16384 has 128 VGPRs per thread; four polynomials of 16 words per thread do not fit).
 // Above, the same operations are COMPOSED (dpfhe_cabi.hip: ct_mul_composed, key_switch_composed) from the batched transforms of
 // kernels.h / ntt_top.h and the streaming kernels below, one HBM pass each, 16 bytes per lane, one workgroup per 512-word chunk of
-// one residue polynomial.  All words canonical in and out; results equal the fused kernels' (tests/test_gpu_large_ring.py).
+// one residue polynomial.  All words canonical in and out; results equal the fused kernels' (tests/test_gpu_parity.py (test_large_rings_multiply_and_key_switch_composed_behind_the_c_abi and the slicing test)).
 #pragma once
 #include "kernels_misc.h"
 

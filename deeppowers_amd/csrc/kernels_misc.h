@@ -698,71 +698,119 @@ __global__ __launch_bounds__(256) void hoisted_qp_stream_kernel(u64* __restrict_
         for (int c = 0; c < PP; ++c)
             if (ok[c]) e[c] = reinterpret_cast<const U64x2*>(tile)[mo[c]];
     };
-    auto mulw = [&](u64 a, u64 b) -> u64 { if constexpr (Arith::kFold) return FoldArith::mul60(a, b, (u32)lc.d); else return ShoupArith::mul_var(a, b, lc); };
-    auto accw = [&](u64 acc, u64 a, u64 b) -> u64 { if constexpr (Arith::kFold) return acc + FoldArith::mul60(a, b, (u32)lc.d); else return add_mod(acc, ShoupArith::mul_var(a, b, lc), lc.q); };
-    U64x2 acc0[PP], acc1[PP], x[PP], e0[PP], e1[PP];
+    u64* o0 = out + ((item * 2 + 0) * L + limb) * N;
+    u64* o1 = out + ((item * 2 + 1) * L + limb) * N;
+    U64x2 x[PP], e0[PP], e1[PP];
 #pragma unroll
-    for (int c = 0; c < PP; ++c) { x[c] = U64x2{0, 0}; e0[c] = U64x2{0, 0}; e1[c] = U64x2{0, 0}; acc0[c] = U64x2{0, 0}; acc1[c] = U64x2{0, 0}; }
-    int lazy_terms = 0;
-    if (limb < Ld) {   // component 0 starts with P perm_g(NTT(c0)) on the data limbs (P = 0 on the special limb)
-        U64x2 c0[PP];
+    for (int c = 0; c < PP; ++c) { x[c] = U64x2{0, 0}; e0[c] = U64x2{0, 0}; e1[c] = U64x2{0, 0}; }
+    if constexpr (Arith::kFold) {
+        // Lazy inner products on 30-bit halves (modarith.h Dot30: FOUR multiply-adds per term, the split of a digit word shared by both key
+        // components, one fold per kDot30Period terms) instead of one mul60 (15 instructions) per product: the pass is VALU-bound once its
+        // traffic is algorithmic.  All operands are canonical residues (< 2^60), which is what split30 needs.
+        typedef FoldArith::Dot30 Dot;
+        typedef FoldArith::Half30 Half;
+        Dot s0[PP][2], s1[PP][2];
+        u64 r0[PP][2], r1[PP][2];
 #pragma unroll
-        for (int c = 0; c < PP; ++c) c0[c] = U64x2{0, 0};
-        gather(c0, xntt + ((size_t)token * 2 * Ld + limb) * N);
-        gather(x, dig);
-        stream(e0, evk);
-        stream(e1, evk + (size_t)L * N);
-        unswap(c0);
-        const u64 pmod = Arith::kFold ? FoldArith::canon(p_special, lc) : ShoupArith::mul_var(p_special, 1, lc);
+        for (int c = 0; c < PP; ++c)
 #pragma unroll
-        for (int c = 0; c < PP; ++c) { acc0[c].a = mulw(c0[c].a, pmod); acc0[c].b = mulw(c0[c].b, pmod); }
-        lazy_terms = 1;
-    } else {
-        gather(x, dig);
-        stream(e0, evk);
-        stream(e1, evk + (size_t)L * N);
-    }
-#pragma unroll 1
-    for (int j = 0; j < Ld; ++j) {
-        U64x2 xn[PP], e0n[PP], e1n[PP];
-        const int jn = j + 1 < Ld ? j + 1 : j;   // the last iteration re-requests its own segments (cache hits) instead of branching
+            for (int h = 0; h < 2; ++h) { s0[c][h] = Dot{0, 0, 0}; s1[c][h] = Dot{0, 0, 0}; r0[c][h] = 0; r1[c][h] = 0; }
+        int terms = 0;
+        auto fold_all = [&]() {
 #pragma unroll
-        for (int c = 0; c < PP; ++c) { xn[c] = x[c]; e0n[c] = e0[c]; e1n[c] = e1[c]; }
-        gather(xn, dig + (size_t)jn * L * N);
-        stream(e0n, evk + (size_t)(jn * 2) * L * N);
-        stream(e1n, evk + (size_t)(jn * 2 + 1) * L * N);
-        unswap(x);
-        if (Arith::kFold) {
-            if (lazy_terms == 13) {   // 13 lazily added products + one reduced word stay below 15 q
+            for (int c = 0; c < PP; ++c)
 #pragma unroll
-                for (int c = 0; c < PP; ++c) {
-                    acc0[c].a = FoldArith::reduce(acc0[c].a, lc); acc0[c].b = FoldArith::reduce(acc0[c].b, lc);
-                    acc1[c].a = FoldArith::reduce(acc1[c].a, lc); acc1[c].b = FoldArith::reduce(acc1[c].b, lc);
+                for (int h = 0; h < 2; ++h) {
+                    r0[c][h] = FoldArith::dot30_fold(s0[c][h], r0[c][h], lc); s0[c][h] = Dot{0, 0, 0};
+                    r1[c][h] = FoldArith::dot30_fold(s1[c][h], r1[c][h], lc); s1[c][h] = Dot{0, 0, 0};
                 }
-                lazy_terms = 1;
+            terms = 0;
+        };
+        if (limb < Ld) {   // component 0 starts with P perm_g(NTT(c0)) on the data limbs (P = 0 on the special limb)
+            U64x2 c0[PP];
+#pragma unroll
+            for (int c = 0; c < PP; ++c) c0[c] = U64x2{0, 0};
+            gather(c0, xntt + ((size_t)token * 2 * Ld + limb) * N);
+            gather(x, dig);
+            stream(e0, evk);
+            stream(e1, evk + (size_t)L * N);
+            unswap(c0);
+            const Half hp = FoldArith::split30(FoldArith::canon(p_special, lc));
+#pragma unroll
+            for (int c = 0; c < PP; ++c) {
+                FoldArith::dot30_mac(s0[c][0], FoldArith::split30(c0[c].a), hp);
+                FoldArith::dot30_mac(s0[c][1], FoldArith::split30(c0[c].b), hp);
             }
-            ++lazy_terms;
+            terms = 1;
+        } else {
+            gather(x, dig);
+            stream(e0, evk);
+            stream(e1, evk + (size_t)L * N);
+        }
+#pragma unroll 1
+        for (int j = 0; j < Ld; ++j) {
+            U64x2 xn[PP], e0n[PP], e1n[PP];
+            const int jn = j + 1 < Ld ? j + 1 : j;   // the last iteration re-requests its own segments (cache hits) instead of branching
+#pragma unroll
+            for (int c = 0; c < PP; ++c) { xn[c] = x[c]; e0n[c] = e0[c]; e1n[c] = e1[c]; }
+            gather(xn, dig + (size_t)jn * L * N);
+            stream(e0n, evk + (size_t)(jn * 2) * L * N);
+            stream(e1n, evk + (size_t)(jn * 2 + 1) * L * N);
+            unswap(x);
+            if (terms == FoldArith::kDot30Period) fold_all();   // workgroup-uniform
+            ++terms;
+#pragma unroll
+            for (int c = 0; c < PP; ++c) {
+                const Half xa = FoldArith::split30(x[c].a), xb = FoldArith::split30(x[c].b);
+                FoldArith::dot30_mac(s0[c][0], xa, FoldArith::split30(e0[c].a));
+                FoldArith::dot30_mac(s0[c][1], xb, FoldArith::split30(e0[c].b));
+                FoldArith::dot30_mac(s1[c][0], xa, FoldArith::split30(e1[c].a));
+                FoldArith::dot30_mac(s1[c][1], xb, FoldArith::split30(e1[c].b));
+            }
+#pragma unroll
+            for (int c = 0; c < PP; ++c) { x[c] = xn[c]; e0[c] = e0n[c]; e1[c] = e1n[c]; }
+        }
+        fold_all();
+#pragma unroll
+        for (int c = 0; c < PP; ++c) {
+            if (!ok[c]) continue;
+            // written once, read by the next launch: around the caches the keys and digits live in
+            st_vec<true>(reinterpret_cast<U64x2*>(o0) + mo[c], U64x2{FoldArith::canon_small(r0[c][0], lc), FoldArith::canon_small(r0[c][1], lc)});
+            st_vec<true>(reinterpret_cast<U64x2*>(o1) + mo[c], U64x2{FoldArith::canon_small(r1[c][0], lc), FoldArith::canon_small(r1[c][1], lc)});
+        }
+    } else {
+        U64x2 acc0[PP], acc1[PP];
+#pragma unroll
+        for (int c = 0; c < PP; ++c) { acc0[c] = U64x2{0, 0}; acc1[c] = U64x2{0, 0}; }
+        auto accw = [&](u64 acc, u64 a, u64 b) -> u64 { return add_mod(acc, ShoupArith::mul_var(a, b, lc), lc.q); };
+        if (limb < Ld) {
+            U64x2 c0[PP];
+#pragma unroll
+            for (int c = 0; c < PP; ++c) c0[c] = U64x2{0, 0};
+            gather(c0, xntt + ((size_t)token * 2 * Ld + limb) * N);
+            unswap(c0);
+            const u64 pmod = ShoupArith::mul_var(p_special, 1, lc);
+#pragma unroll
+            for (int c = 0; c < PP; ++c) { acc0[c].a = ShoupArith::mul_var(c0[c].a, pmod, lc); acc0[c].b = ShoupArith::mul_var(c0[c].b, pmod, lc); }
+        }
+#pragma unroll 1
+        for (int j = 0; j < Ld; ++j) {
+            gather(x, dig + (size_t)j * L * N);
+            stream(e0, evk + (size_t)(j * 2) * L * N);
+            stream(e1, evk + (size_t)(j * 2 + 1) * L * N);
+            unswap(x);
+#pragma unroll
+            for (int c = 0; c < PP; ++c) {
+                acc0[c].a = accw(acc0[c].a, x[c].a, e0[c].a); acc0[c].b = accw(acc0[c].b, x[c].b, e0[c].b);
+                acc1[c].a = accw(acc1[c].a, x[c].a, e1[c].a); acc1[c].b = accw(acc1[c].b, x[c].b, e1[c].b);
+            }
         }
 #pragma unroll
         for (int c = 0; c < PP; ++c) {
-            acc0[c].a = accw(acc0[c].a, x[c].a, e0[c].a); acc0[c].b = accw(acc0[c].b, x[c].b, e0[c].b);
-            acc1[c].a = accw(acc1[c].a, x[c].a, e1[c].a); acc1[c].b = accw(acc1[c].b, x[c].b, e1[c].b);
+            if (!ok[c]) continue;
+            st_vec<true>(reinterpret_cast<U64x2*>(o0) + mo[c], acc0[c]);
+            st_vec<true>(reinterpret_cast<U64x2*>(o1) + mo[c], acc1[c]);
         }
-#pragma unroll
-        for (int c = 0; c < PP; ++c) { x[c] = xn[c]; e0[c] = e0n[c]; e1[c] = e1n[c]; }
-    }
-    u64* o0 = out + ((item * 2 + 0) * L + limb) * N;
-    u64* o1 = out + ((item * 2 + 1) * L + limb) * N;
-#pragma unroll
-    for (int c = 0; c < PP; ++c) {
-        if (!ok[c]) continue;
-        U64x2 r0 = acc0[c], r1 = acc1[c];
-        if (Arith::kFold) {
-            r0.a = FoldArith::canon(r0.a, lc); r0.b = FoldArith::canon(r0.b, lc);
-            r1.a = FoldArith::canon(r1.a, lc); r1.b = FoldArith::canon(r1.b, lc);
-        }
-        st_vec<true>(reinterpret_cast<U64x2*>(o0) + mo[c], r0);   // written once, read by the next launch: around the caches the keys and digits live in
-        st_vec<true>(reinterpret_cast<U64x2*>(o1) + mo[c], r1);
     }
 }
 // grid of the stream kernel (dpfhe_cabi.hip): 8 XCDs x blocks of (16 rotations x n_items) x rotation groups x ceil(L nseg / 8)

@@ -119,10 +119,6 @@ int launch_ct_mul(int log2n, unsigned flags, u64* out3, const u64* a2, const u64
     }
 }
 
-inline unsigned loop_pairs() {   // pairs per workgroup of the looped quad form: kCtMulLoopPairs unless DPFHE_CTMUL_LOOP_PAIRS says otherwise (A/B runs)
-    static const unsigned v = [] { const char* e = std::getenv("DPFHE_CTMUL_LOOP_PAIRS"); const int n = e ? std::atoi(e) : 0; return n > 0 ? (unsigned)n : kCtMulLoopPairs; }();
-    return v;
-}
 // The fused multiply in a NAMED form (coefficient domain in and out, FoldArith, N = 4096 / 8192): what dpfhe_ctx_autotune probes and
 // what a context then launches.  kCtMulQuad / kCtMulDual / kCtMulSingle differ in how many transforms share twiddle fetches and LDS
 // buffers (kernels.h), not in results (bit-identical) or HBM traffic (7 residue polynomials per limb).  -1: not compiled for this ring.
@@ -135,10 +131,6 @@ int launch_ct_mul_variant(int log2n, int variant, u64* out3, const u64* a2, cons
         if (variant == kCtMulQuad) hipLaunchKernelGGL((ct_mul_quad_kernel<Arith, LN, kFusedLoge>), dim3((unsigned)blocks), dim3(Geo<LN, kFusedLoge>::T), 0, s, out3, a2, b2, tb, (u64*)nullptr); \
         else if (variant == kCtMulDual) hipLaunchKernelGGL((ct_mul_dual_kernel<Arith, LN, kFusedLoge, false>), dim3((unsigned)blocks), dim3(Geo<LN, kFusedLoge>::T), 0, s, out3, a2, b2, tb); \
         else if (variant == kCtMulSingle) hipLaunchKernelGGL((ct_mul_kernel<Arith, LN, kFusedLoge, false, false>), dim3((unsigned)blocks), dim3(Geo<LN, kFusedLoge>::T), 0, s, out3, a2, b2, tb); \
-        else if (variant == kCtMulQuadLoop) {                                                                                                         \
-            const unsigned batch = (unsigned)(blocks / (size_t)tb.n_limbs), per = loop_pairs(), groups = (batch + per - 1) / per;                   \
-            hipLaunchKernelGGL((ct_mul_quad_loop_kernel<Arith, LN, kFusedLoge>), dim3(groups * (unsigned)tb.n_limbs), dim3(Geo<LN, kFusedLoge>::T), 0, s, out3, a2, b2, tb, per, batch); \
-        }                                                                                                                                             \
         else return -1;                                                                                                                               \
         return 0
         switch (log2n) {
@@ -207,8 +199,9 @@ int launch_relin(int log2n, int mode, u64* out2, const u64* in3, const u64* evk,
 template <class Arith>
 int launch_hoisted_ks(int log2n, u64* work, const u64* digits, const u64* keys, size_t key_stride, const unsigned* elts, size_t count,
                       size_t n_items, const DevTables<Arith>& tb, hipStream_t s) {
+    if (count > (size_t)kMaxGaloisBatch) return -1;   // the elements travel as kernel arguments: callers chunk by kMaxGaloisBatch
     GaloisElts ge{};
-    for (size_t i = 0; i < count && i < (size_t)kMaxGaloisBatch; ++i) ge.v[i] = elts[i];
+    for (size_t i = 0; i < count; ++i) ge.v[i] = elts[i];
     // few workgroups (one token): one per (rotation, limb, key component), half the serial chain each; many (several tokens, Ld <= 7 so
     // that the lazy sums fit): one per (rotation, limb) doing both components - the digit words are gathered once and the two inverse
     // transforms share their twiddles (kernels.h hoisted_ks2_kernel)
@@ -236,8 +229,9 @@ int launch_hoisted_ks(int log2n, u64* work, const u64* digits, const u64* keys, 
 template <class Arith>
 int launch_hoisted_qp(int log2n, u64* out, const u64* digits, const u64* xntt, const u64* keys, size_t key_stride, const unsigned* elts, size_t count,
                       size_t n_items, u64 p_special, const DevTables<Arith>& tb, hipStream_t s) {
+    if (count > (size_t)kMaxGaloisBatch) return -1;
     GaloisElts ge{};
-    for (size_t i = 0; i < count && i < (size_t)kMaxGaloisBatch; ++i) ge.v[i] = elts[i];
+    for (size_t i = 0; i < count; ++i) ge.v[i] = elts[i];
     const unsigned tiles = (unsigned)(count * (size_t)tb.n_limbs);                  // (rotation, limb)
     const unsigned blocks = ((tiles + 7u) / 8u) * 8u * (unsigned)n_items;           // x token, ids laid out per XCD (kernels.h)
 #define HQ_CASE(LN, LE)                                                                                                                                  \
@@ -250,9 +244,9 @@ int launch_hoisted_qp(int log2n, u64* out, const u64* digits, const u64* xntt, c
 
 template <class Arith>
 int launch_ntt_inv_galois(int log2n, u64* out, const u64* in, const unsigned* elts, size_t n_elts, size_t polys_per_elt, const DevTables<Arith>& tb, hipStream_t s) {
-    if (tb.n_sub != 1) return -1;   // split transforms (N > 16384) have no gather form
+    if (tb.n_sub != 1 || n_elts > (size_t)kMaxGaloisBatch) return -1;   // split transforms (N > 16384) have no gather form; callers chunk by kMaxGaloisBatch
     GaloisElts ge{};
-    for (size_t i = 0; i < n_elts && i < (size_t)kMaxGaloisBatch; ++i) ge.v[i] = elts[i];
+    for (size_t i = 0; i < n_elts; ++i) ge.v[i] = elts[i];
     const unsigned grid = (unsigned)(n_elts * polys_per_elt);
 #define NG_CASE(LN, LE) \
     hipLaunchKernelGGL((ntt_inv_galois_kernel<Arith, LN, LE>), dim3(grid), dim3(Geo<LN, LE>::T), 0, s, out, in, ge, (unsigned)polys_per_elt, tb)

@@ -201,6 +201,18 @@ struct FoldArith {
         const u64 R = mad32((u32)(H >> 32), 4 * (u32)c.d, L);
         return reduce(R, c);
     }
+    // x N^-1 mod q for N = 2^n by EXACT DIVISION instead of a twiddle product (round 4; 6 instructions against mul_tw's 9):
+    // q = 1 (mod 2N), so with m = x mod N the number x - m q is divisible by N, and
+    //     (x - m q) / N = (x + m d) / N - m 2^(60-n);      adding q keeps it positive:   y = ((x + m d) >> n) + (q - (m << (60 - n))).
+    // (m << (60 - n)) has no bits below 2^32 for n <= 28, so the subtraction is one 32-bit op on the high word.
+    // Precondition: x + m d < 2^64 (any x < 2^64 - 2^(n+24)); result < q + 2^(64-n), to be canonicalised by canon_small.
+    static DPF_HD u64 mul_ninv(u64 x, const LimbConst& c, int n) {
+        const u32 m = (u32)x & ((1u << n) - 1u);
+        DPFHE_EMU_ASSERT((unsigned __int128)x + (unsigned __int128)m * c.d < ((unsigned __int128)1 << 64));
+        const u64 t = mad32(m, (u32)c.d, x);
+        const u32 vhi = (u32)(c.q >> 32) - (m << (28 - n));
+        return (t >> n) + (((u64)vhi << 32) | (u32)c.q);
+    }
     // r < 2^60 + 2^59  ->  r mod q in [0, q), without compare/select: r >= q  <=>  r + d >= 2^60, and then
     // r - q = (r + d) - 2^60.  4 instructions (add, shift, multiply-add, and) against 5 for csub.
     static DPF_HD u64 canon_small(u64 r, const LimbConst& c) {

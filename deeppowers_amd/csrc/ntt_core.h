@@ -196,7 +196,9 @@ constexpr GsPlan<LOGE> make_gs_plan(int lb0, int r, int in_bound, int out_bound,
             if (k & bit) continue;
             int bx = bnd[k], by = bnd[k | bit];
             int offq = (by + kUnit - 1) / kUnit;
-            if (bx + by > kWord || bx + offq * kUnit > kWord) {
+            // (last inverse stage, FoldArith::mul_ninv: the sum x' = a + b is divided by N exactly and needs a little headroom below 2^64)
+            const int sum_cap = (last_all_mul && u == r - 1) ? kWord - kUnit / 8 : kWord;
+            if (bx + by > sum_cap || bx + offq * kUnit > kWord) {
                 if (bx > kRedB) { p.red[u][k] = true; bx = kRedB; }
                 if (by > kRedB) { p.red[u][k | bit] = true; by = kRedB; }
                 offq = (by + kUnit - 1) / kUnit;
@@ -673,7 +675,8 @@ struct NttBody {
                     dlt = a - b + two_q;
                 }
                 if (last) {  // N^-1 folded into the last stage: x' = (a+b) N^-1, y' = (a-b) w N^-1
-                    x[k] = Arith::mul_tw(s, w_ninv, lc);
+                    if constexpr (Arith::kFold) x[k] = FoldArith::mul_ninv(s, lc, LOGN);   // exact division by N: 6 instructions instead of 9
+                    else x[k] = Arith::mul_tw(s, w_ninv, lc);
                     x[kk] = Arith::mul_tw(dlt, w_last, lc);
                 } else {
                     x[k] = s;

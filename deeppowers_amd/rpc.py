@@ -60,8 +60,10 @@ CHANNEL_OPTIONS = [("grpc.max_receive_message_length", -1), ("grpc.max_send_mess
 
 
 def message_limit(params: FheParams, max_batch: int) -> int:
-    """bytes of the largest legal message: `max_batch` three-component ciphertexts + the wire header + protobuf framing slack"""
-    return max_batch * 3 * params.n_limbs * params.n * 8 + 4096 + 8 * params.n_limbs
+    """bytes of the largest legal message: `max_batch` three-component ciphertexts or one set of relinearisation keys ([L][2][L][N] words,
+    RegisterKeys) - whichever is larger, so that a server with a small max_batch still accepts keys - + the wire header + protobuf framing slack"""
+    L, n = params.n_limbs, params.n
+    return max(max_batch * 3 * L * n * 8, 2 * L * L * n * 8) + 4096 + 8 * L
 
 
 def _build_messages():
@@ -185,6 +187,7 @@ class EncryptedInferenceServer:
             self.ev = Evaluator(ctx)
         # evaluation keys are MBs of device memory per session: least-recently-used sessions are dropped beyond `max_sessions`
         self.models, self.sessions, self.max_sessions = {}, collections.OrderedDict(), max_sessions
+        self._key_digests = {}   # session id -> sha256 of its registered key words (idempotent re-registration, rpc RegisterKeys)
         self.metrics = _Metrics()
         self._gpu_lock = threading.Lock()   # one evaluation at a time per context: requests queue here, kernels fill the chip anyway
         self._server, self._workers = None, max_workers
@@ -260,21 +263,36 @@ class EncryptedInferenceServer:
         except ValueError as ex:
             self.metrics.error(True)
             context.abort(grpc.StatusCode.INVALID_ARGUMENT, str(ex))
+        import hashlib
+        digest = hashlib.sha256(words.tobytes()).digest()
+        # The session id is the bearer token of its keys (clients draw 128 random bits, EncryptedClient): a second registration under an
+        # existing id - another tenant guessing or replaying it - must not replace the keys its owner's requests rely on.  Checked BEFORE
+        # the upload (a replay costs no GPU copy); re-sending the SAME keys (a client retrying after a deadline whose first call did land)
+        # is idempotent and answers ok.
+        with self._gpu_lock:
+            known = self._key_digests.get(request.session_id) if request.session_id in self.sessions else None
+        if known is not None:
+            if known == digest:
+                return pb["RegisterKeysResponse"](ok=True)
+            self.metrics.error(True)
+            context.abort(grpc.StatusCode.ALREADY_EXISTS, "session already holds other keys: register under a fresh session id")
         if self.ctx is None:
             keys = words
         else:
             from .evaluator import to_device
             keys = to_device(words, self.ctx.device)
         with self._gpu_lock:
-            # The session id is the bearer token of its keys (clients draw 128 random bits, EncryptedClient): a second registration
-            # under an existing id - another tenant guessing or replaying it - must not replace the keys its owner's requests rely on.
-            if request.session_id in self.sessions:
+            if request.session_id in self.sessions:   # lost a race against a concurrent registration of the same id
+                if self._key_digests.get(request.session_id) == digest:
+                    return pb["RegisterKeysResponse"](ok=True)
                 self.metrics.error(True)
-                context.abort(grpc.StatusCode.ALREADY_EXISTS, "session already holds keys: register under a fresh session id")
+                context.abort(grpc.StatusCode.ALREADY_EXISTS, "session already holds other keys: register under a fresh session id")
             self.sessions[request.session_id] = keys
+            self._key_digests[request.session_id] = digest
             self.sessions.move_to_end(request.session_id)
             while len(self.sessions) > self.max_sessions:
-                self.sessions.popitem(last=False)
+                old_id, _ = self.sessions.popitem(last=False)
+                self._key_digests.pop(old_id, None)
         return pb["RegisterKeysResponse"](ok=True)
 
     def _get_metrics(self, request, context):

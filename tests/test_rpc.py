@@ -89,9 +89,14 @@ def test_transport_echo_errors_and_metrics():
         server.max_sessions = 2
         for sid in ("s1", "s2", "s3"):
             c2 = rpc.EncryptedClient(f"127.0.0.1:{port}", p, session_id=sid)
-            assert c2.register_relin_keys(_canonical(rng, p, p.n_limbs, 2))
+            k3 = _canonical(rng, p, p.n_limbs, 2)
+            assert c2.register_relin_keys(k3)
             c2.close()
-        assert list(server.sessions) == ["s2", "s3"]
+        assert list(server.sessions) == ["s2", "s3"] and set(server._key_digests) == {"s2", "s3"}
+        # a retry with the SAME keys (a deadline whose first call did land) is idempotent: ok, no new upload, no error counted
+        owner = rpc.EncryptedClient(f"127.0.0.1:{port}", p, session_id="s3")
+        assert owner.register_relin_keys(k3)
+        owner.close()
         # a session id is the bearer token of its keys: nobody can replace the keys registered under an existing id
         thief = rpc.EncryptedClient(f"127.0.0.1:{port}", p, session_id="s3")
         with pytest.raises(grpc.RpcError) as e:
@@ -100,6 +105,7 @@ def test_transport_echo_errors_and_metrics():
         thief.close()
         # message sizes are bounded by the parameters and the server's maximum batch
         assert rpc.message_limit(p, server.max_batch) < 2**31 and rpc.message_limit(p, 1) > 3 * p.n_limbs * p.n * 8
+        assert rpc.message_limit(p, 1) > 2 * p.n_limbs * p.n_limbs * p.n * 8      # a small max_batch still admits one set of relinearisation keys
         m = client.metrics()
         assert m.total_requests == 7 and m.errors.total_errors == 6 and m.errors.internal_errors == 1 and m.errors.invalid_argument_errors == 5
         assert m.latency.p50_ms > 0 and m.throughput.ciphertexts_per_second > 0

@@ -193,7 +193,9 @@ static int emu_split(int inverse, u64 q, u64 psi, const u64* in, u64* out) {
     const size_t n = (size_t)1 << LOGN;
     std::vector<Tw> top_f(N1), top_i(N1);
     for (int i = 1; i < N1; ++i) { top_f[i] = h_make_tw<Tw>(t.rp[i], q); top_i[i] = h_make_tw<Tw>(t.irp[i], q); }
-    const InvLast<Tw> top_last{h_make_tw<Tw>(t.w_last, q), h_make_tw<Tw>(t.lc.ninv, q)};
+    // (dpfhe_cabi.hip: FoldArith sub-transforms divide by their own length in their last stage, so the column stage carries N1^-1 only)
+    const u64 up = Arith::kFold ? ((u64)N2 % q) : 1;
+    const InvLast<Tw> top_last{h_make_tw<Tw>(h_mulmod(t.w_last, up, q), q), h_make_tw<Tw>(h_mulmod(t.lc.ninv, up, q), q)};
     std::vector<u64> buf(in, in + n), lds(B::G::lds_words());
     auto columns = [&](bool fwd) {
         for (size_t c = 0; c < (size_t)N2; ++c) {
@@ -216,7 +218,9 @@ static int emu_split(int inverse, u64 q, u64 psi, const u64* in, u64* out) {
                 FwdSteps<B, 0>::run(regs, lds, tw.data(), t.lc);
                 for (int tid = 0; tid < T; ++tid) { B::fwd_canon(X(tid), t.lc); B::store_bot(tid, X(tid), res.data()); }
             } else {
-                const Tw wl = h_make_tw<Tw>(words[1], q), wn = h_make_tw<Tw>(1, q);   // no N^-1 inside a block
+                // generic primes: no N^-1 inside a block; FoldArith: sums are divided by N2 exactly, differences carry N2^-1 in their twiddle (dpfhe_cabi.hip)
+                const u64 n2inv = Arith::kFold ? h_powmod((u64)N2 % q, q - 2, q) : 1;
+                const Tw wl = h_make_tw<Tw>(h_mulmod(words[1], n2inv, q), q), wn = h_make_tw<Tw>(1, q);
                 for (int tid = 0; tid < T; ++tid) B::load_bot(tid, X(tid), blk.data());
                 InvSteps<B, B::NPH - 1, kUnit>::run(regs, lds, tw.data(), wl, wn, t.lc);
                 for (int tid = 0; tid < T; ++tid) { B::inv_canon(X(tid), t.lc); B::store_top(tid, X(tid), res.data()); }
