@@ -98,7 +98,7 @@ struct dpfhe_ctx {
 // `reps` back-to-back launches per form over `pairs` synthetic ciphertext pairs, two passes in opposite orders, best pass per form;
 // a non-default form is taken only when it is at least 3 % faster than the default.
 // ------------------------------------------------------------------------------------------------
-static const char* const kCtMulVariantNames[kCtMulVariants] = {"quad", "dual", "single"};
+static const char* const kCtMulVariantNames[kCtMulVariants] = {"quad", "dual", "single", "quadpf"};
 static const float kTuneMargin = 0.97f;
 
 __global__ __launch_bounds__(256) void tune_fill_kernel(u64* __restrict__ p, size_t n) {

@@ -566,9 +566,26 @@ __device__ __forceinline__ u64 trace_stamp(u64 dep) {
     if constexpr (TRACE) asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) : "v"(dep) : "memory");
     return t;
 }
-template <class Arith, int LOGN, int LOGE, bool TRACE = false>
+// PF (the "quadpf" form): every workgroup also REQUESTS the four operand polynomials of the workgroup `pf_dist` ids ahead (same
+// limb, same XCD: pf_dist is a multiple of 8 and of L) with loads whose results are thrown away - they land in that XCD's L2 about when
+// the later workgroup starts, so its first operand word comes from L2 instead of HBM.  The workgroup timeline (tools/ctmul_trace.py)
+// shows ~11 % of a workgroup's life spent waiting for that word, with two waves per SIMD to cover it.  No extra HBM traffic when the
+// prefetch hits its window; the untracked loads only make the compiler's own vmcnt waits conservative (returns are in order).
+typedef unsigned v4u32 __attribute__((ext_vector_type(4)));
+template <int N_WORDS, int T>
+__device__ __forceinline__ void prefetch_poly_l2(const u64* g, int tid) {
+    constexpr int kLoads = N_WORDS * 8 / (T * 16);     // 16 bytes per lane per load
+#pragma unroll
+    for (int r = 0; r < kLoads; ++r) {
+        v4u32 sink;
+        const u64* base = g + (size_t)r * T * 2;       // workgroup-uniform: an SGPR pair, the lane offset stays one 32-bit register
+        asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(sink) : "v"((unsigned)tid * 16u), "s"(base) : "memory");
+    }
+}
+template <class Arith, int LOGN, int LOGE, bool TRACE = false, bool PF = false>
 __global__ __launch_bounds__(1 << (LOGN - LOGE), 2) void ct_mul_quad_kernel(u64* __restrict__ out3, const u64* __restrict__ a2,
-                                                                         const u64* __restrict__ b2, DevTables<Arith> tb, u64* __restrict__ trace = nullptr) {
+                                                                         const u64* __restrict__ b2, DevTables<Arith> tb, u64* __restrict__ trace = nullptr,
+                                                                         unsigned pf_dist = 0) {
     typedef NttBody<Arith, LOGN, LOGE> B;
     static_assert(Arith::kFold && LOGE == kFusedLoge, "FoldArith, fused twiddle layout");
     constexpr int E = B::E, N = B::G::N, W = B::G::lds_words();
@@ -590,6 +607,16 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE), 2) void ct_mul_quad_kernel(u64*
     B::template load_top<true>(tid, y, src_b);
     B::template load_top<true>(tid, z, src_a + cstride);
     B::template load_top<true>(tid, w, src_b + cstride);
+    if constexpr (PF) {
+        const size_t ahead = (size_t)blockIdx.x + pf_dist;
+        if (ahead < gridDim.x) {    // (pf_dist % L == 0: the same limb, pf_dist / L pairs further)
+            const size_t off = (size_t)(pf_dist / (unsigned)L) * 2 * cstride;
+            prefetch_poly_l2<N, B::G::T>(src_a + off, tid);
+            prefetch_poly_l2<N, B::G::T>(src_b + off, tid);
+            prefetch_poly_l2<N, B::G::T>(src_a + off + cstride, tid);
+            prefetch_poly_l2<N, B::G::T>(src_b + off + cstride, tid);
+        }
+    }
     const u64 ts1 = trace_stamp<TRACE>(x[0]);
     FwdChain4<B, 0>::run(tid, x, y, z, w, lds, lds + W, tb.fwd4 + (size_t)limb * N, lc);
     B::fwd_reduce_partner(y, lc);     // of every product below exactly one factor is reduced: b0, b1

@@ -68,7 +68,7 @@ def test_null_context_and_destroy_are_safe(lib):
     assert lib.dpfhe_comm_destroy(None) == 0
     assert lib.dpfhe_ctx_log2n(None) == 0 and lib.dpfhe_ctx_uses_fold(None) == 0
     # the variant machinery of the fused multiply: names are fixed, null contexts are refused
-    assert [lib.dpfhe_ct_mul_variant_name(v) for v in range(-1, 5)] == [b"", b"quad", b"dual", b"single", b"", b""]
+    assert [lib.dpfhe_ct_mul_variant_name(v) for v in range(-1, 5)] == [b"", b"quad", b"dual", b"single", b"quadpf", b""]
     t = _cabi.TuneInfo()
     assert lib.dpfhe_ctx_tune_info(None, C.byref(t)) == 2000 and lib.dpfhe_ctx_set_ct_mul_variant(None, 0) == 2000
     assert lib.dpfhe_ctx_autotune(None, None, 0, 3, None) == 2000
