@@ -718,6 +718,12 @@ def main():
             run = subprocess.run([example("encrypted_gpt2_block"), "8", "2", "json"], capture_output=True, text=True, timeout=600)
             got = [json.loads(l) for l in run.stdout.splitlines() if l.startswith("{")]
             other["packed_linear"]["transformer_block"] = got[0] if got and run.returncode == 0 else {"error": (run.stdout + run.stderr)[-300:]}
+            # the FFN block WITH its non-linearity: x + W_down (W_up x)^2, W_up on five limbs, modulus switch to two, the activation as an exact
+            # ciphertext x ciphertext multiply (the metric op inside the end-to-end example) + relinearisation, W_down on two limbs
+            # (examples/encrypted_gpt2_ffn_act.cpp; gpt_model.cpp:842-859 with the square standing in for GELU)
+            run = subprocess.run([example("encrypted_gpt2_ffn_act"), "8", "2", "json"], capture_output=True, text=True, timeout=600)
+            got = [json.loads(l) for l in run.stdout.splitlines() if l.startswith("{")]
+            other["packed_linear"]["activated_ffn"] = got[0] if got and run.returncode == 0 else {"error": (run.stdout + run.stderr)[-300:]}
         except Exception as e:   # a missing example binary must not take the headline metric down with it
             other.setdefault("packed_linear", {})["error"] = repr(e)[:300]
         return other

@@ -41,6 +41,8 @@ SYMBOLS = {
     "dpfhe_ntt_inv_galois": ([C.c_void_p, _U64P, _U64P, C.c_size_t, C.POINTER(C.c_uint32), C.c_size_t, C.c_void_p], C.c_int),
     "dpfhe_switch_key_qp": ([C.c_void_p, _U64P, _U64P, _U64P, C.c_size_t, C.c_size_t, C.c_void_p], C.c_int),
     "dpfhe_rescale_bsgs": ([C.c_void_p, _U64P, _U64P, _U64P, C.c_size_t, C.c_size_t, C.c_void_p], C.c_int),
+    "dpfhe_base_extend": ([C.c_void_p, _U64P, C.c_size_t, _U64P, C.c_size_t, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_size_t, C.c_void_p], C.c_int),
+    "dpfhe_scale_round": ([C.c_void_p, _U64P, C.c_size_t, _U64P, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, C.c_size_t, C.c_void_p], C.c_int),
     "dpfhe_matvec_plain_multi": ([C.c_void_p, _U64P, _U64P, _U64P, C.c_size_t, C.c_size_t, C.c_size_t, C.c_void_p], C.c_int),
     "dpfhe_rescale": ([C.c_void_p, _U64P, _U64P, C.c_size_t, C.c_void_p], C.c_int),
     "dpfhe_apply_galois": ([C.c_void_p, _U64P, _U64P, C.c_size_t, C.c_uint32, C.c_void_p], C.c_int),

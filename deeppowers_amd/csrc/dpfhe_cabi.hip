@@ -75,6 +75,7 @@ struct dpfhe_ctx {
     int device = 0;
     bool fold = false;
     int n_cu = 256;          // compute units of the device (launch-size caps of the streaming kernels)
+    std::vector<uint64_t> moduli;   // host copy (constants of dpfhe_base_extend / dpfhe_scale_round)
     uint64_t p_special = 0;  // the LAST modulus (the special prime of hybrid key switching when this is an extended context)
     void* d_blob = nullptr;  // one allocation: LimbConst[L] | fwd | inv | last | RescaleConst[L]  (both arithmetic layouts share it)
     const RescaleConst* d_rescale = nullptr;
@@ -244,6 +245,7 @@ extern "C" int dpfhe_ctx_create(dpfhe_ctx** out, uint32_t log2_n, uint32_t n_lim
     dpfhe_ctx* c = new (std::nothrow) dpfhe_ctx;
     if (!c) return fail(DPFHE_OUT_OF_MEMORY, "dpfhe_ctx_create", "host allocation");
     c->log2n = log2_n; c->n_limbs = n_limbs; c->device = device_id; c->fold = fold; c->p_special = moduli[L - 1];
+    c->moduli.assign(moduli, moduli + L);
     { int cus = 0; if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device_id) == hipSuccess && cus > 0) c->n_cu = cus; }
 
     // blob layout (all 256-byte aligned sections).  One twiddle table pair per kernel geometry in use: slot 0 = the
@@ -926,12 +928,14 @@ extern "C" int dpfhe_rotate_hoisted_qp(dpfhe_ctx* c, uint64_t* d_out_qp, const u
         } else {
             QpElts ge{};
             for (size_t i = 0; i < cnt; ++i) ge.v[i] = galois_elts[first + i];
-            const size_t grid = qp_stream_grid((int)c->log2n, (int)L, cnt, T);
+            static const int pp = [] { const char* e = std::getenv("DPFHE_QP_PAIRS"); const int v = e ? std::atoi(e) : 0; return (v == 1 || v == 4) ? v : kQpPairs; }();   // A/B only
+            const size_t grid = qp_stream_grid((int)c->log2n, (int)L, cnt, T, pp);
             if (grid > kMaxGrid) return fail(DPFHE_INVALID_ARGUMENT, what, "batch too large for one launch");
-            if (c->fold) hipLaunchKernelGGL((hoisted_qp_stream_kernel<FoldArith, kQpPairs>), dim3((unsigned)grid), dim3(256), 0, s, dst, d_digits, d_in_ntt, d_keys + first * key_words, key_words, ge,
-                                            (unsigned)cnt, (unsigned)T, p_special, lc, (int)L, (int)c->log2n);
-            else hipLaunchKernelGGL((hoisted_qp_stream_kernel<ShoupArith, kQpPairs>), dim3((unsigned)grid), dim3(256), 0, s, dst, d_digits, d_in_ntt, d_keys + first * key_words, key_words, ge,
-                                    (unsigned)cnt, (unsigned)T, p_special, lc, (int)L, (int)c->log2n);
+#define QP_LAUNCH(ARITH, PP) hipLaunchKernelGGL((hoisted_qp_stream_kernel<ARITH, PP>), dim3((unsigned)grid), dim3(256), 0, s, dst, d_digits, d_in_ntt, d_keys + first * key_words, key_words, ge, \
+                                               (unsigned)cnt, (unsigned)T, p_special, lc, (int)L, (int)c->log2n)
+            if (c->fold) { if (pp == 1) QP_LAUNCH(FoldArith, 1); else if (pp == 4) QP_LAUNCH(FoldArith, 4); else QP_LAUNCH(FoldArith, kQpPairs); }
+            else QP_LAUNCH(ShoupArith, kQpPairs);
+#undef QP_LAUNCH
         }
         if (int e = check_launch("hoisted_qp kernel launch")) return e;
     }
@@ -1170,6 +1174,81 @@ extern "C" int dpfhe_reduce_sum(dpfhe_ctx* c, uint64_t* d_out, const uint64_t* d
     if (int e = check_launch("reduce_sum partial kernel launch")) return e;
     hipLaunchKernelGGL(reduce_final_kernel, dim3((unsigned)(blocks * chunks)), dim3(256), 0, s, d_out, lc, (int)c->n_limbs, n, chunks);
     return check_launch("reduce_sum kernel launch");
+}
+
+// ------------------------------------------------------------------------------------------------
+// exact base extension / scale-and-round between limb ranges of one context (kernels_misc.h base_extend_kernel)
+static int base_extend_common(dpfhe_ctx* c, int mode, uint64_t* d_out, size_t out_stride_limbs, const uint64_t* d_in, size_t in_stride_limbs, uint32_t src0, uint32_t ns,
+                              uint32_t dst0, uint32_t nd, uint64_t multiplier, size_t n_polys, void* stream, const char* what) {
+    if (!c) return fail(DPFHE_INVALID_ARGUMENT, what, "null context");
+    if (n_polys == 0) return DPFHE_SUCCESS;
+    const uint32_t L = c->n_limbs;
+    if (ns == 0 || ns > (uint32_t)kBxMaxSrc || nd == 0 || nd > (uint32_t)kBxMaxDst || src0 + ns > L || dst0 + nd > L)
+        return fail(DPFHE_INVALID_ARGUMENT, what, "1..4 source limbs and 1..8 destination limbs inside the context");
+    if (mode == 1 && !(dst0 >= src0 + ns || dst0 + nd <= src0)) return fail(DPFHE_INVALID_ARGUMENT, what, "the dropped limbs and the kept limbs must be disjoint");
+    if (!d_out || !d_in || misaligned(d_out) || misaligned(d_in) || out_stride_limbs < nd || in_stride_limbs < ns) return fail(DPFHE_INVALID_ARGUMENT, what, "null or misaligned buffer, or an item stride shorter than its limbs");
+    const size_t n = (size_t)1 << c->log2n;
+    const int chunks = (int)((n + 511) / 512);
+    if (n_polys * (size_t)chunks > kMaxGrid) return fail(DPFHE_INVALID_ARGUMENT, what, "batch too large for one launch");
+    if (overlaps(d_out, ((n_polys - 1) * out_stride_limbs + nd) * n, d_in, ((n_polys - 1) * in_stride_limbs + (mode == 1 ? (size_t)L : ns)) * n))
+        return fail(DPFHE_INVALID_ARGUMENT, what, "output overlaps the input");
+    // host constants (a handful of modular inverses; moduli read back from the context's limb constants would need a copy - they are kept on the host)
+    const std::vector<uint64_t>& q = c->moduli;
+    BaseExtArgs a{};
+    a.n_src = (int)ns; a.n_dst = (int)nd;
+    for (uint32_t i = 0; i < ns; ++i) a.src_limb[i] = (int)(src0 + i);
+    for (uint32_t j = 0; j < nd; ++j) a.dst_limb[j] = (int)(dst0 + j);
+    for (uint32_t i = 0; i < ns; ++i)
+        for (uint32_t k = i + 1; k < ns; ++k) {
+            if (q[src0 + i] == q[src0 + k]) return fail(DPFHE_INVALID_ARGUMENT, what, "source limbs must be distinct primes");
+            a.inv[i][k] = h_powmod(q[src0 + i] % q[src0 + k], q[src0 + k] - 2, q[src0 + k]);
+        }
+    {   // mixed-radix digits of floor(Qs / 2): (Qs - 1) / 2 since Qs is odd; digit k of Qs - 1 is q_k - 1, halve with borrow from the top
+        unsigned __int128 carry = 0;   // remainder (0 or 1) carried down, in units of the current radix
+        for (int k = (int)ns - 1; k >= 0; --k) {
+            const unsigned __int128 cur = carry * q[src0 + k] + (q[src0 + k] - 1);
+            a.half[k] = (uint64_t)(cur / 2);
+            carry = cur & 1;
+        }
+    }
+    for (uint32_t j = 0; j < nd; ++j) {
+        const uint64_t pj = q[dst0 + j];
+        uint64_t Qm = 1;
+        for (uint32_t i = 0; i < ns; ++i) { a.q_mod[i][j] = q[src0 + i] % pj; Qm = h_mulmod(Qm, a.q_mod[i][j], pj); }
+        a.Q_mod[j] = Qm;
+        if (mode == 1) {
+            if (Qm == 0) return fail(DPFHE_INVALID_ARGUMENT, what, "a kept limb divides the dropped modulus");
+            a.Q_inv[j] = h_powmod(Qm, pj - 2, pj);
+            a.mul_dst[j] = multiplier % pj;
+        }
+    }
+    for (uint32_t i = 0; i < ns; ++i) a.mul_src[i] = multiplier % q[src0 + i];
+    DPFHE_ON_DEVICE(c, what);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const unsigned grid = (unsigned)(n_polys * (size_t)chunks);
+    const size_t in_dst_off = mode == 1 ? ((size_t)dst0 - (size_t)src0) * n : 0;   // d_in points at the first DROPPED limb of item 0 (may wrap below it: size_t arithmetic, same pointer sum)
+    const LimbConst* lc = c->fold ? c->foldt.lc : c->shoup.lc;
+    if (c->fold) {
+        if (mode == 0) hipLaunchKernelGGL((base_extend_kernel<FoldArith, 0>), dim3(grid), dim3(256), 0, s, d_out, out_stride_limbs * n, d_in, in_stride_limbs * n, in_dst_off, a, lc, (int)n, chunks);
+        else hipLaunchKernelGGL((base_extend_kernel<FoldArith, 1>), dim3(grid), dim3(256), 0, s, d_out, out_stride_limbs * n, d_in, in_stride_limbs * n, in_dst_off, a, lc, (int)n, chunks);
+    } else {
+        if (mode == 0) hipLaunchKernelGGL((base_extend_kernel<ShoupArith, 0>), dim3(grid), dim3(256), 0, s, d_out, out_stride_limbs * n, d_in, in_stride_limbs * n, in_dst_off, a, lc, (int)n, chunks);
+        else hipLaunchKernelGGL((base_extend_kernel<ShoupArith, 1>), dim3(grid), dim3(256), 0, s, d_out, out_stride_limbs * n, d_in, in_stride_limbs * n, in_dst_off, a, lc, (int)n, chunks);
+    }
+    return check_launch("base_extend kernel launch");
+}
+extern "C" int dpfhe_base_extend(dpfhe_ctx* c, uint64_t* d_out, size_t out_stride_limbs, const uint64_t* d_in, size_t in_stride_limbs, uint32_t src_limb0, uint32_t n_src,
+                                 uint32_t dst_limb0, uint32_t n_dst, size_t n_polys, void* stream) {
+    return base_extend_common(c, 0, d_out, out_stride_limbs, d_in, in_stride_limbs, src_limb0, n_src, dst_limb0, n_dst, 1, n_polys, stream, "dpfhe_base_extend");
+}
+extern "C" int dpfhe_scale_round(dpfhe_ctx* c, uint64_t* d_out, size_t out_stride_limbs, const uint64_t* d_in, uint32_t drop_limb0, uint32_t n_drop, uint32_t keep_limb0,
+                                 uint32_t n_keep, uint64_t multiplier, size_t n_polys, void* stream) {
+    if (!c) return fail(DPFHE_INVALID_ARGUMENT, "dpfhe_scale_round", "null context");
+    if (multiplier == 0) return fail(DPFHE_INVALID_ARGUMENT, "dpfhe_scale_round", "multiplier must be > 0");
+    // d_in: [n_polys][L][N], ALL limbs of the context; the kernel reads the dropped limbs at drop_limb0 and the kept ones at keep_limb0
+    const size_t n = (size_t)1 << c->log2n;
+    return base_extend_common(c, 1, d_out, out_stride_limbs, d_in ? d_in + (size_t)drop_limb0 * n : nullptr, c->n_limbs, drop_limb0, n_drop, keep_limb0, n_keep, multiplier, n_polys, stream,
+                              "dpfhe_scale_round");
 }
 
 extern "C" int dpfhe_copy(dpfhe_ctx* c, uint64_t* d_dst, const uint64_t* d_src, size_t n_words, void* stream) {

@@ -10,6 +10,7 @@
 #include <cstdio>
 #include <algorithm>
 #include <cstdlib>
+#include <cmath>
 #include <cstring>
 #include <istream>
 #include <ostream>
@@ -308,6 +309,57 @@ void Evaluator::rescale(const Ciphertext& in, Ciphertext& out, Stream* s) const 
     check(dpfhe_rescale(impl_->h(), out.data(), in.data(), in.batch() * in.size(), s), "dpfhe_rescale");
     out.set_ntt(false);
 }
+// ---- ExactMultiplier ------------------------------------------------------------------------------------------------------------
+class ExactMultiplier::Impl {
+public:
+    const Context* work = nullptr;
+    const Context* level = nullptr;
+    uint64_t t = 0;
+    size_t ll = 0, L = 0, n = 0;
+    std::unique_ptr<Ciphertext> A, B, T;     // operands and tensor product on all work limbs
+    std::unique_ptr<PolyBuffer> W;           // scaled product on the workspace limbs: [batch * 3][L - ll][N], kept as a 1-component buffer on `work`-sized storage
+    size_t cap = 0;
+    void ensure(size_t batch) {
+        if (batch <= cap) return;
+        A.reset(new Ciphertext(*work, 2, batch));
+        B.reset(new Ciphertext(*work, 2, batch));
+        T.reset(new Ciphertext(*work, 3, batch));
+        W.reset(new PolyBuffer(*work, batch, 3, false));   // 3 L N words per item: room for 3 (L - ll) N
+        cap = batch;
+    }
+};
+ExactMultiplier::ExactMultiplier(const Context& work_ctx, const Context& level_ctx, uint64_t plain_modulus) : impl_(new Impl) {
+    const FheParams &pw = work_ctx.params(), &pl = level_ctx.params();
+    impl_->work = &work_ctx; impl_->level = &level_ctx; impl_->t = plain_modulus;
+    impl_->ll = pl.n_limbs(); impl_->L = pw.n_limbs(); impl_->n = pw.n();
+    if (pl.log2_n != pw.log2_n || impl_->ll == 0 || impl_->ll >= impl_->L || impl_->ll > 4 || work_ctx.device_id() != level_ctx.device_id() || plain_modulus < 2)
+        throw Exception(ErrorCode::INVALID_ARGUMENT, "ExactMultiplier: the level context must hold the first 1..4 limbs of the work context (same ring degree and device)");
+    for (size_t i = 0; i < impl_->ll; ++i)
+        if (pl.moduli[i] != pw.moduli[i]) throw Exception(ErrorCode::INVALID_ARGUMENT, "ExactMultiplier: the level's moduli must be the first moduli of the work context");
+    double lq = 0, lQ = 0, lW = 0;
+    for (size_t i = 0; i < impl_->L; ++i) { const double b = std::log2((double)pw.moduli[i]); lQ += b; if (i < impl_->ll) lq += b; else lW += b; }
+    const double lnt = (double)pw.log2_n + std::log2((double)plain_modulus);
+    if (lQ - 1 <= lnt + 2 * lq + 1 || lW - 1 <= lnt + lq + 2)
+        throw Exception(ErrorCode::INVALID_STATE, "ExactMultiplier: the work context is too small for the integer tensor product of this level (needs Q > 2 N t q^2)");
+}
+ExactMultiplier::~ExactMultiplier() = default;
+void ExactMultiplier::multiply(const Ciphertext& a, const Ciphertext& b, Ciphertext& out3, Stream* s) {
+    Impl& I = *impl_;
+    const size_t batch = a.batch(), lvl_words = I.ll * I.n;
+    if (a.is_ntt() || b.is_ntt()) throw Exception(ErrorCode::INVALID_STATE, "ExactMultiplier::multiply: operands must be in the coefficient domain");
+    if (a.size() != 2 || b.size() != 2 || out3.size() != 3 || b.batch() != batch || out3.batch() != batch || a.words() != batch * 2 * lvl_words || out3.words() != batch * 3 * lvl_words)
+        throw Exception(ErrorCode::INVALID_ARGUMENT, "ExactMultiplier::multiply: 2-component operands and a 3-component output of one batch on the level context");
+    I.ensure(batch);
+    dpfhe_ctx* h = static_cast<dpfhe_ctx*>(I.work->handle());
+    const bool square = a.data() == b.data();
+    check(dpfhe_base_extend(h, I.A->data(), I.L, a.data(), I.ll, 0, (uint32_t)I.ll, 0, (uint32_t)I.L, batch * 2, s), "dpfhe_base_extend");
+    if (!square) check(dpfhe_base_extend(h, I.B->data(), I.L, b.data(), I.ll, 0, (uint32_t)I.ll, 0, (uint32_t)I.L, batch * 2, s), "dpfhe_base_extend");
+    check(dpfhe_ct_mul(h, I.T->data(), I.A->data(), square ? I.A->data() : I.B->data(), batch, 0, s), "dpfhe_ct_mul");
+    check(dpfhe_scale_round(h, I.W->data(), I.L - I.ll, I.T->data(), 0, (uint32_t)I.ll, (uint32_t)I.ll, (uint32_t)(I.L - I.ll), I.t, batch * 3, s), "dpfhe_scale_round");
+    check(dpfhe_base_extend(h, out3.data(), I.ll, I.W->data(), I.L - I.ll, (uint32_t)I.ll, (uint32_t)(I.L - I.ll), 0, (uint32_t)I.ll, batch * 3, s), "dpfhe_base_extend");
+    out3.set_ntt(false);
+}
+
 void Evaluator::apply_galois(const Ciphertext& in2, const GaloisKeys& keys, Ciphertext& out2, Stream* s) const {
     if (in2.is_ntt()) throw Exception(ErrorCode::INVALID_STATE, "apply_galois: input must be in the coefficient domain");
     if (in2.size() != 2 || out2.size() != 2 || out2.batch() != in2.batch())

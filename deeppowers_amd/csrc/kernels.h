@@ -556,10 +556,12 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE), 2) void ct_mul_dual_kernel(u64*
 // All four forward transforms and all three inverse transforms of the workgroup share their twiddle fetches (FwdChain4 / InvChain3
 // on two LDS buffers): 2 x 64 KiB of per-thread twiddle reads per workgroup instead of 4 x 64 KiB in ct_mul_dual_kernel.
 // TRACE (diagnostics only, dpfhe_debug_ct_mul_trace): thread 0 of every workgroup stamps s_memrealtime (100 MHz) at the kernel's
-// milestones into trace[blockIdx.x * 8 ..]: 0 start, 1 first operand word arrived, 2 forward transforms done, 3 tensor product done,
-// 4 inverse transforms done, 5 stores issued, 6 stores drained, 7 = HW_ID | XCC_ID << 32 (where the workgroup ran).
+// milestones into trace[blockIdx.x * 12 ..]: 0 start, 1 first operand word arrived, 2 forward transforms done, 3 tensor product done,
+// 4 inverse transforms done, 5 stores issued, 6 stores drained, 7 = HW_ID | XCC_ID << 32 (where the workgroup ran), 8 prologue done,
+// 9 first operand's loads issued, 10 all loads issued, 11 whole first operand arrived.
 // The stamps stay in scalar registers until the end (the kernel has no vector register to spare); `dep` is a value the milestone must have
 // produced: as an input operand it orders the stamp after it (and makes the compiler wait for it, if it is a load).
+constexpr int kTraceWords = 12;
 template <bool TRACE>
 __device__ __forceinline__ u64 trace_stamp(u64 dep) {
     u64 t = 0;
@@ -603,10 +605,13 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE), 2) void ct_mul_quad_kernel(u64*
     const InvLast<typename B::Tw> last = tb.last[limb];
     constexpr int kInvIn = 2 * kMulB;
     u64 x[E], y[E], z[E], w[E];
+    const u64 ts_p = trace_stamp<TRACE>((u64)(uintptr_t)src_a ^ (u64)lc.q);   // prologue done: kernel arguments and limb constants are in registers
     B::template load_top<true>(tid, x, src_a);
+    const u64 ts_x = trace_stamp<TRACE>((u64)tid);                              // the first operand's 16 loads are issued
     B::template load_top<true>(tid, y, src_b);
     B::template load_top<true>(tid, z, src_a + cstride);
     B::template load_top<true>(tid, w, src_b + cstride);
+    const u64 ts_i = trace_stamp<TRACE>((u64)tid);                              // all 64 loads are issued
     if constexpr (PF) {
         const size_t ahead = (size_t)blockIdx.x + pf_dist;
         if (ahead < gridDim.x) {    // (pf_dist % L == 0: the same limb, pf_dist / L pairs further)
@@ -618,6 +623,7 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE), 2) void ct_mul_quad_kernel(u64*
         }
     }
     const u64 ts1 = trace_stamp<TRACE>(x[0]);
+    const u64 ts_xl = trace_stamp<TRACE>(x[E - 1]);                             // the whole first operand has arrived
     FwdChain4<B, 0>::run(tid, x, y, z, w, lds, lds + W, tb.fwd4 + (size_t)limb * N, lc);
     B::fwd_reduce_partner(y, lc);     // of every product below exactly one factor is reduced: b0, b1
     B::fwd_reduce_partner(w, lc);
@@ -649,9 +655,10 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE), 2) void ct_mul_quad_kernel(u64*
             unsigned hw, xcc;
             asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
             asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-            u64* t = trace + (size_t)blockIdx.x * 8;
+            u64* t = trace + (size_t)blockIdx.x * kTraceWords;
             t[0] = ts0; t[1] = ts1; t[2] = ts2; t[3] = ts3; t[4] = ts4; t[5] = ts5; t[6] = ts6;
             t[7] = (u64)hw | ((u64)xcc << 32);
+            t[8] = ts_p; t[9] = ts_x; t[10] = ts_i; t[11] = ts_xl;
         }
     }
 }

@@ -465,6 +465,51 @@ class Evaluator:
         _cabi.check(self._lib.dpfhe_rescale(self.ctx.handle, out.data_ptr(), t.data_ptr(), self._npolys(t), self._sp(stream)), "dpfhe_rescale")
         return out
 
+    # ---- round 4: exact base extension, scale-and-round, and the exact (BFV-style) multiply built on them ----------------------
+    def base_extend(self, t: torch.Tensor, src_limb0: int, dst_limb0: int, n_dst: int, stream=None) -> torch.Tensor:
+        """t: [..., n_src, N] residues modulo this context's limbs src_limb0 .. -> [..., n_dst, N] residues of the SAME centred integers
+        modulo limbs dst_limb0 ..  (exact; include/dpfhe.h dpfhe_base_extend)."""
+        p = self.ctx.params
+        if t.dtype != torch.int64 or not t.is_contiguous() or t.device != self.ctx.device or t.dim() < 2 or t.shape[-1] != p.n:
+            raise _cabi.DpfheError(2000, "base_extend: contiguous int64 [..., n_src, N] on the context's device")
+        ns = t.shape[-2]
+        out = self._empty(tuple(t.shape[:-2]) + (n_dst, p.n), stream)
+        npolys = t.numel() // (ns * p.n)
+        _cabi.check(self._lib.dpfhe_base_extend(self.ctx.handle, out.data_ptr(), n_dst, t.data_ptr(), ns, src_limb0, ns, dst_limb0, n_dst, npolys, self._sp(stream)), "dpfhe_base_extend")
+        return out
+
+    def scale_round(self, t: torch.Tensor, drop_limb0: int, n_drop: int, keep_limb0: int, n_keep: int, multiplier: int, stream=None) -> torch.Tensor:
+        """t: [..., L, N] on all limbs -> [..., n_keep, N]: round(multiplier * X / (product of the dropped limbs)) on the kept limbs."""
+        self._chk(t)
+        p = self.ctx.params
+        out = self._empty(tuple(t.shape[:-2]) + (n_keep, p.n), stream)
+        _cabi.check(self._lib.dpfhe_scale_round(self.ctx.handle, out.data_ptr(), n_keep, t.data_ptr(), drop_limb0, n_drop, keep_limb0, n_keep, multiplier, self._npolys(t),
+                                                self._sp(stream)), "dpfhe_scale_round")
+        return out
+
+    def multiply_exact(self, a: torch.Tensor, b: torch.Tensor, level_limbs: int, plain_modulus: int, stream=None) -> torch.Tensor:
+        """EXACT ciphertext x ciphertext multiply of BFV-style ciphertexts (scale floor(q / t), Encryptor::encrypt_exact) whose modulus q is the
+        product of this context's FIRST `level_limbs` limbs: a, b [batch][2][level_limbs][N] -> [batch][3][level_limbs][N], the tensor product
+        over the integers scaled by t / q and rounded, reduced mod q.  The context's remaining limbs are the workspace: it needs
+        Q > 2 N t q^2 (N = 8192, t = 65537, two 60-bit level limbs: five limbs).  Steps: dpfhe_base_extend (both operands to all limbs), the
+        fused dpfhe_ct_mul (THE METRIC OP) on all limbs, dpfhe_scale_round (x t / q on the workspace limbs), dpfhe_base_extend back."""
+        p = self.ctx.params
+        L, ll = p.n_limbs, level_limbs
+        if a.shape != b.shape or a.dim() != 4 or a.shape[1] != 2 or a.shape[2] != ll or not (0 < ll < L and ll <= 4):
+            raise _cabi.DpfheError(2000, "multiply_exact: [batch][2][level_limbs][N] operands, 0 < level_limbs <= min(4, L - 1)")
+        # workspace check (exactness): log2 Q - 1 > log2(N) + log2(t) + 2 log2(q) + 1
+        import math
+        lq = sum(math.log2(m) for m in p.moduli[:ll])
+        if sum(math.log2(m) for m in p.moduli) - 1 <= math.log2(p.n) + math.log2(plain_modulus) + 2 * lq + 1:
+            raise _cabi.DpfheError(2002, "multiply_exact: the context's limbs cannot hold the integer tensor product of this level")
+        if sum(math.log2(m) for m in p.moduli[ll:]) - 1 <= math.log2(p.n) + math.log2(plain_modulus) + lq + 2:
+            raise _cabi.DpfheError(2002, "multiply_exact: the workspace limbs cannot hold the scaled product")
+        A = self.base_extend(a, 0, 0, L, stream=stream)
+        B = A if b is a else self.base_extend(b, 0, 0, L, stream=stream)
+        T = self.multiply(Ciphertext(A), Ciphertext(B), stream=stream).data                       # [batch][3][L][N]
+        W = self.scale_round(T, 0, ll, ll, L - ll, plain_modulus, stream=stream)                    # [batch][3][L - ll][N]
+        return self.base_extend(W, ll, 0, ll, stream=stream)                                        # [batch][3][ll][N]
+
     # ---- N3 (SURVEY.md 8f): Galois automorphism + key switch ----------------------------------------------------
     def apply_galois_words(self, t: torch.Tensor, galois_elt: int, out: torch.Tensor | None = None, stream=None) -> torch.Tensor:
         """a(X) -> a(X^galois_elt) on every RNS polynomial of t (coefficient domain, out of place)."""

@@ -197,6 +197,31 @@ private:
     std::unique_ptr<Impl> impl_;
 };
 
+// ---- round 4: EXACT ciphertext x ciphertext multiply (BFV-style) around the fused tensor-product kernel ---------------------------------
+// For ciphertexts that carry their message as floor(q / t) * m (Encryptor::encrypt_exact: slot-packed exact arithmetic mod t) a tensor
+// product modulo q is not enough: the product carries floor(q/t)^2 and has to be scaled by t / q over the INTEGERS.  ExactMultiplier does
+// that with the level's modulus q = the first `level` limbs of a larger work context (the remaining limbs hold the integer product):
+//     extend both operands exactly to all work limbs (dpfhe_base_extend)  ->  Evaluator::multiply on the work context (the fused
+//     ct x ct kernel: the metric op)  ->  x t / q with rounding on the workspace limbs (dpfhe_scale_round)  ->  back to the level's limbs.
+// Needs prod(work limbs) > 2 N t q^2 (N = 8192, t = 65537, a two-limb level: five 60-bit limbs).  The result has 3 components on the LEVEL
+// context (relinearise there).  This is what lets a packed layer's output go through a polynomial activation (x -> x^2 between W_up and
+// W_down: /root/reference/src/core/execution/models/gpt_model.cpp:842-859 with the square standing in for GELU).
+class ExactMultiplier {
+public:
+    // level_ctx's moduli must be the first level_ctx.params().n_limbs() moduli of work_ctx, same ring degree, same device
+    ExactMultiplier(const Context& work_ctx, const Context& level_ctx, uint64_t plain_modulus);
+    ~ExactMultiplier();
+    ExactMultiplier(const ExactMultiplier&) = delete;
+    ExactMultiplier& operator=(const ExactMultiplier&) = delete;
+    // a, b: 2 components on level_ctx (coefficient domain; may be the same object: squaring); out3: 3 components on level_ctx, same batch.
+    // Enqueues on `stream`; scratch belongs to the object and grows to the largest batch seen (one multiply() at a time per object).
+    void multiply(const Ciphertext& a, const Ciphertext& b, Ciphertext& out3, Stream* stream = nullptr);
+
+private:
+    class Impl;
+    std::unique_ptr<Impl> impl_;
+};
+
 // ---- (e) SURVEY.md section 8e: the one collective of the sharded path -------------------------------------------------
 // One process per GPU.  Rank 0 obtains an id, ships its 128 bytes to the other ranks by the host program's own rendezvous
 // (a file, a pipe, MPI ...), every rank constructs a Communicator.  all_gather is RCCL's all-gather over xGMI on the caller's

@@ -124,8 +124,9 @@ int dpfhe_ct_mul(dpfhe_ctx* ctx, uint64_t* d_out3, const uint64_t* d_a2, const u
                  uint32_t flags, void* stream);
 
 /* diagnostics (tools/ctmul_trace.py): the "quad" form of dpfhe_ct_mul(flags = 0) with timestamps - thread 0 of workgroup w (= pair w / L, limb w % L)
- * writes d_trace[8 w .. 8 w + 7]: s_memrealtime (100 MHz) at start / first operand word arrived / forward transforms done / tensor
- * product done / inverse transforms done / stores issued / stores drained, then HW_ID | XCC_ID << 32.  N = 4096 fold contexts only. */
+ * writes d_trace[12 w .. 12 w + 11]: s_memrealtime (100 MHz) at start / first operand word arrived / forward transforms done / tensor
+ * product done / inverse transforms done / stores issued / stores drained, then HW_ID | XCC_ID << 32, then prologue done / first operand's
+ * loads issued / all loads issued / whole first operand arrived.  d_trace: batch * L * 12 words.  N = 4096 fold contexts only. */
 int dpfhe_debug_ct_mul_trace(dpfhe_ctx* ctx, uint64_t* d_out3, const uint64_t* d_a2, const uint64_t* d_b2, size_t batch, uint64_t* d_trace, void* stream);
 
 /* -- N1 (first "next" row): relinearisation 3 -> 2 components with RNS-digit evaluation keys ----
@@ -202,6 +203,21 @@ int dpfhe_ntt_inv_galois(dpfhe_ctx* ctx, uint64_t* d_out, const uint64_t* d_in, 
 int dpfhe_switch_key_qp(dpfhe_ctx* ctx_ext, uint64_t* d_out_qp, const uint64_t* d_in2, const uint64_t* d_keys, size_t n_keys, size_t group, void* stream);
 int dpfhe_rescale_bsgs(dpfhe_ctx* ctx_ext, uint64_t* d_out2, const uint64_t* d_in_qp, const uint64_t* d_addends, size_t n_add, size_t batch,
                        void* stream);
+
+/* -- round 4 (what an EXACT ciphertext x ciphertext multiply needs around dpfhe_ct_mul): limb ranges of one context ------------
+ * dpfhe_base_extend: per coefficient, the integer X in (-Qs/2, Qs/2] whose residues modulo the source limbs [src_limb0, src_limb0 + n_src)
+ *   are given (Qs their product, n_src <= 4) is reduced modulo the destination limbs [dst_limb0, dst_limb0 + n_dst) (n_dst <= 8; the ranges may
+ *   overlap - a destination limb that is also a source limb gets its own residue back).  Exact (mixed-radix reconstruction), not approximate.
+ *   d_in: item p's source residues at d_in + (p * in_stride_limbs + i) * N, i < n_src;  d_out: item p's results at d_out + (p * out_stride_limbs + j) * N.
+ * dpfhe_scale_round: d_in [n_polys][L][N] holds ALL limbs of the context;  d_out (item stride out_stride_limbs) receives, on the kept limbs
+ *   [keep_limb0, keep_limb0 + n_keep),  round(multiplier * X / Qd)  where X is the (centred) integer the L limbs represent and Qd the product of the
+ *   dropped limbs [drop_limb0, drop_limb0 + n_drop) (n_drop <= 4, disjoint from the kept ones) - exact as long as |multiplier * X| < Q / 2.
+ *   With multiplier = the plaintext modulus t and Qd = the operands' ciphertext modulus this is the scale-and-round of a BFV-style multiply:
+ *   extend both operands to the whole context, dpfhe_ct_mul there, dpfhe_scale_round, dpfhe_base_extend back (Evaluator::multiply_exact). */
+int dpfhe_base_extend(dpfhe_ctx* ctx, uint64_t* d_out, size_t out_stride_limbs, const uint64_t* d_in, size_t in_stride_limbs, uint32_t src_limb0, uint32_t n_src,
+                      uint32_t dst_limb0, uint32_t n_dst, size_t n_polys, void* stream);
+int dpfhe_scale_round(dpfhe_ctx* ctx, uint64_t* d_out, size_t out_stride_limbs, const uint64_t* d_in, uint32_t drop_limb0, uint32_t n_drop, uint32_t keep_limb0,
+                      uint32_t n_keep, uint64_t multiplier, size_t n_polys, void* stream);
 
 /* -- N3: Galois automorphism a(X) -> a(X^galois_elt) (galois_elt odd, < 2N), coefficient domain, d_out != d_in;
  *        and the key switch that follows it:  (c0', c1') = (c0 + sum_j [c1]_{q_j} (.) key_j[0], sum_j [c1]_{q_j} (.) key_j[1]),

@@ -47,6 +47,8 @@ def _load():
     lib.orc_switch_key_qp.argtypes = [C.c_void_p, _U64P, _U64P, _U64P, C.c_size_t, C.c_int]
     lib.orc_switch_key_qp.restype = None
     lib.orc_rescale.argtypes = [C.c_void_p, _U64P, _U64P, C.c_size_t]
+    lib.orc_base_extend.argtypes = [C.c_void_p, C.c_int, _U64P, C.c_size_t, _U64P, C.c_size_t, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, C.c_size_t]
+    lib.orc_base_extend.restype = None
     lib.orc_apply_galois.argtypes = [C.c_void_p, _U64P, _U64P, C.c_size_t, C.c_uint32]
     lib.orc_switch_key.argtypes = [C.c_void_p, _U64P, _U64P, _U64P, C.c_size_t, C.c_int]
     lib.orc_matvec_plain.argtypes = [C.c_void_p, _U64P, _U64P, _U64P, C.c_size_t, C.c_size_t, C.c_size_t, C.c_int]
@@ -197,6 +199,23 @@ class Oracle:
         out = np.empty(npolys * (self.L - 1) * self.n, np.uint64)
         lib().orc_rescale(self._h, _p(out), _p(x), npolys)
         return out.reshape(x.shape[:-2] + (self.L - 1, self.n))
+
+    def base_extend(self, x, src_limb0, dst_limb0, n_dst):
+        """x: [..., n_src, N] residues mod limbs src_limb0.. -> the same centred integers mod limbs dst_limb0.. ([..., n_dst, N])"""
+        x = np.ascontiguousarray(x)
+        ns = x.shape[-2]
+        npolys = x.size // (ns * self.n)
+        out = np.empty(x.shape[:-2] + (n_dst, self.n), np.uint64)
+        lib().orc_base_extend(self._h, 0, _p(out), n_dst, _p(x), ns, src_limb0, ns, dst_limb0, n_dst, 1, npolys)
+        return out
+
+    def scale_round(self, x, drop_limb0, n_drop, keep_limb0, n_keep, multiplier):
+        """x: [..., L, N] on all limbs -> round(multiplier * X / prod(dropped limbs)) on the kept limbs ([..., n_keep, N])"""
+        x = np.ascontiguousarray(x)
+        npolys = self._npolys(x)
+        out = np.empty(x.shape[:-2] + (n_keep, self.n), np.uint64)
+        lib().orc_base_extend(self._h, 1, _p(out), n_keep, _p(x), self.L, drop_limb0, n_drop, keep_limb0, n_keep, int(multiplier), npolys)
+        return out
 
     def apply_galois(self, x, galois_elt):
         x = np.ascontiguousarray(x)

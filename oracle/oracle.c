@@ -643,6 +643,45 @@ void orc_switch_key_qp(const orc_ctx* c, uint64_t* out, const uint64_t* in2, con
     }
 }
 
+/* Round 4: exact base extension / scale-and-round between limb ranges of one context (include/dpfhe.h dpfhe_base_extend,
+ * dpfhe_scale_round).  Restated with 128-bit arithmetic on the mixed-radix (Garner) digits; oracle/pyoracle.py holds the DEFINITION
+ * (Python big integers: CRT, centre, reduce) that pins this function.
+ *   mode 0: out_j = X mod p_j;   mode 1: out_j = round(mul * X_all / Qs) mod p_j  where the sources are mul * x_i and the input holds all limbs. */
+static uint64_t mulmod_(uint64_t a, uint64_t b, uint64_t q) { return (uint64_t)((u128)a * b % q); }
+static uint64_t powmod_(uint64_t b, uint64_t e, uint64_t q) { uint64_t r = 1; b %= q; while (e) { if (e & 1) r = mulmod_(r, b, q); b = mulmod_(b, b, q); e >>= 1; } return r; }
+void orc_base_extend(const orc_ctx* c, int mode, uint64_t* out, size_t out_stride_limbs, const uint64_t* in, size_t in_stride_limbs, uint32_t src0, uint32_t ns,
+                     uint32_t dst0, uint32_t nd, uint64_t mul, size_t n_polys) {
+    const size_t n = (size_t)1 << c->log2n;
+    uint64_t q[4], p[8], inv[4][4], half[4];
+    for (uint32_t i = 0; i < ns; ++i) q[i] = c->limb[src0 + i].q;
+    for (uint32_t j = 0; j < nd; ++j) p[j] = c->limb[dst0 + j].q;
+    for (uint32_t i = 0; i < ns; ++i) for (uint32_t k = i + 1; k < ns; ++k) inv[i][k] = powmod_(q[i] % q[k], q[k] - 2, q[k]);
+    { u128 carry = 0; for (int k = (int)ns - 1; k >= 0; --k) { u128 cur = carry * q[k] + (q[k] - 1); half[k] = (uint64_t)(cur / 2); carry = cur & 1; } }
+    for (size_t pi = 0; pi < n_polys; ++pi)
+        for (size_t w = 0; w < n; ++w) {
+            uint64_t v[4];
+            for (uint32_t k = 0; k < ns; ++k) {
+                uint64_t t = in[(pi * in_stride_limbs + (mode ? src0 : 0) + k) * n + w];
+                if (mode) t = mulmod_(t, mul % q[k], q[k]);
+                for (uint32_t i = 0; i < k; ++i) t = mulmod_((t + q[k] - v[i] % q[k]) % q[k], inv[i][k], q[k]);
+                v[k] = t;
+            }
+            int neg = 0;
+            for (int k = (int)ns - 1; k >= 0; --k) if (v[k] != half[k]) { neg = v[k] > half[k]; break; }
+            for (uint32_t j = 0; j < nd; ++j) {
+                uint64_t acc = v[ns - 1] % p[j], Qm = 1;
+                for (int k = (int)ns - 2; k >= 0; --k) acc = (uint64_t)(((u128)acc * (q[k] % p[j]) + v[k]) % p[j]);
+                for (uint32_t i = 0; i < ns; ++i) Qm = mulmod_(Qm, q[i] % p[j], p[j]);
+                if (neg) acc = (acc + p[j] - Qm) % p[j];
+                if (mode) {
+                    const uint64_t x = in[(pi * in_stride_limbs + dst0 + j) * n + w];
+                    acc = mulmod_((mulmod_(x, mul % p[j], p[j]) + p[j] - acc) % p[j], powmod_(Qm, p[j] - 2, p[j]), p[j]);
+                }
+                out[(pi * out_stride_limbs + j) * n + w] = acc;
+            }
+        }
+}
+
 void orc_apply_galois(const orc_ctx* c, uint64_t* out, const uint64_t* in, size_t n_rns_polys, uint32_t g) {
     const size_t n = 1ull << c->log2n, L = c->n_limbs;
     for (size_t p = 0; p < n_rns_polys * L; ++p) {

@@ -271,3 +271,44 @@ def unflatten_ct(words, ncomp, nlimbs, n):
 
 def words_to_bytes(words) -> bytes:
     return b"".join(int(w).to_bytes(8, "little") for w in words)
+
+
+# ---- round 4: exact base extension / scale-and-round, DEFINITION form (big integers) - pins oracle.c orc_base_extend ------------------
+def crt_centered(residues, moduli):
+    """the integer in (-Q/2, Q/2] with the given residues (Q = prod moduli, pairwise coprime)"""
+    Q = 1
+    for m in moduli:
+        Q *= m
+    x = 0
+    for r, m in zip(residues, moduli):
+        Qi = Q // m
+        x += int(r) * Qi * pow(Qi, -1, m)
+    x %= Q
+    return x - Q if x > Q // 2 else x
+
+
+def base_extend(words, src_moduli, dst_moduli):
+    """words[i][k]: residue k of limb i -> out[j][k] = X_k mod dst_moduli[j], X_k the centred CRT lift"""
+    n = len(words[0])
+    out = [[0] * n for _ in dst_moduli]
+    for k in range(n):
+        x = crt_centered([w[k] for w in words], src_moduli)
+        for j, p in enumerate(dst_moduli):
+            out[j][k] = x % p
+    return out
+
+
+def scale_round(words, moduli, drop, keep, multiplier):
+    """words[i][k] on ALL limbs (moduli); drop / keep: limb index lists -> out[j][k] = round(multiplier * X / prod(drop moduli)) mod keep limb j,
+    rounding to nearest (ties cannot occur: the divisor is odd)"""
+    n = len(words[0])
+    Qd = 1
+    for i in drop:
+        Qd *= moduli[i]
+    out = [[0] * n for _ in keep]
+    for k in range(n):
+        x = multiplier * crt_centered([w[k] for w in words], moduli)
+        y = (2 * x + Qd) // (2 * Qd)          # floor(x / Qd + 1/2)
+        for j, i in enumerate(keep):
+            out[j][k] = y % moduli[i]
+    return out

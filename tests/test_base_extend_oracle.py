@@ -1,0 +1,86 @@
+"""CPU: the C oracle's base extension / scale-and-round (oracle.c orc_base_extend, the checker of dpfhe_base_extend / dpfhe_scale_round)
+against the DEFINITION in Python big integers (oracle/pyoracle.py crt_centered), and the exact-multiply pipeline built from them against
+the integer negacyclic product."""
+import numpy as np
+import pytest
+
+from deeppowers_amd.params import PRIMES_60, FheParams
+from oracle import pyoracle as po
+from oracle.cbind import Oracle
+
+
+def params(log2n, limbs):
+    n = 1 << log2n
+    qs = [PRIMES_60[i][0] for i in range(limbs)]
+    return FheParams(log2n, tuple(qs), tuple(pow(PRIMES_60[i][2], 8192 // n, PRIMES_60[i][0]) for i in range(limbs)))
+
+
+@pytest.mark.parametrize("ns,src0,dst0,nd", [(1, 0, 0, 5), (2, 0, 0, 5), (3, 2, 0, 2), (4, 1, 0, 5), (2, 3, 1, 2)])
+def test_base_extend_equals_the_big_integer_definition(ns, src0, dst0, nd):
+    p = params(8, 5)
+    orc = Oracle.from_params(p)
+    rng = np.random.default_rng(5)
+    src = list(p.moduli[src0:src0 + ns])
+    x = np.stack([rng.integers(0, q, (3, p.n), dtype=np.uint64) for q in src], axis=1)          # [3][ns][N]
+    x[0, :, :4] = 0                                                                               # X = 0
+    x[0, :, 4:8] = np.array(src, np.uint64)[:, None] - np.uint64(1)                              # X = -1
+    Qs = int(np.prod([int(q) for q in src], dtype=object))
+    for k, val in enumerate((Qs // 2, Qs // 2 + 1, Qs // 2 - 1)):                                 # around the centring threshold
+        x[1, :, k] = [val % q for q in src]
+    got = orc.base_extend(x, src0, dst0, nd)
+    for b in range(3):
+        want = po.base_extend([list(map(int, x[b, i])) for i in range(ns)], src, p.moduli[dst0:dst0 + nd])
+        assert np.array_equal(got[b], np.array(want, dtype=np.uint64))
+
+
+@pytest.mark.parametrize("drop0,nd,keep0,nk,mul", [(0, 2, 2, 3, 65537), (4, 1, 0, 4, 1), (1, 3, 4, 1, 12289), (0, 4, 4, 1, 3)])
+def test_scale_round_equals_the_big_integer_definition(drop0, nd, keep0, nk, mul):
+    p = params(8, 5)
+    orc = Oracle.from_params(p)
+    rng = np.random.default_rng(6)
+    Q = int(np.prod([int(q) for q in p.moduli], dtype=object))
+    # integers small enough that mul * X stays centred in Q (the entry's precondition), incl. negatives and exact multiples of the divisor
+    Qd = int(np.prod([int(q) for q in p.moduli[drop0:drop0 + nd]], dtype=object))
+    vals = [int(rng.integers(0, 2**62)) * int(rng.integers(0, 2**62)) * int(rng.integers(0, 2**62)) * int(rng.integers(0, 2**62)) % (Q // (4 * mul)) for _ in range(2 * p.n)]
+    vals[:6] = [0, Qd, -Qd, Qd // 2, Qd // 2 + 1, -(Qd // 2) - 1]
+    vals = [v if i % 2 else -v for i, v in enumerate(vals)]
+    x = np.array([[[v % q for v in vals[b * p.n:(b + 1) * p.n]] for q in p.moduli] for b in range(2)], dtype=np.uint64)   # [2][L][N]
+    got = orc.scale_round(x, drop0, nd, keep0, nk, mul)
+    for b in range(2):
+        want = po.scale_round([list(map(int, x[b, i])) for i in range(p.n_limbs)], p.moduli, list(range(drop0, drop0 + nd)), list(range(keep0, keep0 + nk)), mul)
+        assert np.array_equal(got[b], np.array(want, dtype=np.uint64))
+
+
+def test_exact_multiply_pipeline_is_the_scaled_integer_tensor_product():
+    """extend -> tensor product on all limbs -> scale by t / q and round -> back to the level's limbs  ==  round(t * (a (x) b over Z) / q) mod q,
+    computed with Python integers (negacyclic schoolbook) on a small ring."""
+    p = params(8, 5)
+    orc = Oracle.from_params(p)
+    ll, t, n = 2, 65537, p.n
+    q = p.moduli[0] * p.moduli[1]
+    rng = np.random.default_rng(7)
+    lvl = [rng.integers(0, m, (2, 2, n), dtype=np.uint64) for m in p.moduli[:ll]]                  # two ciphertexts: [ct][comp][N] per limb
+    a = np.stack([lvl[i][0] for i in range(ll)], axis=1)[None]                                     # [1][2][ll][N]
+    b = np.stack([lvl[i][1] for i in range(ll)], axis=1)[None]
+    A, B = orc.base_extend(a, 0, 0, 5), orc.base_extend(b, 0, 0, 5)
+    T = orc.ct_mul(np.ascontiguousarray(A), np.ascontiguousarray(B), threads=1)
+    W = orc.scale_round(T, 0, ll, ll, 5 - ll, t)
+    R = orc.base_extend(W, ll, 0, ll)                                                              # [1][3][ll][N]
+    ai = [[po.crt_centered([int(a[0, c, i, k]) for i in range(ll)], p.moduli[:ll]) for k in range(n)] for c in range(2)]
+    bi = [[po.crt_centered([int(b[0, c, i, k]) for i in range(ll)], p.moduli[:ll]) for k in range(n)] for c in range(2)]
+
+    def nega(u, v):
+        out = [0] * n
+        for i in range(n):
+            for j in range(n):
+                if i + j < n:
+                    out[i + j] += u[i] * v[j]
+                else:
+                    out[i + j - n] -= u[i] * v[j]
+        return out
+    c0, c2 = nega(ai[0], bi[0]), nega(ai[1], bi[1])
+    c1 = [x + y for x, y in zip(nega(ai[0], bi[1]), nega(ai[1], bi[0]))]
+    for comp, ints in enumerate((c0, c1, c2)):
+        for i in range(ll):
+            want = [((2 * t * v + q) // (2 * q)) % p.moduli[i] for v in ints]
+            assert list(map(int, R[0, comp, i])) == want

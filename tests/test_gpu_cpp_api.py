@@ -30,7 +30,7 @@ def build_example(name="encrypted_multiply"):
 
 
 def test_example_compiles():
-    assert all(os.path.exists(build_example(e)) for e in ("encrypted_multiply", "bench_ct_mul", "encrypted_linear", "encrypted_gpt2_linear", "encrypted_gpt2_ffn",
+    assert all(os.path.exists(build_example(e)) for e in ("encrypted_multiply", "bench_ct_mul", "encrypted_linear", "encrypted_gpt2_linear", "encrypted_gpt2_ffn", "encrypted_gpt2_ffn_act",
                                                           "encrypted_gpt2_block", "sharded_ct_mul", "sharded_ffn"))
 
 
@@ -106,6 +106,20 @@ def test_example_encrypted_ffn_block_chained_on_the_device():
 
 
 @pytest.mark.gpu
+@pytest.mark.gpu
+def test_example_activated_ffn_block_uses_the_metric_op_and_switches_modulus():
+    """y = x + W_down (W_up x)^2 over Z_65537 at the reference's FFN shapes (gpt_model.cpp:842-859 with the square standing in for GELU): W_up on five
+    limbs, modulus switch to two, the activation as an EXACT ciphertext x ciphertext multiply (ExactMultiplier around the fused ct x ct kernel)
+    + relinearisation, W_down on two limbs; every stage decrypted; the noise budget falls monotonically and stays positive."""
+    import json
+    out = subprocess.run([build_example("encrypted_gpt2_ffn_act"), "2", "1", "json"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and out.stdout.strip().endswith("OK"), out.stdout[-1500:] + out.stderr[-500:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
+    assert d["correct"] is True and d["activation_correct"] is True and d["ct_ct_multiplies_per_token"] == 1
+    b = d["budget_bits"]
+    assert b[0] > b[1] > 0 and b[2] > b[3] > b[4] > 0, b       # fresh > after W_up;  switched > squared > after W_down
+
+
 def test_example_tensor_parallel_encrypted_ffn():
     """configs[4]'s shape: the encrypted FFN linear path sharded over the inner dimension, one process per GPU, partial ciphertexts
     all-gathered over the library's communicator and summed.  World size 1 runs the real multi-process program (fork, id through a

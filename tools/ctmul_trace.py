@@ -36,7 +36,7 @@ def run(pairs=2048, reps=3):
     b = torch.randint(0, 2**62, (pairs, 2, L, N), generator=g, dtype=torch.int64, device=dev) % q
     o = ctx.empty(pairs, components=3)
     o2 = ctx.empty(pairs, components=3)
-    trace = torch.zeros(pairs * L * 8, dtype=torch.int64, device=dev)
+    trace = torch.zeros(pairs * L * 12, dtype=torch.int64, device=dev)
     s = torch.cuda.current_stream(dev).cuda_stream
 
     def traced():
@@ -57,7 +57,8 @@ def run(pairs=2048, reps=3):
     t_plain, t_trace = timed(plain), timed(traced)
     t_plain, t_trace = min(t_plain, timed(plain)), min(t_trace, timed(traced))
     same = bool(torch.equal(o, o2))
-    tr = trace.cpu().numpy().view(np.uint64).reshape(pairs * L, 8)
+    tr = trace.cpu().numpy().view(np.uint64).reshape(pairs * L, 12)
+    fine = (tr[:, 8:12].astype(np.int64) - tr[:, 0:1].astype(np.int64)) / 100.0   # prologue / x issued / all issued / x complete, us after start
     t = tr[:, :7].astype(np.int64)
     t0 = t[:, 0].min()
     t = (t - t0) / 100.0                                    # 100 MHz -> microseconds
@@ -73,6 +74,8 @@ def run(pairs=2048, reps=3):
     for k, v in seg.items():
         w = v[steady]
         out["segments_us"][k] = {"median": float(np.median(w)), "p10": float(np.percentile(w, 10)), "p90": float(np.percentile(w, 90)), "mean": float(w.mean())}
+    out["first_operand_us_after_start"] = {nm: {"median": float(np.median(fine[steady, i])), "p90": float(np.percentile(fine[steady, i], 90))}
+                                           for i, nm in enumerate(("prologue_done", "first_operand_issued", "all_loads_issued", "first_operand_complete"))}
     med = out["segments_us"]["lifetime"]["median"]
     out["share_of_lifetime"] = {k: out["segments_us"][k]["mean"] / out["segments_us"]["lifetime"]["mean"] for k in seg if k != "lifetime"}
     ph = np.exp(2j * np.pi * t[steady, 0] / med)
@@ -110,6 +113,7 @@ if __name__ == "__main__":
         for k, v in r["segments_us"].items():
             sh = r["share_of_lifetime"].get(k)
             print(f"{k:16s} median {v['median']:8.2f} us  p10 {v['p10']:8.2f}  p90 {v['p90']:8.2f}  mean {v['mean']:8.2f}" + (f"  = {100 * sh:5.1f} % of a lifetime" if sh is not None else ""))
+        print("inside wait_first_load, us after the workgroup's start: " + ", ".join(f"{k} {v['median']:.2f} (p90 {v['p90']:.2f})" for k, v in r["first_operand_us_after_start"].items()))
         print(f"resident workgroups (512 slots): mean {r['resident_workgroups']['mean']:.0f}, min {r['resident_workgroups']['min']}, max {r['resident_workgroups']['max']}")
         print(f"start-phase concentration R = {r['start_phase_concentration_R']:.3f} (0 = uniformly de-phased, 1 = lockstep generations)")
         if "per_cu_start_gap_over_lifetime" in r:
