@@ -840,6 +840,31 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    def workgroup_timeline():
+        """median microseconds per segment of a quad-form workgroup's life over a 2048-pair launch (steady-state workgroups only): the share
+        spent waiting for the first operand word is what two waves per SIMD cannot hide, and what differs between the boxes of the pool"""
+        from deeppowers_amd import _cabi
+        nb = min(B, 2048)
+        if not ctx.variants() or nb < 256:
+            return None
+        tr = torch.zeros(nb * L * 12, dtype=torch.int64, device=dev)
+        for _ in range(2):
+            _cabi.check(ctx._lib.dpfhe_debug_ct_mul_trace(ctx.handle, outs[0].data_ptr(), a.data.data_ptr(), b.data.data_ptr(), nb, tr.data_ptr(), main.cuda_stream), "dpfhe_debug_ct_mul_trace")
+        torch.cuda.synchronize()
+        t = tr.cpu().numpy().view(np.uint64).reshape(nb * L, 12).astype(np.int64)
+        rel = (t - t[:, 0].min()) / 100.0
+        span = rel[:, 6].max()
+        keep = (rel[:, 0] > 0.15 * span) & (rel[:, 6] < 0.85 * span)
+        if keep.sum() < 64:
+            keep[:] = True
+        med = lambda v: round(float(np.median(v[keep])), 2)
+        life = rel[:, 6] - rel[:, 0]
+        return {"lifetime": med(life), "wait_first_operand": med(rel[:, 1] - rel[:, 0]), "prologue": med(rel[:, 8] - rel[:, 0]), "loads_issued": med(rel[:, 10] - rel[:, 0]),
+                "first_operand_complete": med(rel[:, 11] - rel[:, 0]), "forward_x4": med(rel[:, 2] - rel[:, 1]), "tensor_product": med(rel[:, 3] - rel[:, 2]),
+                "inverse_x3": med(rel[:, 4] - rel[:, 3]), "stores": med(rel[:, 6] - rel[:, 4]),
+                "wait_share_of_lifetime": round(float(np.mean((rel[:, 1] - rel[:, 0])[keep]) / np.mean(life[keep])), 4),
+                "launch": f"{nb} pairs, traced quad form (timestamps in scalar registers; same words as the timed kernel)"}
+
     def first_profile(*names):
         for nm in names:
             path = os.path.join(ROOT, "profiles", nm)
@@ -894,7 +919,7 @@ def main():
         # `frac` keeps the contract's meaning (algorithmic bytes / launch time / HBM peak); the kernel's real bound is VALU issue,
         # so both fractions are first-class: frac_hbm (= frac) and frac_alu (butterflies/s over the register-only ceiling).
         "roofline": {
-            "kernel": {"quad": "ct_mul_quad_kernel<FoldArith,12,4>", "dual": "ct_mul_dual_kernel<FoldArith,12,4,false>", "single": "ct_mul_kernel<FoldArith,12,4,false,false>", "quadpf": "ct_mul_quad_kernel<FoldArith,12,4,false,true> (operands of the workgroup 48 ids ahead requested into L2)"}.get(autotune.get("chosen"), "ct_mul_quad_kernel<FoldArith,12,4>"),
+            "kernel": {"quad": "ct_mul_quad_kernel<FoldArith,12,4>", "dual": "ct_mul_dual_kernel<FoldArith,12,4,false>", "single": "ct_mul_kernel<FoldArith,12,4,false,false>", "quadpf": "ct_mul_quad_kernel<FoldArith,12,4,false,true> (operands of the workgroup 96 ids ahead requested into L2)"}.get(autotune.get("chosen"), "ct_mul_quad_kernel<FoldArith,12,4>"),
             "bound": "valu", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
             "frac": achieved / HBM_PEAK, "frac_hbm": achieved / HBM_PEAK, "frac_alu": (bfly_per_s / alu_peak) if alu_peak else None,
             "traffic": traffic,
@@ -943,6 +968,10 @@ def main():
     if sustained_result is not None:
         detail["sustained"] = sustained_result
     if rank == 0:
+        try:   # where a workgroup of the multiply spends its life ON THIS BOX (diagnostic launch after the timed region; include/dpfhe.h dpfhe_debug_ct_mul_trace)
+            regime_result["workgroup_timeline_us"] = workgroup_timeline()
+        except Exception as e:
+            regime_result["workgroup_timeline_us"] = {"error": repr(e)[:160]}
         result["roofline"]["regime"] = regime_result
     if other_result is not None:
         detail["other_configs"] = other_result

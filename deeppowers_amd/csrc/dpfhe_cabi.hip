@@ -928,14 +928,13 @@ extern "C" int dpfhe_rotate_hoisted_qp(dpfhe_ctx* c, uint64_t* d_out_qp, const u
         } else {
             QpElts ge{};
             for (size_t i = 0; i < cnt; ++i) ge.v[i] = galois_elts[first + i];
-            static const int pp = [] { const char* e = std::getenv("DPFHE_QP_PAIRS"); const int v = e ? std::atoi(e) : 0; return (v == 1 || v == 4) ? v : kQpPairs; }();   // A/B only
-            const size_t grid = qp_stream_grid((int)c->log2n, (int)L, cnt, T, pp);
+            // (pairs per thread: 2 measured best at 8 tokens - 291 us against 300 with 1 and 329 with 4 -, 1 is 5 % ahead at one token: profiles/r04_ab_baby_steps.txt)
+            const size_t grid = qp_stream_grid((int)c->log2n, (int)L, cnt, T);
             if (grid > kMaxGrid) return fail(DPFHE_INVALID_ARGUMENT, what, "batch too large for one launch");
-#define QP_LAUNCH(ARITH, PP) hipLaunchKernelGGL((hoisted_qp_stream_kernel<ARITH, PP>), dim3((unsigned)grid), dim3(256), 0, s, dst, d_digits, d_in_ntt, d_keys + first * key_words, key_words, ge, \
-                                               (unsigned)cnt, (unsigned)T, p_special, lc, (int)L, (int)c->log2n)
-            if (c->fold) { if (pp == 1) QP_LAUNCH(FoldArith, 1); else if (pp == 4) QP_LAUNCH(FoldArith, 4); else QP_LAUNCH(FoldArith, kQpPairs); }
-            else QP_LAUNCH(ShoupArith, kQpPairs);
-#undef QP_LAUNCH
+            if (c->fold) hipLaunchKernelGGL((hoisted_qp_stream_kernel<FoldArith, kQpPairs>), dim3((unsigned)grid), dim3(256), 0, s, dst, d_digits, d_in_ntt, d_keys + first * key_words, key_words, ge,
+                                            (unsigned)cnt, (unsigned)T, p_special, lc, (int)L, (int)c->log2n);
+            else hipLaunchKernelGGL((hoisted_qp_stream_kernel<ShoupArith, kQpPairs>), dim3((unsigned)grid), dim3(256), 0, s, dst, d_digits, d_in_ntt, d_keys + first * key_words, key_words, ge,
+                                    (unsigned)cnt, (unsigned)T, p_special, lc, (int)L, (int)c->log2n);
         }
         if (int e = check_launch("hoisted_qp kernel launch")) return e;
     }
@@ -1190,8 +1189,11 @@ static int base_extend_common(dpfhe_ctx* c, int mode, uint64_t* d_out, size_t ou
     const size_t n = (size_t)1 << c->log2n;
     const int chunks = (int)((n + 511) / 512);
     if (n_polys * (size_t)chunks > kMaxGrid) return fail(DPFHE_INVALID_ARGUMENT, what, "batch too large for one launch");
-    if (overlaps(d_out, ((n_polys - 1) * out_stride_limbs + nd) * n, d_in, ((n_polys - 1) * in_stride_limbs + (mode == 1 ? (size_t)L : ns)) * n))
-        return fail(DPFHE_INVALID_ARGUMENT, what, "output overlaps the input");
+    {   // mode 1: d_in points at the first dropped limb of item 0 inside a [n_polys][L][N] buffer that starts src0 limbs earlier
+        const uint64_t* in_lo = mode == 1 ? d_in - (size_t)src0 * n : d_in;
+        const size_t in_words = mode == 1 ? n_polys * (size_t)L * n : ((n_polys - 1) * in_stride_limbs + ns) * n;
+        if (overlaps(d_out, ((n_polys - 1) * out_stride_limbs + nd) * n, in_lo, in_words)) return fail(DPFHE_INVALID_ARGUMENT, what, "output overlaps the input");
+    }
     // host constants (a handful of modular inverses; moduli read back from the context's limb constants would need a copy - they are kept on the host)
     const std::vector<uint64_t>& q = c->moduli;
     BaseExtArgs a{};

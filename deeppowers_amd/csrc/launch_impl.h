@@ -119,10 +119,10 @@ int launch_ct_mul(int log2n, unsigned flags, u64* out3, const u64* a2, const u64
     }
 }
 
-// how many workgroup ids ahead the "quadpf" form prefetches: a multiple of 8 (same XCD) and of L (same limb), ~10 % of the 512 resident
-// workgroups by default - the share of its life a workgroup spends waiting for its first operand word; DPFHE_CTMUL_PF_DIST overrides (A/B runs)
+// how many workgroup ids ahead the "quadpf" form prefetches: a multiple of 8 (same XCD) and of L (same limb), 96 by default (two operand
+// round trips at the measured 3.6 us first-word latency; 16 ... 192 measured, profiles/r04_ab_quadpf.txt); DPFHE_CTMUL_PF_DIST overrides (A/B runs)
 inline unsigned pf_distance(int n_limbs) {
-    static const unsigned want = [] { const char* e = std::getenv("DPFHE_CTMUL_PF_DIST"); const int n = e ? std::atoi(e) : 0; return n > 0 ? (unsigned)n : 48u; }();
+    static const unsigned want = [] { const char* e = std::getenv("DPFHE_CTMUL_PF_DIST"); const int n = e ? std::atoi(e) : 0; return n > 0 ? (unsigned)n : 96u; }();
     unsigned lcm = 8u;
     while (lcm % (unsigned)n_limbs) lcm += 8u;
     const unsigned d = (want + lcm - 1) / lcm * lcm;

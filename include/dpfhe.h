@@ -77,7 +77,7 @@ int dpfhe_ctx_uses_fold(const dpfhe_ctx* ctx);
 /* -- A0, continued: which FORM of the fused multiply a context launches -------------------------------------------------
  * dpfhe_ct_mul(flags = 0) has four forms at N = 4096 / 8192 on fold-reduction contexts - "quad" (all four forward and all three inverse
  * transforms of a workgroup share twiddle fetches), "dual" (transforms in pairs), "single" (one at a time, half the LDS), "quadpf" (quad,
- * each workgroup also requesting the operands of a workgroup 48 ids ahead into its XCD's L2) - with identical results and identical HBM traffic; which is fastest depends on the box (how well two waves per SIMD hide its memory latency).
+ * each workgroup also requesting the operands of a workgroup 96 ids ahead into its XCD's L2) - with identical results and identical HBM traffic; which is fastest depends on the box (how well two waves per SIMD hide its memory latency).
  * dpfhe_ctx_create measures them once (three launches each, twice, on <= 256 MiB of transient device memory it frees again: the only
  * device work and the only allocation besides the tables) and keeps the default unless another form is >= 3 % faster.
  * Environment: DPFHE_AUTOTUNE=0 skips the probe; DPFHE_CTMUL_VARIANT=quad|dual|single|quadpf forces a form.

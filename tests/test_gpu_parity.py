@@ -276,7 +276,7 @@ def test_every_form_of_the_fused_multiply_is_bit_exact_and_tunable(rigs, name):
     forms = ("quad", "dual", "single", "quadpf")
     assert info["n_variants"] == len(forms) and info["chosen"] in forms
     assert info["source"] == "probe at dpfhe_ctx_create" and set(info["probe_us"]) == set(forms) and all(v > 0 for v in info["probe_us"].values())
-    batch = 29   # the prefetching form reaches 48 workgroup ids ahead: some workgroups have a successor there, the last ones do not
+    batch = 29   # the prefetching form reaches 96 workgroup ids ahead: some workgroups have a successor there, the last ones do not
     a = r.orc.fill(batch * 2, 33).reshape(batch, 2, L, n)
     b = r.orc.fill(batch * 2, 34).reshape(batch, 2, L, n)
     qs = np.array(r.p.moduli, np.uint64)[None, :, None]

@@ -71,9 +71,13 @@ def main():
     want = {"ct_mul_quad_kernel<FoldArith,12,4>": ("ct_mul_quad_kernel<FoldArith, 12, 4>", 8192 * 4 * 256),
             "ntt_fwd_kernel<FoldArith,12,4>": ("ntt_fwd_kernel<FoldArith, 12, 4>", 4096 * 256),
             "ntt_inv_kernel<FoldArith,12,4>": ("ntt_inv_kernel<FoldArith, 12, 4>", 4096 * 256)}
+    def lookup(table, k, grid, counter):   # kernel names carry further template arguments (non-temporal / trace / prefetch flags): prefix match, plain form first
+        stem = k[:-1]
+        hits = sorted((kk for (kk, g) in table if g == grid and kk.startswith(stem) and "true" not in kk[len(stem):]), key=len)
+        return table[(hits[0], grid)].get(counter) if hits else None
     for name, (k, grid) in want.items():
-        f = fetch.get((k, grid), {}).get("FETCH_SIZE")
-        w = write.get((k, grid), {}).get("WRITE_SIZE")
+        f = lookup(fetch, k, grid, "FETCH_SIZE")
+        w = lookup(write, k, grid, "WRITE_SIZE")
         if f is None or w is None:
             continue
         total = (2 * f + w) * 1024
