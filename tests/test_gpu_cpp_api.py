@@ -106,7 +106,6 @@ def test_example_encrypted_ffn_block_chained_on_the_device():
 
 
 @pytest.mark.gpu
-@pytest.mark.gpu
 def test_example_activated_ffn_block_uses_the_metric_op_and_switches_modulus():
     """y = x + W_down (W_up x)^2 over Z_65537 at the reference's FFN shapes (gpt_model.cpp:842-859 with the square standing in for GELU): W_up on five
     limbs, modulus switch to two, the activation as an EXACT ciphertext x ciphertext multiply (ExactMultiplier around the fused ct x ct kernel)
@@ -120,6 +119,7 @@ def test_example_activated_ffn_block_uses_the_metric_op_and_switches_modulus():
     assert b[0] > b[1] > 0 and b[2] > b[3] > b[4] > 0, b       # fresh > after W_up;  switched > squared > after W_down
 
 
+@pytest.mark.gpu
 def test_example_tensor_parallel_encrypted_ffn():
     """configs[4]'s shape: the encrypted FFN linear path sharded over the inner dimension, one process per GPU, partial ciphertexts
     all-gathered over the library's communicator and summed.  World size 1 runs the real multi-process program (fork, id through a
