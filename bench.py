@@ -745,7 +745,7 @@ def main():
                     return peak, clock, "tools/bin/ubench2 bfly, run by this bench.py before the timed region", True
             except Exception:
                 pass
-        for nm in ("r03_ubench2.log", "r02_ubench2.log"):
+        for nm in ("r04_ubench2.log", "r03_ubench2.log", "r02_ubench2.log"):
             path = os.path.join(ROOT, "profiles", nm)
             if os.path.exists(path):
                 peak, clock = parse(open(path).read())
@@ -874,7 +874,7 @@ def main():
 
     # HBM traffic of the dominant kernel from the committed PMC passes (collected with rocprofv3 --pmc in their own
     # runs, corrected as MI355X_MICROARCH.md prescribes); scaled per ct-mul because traffic is linear in the batch.
-    traffic, traffic_src = None, first_profile("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json")
+    traffic, traffic_src = None, first_profile("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json")
     try:
         with open(traffic_src) as f:
             tj = json.load(f)
