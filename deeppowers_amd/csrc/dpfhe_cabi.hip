@@ -917,15 +917,10 @@ extern "C" int dpfhe_rotate_hoisted_qp(dpfhe_ctx* c, uint64_t* d_out_qp, const u
     else hipLaunchKernelGGL((lift_qp_kernel<ShoupArith>), dim3(idg), dim3(256), 0, s, d_out_qp, d_in_ntt, lc, p_special, (int)L, n, chunks);
     if (int e = check_launch("lift_qp kernel launch")) return e;
     // 4. the rotations: permuted digit segments x key segments as a stream (kernels_misc.h hoisted_qp_stream_kernel), 64 rotations per launch
-    static const bool old_form = [] { const char* e = std::getenv("DPFHE_HOISTED_QP"); return e && !std::strcmp(e, "fused"); }();   // A/B only
     for (size_t first = 0; first < batch; first += kMaxGaloisBatch) {
         const size_t cnt = batch - first < (size_t)kMaxGaloisBatch ? batch - first : (size_t)kMaxGaloisBatch;
         uint64_t* dst = d_out_qp + (1 + first) * T * 2 * L * n;
-        if (old_form) {
-            const int rc = c->fold ? launch_hoisted_qp<FoldArith>((int)c->log2n, dst, d_digits, d_in_ntt, d_keys + first * key_words, key_words, galois_elts + first, cnt, T, p_special, c->foldt, s)
-                                   : launch_hoisted_qp<ShoupArith>((int)c->log2n, dst, d_digits, d_in_ntt, d_keys + first * key_words, key_words, galois_elts + first, cnt, T, p_special, c->shoup, s);
-            if (rc) return fail(DPFHE_INVALID_STATE, what, "no kernel geometry for this log2_n");
-        } else {
+        {
             QpElts ge{};
             for (size_t i = 0; i < cnt; ++i) ge.v[i] = galois_elts[first + i];
             // (pairs per thread: 2 measured best at 8 tokens - 291 us against 300 with 1 and 329 with 4 -, 1 is 5 % ahead at one token: profiles/r04_ab_baby_steps.txt)

@@ -3,5 +3,4 @@ namespace dpfhe {
 template int launch_ct_mul<ShoupArith>(int, unsigned, u64*, const u64*, const u64*, size_t, const DevTables<ShoupArith>&, hipStream_t);
 template int launch_relin<ShoupArith>(int, int, u64*, const u64*, const u64*, size_t, unsigned, size_t, const DevTables<ShoupArith>&, hipStream_t);
 template int launch_hoisted_ks<ShoupArith>(int, u64*, const u64*, const u64*, size_t, const unsigned*, size_t, size_t, const DevTables<ShoupArith>&, hipStream_t);
-template int launch_hoisted_qp<ShoupArith>(int, u64*, const u64*, const u64*, const u64*, size_t, const unsigned*, size_t, size_t, u64, const DevTables<ShoupArith>&, hipStream_t);
 }

@@ -1091,138 +1091,7 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE), 2) void hoisted_ks2_kernel(u64*
     B::store_top(tid, acc1, work + ((item * 2 + 1) * L + limb) * N);
 }
 
-// ------------------------------------------------------------------------------------------------
-// N3, round 3: hoisted rotations whose results STAY in the NTT domain over the extended basis Q P ("double hoisting", Bossuat et
-// al. 2021): item (rotation r, token t) =
-//     ( sum_j perm_g(digit_j) (.) key_{g,j,0}  +  P perm_g(NTT(c0)),   sum_j perm_g(digit_j) (.) key_{g,j,1} )      over all L limbs
-// (the P c0 term vanishes on the special limb), i.e. P sigma_g(ct) + key-switching noise before the division by P.  The plaintext
-// products of a packed matrix-vector product are taken on these, and ONE inverse transform + divide-by-P is paid per inner SUM
-// instead of one per rotation: the kernel is a gather + multiply-accumulate stream - no transform, no LDS.  One workgroup per
-// (rotation, limb, token), both key components; same XCD-aware id layout as hoisted_ks2_kernel.
-// `xntt`: NTT of the input ciphertexts on the data limbs, [token][2][Ld][N].  Output canonical, forward-output order.
-// ------------------------------------------------------------------------------------------------
-template <class Arith, int LOGN, int LOGE>
-__global__ __launch_bounds__(1 << (LOGN - LOGE), (Arith::kFold ? 2 : 1)) void hoisted_qp_kernel(u64* __restrict__ out, const u64* __restrict__ digits,
-                                                                                           const u64* __restrict__ xntt, const u64* __restrict__ keys,
-                                                                                           size_t key_stride, GaloisElts elts, unsigned n_items, unsigned n_tiles,
-                                                                                           u64 p_special, DevTables<Arith> tb) {
-    typedef NttBody<Arith, LOGN, LOGE> B;
-    constexpr int E = B::E, N = B::G::N;
-    // Every operand tile goes through the wave's private LDS rows (ntt_core.h stage_*): key tiles row by row, the permuted digit
-    // words and c0 by stage_gather - coalesced 16-byte global loads only, no register transposition (80 VALU instructions per tile)
-    // and no 8-byte gathers.  Geometries without the row layout (N < 1024) keep register transposes and global gathers.
-    constexpr bool kStage = B::kLdsIO && Arith::kFold;   // (the generic-prime path keeps its registers for the 128-bit Barrett products)
-    __shared__ __attribute__((aligned(16))) u64 lds[kStage ? B::G::lds_words() : 16];
-    const int tid = threadIdx.x;
-    const int L = tb.n_limbs, Ld = L - 1;
-    const unsigned q = blockIdx.x >> 3, token = q % n_items, tile = (q / n_items) * 8u + (blockIdx.x & 7u);
-    if (tile >= n_tiles) return;
-    const size_t rot = tile / (unsigned)L;
-    const int limb = (int)(tile % (unsigned)L);
-    const size_t item = rot * n_items + token;
-    digits += (size_t)token * (size_t)Ld * L * N;
-    const LimbConst lc = tb.lc[limb];
-    const unsigned g = elts.v[rot];
-    const u64* evk = keys + rot * key_stride;
-    const u64 pmod = canon_any<Arith>(p_special, lc);
-    u64 acc0[E], acc1[E], x[E], e[E];
-    auto mac = [&](u64 (&acc)[E], bool first) {
-#pragma unroll
-        for (int k = 0; k < E; ++k) {
-            if (Arith::kFold) acc[k] = (first ? 0 : acc[k]) + FoldArith::mul60(x[k], e[k], (u32)lc.d);
-            else acc[k] = first ? ShoupArith::mul_var(x[k], e[k], lc) : add_mod(acc[k], ShoupArith::mul_var(x[k], e[k], lc), lc.q);
-        }
-    };
-    int lazy_terms = 0;
-    auto lazy_guard = [&]() {   // 13 lazily added products + one reduced word stay below 15 q
-        if (Arith::kFold) {
-            if (lazy_terms == 13) {
-#pragma unroll
-                for (int k = 0; k < E; ++k) { acc0[k] = FoldArith::reduce(acc0[k], lc); acc1[k] = FoldArith::reduce(acc1[k], lc); }
-                lazy_terms = 1;
-            }
-            ++lazy_terms;
-        }
-    };
-    if constexpr (kStage) {
-        unsigned addr[E];
-        const long shift = B::gather_plan(tid, g, addr);
-        u64 ve[E], vx[E];   // two tiles in flight (a third prefetch buffer spills at 2 waves per SIMD)
-        // component 0 starts with P perm_g(NTT(c0)) on the data limbs
-        if (limb < Ld) {
-            B::stage_load(tid, vx, xntt + ((size_t)token * 2 * Ld + limb) * N + shift);
-            B::stage_gather(tid, x, vx, lds, addr);
-#pragma unroll
-            for (int k = 0; k < E; ++k) {
-                acc0[k] = Arith::kFold ? FoldArith::mul60(x[k], pmod, (u32)lc.d) : ShoupArith::mul_var(x[k], pmod, lc);
-                acc1[k] = 0;
-            }
-            lazy_terms = 1;
-        } else {
-#pragma unroll
-            for (int k = 0; k < E; ++k) acc0[k] = acc1[k] = 0;
-        }
-        B::stage_load(tid, ve, evk + ((size_t)0 * L + limb) * N);
-        B::stage_load(tid, vx, digits + (size_t)limb * N + shift);
-#pragma unroll 1
-        for (int j = 0; j < Ld; ++j) {
-            B::stage_rows(tid, e, ve, lds);
-            B::stage_gather(tid, x, vx, lds, addr);
-            const int jn = j + 1 < Ld ? j + 1 : j;   // the last iteration re-requests its own tiles (cache hits) instead of branching
-            B::stage_load(tid, ve, evk + (((size_t)j * 2 + 1) * L + limb) * N);       // in flight during the first component's products
-            B::stage_load(tid, vx, digits + ((size_t)jn * L + limb) * N + shift);
-            lazy_guard();
-            mac(acc0, false);
-            B::stage_rows(tid, e, ve, lds);
-            B::stage_load(tid, ve, evk + (((size_t)jn * 2 + 0) * L + limb) * N);      // ... during the second component's
-            mac(acc1, false);
-        }
-    } else {
-        unsigned src[E];
-#pragma unroll
-        for (int kk = 0; kk < E; ++kk) {
-            const unsigned p = (unsigned)tid * E + kk;
-            const unsigned ee = 2u * (__brev(p) >> (32 - LOGN)) + 1u;
-            const unsigned e2 = (g * ee) & (2u * N - 1u);
-            src[kk] = __brev((e2 - 1u) >> 1) >> (32 - LOGN);
-        }
-        if (limb < Ld) {
-            const u64* c0 = xntt + ((size_t)token * 2 * Ld + limb) * N;
-#pragma unroll
-            for (int k = 0; k < E; ++k) {
-                const u64 v = c0[src[k]];
-                acc0[k] = Arith::kFold ? FoldArith::mul60(v, pmod, (u32)lc.d) : ShoupArith::mul_var(v, pmod, lc);
-                acc1[k] = 0;
-            }
-            lazy_terms = 1;
-        } else {
-#pragma unroll
-            for (int k = 0; k < E; ++k) acc0[k] = acc1[k] = 0;
-        }
-#pragma unroll 1
-        for (int j = 0; j < Ld; ++j) {
-            const u64* d = digits + ((size_t)j * L + limb) * N;
-#pragma unroll
-            for (int k = 0; k < E; ++k) x[k] = d[src[k]];
-            B::load_bot(tid, e, evk + (((size_t)j * 2 + 0) * L + limb) * N);
-            lazy_guard();
-            mac(acc0, false);
-            B::load_bot(tid, e, evk + (((size_t)j * 2 + 1) * L + limb) * N);
-            mac(acc1, false);
-        }
-    }
-    if (Arith::kFold) {
-#pragma unroll
-        for (int k = 0; k < E; ++k) { acc0[k] = FoldArith::canon(acc0[k], lc); acc1[k] = FoldArith::canon(acc1[k], lc); }
-    }
-    if constexpr (kStage) {
-        B::store_bot_lds(tid, acc0, out + ((item * 2 + 0) * L + limb) * N, lds);
-        wave_sync();
-        B::store_bot_lds(tid, acc1, out + ((item * 2 + 1) * L + limb) * N, lds);
-    } else {
-        B::store_bot(tid, acc0, out + ((item * 2 + 0) * L + limb) * N);
-        B::store_bot(tid, acc1, out + ((item * 2 + 1) * L + limb) * N);
-    }
-}
+// (N3, round 3's hoisted_qp_kernel - one workgroup per (rotation, limb, token) on the transform geometry - lived here; round 4 replaced it by
+// kernels_misc.h hoisted_qp_stream_kernel: no transform in that pass, so no transform geometry, and 0.99 x instead of 2.3 x its algorithmic bytes.)
 
 }  // namespace dpfhe

@@ -50,10 +50,6 @@ template <class Arith>
 int launch_hoisted_ks(int log2n, u64* work, const u64* digits, const u64* keys, size_t key_stride, const unsigned* elts, size_t count,
                       size_t n_items, const DevTables<Arith>& tb, hipStream_t s);
 
-// hoisted rotations left in the NTT domain over Q P (kernels.h hoisted_qp_kernel): out[(rot, item)][2][L][N]
-template <class Arith>
-int launch_hoisted_qp(int log2n, u64* out, const u64* digits, const u64* xntt, const u64* keys, size_t key_stride, const unsigned* elts, size_t count,
-                      size_t n_items, u64 p_special, const DevTables<Arith>& tb, hipStream_t s);
 // out = sigma_g(INTT(in)), the automorphism applied as a gather in the NTT domain; `polys_per_elt` residue polynomials per element (<= 64 elements)
 template <class Arith>
 int launch_ntt_inv_galois(int log2n, u64* out, const u64* in, const unsigned* elts, size_t n_elts, size_t polys_per_elt, const DevTables<Arith>& tb, hipStream_t s);

@@ -237,22 +237,6 @@ int launch_hoisted_ks(int log2n, u64* work, const u64* digits, const u64* keys, 
 }
 
 template <class Arith>
-int launch_hoisted_qp(int log2n, u64* out, const u64* digits, const u64* xntt, const u64* keys, size_t key_stride, const unsigned* elts, size_t count,
-                      size_t n_items, u64 p_special, const DevTables<Arith>& tb, hipStream_t s) {
-    if (count > (size_t)kMaxGaloisBatch) return -1;
-    GaloisElts ge{};
-    for (size_t i = 0; i < count; ++i) ge.v[i] = elts[i];
-    const unsigned tiles = (unsigned)(count * (size_t)tb.n_limbs);                  // (rotation, limb)
-    const unsigned blocks = ((tiles + 7u) / 8u) * 8u * (unsigned)n_items;           // x token, ids laid out per XCD (kernels.h)
-#define HQ_CASE(LN, LE)                                                                                                                                  \
-    hipLaunchKernelGGL((hoisted_qp_kernel<Arith, LN, kFusedLoge>), dim3(blocks), dim3(Geo<LN, kFusedLoge>::T), 0, s, out, digits, xntt, keys, key_stride, ge, \
-                       (unsigned)n_items, tiles, p_special, tb)
-    DPFHE_GEO_SWITCH(log2n, HQ_CASE)
-#undef HQ_CASE
-    return 0;
-}
-
-template <class Arith>
 int launch_ntt_inv_galois(int log2n, u64* out, const u64* in, const unsigned* elts, size_t n_elts, size_t polys_per_elt, const DevTables<Arith>& tb, hipStream_t s) {
     if (tb.n_sub != 1 || n_elts > (size_t)kMaxGaloisBatch) return -1;   // split transforms (N > 16384) have no gather form; callers chunk by kMaxGaloisBatch
     GaloisElts ge{};
