@@ -329,7 +329,7 @@ def main():
                     help="all-gather through the library's own communicator (dpfhe_comm_*, RCCL behind the C ABI) instead of torch.distributed")
     ap.add_argument("--sustained-seconds", type=float, default=2.0, help="length of each sustained NTT / copy window (0 = skip the block)")
     ap.add_argument("--skip-other", action="store_true", help="skip the other_configs block (profiling runs: every launch is serialised under rocprofv3)")
-    ap.add_argument("--ct-mul-form", default="auto", choices=["auto", "quad", "dual", "single", "quadpf"],
+    ap.add_argument("--ct-mul-form", default="auto", choices=["auto", "quad", "dual", "single", "quadpf", "quad2"],
                     help="form of the fused multiply: auto = measured on this box (library probe + three timed steps per form), or forced")
     ap.add_argument("--dry-run", action="store_true", help="CPU + gloo: walk the multi-rank host path (collectives, barriers, report) without kernels")
     args = ap.parse_args()
@@ -919,7 +919,7 @@ def main():
         # `frac` keeps the contract's meaning (algorithmic bytes / launch time / HBM peak); the kernel's real bound is VALU issue,
         # so both fractions are first-class: frac_hbm (= frac) and frac_alu (butterflies/s over the register-only ceiling).
         "roofline": {
-            "kernel": {"quad": "ct_mul_quad_kernel<FoldArith,12,4>", "dual": "ct_mul_dual_kernel<FoldArith,12,4,false>", "single": "ct_mul_kernel<FoldArith,12,4,false,false>", "quadpf": "ct_mul_quad_kernel<FoldArith,12,4,false,true> (operands of the workgroup 96 ids ahead requested into L2)"}.get(autotune.get("chosen"), "ct_mul_quad_kernel<FoldArith,12,4>"),
+            "kernel": {"quad": "ct_mul_quad_kernel<FoldArith,12,4>", "dual": "ct_mul_dual_kernel<FoldArith,12,4,false>", "single": "ct_mul_kernel<FoldArith,12,4,false,false>", "quadpf": "ct_mul_quad_kernel<FoldArith,12,4,false,true> (operands of the workgroup 96 ids ahead requested into L2)", "quad2": "ct_mul_quad2_kernel<FoldArith,12,4> (two pairs per workgroup, the second pair's operands requested during the first pair's last inverse phase)"}.get(autotune.get("chosen"), "ct_mul_quad_kernel<FoldArith,12,4>"),
             "bound": "valu", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
             "frac": achieved / HBM_PEAK, "frac_hbm": achieved / HBM_PEAK, "frac_alu": (bfly_per_s / alu_peak) if alu_peak else None,
             "traffic": traffic,

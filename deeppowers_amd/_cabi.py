@@ -65,7 +65,7 @@ IN_NTT, OUT_NTT = 1, 2
 class TuneInfo(C.Structure):
     """dpfhe_tune_info (include/dpfhe.h)"""
     _fields_ = [("chosen", C.c_int32), ("n_variants", C.c_int32), ("source", C.c_int32), ("probe_pairs", C.c_uint32),
-                ("probe_reps", C.c_uint32), ("probe_us", C.c_float * 4)]
+                ("probe_reps", C.c_uint32), ("probe_us", C.c_float * 8)]
 
 
 TUNE_SOURCES = ("default", "probe at dpfhe_ctx_create", "dpfhe_ctx_autotune", "forced")

@@ -99,7 +99,7 @@ struct dpfhe_ctx {
 // `reps` back-to-back launches per form over `pairs` synthetic ciphertext pairs, two passes in opposite orders, best pass per form;
 // a non-default form is taken only when it is at least 3 % faster than the default.
 // ------------------------------------------------------------------------------------------------
-static const char* const kCtMulVariantNames[kCtMulVariants] = {"quad", "dual", "single", "quadpf"};
+static const char* const kCtMulVariantNames[kCtMulVariants] = {"quad", "dual", "single", "quadpf", "quad2"};
 static const float kTuneMargin = 0.97f;
 
 __global__ __launch_bounds__(256) void tune_fill_kernel(u64* __restrict__ p, size_t n) {
@@ -161,7 +161,7 @@ static void tune_at_create(dpfhe_ctx* c) {
     c->tune = dpfhe_tune_info{};
     c->tune.chosen = def;
     c->tune.n_variants = ct_mul_variant_compiled(c, def) ? kCtMulVariants : 0;
-    for (int v = 0; v < 4; ++v) c->tune.probe_us[v] = -1.0f;
+    for (int v = 0; v < 8; ++v) c->tune.probe_us[v] = -1.0f;
     if (!ct_mul_variant_compiled(c, def)) return;
     if (const char* f = std::getenv("DPFHE_CTMUL_VARIANT")) {
         for (int v = 0; v < kCtMulVariants; ++v)

@@ -89,7 +89,7 @@ Context::TuneInfo Context::tune_info() const {
     r.source = (t.source >= 0 && t.source < 4) ? src[t.source] : "?";
     r.probe_pairs = t.probe_pairs;
     r.probe_reps = t.probe_reps;
-    for (int v = 0; v < t.n_variants && v < 4; ++v)
+    for (int v = 0; v < t.n_variants && v < 8; ++v)
         if (t.probe_us[v] >= 0) r.probe_us.emplace_back(dpfhe_ct_mul_variant_name(v), t.probe_us[v]);
     return r;
 }

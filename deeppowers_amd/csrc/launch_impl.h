@@ -141,6 +141,10 @@ int launch_ct_mul_variant(int log2n, int variant, u64* out3, const u64* a2, cons
         else if (variant == kCtMulDual) hipLaunchKernelGGL((ct_mul_dual_kernel<Arith, LN, kFusedLoge, false>), dim3((unsigned)blocks), dim3(Geo<LN, kFusedLoge>::T), 0, s, out3, a2, b2, tb); \
         else if (variant == kCtMulSingle) hipLaunchKernelGGL((ct_mul_kernel<Arith, LN, kFusedLoge, false, false>), dim3((unsigned)blocks), dim3(Geo<LN, kFusedLoge>::T), 0, s, out3, a2, b2, tb); \
         else if (variant == kCtMulQuadPf) hipLaunchKernelGGL((ct_mul_quad_kernel<Arith, LN, kFusedLoge, false, true>), dim3((unsigned)blocks), dim3(Geo<LN, kFusedLoge>::T), 0, s, out3, a2, b2, tb, (u64*)nullptr, pf_distance(tb.n_limbs)); \
+        else if (variant == kCtMulQuad2) {                                                                                                            \
+            const unsigned batch = (unsigned)(blocks / (size_t)tb.n_limbs);                                                                           \
+            hipLaunchKernelGGL((ct_mul_quad2_kernel<Arith, LN, kFusedLoge>), dim3(((batch + 1u) / 2u) * (unsigned)tb.n_limbs), dim3(Geo<LN, kFusedLoge>::T), 0, s, out3, a2, b2, tb, batch); \
+        }                                                                                                                                             \
         else return -1;                                                                                                                               \
         return 0
         switch (log2n) {

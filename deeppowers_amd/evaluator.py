@@ -82,7 +82,7 @@ class Context:
         return [self._lib.dpfhe_ct_mul_variant_name(v).decode() for v in range(self.tune_info()["n_variants"])]
 
     def set_ct_mul_variant(self, name: str):
-        names = [self._lib.dpfhe_ct_mul_variant_name(v).decode() for v in range(4)]
+        names = [self._lib.dpfhe_ct_mul_variant_name(v).decode() for v in range(8)]
         if name not in names or not name:
             raise _cabi.DpfheError(2000, f"unknown form {name!r}")
         _cabi.check(self._lib.dpfhe_ctx_set_ct_mul_variant(self._h, names.index(name)), "dpfhe_ctx_set_ct_mul_variant")

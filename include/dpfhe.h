@@ -75,12 +75,13 @@ uint32_t dpfhe_ctx_limbs(const dpfhe_ctx* ctx);
 int dpfhe_ctx_uses_fold(const dpfhe_ctx* ctx);
 
 /* -- A0, continued: which FORM of the fused multiply a context launches -------------------------------------------------
- * dpfhe_ct_mul(flags = 0) has four forms at N = 4096 / 8192 on fold-reduction contexts - "quad" (all four forward and all three inverse
+ * dpfhe_ct_mul(flags = 0) has five forms at N = 4096 / 8192 on fold-reduction contexts - "quad" (all four forward and all three inverse
  * transforms of a workgroup share twiddle fetches), "dual" (transforms in pairs), "single" (one at a time, half the LDS), "quadpf" (quad,
- * each workgroup also requesting the operands of a workgroup 96 ids ahead into its XCD's L2) - with identical results and identical HBM traffic; which is fastest depends on the box (how well two waves per SIMD hide its memory latency).
+ * each workgroup also requesting the operands of a workgroup 96 ids ahead into its XCD's L2), "quad2" (quad over two consecutive pairs per
+ * workgroup, straight-line, the second pair's operands requested during the first pair's last inverse phase) - with identical results and identical HBM traffic; which is fastest depends on the box (how well two waves per SIMD hide its memory latency).
  * dpfhe_ctx_create measures them once (three launches each, twice, on <= 256 MiB of transient device memory it frees again: the only
  * device work and the only allocation besides the tables) and keeps the default unless another form is >= 3 % faster.
- * Environment: DPFHE_AUTOTUNE=0 skips the probe; DPFHE_CTMUL_VARIANT=quad|dual|single|quadpf forces a form.
+ * Environment: DPFHE_AUTOTUNE=0 skips the probe; DPFHE_CTMUL_VARIANT=quad|dual|single|quadpf|quad2 forces a form.
  * dpfhe_ctx_autotune repeats the measurement on CALLER-provided scratch (work_words >= 7 L N; pairs = work_words / (7 L N) synthetic
  * ciphertext pairs; contents are overwritten; synchronises `stream`).  It changes the context: call it before the context is shared
  * between threads.  Other contexts (generic primes, other ring degrees) have one form; both calls are no-ops there. */
@@ -91,7 +92,7 @@ typedef struct dpfhe_tune_info {
     int32_t source;        /* DPFHE_TUNE_* : how `chosen` was decided */
     uint32_t probe_pairs;  /* ciphertext pairs per probe launch */
     uint32_t probe_reps;   /* launches per form and pass */
-    float probe_us[4];     /* best-pass microseconds per launch of each form (< 0: not measured) */
+    float probe_us[8];     /* best-pass microseconds per launch of each form (< 0: not measured) */
 } dpfhe_tune_info;
 int dpfhe_ctx_autotune(dpfhe_ctx* ctx, uint64_t* d_work, size_t work_words, uint32_t reps, void* stream);
 int dpfhe_ctx_tune_info(const dpfhe_ctx* ctx, dpfhe_tune_info* out);

@@ -273,10 +273,10 @@ def test_every_form_of_the_fused_multiply_is_bit_exact_and_tunable(rigs, name):
         with pytest.raises(_cabi.DpfheError):
             r.ctx.set_ct_mul_variant("dual")
         return
-    forms = ("quad", "dual", "single", "quadpf")
+    forms = ("quad", "dual", "single", "quadpf", "quad2")
     assert info["n_variants"] == len(forms) and info["chosen"] in forms
     assert info["source"] == "probe at dpfhe_ctx_create" and set(info["probe_us"]) == set(forms) and all(v > 0 for v in info["probe_us"].values())
-    batch = 29   # the prefetching form reaches 96 workgroup ids ahead: some workgroups have a successor there, the last ones do not
+    batch = 29   # odd: the two-pair form's last workgroup has one pair; the prefetching form reaches 96 workgroup ids ahead: some workgroups have a successor there, the last ones do not
     a = r.orc.fill(batch * 2, 33).reshape(batch, 2, L, n)
     b = r.orc.fill(batch * 2, 34).reshape(batch, 2, L, n)
     qs = np.array(r.p.moduli, np.uint64)[None, :, None]
@@ -570,8 +570,8 @@ def test_bench_distributed_path_world_size_one():
     # what the driver's record keeps: the NTT verdict inside `roofline`, the form of the multiply and its measurements inside `config`
     nv, at = d["roofline"]["ntt"], d["config"]["autotune"]
     assert 0 < nv["fwd_frac"] < 1 and 0 < nv["inv_frac"] < 1 and nv["round_trip_exact"] is True and "sustained_2s" in nv
-    assert at["chosen"] in ("quad", "dual", "single", "quadpf") and set(at["step_probe_ms"]) == {"quad", "dual", "single", "quadpf"} and at["at_ctx_create"]["probe_us"]
-    assert at["chosen"].replace("quadpf", "quad") in d["roofline"]["kernel"].replace("ct_mul_kernel", "single") and "regime" in d["roofline"] and len(line) < 12000
+    assert at["chosen"] in ("quad", "dual", "single", "quadpf", "quad2") and set(at["step_probe_ms"]) == {"quad", "dual", "single", "quadpf", "quad2"} and at["at_ctx_create"]["probe_us"]
+    assert at["chosen"].replace("quadpf", "quad").replace("quad2", "quad") in d["roofline"]["kernel"].replace("ct_mul_kernel", "single") and "regime" in d["roofline"] and len(line) < 12000
     # the same launch with the library's own communicator as the transport
     out = subprocess.run(cmd[:-1] + ["--no-cpu-baseline", "--native-comm"], capture_output=True, text=True, timeout=600, env=env, cwd=root)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
