@@ -301,7 +301,7 @@ def digest_other(o):
         e = {"all_correct": pl.get("all_correct")}
         if pl.get("layers"):
             e["ms_per_token"] = {f"{l.get('layer', '?')}@{l.get('tokens', '?')}": r3(l.get("ms_per_token")) for l in pl["layers"]}
-        for blk in ("ffn_block", "transformer_block", "activated_ffn"):
+        for blk in ("ffn_block", "transformer_block", "activated_ffn", "activated_block"):
             if isinstance(pl.get(blk), dict):
                 e[blk] = {x: pl[blk].get(x) for x in ("ms_per_token", "correct", "tokens", "error", "budget_bits", "levels") if pl[blk].get(x) is not None}
         ks = pl.get("kernels") or {}
@@ -724,6 +724,10 @@ def main():
             run = subprocess.run([example("encrypted_gpt2_ffn_act"), "8", "2", "json"], capture_output=True, text=True, timeout=600)
             got = [json.loads(l) for l in run.stdout.splitlines() if l.startswith("{")]
             other["packed_linear"]["activated_ffn"] = got[0] if got and run.returncode == 0 else {"error": (run.stdout + run.stderr)[-300:]}
+            # ... and the whole block with that activation (attention half + W_up on five limbs, square + W_down on two): examples/encrypted_gpt2_block_act.cpp
+            run = subprocess.run([example("encrypted_gpt2_block_act"), "8", "2", "json"], capture_output=True, text=True, timeout=600)
+            got = [json.loads(l) for l in run.stdout.splitlines() if l.startswith("{")]
+            other["packed_linear"]["activated_block"] = got[0] if got and run.returncode == 0 else {"error": (run.stdout + run.stderr)[-300:]}
         except Exception as e:   # a missing example binary must not take the headline metric down with it
             other.setdefault("packed_linear", {})["error"] = repr(e)[:300]
         return other

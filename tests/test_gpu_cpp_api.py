@@ -30,7 +30,7 @@ def build_example(name="encrypted_multiply"):
 
 
 def test_example_compiles():
-    assert all(os.path.exists(build_example(e)) for e in ("encrypted_multiply", "bench_ct_mul", "encrypted_linear", "encrypted_gpt2_linear", "encrypted_gpt2_ffn", "encrypted_gpt2_ffn_act",
+    assert all(os.path.exists(build_example(e)) for e in ("encrypted_multiply", "bench_ct_mul", "encrypted_linear", "encrypted_gpt2_linear", "encrypted_gpt2_ffn", "encrypted_gpt2_ffn_act", "encrypted_gpt2_block_act",
                                                           "encrypted_gpt2_block", "sharded_ct_mul", "sharded_ffn"))
 
 
@@ -117,6 +117,18 @@ def test_example_activated_ffn_block_uses_the_metric_op_and_switches_modulus():
     assert d["correct"] is True and d["activation_correct"] is True and d["ct_ct_multiplies_per_token"] == 1
     b = d["budget_bits"]
     assert b[0] > b[1] > 0 and b[2] > b[3] > b[4] > 0, b       # fresh > after W_up;  switched > squared > after W_down
+
+
+@pytest.mark.gpu
+def test_example_whole_block_with_activation():
+    """configs[4] as a forward pass of ONE block with its non-linearity: qkv -> v hand-over -> W_o + residual -> W_up -> modulus switch 5 -> 2 limbs ->
+    square (exact ct x ct multiply) + relinearise -> W_down + residual; h1, the activation and h2 decrypted and compared; eight budget readings."""
+    import json
+    out = subprocess.run([build_example("encrypted_gpt2_block_act"), "2", "1", "json"], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0 and out.stdout.strip().endswith("OK"), out.stdout[-1500:] + out.stderr[-500:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
+    b = d["budget_bits"]
+    assert d["correct"] is True and len(b) == 8 and b[0] > b[1] > b[2] > b[3] > b[4] > 0 and b[5] > b[6] > b[7] > 0, b
 
 
 @pytest.mark.gpu
