@@ -725,7 +725,7 @@ def main():
             got = [json.loads(l) for l in run.stdout.splitlines() if l.startswith("{")]
             other["packed_linear"]["activated_ffn"] = got[0] if got and run.returncode == 0 else {"error": (run.stdout + run.stderr)[-300:]}
             # ... and the whole block with that activation (attention half + W_up on five limbs, square + W_down on two): examples/encrypted_gpt2_block_act.cpp
-            run = subprocess.run([example("encrypted_gpt2_block_act"), "8", "2", "json"], capture_output=True, text=True, timeout=600)
+            run = subprocess.run([example("encrypted_gpt2_block_act"), "8", "2", "json", "ladder"], capture_output=True, text=True, timeout=600)   # modulus 5 / 4 / 3 / 2 limbs inside the block
             got = [json.loads(l) for l in run.stdout.splitlines() if l.startswith("{")]
             other["packed_linear"]["activated_block"] = got[0] if got and run.returncode == 0 else {"error": (run.stdout + run.stderr)[-300:]}
         except Exception as e:   # a missing example binary must not take the headline metric down with it

@@ -6,11 +6,13 @@
 // to two limbs, the activation is an EXACT ciphertext x ciphertext multiply (ExactMultiplier: the fused tensor-product kernel, i.e. the
 // metric op, inside the forward) + relinearisation, and W_down and the residual run on two limbs.  Every stage is decrypted and compared
 // with the plaintext computation; the noise budget is reported after every stage (six levels: qkv, the v mask, W_o, W_up, the square, W_down).
-//   usage: encrypted_gpt2_block_act [tokens = 4] [reps = 2] [json | text]
+//   usage: encrypted_gpt2_block_act [tokens = 4] [reps = 2] [json | text] [ladder]
+// `ladder`: the modulus falls WITH the noise budget inside the block: qkv on 5 limbs, the v hand-over and W_o on 4, W_up on 3, the square and W_down on 2.
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <vector>
 
 #include <deeppowers/fhe.hpp>
@@ -36,21 +38,34 @@ int main(int argc, char** argv) {
     const size_t T = argc > 1 ? (size_t)std::atol(argv[1]) : 4;
     const int reps = argc > 2 ? std::atoi(argv[2]) : 2;
     const bool json = argc > 3 && !std::strcmp(argv[3], "json");
+    // "ladder": the modulus falls WITH the budget - qkv on 5 limbs, the v hand-over and W_o on 4, W_up on 3, the square and W_down on 2 (a layer's
+    // cost goes with digits x limbs: 30 / 20 / 12 / 6 instead of 30 / 30 / 30 / 6); default: the attention half and W_up all on 5 limbs
+    const bool ladder = argc > 4 && !std::strcmp(argv[4], "ladder");
+    const int lv_attn = ladder ? 4 : 5, lv_up = ladder ? 3 : 5;
     try {
         FheParams p5 = FheParams::n8192_l6();
         const uint64_t special = p5.moduli.back(), special_psi = p5.psi.back();
         p5.moduli.pop_back(); p5.psi.pop_back();
-        const FheParams p4 = p5.drop_last_limb(), p3 = p4.drop_last_limb(), p2 = p3.drop_last_limb();
+        FheParams pl[6];
+        pl[5] = p5; pl[4] = pl[5].drop_last_limb(); pl[3] = pl[4].drop_last_limb(); pl[2] = pl[3].drop_last_limb();
         const size_t n = p5.n();
-        Context ctx5(p5, 0), ctx4(p4, 0), ctx3(p3, 0), ctx2(p2, 0);
-        Evaluator ev5(ctx5), ev4(ctx4), ev3(ctx3), ev2(ctx2);
-        KeyGenerator kg(ctx5);
-        SecretKey sk2(ctx2, kg.secret_key().coefficients());
-        Encryptor enc(ctx5, kg.secret_key());
-        Decryptor dec5(ctx5, kg.secret_key()), dec2(ctx2, sk2);
-        BatchEncoder be5(ctx5, TM), be2(ctx2, TM);
-        HybridKeySwitcher hks5(ctx5, kg.secret_key(), special, special_psi), hks2(ctx2, sk2, special, special_psi);
-        ExactMultiplier mul(ctx5, ctx2, TM);
+        std::unique_ptr<Context> ctx[6];
+        std::unique_ptr<Evaluator> ev[6];
+        for (int l = 2; l <= 5; ++l) { ctx[l].reset(new Context(pl[l], 0)); ev[l].reset(new Evaluator(*ctx[l])); }
+        KeyGenerator kg(*ctx[5]);
+        std::unique_ptr<SecretKey> sk[6];
+        std::unique_ptr<Decryptor> dec[6];
+        std::unique_ptr<BatchEncoder> be[6];
+        std::unique_ptr<HybridKeySwitcher> hks[6];
+        for (int l = 2; l <= 5; ++l) {
+            if (l < 5) sk[l].reset(new SecretKey(*ctx[l], kg.secret_key().coefficients()));            // the same secret, seen at that level
+            const SecretKey& s = l == 5 ? kg.secret_key() : *sk[l];
+            dec[l].reset(new Decryptor(*ctx[l], s));
+            be[l].reset(new BatchEncoder(*ctx[l], TM));
+            if (l == 5 || l == lv_attn || l == lv_up || l == 2) hks[l].reset(new HybridKeySwitcher(*ctx[l], s, special, special_psi));
+        }
+        Encryptor enc(*ctx[5], kg.secret_key());
+        ExactMultiplier mul(*ctx[5], *ctx[2], TM);
 
         std::vector<uint64_t> Wqkv(3 * D * D), Wo(D * D), Wu(H * D), Wd(D * H), x(T * D);
         fill8(Wqkv); fill8(Wo); fill8(Wu); fill8(Wd); fill8(x);
@@ -67,80 +82,97 @@ int main(int argc, char** argv) {
         }
 
         auto t0 = std::chrono::steady_clock::now();
-        PackedLinear lqkv(ctx5, be5, hks5, Wqkv.data(), 3 * D, D), lo(ctx5, be5, hks5, Wo.data(), D, D), lup(ctx5, be5, hks5, Wu.data(), H, D);
-        PackedLinear ldown(ctx2, be2, hks2, Wd.data(), D, H);
-        PackedSelect take_v(ctx5, be5, hks5, 2 * D, D, lo.input_period());
+        PackedLinear lqkv(*ctx[5], *be[5], *hks[5], Wqkv.data(), 3 * D, D);
+        PackedLinear lo(*ctx[lv_attn], *be[lv_attn], *hks[lv_attn], Wo.data(), D, D);
+        PackedLinear lup(*ctx[lv_up], *be[lv_up], *hks[lv_up], Wu.data(), H, D);
+        PackedLinear ldown(*ctx[2], *be[2], *hks[2], Wd.data(), D, H);
+        PackedSelect take_v(*ctx[lv_attn], *be[lv_attn], *hks[lv_attn], 2 * D, D, lo.input_period());
         const uint32_t row_swap = (uint32_t)(2 * n - 1);
-        hks5.add_galois_element(row_swap);
+        hks[lv_up]->add_galois_element(row_swap);
         const double setup_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
 
         std::vector<uint64_t> slots(n);
         std::vector<int64_t> coeffs(T * n);
         for (size_t tk = 0; tk < T; ++tk) {
             lqkv.pack_input(&x[tk * D], slots.data());
-            be5.encode(slots.data(), &coeffs[tk * n]);
+            be[5]->encode(slots.data(), &coeffs[tk * n]);
         }
-        Ciphertext cx(ctx5, 2, T), cqkv(ctx5, 2, T), ca(ctx5, 2, T), co(ctx5, 2, T), ch1(ctx5, 2, T), cu(ctx5, 2, T), cus(ctx5, 2, T), cur(ctx5, 2, T);
-        Ciphertext u4(ctx4, 2, T), u3(ctx3, 2, T), u2(ctx2, 2, T), g4(ctx4, 2, T), g3(ctx3, 2, T), g2(ctx2, 2, T);
-        Ciphertext sq3(ctx2, 3, T), sq(ctx2, 2, T), cdn(ctx2, 2, T), ch2(ctx2, 2, T);
+        // one set of buffers per level; down(from, to, in) walks `in` down the ladder through them and returns the ciphertext at level `to`
+        std::unique_ptr<Ciphertext> lad_a[6], lad_b[6], lad_c[6];
+        for (int l = 2; l <= 5; ++l) { lad_a[l].reset(new Ciphertext(*ctx[l], 2, T)); lad_b[l].reset(new Ciphertext(*ctx[l], 2, T)); lad_c[l].reset(new Ciphertext(*ctx[l], 2, T)); }
+        auto down = [&](const Ciphertext& in, int from, int to, std::unique_ptr<Ciphertext> (&buf)[6]) -> const Ciphertext& {
+            const Ciphertext* cur = &in;
+            for (int l = from; l > to; --l) { ev[l]->rescale(*cur, *buf[l - 1]); cur = buf[l - 1].get(); }
+            return *cur;
+        };
+        Ciphertext cx(*ctx[5], 2, T), cqkv(*ctx[5], 2, T);
+        Ciphertext ca(*ctx[lv_attn], 2, T), co(*ctx[lv_attn], 2, T), ch1(*ctx[lv_attn], 2, T);
+        Ciphertext cu(*ctx[lv_up], 2, T), cus(*ctx[lv_up], 2, T), cur(*ctx[lv_up], 2, T);
+        Ciphertext sq3(*ctx[2], 3, T), sq(*ctx[2], 2, T), cdn(*ctx[2], 2, T), ch2(*ctx[2], 2, T);
         enc.encrypt_exact(coeffs.data(), TM, cx);
         const std::vector<uint32_t> swaps(T, row_swap);
+        const Ciphertext* u2 = nullptr;
         auto block = [&] {
-            lqkv.apply(cx, cqkv);                               // q | k | v at slots 0 .. 3d-1 of row 0                       (gpt_model.cpp:793)
-            take_v.apply(cqkv, ca);                             // attention over one position: v, re-packed as a layer input    (one mask level)
+            lqkv.apply(cx, cqkv);                                          // q | k | v at slots 0 .. 3d-1 of row 0, five limbs               (gpt_model.cpp:793)
+            const Ciphertext& qkv_l = down(cqkv, 5, lv_attn, lad_a);       // (ladder: to four limbs)
+            const Ciphertext& x_l = down(cx, 5, lv_attn, lad_b);
+            take_v.apply(qkv_l, ca);                                       // attention over one position: v, re-packed as a layer input        (one mask level)
             lo.apply(ca, co);
-            ev5.add(cx, co, ch1);                               // h1 = x + W_o a
-            lup.apply(ch1, cu);                                 // W_up h1                                                        (gpt_model.cpp:848)
-            hks5.apply_galois_many(cu, swaps, cus);
-            ev5.add(cu, cus, cur);                              // W_down's input packing
-            ev5.rescale(cur, u4); ev4.rescale(u4, u3); ev3.rescale(u3, u2);        // modulus switch 5 -> 2 limbs
-            mul.multiply(u2, u2, sq3);                          // the activation (exact multiply around the fused ct x ct kernel)
-            hks2.relinearize(sq3, sq);
-            ldown.apply(sq, cdn);                               // W_down on two limbs
-            ev5.rescale(ch1, g4); ev4.rescale(g4, g3); ev3.rescale(g3, g2);        // the residual's operand at that level
-            ev2.add(g2, cdn, ch2);                              // h2 = h1 + W_down (W_up h1)^2
+            ev[lv_attn]->add(x_l, co, ch1);                                // h1 = x + W_o a
+            const Ciphertext& h1_l = down(ch1, lv_attn, lv_up, lad_c);     // (ladder: to three limbs)
+            lup.apply(h1_l, cu);                                           // W_up h1                                                            (gpt_model.cpp:848)
+            hks[lv_up]->apply_galois_many(cu, swaps, cus);
+            ev[lv_up]->add(cu, cus, cur);                                  // W_down's input packing
+            u2 = &down(cur, lv_up, 2, lad_a);                              // modulus switch to two limbs
+            mul.multiply(*u2, *u2, sq3);                                   // the activation (exact multiply around the fused ct x ct kernel)
+            hks[2]->relinearize(sq3, sq);
+            ldown.apply(sq, cdn);                                          // W_down on two limbs
+            const Ciphertext& h1_2 = down(ch1, lv_attn, 2, lad_b);         // the residual's operand at that level
+            ev[2]->add(h1_2, cdn, ch2);                                    // h2 = h1 + W_down (W_up h1)^2
         };
         block();
-        ctx5.synchronize();
+        ctx[5]->synchronize();
         t0 = std::chrono::steady_clock::now();
         for (int i = 0; i < reps; ++i) block();
-        ctx5.synchronize();
+        ctx[5]->synchronize();
         const double ms_per_token = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() * 1e3 / reps / (double)T;
 
         std::vector<uint64_t> dm(T * n), got(n), expect(n), yv(D);
         size_t bad_h1 = 0, bad_act = 0, bad = 0;
-        dec5.decrypt_exact(ch1, TM, dm.data());
+        dec[lv_attn]->decrypt_exact(ch1, TM, dm.data());
         for (size_t tk = 0; tk < T; ++tk) {
-            be5.decode(dm.data() + tk * n, got.data());
+            be[lv_attn]->decode(dm.data() + tk * n, got.data());
             lup.pack_input(&h1[tk * D], expect.data());
             for (size_t i = 0; i < n; ++i) bad_h1 += got[i] != expect[i];
         }
-        dec2.decrypt_exact(sq, TM, dm.data());
+        dec[2]->decrypt_exact(sq, TM, dm.data());
         for (size_t tk = 0; tk < T; ++tk) {
-            be2.decode(dm.data() + tk * n, got.data());
+            be[2]->decode(dm.data() + tk * n, got.data());
             ldown.pack_input(&act[tk * H], expect.data());
             for (size_t i = 0; i < n; ++i) bad_act += got[i] != expect[i];
         }
-        dec2.decrypt_exact(ch2, TM, dm.data());
+        dec[2]->decrypt_exact(ch2, TM, dm.data());
         for (size_t tk = 0; tk < T; ++tk) {
-            be2.decode(dm.data() + tk * n, got.data());
+            be[2]->decode(dm.data() + tk * n, got.data());
             ldown.unpack_output(got.data(), yv.data());
             for (size_t r = 0; r < D; ++r) bad += yv[r] != h2[tk * D + r];
         }
-        const double b[8] = {dec5.noise_budget_bits(cx, TM), dec5.noise_budget_bits(cqkv, TM), dec5.noise_budget_bits(ca, TM), dec5.noise_budget_bits(ch1, TM),
-                             dec5.noise_budget_bits(cur, TM), dec2.noise_budget_bits(u2, TM), dec2.noise_budget_bits(sq, TM), dec2.noise_budget_bits(ch2, TM)};
+        const double b[8] = {dec[5]->noise_budget_bits(cx, TM), dec[5]->noise_budget_bits(cqkv, TM), dec[lv_attn]->noise_budget_bits(ca, TM), dec[lv_attn]->noise_budget_bits(ch1, TM),
+                             dec[lv_up]->noise_budget_bits(cur, TM), dec[2]->noise_budget_bits(*u2, TM), dec[2]->noise_budget_bits(sq, TM), dec[2]->noise_budget_bits(ch2, TM)};
         const size_t ks = lqkv.key_switches_per_apply() + take_v.key_switches_per_apply() + lo.key_switches_per_apply() + lup.key_switches_per_apply() + 1 +
                           ldown.key_switches_per_apply() + 1;
         const bool ok = !(bad || bad_act || bad_h1);
+        char levels[96];
+        std::snprintf(levels, sizeof levels, "qkv 5, v + W_o %d, W_up %d, square + W_down 2 limbs", lv_attn, lv_up);
         if (json)
-            std::printf("{\"block\": \"transformer_block_square_activation\", \"hidden\": %zu, \"inner\": %zu, \"log2_n\": 13, \"levels\": \"5 limbs (attention half, W_up) -> 2 limbs (square, W_down)\", "
+            std::printf("{\"block\": \"transformer_block_square_activation\", \"hidden\": %zu, \"inner\": %zu, \"log2_n\": 13, \"levels\": \"%s\", "
                         "\"plain_modulus\": %llu, \"tokens\": %zu, \"key_switches_per_token\": %zu, \"ct_ct_multiplies_per_token\": 1, \"setup_s\": %.2f, \"ms_per_token\": %.3f, "
                         "\"budget_bits\": [%.0f, %.0f, %.0f, %.0f, %.0f, %.0f, %.0f, %.0f], \"correct\": %s}\n",
-                        D, H, (unsigned long long)TM, T, ks, setup_s, ms_per_token, b[0], b[1], b[2], b[3], b[4], b[5], b[6], b[7], ok ? "true" : "false");
+                        D, H, levels, (unsigned long long)TM, T, ks, setup_s, ms_per_token, b[0], b[1], b[2], b[3], b[4], b[5], b[6], b[7], ok ? "true" : "false");
         else
-            std::printf("transformer block with a square activation, %zu token(s) per application, %zu key switches + one ct x ct multiply per token; setup %.2f s, %.3f ms per token\n"
+            std::printf("transformer block with a square activation (%s), %zu token(s) per application, %zu key switches + one ct x ct multiply per token; setup %.2f s, %.3f ms per token\n"
                         "  noise budget (bits): fresh %.0f -> qkv %.0f -> v hand-over %.0f -> h1 %.0f -> W_up hand-over %.0f -> 2 limbs %.0f -> squared %.0f -> h2 %.0f\n"
-                        "  h1 %s, activation %s, h2 %s\n", T, ks, setup_s, ms_per_token, b[0], b[1], b[2], b[3], b[4], b[5], b[6], b[7],
+                        "  h1 %s, activation %s, h2 %s\n", levels, T, ks, setup_s, ms_per_token, b[0], b[1], b[2], b[3], b[4], b[5], b[6], b[7],
                         bad_h1 ? "MISMATCH" : "ok", bad_act ? "MISMATCH" : "ok", bad ? "MISMATCH" : "decrypts to h1 + W_down (W_up h1)^2 mod t");
         std::printf(ok ? "OK\n" : "FAILED\n");
         return ok ? 0 : 1;

@@ -120,15 +120,17 @@ def test_example_activated_ffn_block_uses_the_metric_op_and_switches_modulus():
 
 
 @pytest.mark.gpu
-def test_example_whole_block_with_activation():
-    """configs[4] as a forward pass of ONE block with its non-linearity: qkv -> v hand-over -> W_o + residual -> W_up -> modulus switch 5 -> 2 limbs ->
-    square (exact ct x ct multiply) + relinearise -> W_down + residual; h1, the activation and h2 decrypted and compared; eight budget readings."""
+@pytest.mark.parametrize("mode", ["flat", "ladder"])
+def test_example_whole_block_with_activation(mode):
+    """configs[4] as a forward pass of ONE block with its non-linearity: qkv -> v hand-over -> W_o + residual -> W_up -> modulus switch to 2 limbs ->
+    square (exact ct x ct multiply) + relinearise -> W_down + residual; h1, the activation and h2 decrypted and compared; eight budget readings.
+    `ladder`: the modulus falls with the budget inside the block (5 / 4 / 3 / 2 limbs) - same final budget, a sixth less time."""
     import json
-    out = subprocess.run([build_example("encrypted_gpt2_block_act"), "2", "1", "json"], capture_output=True, text=True, timeout=900)
+    out = subprocess.run([build_example("encrypted_gpt2_block_act"), "2", "1", "json"] + (["ladder"] if mode == "ladder" else []), capture_output=True, text=True, timeout=900)
     assert out.returncode == 0 and out.stdout.strip().endswith("OK"), out.stdout[-1500:] + out.stderr[-500:]
     d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
     b = d["budget_bits"]
-    assert d["correct"] is True and len(b) == 8 and b[0] > b[1] > b[2] > b[3] > b[4] > 0 and b[5] > b[6] > b[7] > 0, b
+    assert d["correct"] is True and len(b) == 8 and b[0] > b[1] > b[2] > b[3] > b[4] > 0 and b[5] > b[6] > b[7] > 20, b
 
 
 @pytest.mark.gpu
