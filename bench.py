@@ -331,6 +331,7 @@ def main():
     ap.add_argument("--skip-other", action="store_true", help="skip the other_configs block (profiling runs: every launch is serialised under rocprofv3)")
     ap.add_argument("--ct-mul-form", default="auto", choices=["auto", "quad", "dual", "single", "quadpf", "quad2"],
                     help="form of the fused multiply: auto = measured on this box (library probe + three timed steps per form), or forced")
+    ap.add_argument("--no-live-traffic", action="store_true", help="do not profile the multiply's HBM traffic with rocprofv3 after the timed region (roofline.traffic then quotes the committed profile)")
     ap.add_argument("--dry-run", action="store_true", help="CPU + gloo: walk the multi-rank host path (collectives, barriers, report) without kernels")
     args = ap.parse_args()
     if args.dry_run:
@@ -885,6 +886,20 @@ def main():
             traffic = next(tj[k] for k in ("ct_mul_quad_kernel<FoldArith,12,4>", "ct_mul_dual_kernel<FoldArith,12,4>", "ct_mul_kernel<FoldArith,12,4>") if k in tj)["hbm_bytes_per_ct_mul"] * B
     except Exception:
         pass
+    # ... and, when rocprofv3 is on this box, MEASURED in this run: tools/live_traffic.py profiles 2048-pair launches of the same kernel form with
+    # FETCH_SIZE and WRITE_SIZE in two separate --pmc passes (after the timed region; ~20 s), scaled per ct-mul
+    live_traffic = None
+    if rank == 0 and world == 1 and not args.no_live_traffic:
+        try:
+            import subprocess
+            torch.cuda.synchronize()
+            run = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "live_traffic.py"), autotune.get("chosen") or ""], capture_output=True, text=True, timeout=400)
+            live_traffic = json.loads([l for l in run.stdout.splitlines() if l.startswith("{")][-1])
+            if "hbm_bytes_per_ct_mul" in live_traffic:
+                traffic = live_traffic["hbm_bytes_per_ct_mul"] * B
+                traffic_src = None
+        except Exception as e:
+            live_traffic = {"error": repr(e)[:160]}
     # The bound of this kernel is VALU issue (integer multiply-adds), not HBM: its ceiling is the register-only butterfly loop
     # of tools/ubench2 (same 12-instruction butterfly, no memory traffic, shader clock measured inside the kernel) - measured
     # LIVE by alu_ceiling() before the timed region when tools/bin/ubench2 exists (built by build()), else quoted from the
@@ -927,9 +942,14 @@ def main():
             "bound": "valu", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
             "frac": achieved / HBM_PEAK, "frac_hbm": achieved / HBM_PEAK, "frac_alu": (bfly_per_s / alu_peak) if alu_peak else None,
             "traffic": traffic,
-            "traffic_source": (os.path.relpath(traffic_src, ROOT) + " (committed profile, NOT measured in this run: rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE in their own passes, bytes per launch)") if traffic else None,
-            "measured_in_this_run": ["achieved", "frac", "frac_hbm", "avg_launch_ms", "power"] + (["frac_alu", "alu.achieved", "alu.peak"] if alu_live else ["alu.achieved"]),
-            "quoted_from_committed_profiles": ["traffic"] + ([] if alu_live else ["alu.peak", "frac_alu (its denominator)"]),
+            "traffic_source": ("measured in this run: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (two separate passes of tools/live_traffic.py after the timed region: 2048-pair launches of the same kernel form), (2 x FETCH_SIZE + WRITE_SIZE) x 1024 per ct-mul x batch"
+                               if (live_traffic and "hbm_bytes_per_ct_mul" in live_traffic) else
+                               (os.path.relpath(traffic_src, ROOT) + " (committed profile, NOT measured in this run: rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE in their own passes, bytes per launch)") if (traffic and traffic_src) else None),
+            "traffic_live": live_traffic,
+            "traffic_over_algorithmic": (traffic / alg_bytes) if traffic else None,
+            "measured_in_this_run": ["achieved", "frac", "frac_hbm", "avg_launch_ms", "power"] + (["frac_alu", "alu.achieved", "alu.peak"] if alu_live else ["alu.achieved"])
+                                    + (["traffic"] if (live_traffic and "hbm_bytes_per_ct_mul" in live_traffic) else []),
+            "quoted_from_committed_profiles": ([] if (live_traffic and "hbm_bytes_per_ct_mul" in live_traffic) else ["traffic"]) + ([] if alu_live else ["alu.peak", "frac_alu (its denominator)"]),
             "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": k_avg * 1e3,
             "power": power_result,
             "alu": {"unit": "butterflies/s", "achieved": bfly_per_s, "peak": alu_peak, "peak_clock_mhz": alu_clock,

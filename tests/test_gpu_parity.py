@@ -570,10 +570,12 @@ def test_bench_distributed_path_world_size_one():
     # what the driver's record keeps: the NTT verdict inside `roofline`, the form of the multiply and its measurements inside `config`
     nv, at = d["roofline"]["ntt"], d["config"]["autotune"]
     assert 0 < nv["fwd_frac"] < 1 and 0 < nv["inv_frac"] < 1 and nv["round_trip_exact"] is True and "sustained_2s" in nv
+    lt = d["roofline"]["traffic_live"]   # measured by rocprofv3 in this very run (or an error string when the box has no profiler): never silently absent
+    assert lt is not None and ("error" in lt or 0.99 < lt["hbm_bytes_per_ct_mul"] / lt["algorithmic_bytes_per_ct_mul"] < 1.02), lt
     assert at["chosen"] in ("quad", "dual", "single", "quadpf", "quad2") and set(at["step_probe_ms"]) == {"quad", "dual", "single", "quadpf", "quad2"} and at["at_ctx_create"]["probe_us"]
     assert at["chosen"].replace("quadpf", "quad").replace("quad2", "quad") in d["roofline"]["kernel"].replace("ct_mul_kernel", "single") and "regime" in d["roofline"] and len(line) < 12000
     # the same launch with the library's own communicator as the transport
-    out = subprocess.run(cmd[:-1] + ["--no-cpu-baseline", "--native-comm"], capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    out = subprocess.run(cmd[:-1] + ["--no-cpu-baseline", "--native-comm", "--no-live-traffic"], capture_output=True, text=True, timeout=600, env=env, cwd=root)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert d["reduce_consistent"] is True and "dpfhe_comm_allgather" in d["config"]["collective"]

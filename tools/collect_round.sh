@@ -7,7 +7,7 @@ STEPS=${@:-bench probes prof packed pmc}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-PROF_ARGS="--steps 5 --warmup 1 --no-cpu-baseline --sustained-seconds 0 --skip-other"
+PROF_ARGS="--steps 5 --warmup 1 --no-cpu-baseline --sustained-seconds 0 --skip-other --no-live-traffic"
 db() { find $1 -name "*.db" | head -1; }
 for step in $STEPS; do
 case $step in
