@@ -924,6 +924,17 @@ extern "C" int dpfhe_rotate_hoisted_qp(dpfhe_ctx* c, uint64_t* d_out_qp, const u
             QpElts ge{};
             for (size_t i = 0; i < cnt; ++i) ge.v[i] = galois_elts[first + i];
             // (pairs per thread: 2 measured best at 8 tokens - 291 us against 300 with 1 and 329 with 4 -, 1 is 5 % ahead at one token: profiles/r04_ab_baby_steps.txt)
+            static const bool upfront = [] { const char* e = std::getenv("DPFHE_QP_UPFRONT"); return !(e && e[0] == '0'); }();   // A/B: DPFHE_QP_UPFRONT=0 keeps the loop form
+            if (c->fold && upfront && Ld >= 1 && Ld <= 6) {   // every segment of the workgroup requested up front (one pair of words per thread)
+                const size_t grid1 = qp_stream_grid((int)c->log2n, (int)L, cnt, T, 1);
+                if (grid1 > kMaxGrid) return fail(DPFHE_INVALID_ARGUMENT, what, "batch too large for one launch");
+#define QPU(LD) case LD: hipLaunchKernelGGL((hoisted_qp_upfront_kernel<LD>), dim3((unsigned)grid1), dim3(256), 0, s, dst, d_digits, d_in_ntt, d_keys + first * key_words, key_words, ge, \
+                                            (unsigned)cnt, (unsigned)T, p_special, lc, (int)c->log2n); break
+                switch (Ld) { QPU(1); QPU(2); QPU(3); QPU(4); QPU(5); QPU(6); }
+#undef QPU
+                if (int e = check_launch("hoisted_qp kernel launch")) return e;
+                continue;
+            }
             const size_t grid = qp_stream_grid((int)c->log2n, (int)L, cnt, T);
             if (grid > kMaxGrid) return fail(DPFHE_INVALID_ARGUMENT, what, "batch too large for one launch");
             if (c->fold) hipLaunchKernelGGL((hoisted_qp_stream_kernel<FoldArith, kQpPairs>), dim3((unsigned)grid), dim3(256), 0, s, dst, d_digits, d_in_ntt, d_keys + first * key_words, key_words, ge,

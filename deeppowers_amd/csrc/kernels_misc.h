@@ -903,6 +903,74 @@ __global__ __launch_bounds__(256) void hoisted_qp_stream_kernel(u64* __restrict_
         }
     }
 }
+// The same pass with EVERY operand segment of the workgroup requested up front (round 4, after the workgroup timeline of the multiply put the
+// cost of a first HBM touch at ~3.6 us): the loop form above keeps one digit's segments in flight while it multiplies the previous one, i.e. it
+// pays that latency once per digit; here a thread owns ONE pair of words, the digit count LD is a template parameter, and the 3 LD + 1 loads of
+// the thread are all issued before the first product (straight-line code: hipcc counts vmcnt exactly).  FoldArith, LD <= 6.
+template <int LD>
+__global__ __launch_bounds__(256) void hoisted_qp_upfront_kernel(u64* __restrict__ out, const u64* __restrict__ digits, const u64* __restrict__ xntt,
+                                                                 const u64* __restrict__ keys, size_t key_stride, QpElts elts, unsigned n_rot, unsigned n_items,
+                                                                 u64 p_special, const LimbConst* __restrict__ lcs, int log2n) {
+    constexpr int L = LD + 1;
+    const int n1 = log2n - 1;
+    const unsigned half = 1u << n1, n = 2u << n1, seg_pairs = 256u;
+    const unsigned nseg = half > seg_pairs ? half / seg_pairs : 1u, tbits = 31u - (unsigned)__clz((int)nseg);
+    const unsigned combos = (unsigned)L * nseg, n_rg = (n_rot + kQpRotGroup - 1) / kQpRotGroup, bs = (unsigned)kQpRotGroup * n_items;
+    const unsigned xcd = blockIdx.x & 7u, q = blockIdx.x >> 3, within = q % bs, t1 = q / bs, rg = t1 % n_rg, combo = (t1 / n_rg) * 8u + xcd;
+    const unsigned rot = rg * kQpRotGroup + within / n_items, token = within % n_items;
+    if (combo >= combos || rot >= n_rot) return;
+    const int limb = (int)(combo % (unsigned)L);
+    const unsigned sseg = combo / (unsigned)L;
+    const unsigned g = elts.v[rot];
+    unsigned ginv = g;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) ginv *= 2u - g * ginv;
+    const unsigned uo = (ginv * (2u * qp_brev(sseg, (int)tbits) + 1u)) & (2u * nseg - 1u);
+    const unsigned oseg = qp_brev((uo - 1u) >> 1, (int)tbits);
+    const LimbConst lc = lcs[limb];
+    const size_t N = n;
+    const unsigned mo = oseg * seg_pairs + threadIdx.x;
+    if (mo >= half) return;
+    const unsigned cf = (g * (2u * qp_brev(mo, n1) + 1u)) & (2u * n - 1u);
+    const bool sw = cf >= n;
+    const unsigned ms = qp_brev(((cf & (n - 1u)) - 1u) >> 1, n1);
+    const size_t item = (size_t)rot * n_items + token;
+    const U64x2* dig = reinterpret_cast<const U64x2*>(digits + ((size_t)token * LD * L + limb) * N) + ms;      // digit j at + j L N words
+    const U64x2* evk = reinterpret_cast<const U64x2*>(keys + (size_t)rot * key_stride + (size_t)limb * N) + mo;  // key (j, comp) at + (j 2 + comp) L N words
+    const size_t tile = (size_t)L * N / 2;   // in 16-byte units
+    U64x2 x[LD], e0[LD], e1[LD], c0{0, 0};
+    const bool data_limb = limb < LD;
+    if (data_limb) c0 = (reinterpret_cast<const U64x2*>(xntt + ((size_t)token * 2 * LD + limb) * N))[ms];
+#pragma unroll
+    for (int j = 0; j < LD; ++j) {
+        x[j] = dig[(size_t)j * tile];
+        e0[j] = evk[(size_t)(2 * j) * tile];
+        e1[j] = evk[(size_t)(2 * j + 1) * tile];
+    }
+    typedef FoldArith::Dot30 Dot;
+    typedef FoldArith::Half30 Half;
+    static_assert(LD + 1 <= FoldArith::kDot30Period, "one fold per accumulator");
+    Dot s0[2] = {Dot{0, 0, 0}, Dot{0, 0, 0}}, s1[2] = {Dot{0, 0, 0}, Dot{0, 0, 0}};
+    if (data_limb) {   // P perm_g(NTT(c0)) on the data limbs
+        const Half hp = FoldArith::split30(FoldArith::canon(p_special, lc));
+        FoldArith::dot30_mac(s0[0], FoldArith::split30(sw ? c0.b : c0.a), hp);
+        FoldArith::dot30_mac(s0[1], FoldArith::split30(sw ? c0.a : c0.b), hp);
+    }
+#pragma unroll
+    for (int j = 0; j < LD; ++j) {
+        const Half xa = FoldArith::split30(sw ? x[j].b : x[j].a), xb = FoldArith::split30(sw ? x[j].a : x[j].b);
+        FoldArith::dot30_mac(s0[0], xa, FoldArith::split30(e0[j].a));
+        FoldArith::dot30_mac(s0[1], xb, FoldArith::split30(e0[j].b));
+        FoldArith::dot30_mac(s1[0], xa, FoldArith::split30(e1[j].a));
+        FoldArith::dot30_mac(s1[1], xb, FoldArith::split30(e1[j].b));
+    }
+    U64x2 r0, r1;
+    r0.a = FoldArith::canon_small(FoldArith::dot30_fold(s0[0], 0, lc), lc); r0.b = FoldArith::canon_small(FoldArith::dot30_fold(s0[1], 0, lc), lc);
+    r1.a = FoldArith::canon_small(FoldArith::dot30_fold(s1[0], 0, lc), lc); r1.b = FoldArith::canon_small(FoldArith::dot30_fold(s1[1], 0, lc), lc);
+    st_vec<true>(reinterpret_cast<U64x2*>(out + ((item * 2 + 0) * L + limb) * N) + mo, r0);
+    st_vec<true>(reinterpret_cast<U64x2*>(out + ((item * 2 + 1) * L + limb) * N) + mo, r1);
+}
+
 // grid of the stream kernel (dpfhe_cabi.hip): 8 XCDs x blocks of (16 rotations x n_items) x rotation groups x ceil(L nseg / 8)
 inline size_t qp_stream_grid(int log2n, int n_limbs, size_t n_rot, size_t n_items, int pairs = kQpPairs) {
     const size_t half = (size_t)1 << (log2n - 1), seg_pairs = 256 * (size_t)pairs, nseg = half > seg_pairs ? half / seg_pairs : 1;
