@@ -371,6 +371,9 @@ extern "C" int dpfhe_ctx_uses_fold(const dpfhe_ctx* c) { return c && c->fold ? 1
 #ifndef DPFHE_MATVEC_WPT4
 #define DPFHE_MATVEC_WPT4 1
 #endif
+#ifndef DPFHE_MATVEC_WD
+#define DPFHE_MATVEC_WD 1     // columns of W lookahead in the multi-right-hand-side product (tools/ab_variant.sh mvwd2 -DDPFHE_MATVEC_WD=2 ... for A/B runs)
+#endif
 #ifndef DPFHE_MATVEC_RT4
 #define DPFHE_MATVEC_RT4 4    // rows per workgroup of the 4-polynomial (2-token) kernel; tools/ab_variant.sh mvrt8 -DDPFHE_MATVEC_RT4=8 for A/B runs
 #endif
@@ -1094,7 +1097,7 @@ extern "C" int dpfhe_matvec_plain_multi(dpfhe_ctx* c, uint64_t* d_y, const uint6
         const size_t slabs = c->n_limbs * (size_t)chunks, rtiles = (rows + RT - 1) / RT, tiles = rtiles * slabs;                                         \
         const size_t blocks = ((slabs + 7) / 8) * 8 * rtiles * (GROUPS);                                                                                 \
         if (blocks > kMaxGrid) return fail(DPFHE_INVALID_ARGUMENT, what, "too many rows for one launch");                                             \
-        hipLaunchKernelGGL((matvec_fold_kernel<RT, C, WPT>), dim3((unsigned)blocks), dim3(256), 0, s, YS, d_W, XS, c->foldt.lc, (int)c->n_limbs, n, chunks, rows, cols, \
+        hipLaunchKernelGGL((matvec_fold_kernel<RT, C, WPT, false, DPFHE_MATVEC_WD>), dim3((unsigned)blocks), dim3(256), 0, s, YS, d_W, XS, c->foldt.lc, (int)c->n_limbs, n, chunks, rows, cols, \
                            n_rhs * 2, (unsigned)(GROUPS), (unsigned)tiles);                                                                              \
     }
         if (pairs) {

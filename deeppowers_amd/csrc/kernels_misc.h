@@ -367,7 +367,10 @@ __device__ __forceinline__ WordVec<WPT> load_words(const u64* p, bool in_range) 
 }
 
 // NTW: the W tiles are read once by ONE workgroup (a single group of right-hand sides) and W does not fit the Infinity Cache: non-temporal loads
-template <int RT, int C, int WPT, bool NTW = false>
+// WD: how many columns AHEAD the W words are requested (a register ring of WD x RT words; WD divides the period).  The W stream is the one
+// operand that comes from HBM (one workgroup group reads each tile once), x comes from L2: round 4 measured ~3.6 us from issue to first word for
+// an HBM burst under load, against ~0.5 us of products per column - one column of lookahead cannot cover it.
+template <int RT, int C, int WPT, bool NTW = false, int WD = 1>
 __global__ __launch_bounds__(256) void matvec_fold_kernel(u64* y, const u64* W, const u64* x, const LimbConst* lcs, int n_limbs, int n,
                                                           int chunks, size_t rows, size_t cols, size_t polys_per_col, unsigned n_groups,
                                                           unsigned n_tiles) {
@@ -400,9 +403,12 @@ __global__ __launch_bounds__(256) void matvec_fold_kernel(u64* y, const u64* W, 
         for (int c = 0; c < C; ++c)
 #pragma unroll
             for (int k = 0; k < WPT; ++k) run[r][c][k] = 0;
-    V w[RT], xv[C];
+    static_assert(WD >= 1 && FoldArith::kDot30Period % WD == 0, "the W ring must divide the period");
+    V wq[WD][RT], xv[C];
 #pragma unroll
-    for (int r = 0; r < RT; ++r) w[r] = ld_w(r, 0);
+    for (int d = 0; d < WD; ++d)
+#pragma unroll
+        for (int r = 0; r < RT; ++r) wq[d][r] = ld_w(r, (size_t)d < cols ? (size_t)d : cols - 1);
 #pragma unroll
     for (int c = 0; c < C; ++c) xv[c] = ld_x(c, 0);
     // Periods of P columns, unrolled: the accumulators of a period start from {running word, 0, 0} as multiply-add addends (no
@@ -416,10 +422,10 @@ __global__ __launch_bounds__(256) void matvec_fold_kernel(u64* y, const u64* W, 
                 if (u == 0) break;
                 continue;
             }
-            const size_t jn = j + 1 < cols ? j + 1 : j;
-            V wn[RT], xn[C];
+            const size_t jn = j + 1 < cols ? j + 1 : j, jw = j + WD < cols ? j + WD : cols - 1;
+            V w[RT], xn[C];
 #pragma unroll
-            for (int r = 0; r < RT; ++r) wn[r] = ld_w(r, jn);
+            for (int r = 0; r < RT; ++r) { w[r] = wq[u % WD][r]; wq[u % WD][r] = ld_w(r, jw); }   // slot of column j is free: column j + WD goes there
 #pragma unroll
             for (int c = 0; c < C; ++c) xn[c] = ld_x(c, jn);
 #pragma unroll
@@ -437,8 +443,6 @@ __global__ __launch_bounds__(256) void matvec_fold_kernel(u64* y, const u64* W, 
                         FoldArith::dot30_mac(acc[r][c][k], wh[r], xh[c]);
                     }
             }
-#pragma unroll
-            for (int r = 0; r < RT; ++r) w[r] = wn[r];
 #pragma unroll
             for (int c = 0; c < C; ++c) xv[c] = xn[c];
         }
