@@ -53,21 +53,18 @@ __device__ __forceinline__ void exch_sync_after_write() {
 // ------------------------------------------------------------------------------------------------
 // The per-thread twiddles of phase P+1 are requested BEFORE the LDS exchange that follows phase P (the registers of
 // phase P's twiddles are dead by then), so their L2 latency overlaps the exchange instead of stalling the next phase.
-struct NoHook { __device__ __forceinline__ void operator()() const {} };
-// `at_last_phase` (run<false> / run_with only): called when the LAST forward phase is about to start - from there on no further twiddles are
-// requested, so ~60 vector registers are free for the caller's own loads (relin_kernel requests the first key tile of the digit there).
 template <class B, int P>
 struct FwdChain {
     typedef typename B::TwRegs TwRegs;
     // entry point (P = 0): the top window's twiddles are workgroup-uniform scalars, so the per-thread twiddles of phase 1
     // are requested right away, together with the caller's data loads, a whole phase ahead of their first use
     // (EARLY = false where the extra 4 (E-1) live registers during phase 0 would spill: the fused kernels)
-    template <bool EARLY = true, class Hook = NoHook>
-    static __device__ __forceinline__ void run(int tid, u64 (&x)[B::E], u64* lds, const typename B::Tw* tw, const LimbConst& lc, Hook&& at_last_phase = Hook()) {
+    template <bool EARLY = true>
+    static __device__ __forceinline__ void run(int tid, u64 (&x)[B::E], u64* lds, const typename B::Tw* tw, const LimbConst& lc) {
         TwRegs twr;
         B::template load_tw<P, true>(tid, tw, twr);
         if constexpr (!EARLY) {
-            run_with(tid, x, lds, tw, lc, twr, at_last_phase);
+            run_with(tid, x, lds, tw, lc, twr);
         } else if constexpr (P + 1 < B::NPH) {
             TwRegs nxt;
             B::template load_tw<P + 1, true>(tid, tw, nxt);
@@ -76,15 +73,13 @@ struct FwdChain {
             B::template lds_write<P, P, true>(tid, x, lds);
             exch_sync_after_write<typename B::G, P>();
             B::template lds_read<P, P + 1, true>(tid, x, lds);
-            FwdChain<B, P + 1>::run_with(tid, x, lds, tw, lc, nxt, at_last_phase);
+            FwdChain<B, P + 1>::run_with(tid, x, lds, tw, lc, nxt);
         } else {
             B::template fwd_phase_r<P>(x, twr, lc);
         }
     }
-    template <class Hook = NoHook>
     static __device__ __forceinline__ void run_with(int tid, u64 (&x)[B::E], u64* lds, const typename B::Tw* tw, const LimbConst& lc,
-                                                    const TwRegs& twr, Hook&& at_last_phase = Hook()) {
-        if constexpr (P + 1 == B::NPH) at_last_phase();
+                                                    const TwRegs& twr) {
         B::template fwd_phase_r<P>(x, twr, lc);
         if constexpr (P + 1 < B::NPH) {
             TwRegs nxt;
@@ -93,7 +88,7 @@ struct FwdChain {
             B::template lds_write<P, P, true>(tid, x, lds);
             exch_sync_after_write<typename B::G, P>();
             B::template lds_read<P, P + 1, true>(tid, x, lds);
-            FwdChain<B, P + 1>::run_with(tid, x, lds, tw, lc, nxt, at_last_phase);
+            FwdChain<B, P + 1>::run_with(tid, x, lds, tw, lc, nxt);
         }
     }
 };
@@ -232,6 +227,7 @@ struct InvChain2 {
 // Three inverse transforms of one limb on two LDS buffers (x | y, then z reuses buffer 0), one set of twiddle fetches.
 // `at_last_phase` runs when the LAST phase (the top window: workgroup-uniform twiddles in scalar registers) is about to start: the ~60 vector
 // registers of the per-thread twiddles are free from there on, which is where a caller can have the next operands requested (ct_mul_quad2_kernel).
+struct NoHook { __device__ __forceinline__ void operator()() const {} };
 template <class B, int P, int IN>
 struct InvChain3 {
     typedef typename B::TwRegs TwRegs;
@@ -815,46 +811,6 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE), (Arith::kFold ? 2 : 1)) void re
 #pragma unroll
     for (int k = 0; k < E; ++k) acc0[k] = acc1[k] = 0;
     int lazy_terms = 0;
-    // key polynomials are NTT-domain tiles: transposed through LDS (rows private to the wave) where that measured
-    // faster (N = 8192: -7 %), in registers otherwise (N = 4096: the LDS path is 5 % slower at 2 waves per SIMD)
-    constexpr bool kLdsKeys = B::kLdsIO && LOGN >= 13;
-    if constexpr (kLdsKeys && Arith::kFold) {
-        // Round 4: SOFTWARE-PIPELINED over the digits.  One 8-wave workgroup owns the CU here, so every exposed load idles it: the first key
-        // tile of a digit is requested when the LAST forward phase starts (its registers are free from there: FwdChain's hook), the second key
-        // tile and the NEXT digit during the first component's products.
-        u64 x[E];
-        B::load_top(tid, x, c2);
-#pragma unroll 1
-        for (int j = 0; j < Ld; ++j) {
-            asm volatile("" : "+v"(tid));
-#pragma unroll
-            for (int k = 0; k < E; ++k) x[k] = canon_any<Arith>(x[k], lc);   // [c2]_{q_j} mod q_i
-            const u64* k0 = evk + (((size_t)j * 2 + 0) * L + limb) * N;      // key polynomials, NTT domain (window-0 mapping)
-            const u64* k1 = evk + (((size_t)j * 2 + 1) * L + limb) * N;
-            if (j > 0) lds_barrier();
-            u64 ve[E];
-            FwdChain<B, 0>::template run<false>(tid, x, lds, tb.fwd4 + (size_t)limb * N, lc, [&]() { B::stage_load(tid, ve, k0); });
-            static_assert(13 * kMulB + kRedB <= kWord, "13 lazily added products + one reduced word must fit a 64-bit word");
-            if (lazy_terms == 13) {  // 13 products + one reduced word stay below 15 q
-#pragma unroll
-                for (int k = 0; k < E; ++k) { acc0[k] = FoldArith::reduce(acc0[k], lc); acc1[k] = FoldArith::reduce(acc1[k], lc); }
-                lazy_terms = 1;
-            }
-            ++lazy_terms;
-            u64 e[E], xn[E];
-            B::stage_rows(tid, e, ve, lds);
-            B::stage_load(tid, ve, k1);
-            const int jn = j + 1 < Ld ? j + 1 : j;   // the last iteration re-requests its own digit (a cache hit) instead of branching
-            B::load_top(tid, xn, c2 + (size_t)jn * N);
-#pragma unroll
-            for (int k = 0; k < E; ++k) acc0[k] += FoldArith::mul60(x[k], e[k], (u32)lc.d);
-            B::stage_rows(tid, e, ve, lds);
-#pragma unroll
-            for (int k = 0; k < E; ++k) acc1[k] += FoldArith::mul60(x[k], e[k], (u32)lc.d);
-#pragma unroll
-            for (int k = 0; k < E; ++k) x[k] = xn[k];
-        }
-    } else {
 #pragma unroll 1
     for (int j = 0; j < Ld; ++j) {
         asm volatile("" : "+v"(tid));
@@ -881,6 +837,7 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE), (Arith::kFold ? 2 : 1)) void re
             u64 e[E];
             // key polynomials are NTT-domain tiles: transposed through LDS (rows private to the wave) where that measured
             // faster (N = 8192: -7 %), in registers otherwise (N = 4096: the LDS path is 5 % slower at 2 waves per SIMD)
+            constexpr bool kLdsKeys = B::kLdsIO && LOGN >= 13;
             if constexpr (kLdsKeys) B::load_bot_lds(tid, e, k0, lds); else B::load_bot(tid, e, k0);
 #pragma unroll
             for (int k = 0; k < E; ++k)
@@ -891,7 +848,6 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE), (Arith::kFold ? 2 : 1)) void re
             for (int k = 0; k < E; ++k)
                 acc1[k] = Arith::kFold ? acc1[k] + FoldArith::mul60(x[k], e[k], (u32)lc.d) : add_mod(acc1[k], ShoupArith::mul_var(x[k], e[k], lc), lc.q);
         }
-    }
     }
     if (Arith::kFold) {
 #pragma unroll
