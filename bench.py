@@ -893,7 +893,7 @@ def main():
         try:
             import subprocess
             torch.cuda.synchronize()
-            run = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "live_traffic.py"), autotune.get("chosen") or ""], capture_output=True, text=True, timeout=400)
+            run = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "live_traffic.py"), autotune.get("chosen") or ""], capture_output=True, text=True, timeout=170)
             live_traffic = json.loads([l for l in run.stdout.splitlines() if l.startswith("{")][-1])
             if "hbm_bytes_per_ct_mul" in live_traffic:
                 traffic = live_traffic["hbm_bytes_per_ct_mul"] * B

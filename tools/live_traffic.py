@@ -67,7 +67,7 @@ def main():
         d = tempfile.mkdtemp(prefix="dpfhe_pmc_", dir="/tmp")
         try:
             run = subprocess.run([exe, "--pmc", counter, "-d", d, "-o", "pmc", "--", sys.executable, os.path.abspath(__file__), "worker", str(PAIRS)],
-                                 capture_output=True, text=True, timeout=150, env=env, cwd="/tmp")
+                                 capture_output=True, text=True, timeout=75, env=env, cwd="/tmp")
             dbs = glob.glob(os.path.join(d, "**", "*.db"), recursive=True)
             if run.returncode != 0 or not dbs:
                 out["error"] = f"{counter}: rc {run.returncode}: " + (run.stderr or run.stdout)[-200:]
