@@ -301,9 +301,10 @@ def digest_other(o):
         e = {"all_correct": pl.get("all_correct")}
         if pl.get("layers"):
             e["ms_per_token"] = {f"{l.get('layer', '?')}@{l.get('tokens', '?')}": r3(l.get("ms_per_token")) for l in pl["layers"]}
-        for blk in ("ffn_block", "transformer_block", "activated_ffn", "activated_block"):
+        for blk in ("ffn_block", "transformer_block", "activated_ffn", "activated_block", "activated_stack"):
             if isinstance(pl.get(blk), dict):
-                e[blk] = {x: pl[blk].get(x) for x in ("ms_per_token", "correct", "tokens", "error", "budget_bits", "levels") if pl[blk].get(x) is not None}
+                e[blk] = {x: pl[blk].get(x) for x in ("ms_per_token", "ms_per_token_per_block", "correct", "blocks", "correct_blocks", "data_limbs", "tokens", "error", "budget_bits",
+                                                      "levels", "limbs_per_level") if pl[blk].get(x) is not None}
         ks = pl.get("kernels") or {}
         if ks.get("stages"):
             e["stages"] = [{"stage": st["stage"].split(" (")[0][:40], "us": round(st["median_us"], 1), "frac_hbm": r3(st["frac_of_hbm_peak"]),
@@ -729,6 +730,12 @@ def main():
             run = subprocess.run([example("encrypted_gpt2_block_act"), "8", "2", "json", "ladder"], capture_output=True, text=True, timeout=600)   # modulus 5 / 4 / 3 / 2 limbs inside the block
             got = [json.loads(l) for l in run.stdout.splitlines() if l.startswith("{")]
             other["packed_linear"]["activated_block"] = got[0] if got and run.returncode == 0 else {"error": (run.stdout + run.stderr)[-300:]}
+            # ... and THREE such blocks in a row on ten data limbs (600 bits), the limb count of every level planned from a budget model and falling
+            # 10 -> 2 over the 18 levels, the activations as exact multiplies at eight-, five- and two-limb levels; every block's output decrypted
+            # and compared (examples/encrypted_gpt2_stack.cpp; gpt_model.cpp:626-672, the layer loop)
+            run = subprocess.run([example("encrypted_gpt2_stack"), "8", "1", "json", "10"], capture_output=True, text=True, timeout=600)
+            got = [json.loads(l) for l in run.stdout.splitlines() if l.startswith("{")]
+            other["packed_linear"]["activated_stack"] = got[0] if got and run.returncode == 0 else {"error": (run.stdout + run.stderr)[-300:]}
         except Exception as e:   # a missing example binary must not take the headline metric down with it
             other.setdefault("packed_linear", {})["error"] = repr(e)[:300]
         return other

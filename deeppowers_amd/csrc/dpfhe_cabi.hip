@@ -20,6 +20,7 @@
 #include <vector>
 
 #include "../../include/dpfhe.h"
+#include "base_ext.h"
 #include "kernels_large.h"
 #include "kernels_misc.h"
 #include "launch.h"
@@ -1192,7 +1193,7 @@ static int base_extend_common(dpfhe_ctx* c, int mode, uint64_t* d_out, size_t ou
     if (n_polys == 0) return DPFHE_SUCCESS;
     const uint32_t L = c->n_limbs;
     if (ns == 0 || ns > (uint32_t)kBxMaxSrc || nd == 0 || nd > (uint32_t)kBxMaxDst || src0 + ns > L || dst0 + nd > L)
-        return fail(DPFHE_INVALID_ARGUMENT, what, "1..4 source limbs and 1..8 destination limbs inside the context");
+        return fail(DPFHE_INVALID_ARGUMENT, what, "1..10 source limbs and 1..20 destination limbs inside the context");
     if (mode == 1 && !(dst0 >= src0 + ns || dst0 + nd <= src0)) return fail(DPFHE_INVALID_ARGUMENT, what, "the dropped limbs and the kept limbs must be disjoint");
     if (!d_out || !d_in || misaligned(d_out) || misaligned(d_in) || out_stride_limbs < nd || in_stride_limbs < ns) return fail(DPFHE_INVALID_ARGUMENT, what, "null or misaligned buffer, or an item stride shorter than its limbs");
     const size_t n = (size_t)1 << c->log2n;
@@ -1239,13 +1240,9 @@ static int base_extend_common(dpfhe_ctx* c, int mode, uint64_t* d_out, size_t ou
     const unsigned grid = (unsigned)(n_polys * (size_t)chunks);
     const size_t in_dst_off = mode == 1 ? ((size_t)dst0 - (size_t)src0) * n : 0;   // d_in points at the first DROPPED limb of item 0 (may wrap below it: size_t arithmetic, same pointer sum)
     const LimbConst* lc = c->fold ? c->foldt.lc : c->shoup.lc;
-    if (c->fold) {
-        if (mode == 0) hipLaunchKernelGGL((base_extend_kernel<FoldArith, 0>), dim3(grid), dim3(256), 0, s, d_out, out_stride_limbs * n, d_in, in_stride_limbs * n, in_dst_off, a, lc, (int)n, chunks);
-        else hipLaunchKernelGGL((base_extend_kernel<FoldArith, 1>), dim3(grid), dim3(256), 0, s, d_out, out_stride_limbs * n, d_in, in_stride_limbs * n, in_dst_off, a, lc, (int)n, chunks);
-    } else {
-        if (mode == 0) hipLaunchKernelGGL((base_extend_kernel<ShoupArith, 0>), dim3(grid), dim3(256), 0, s, d_out, out_stride_limbs * n, d_in, in_stride_limbs * n, in_dst_off, a, lc, (int)n, chunks);
-        else hipLaunchKernelGGL((base_extend_kernel<ShoupArith, 1>), dim3(grid), dim3(256), 0, s, d_out, out_stride_limbs * n, d_in, in_stride_limbs * n, in_dst_off, a, lc, (int)n, chunks);
-    }
+    const int rc = c->fold ? launch_base_extend<FoldArith>(mode, d_out, out_stride_limbs * n, d_in, in_stride_limbs * n, in_dst_off, a, lc, (int)n, chunks, grid, s)
+                           : launch_base_extend<ShoupArith>(mode, d_out, out_stride_limbs * n, d_in, in_stride_limbs * n, in_dst_off, a, lc, (int)n, chunks, grid, s);
+    if (rc) return fail(DPFHE_INVALID_STATE, what, "no kernel for this number of source limbs");
     return check_launch("base_extend kernel launch");
 }
 extern "C" int dpfhe_base_extend(dpfhe_ctx* c, uint64_t* d_out, size_t out_stride_limbs, const uint64_t* d_in, size_t in_stride_limbs, uint32_t src_limb0, uint32_t n_src,

@@ -34,10 +34,20 @@ void hip_check(hipError_t e, const char* what) {
     if (e != hipSuccess)
         throw Exception(e == hipErrorOutOfMemory ? ErrorCode::OUT_OF_MEMORY : ErrorCode::DEVICE_ERROR, std::string(what) + ": " + hipGetErrorString(e));
 }
-const uint64_t kPrimes60[6][3] = {
-    {1152921504606830593ull, 116777451583545ull, 25959043411404ull},  {1152921504606748673ull, 271802498405390ull, 100406242475323ull},
-    {1152921504606683137ull, 134367042585739ull, 45474351589225ull},  {1152921504606601217ull, 276147373136904ull, 92707844590835ull},
-    {1152921504606584833ull, 317490233586139ull, 23981819781494ull},  {1152921504606109697ull, 279138086580908ull, 253932030982881ull}};
+// the 20 largest primes below 2^60 that are 1 mod 2^14, largest first (deeppowers_amd/params.py ntt_primes(13, 20) generates the same list): {q, smallest
+// primitive 8192-th root (N = 4096; 0 = not tabulated), smallest primitive 16384-th root (N = 8192)}
+constexpr size_t kChainPrimes = 20;
+const uint64_t kPrimes60[kChainPrimes][3] = {
+    {1152921504606830593ull, 116777451583545ull, 25959043411404ull}, {1152921504606748673ull, 271802498405390ull, 100406242475323ull},
+    {1152921504606683137ull, 134367042585739ull, 45474351589225ull}, {1152921504606601217ull, 276147373136904ull, 92707844590835ull},
+    {1152921504606584833ull, 317490233586139ull, 23981819781494ull}, {1152921504606109697ull, 279138086580908ull, 253932030982881ull},
+    {1152921504605962241ull, 0ull, 64984728504994ull}, {1152921504605913089ull, 0ull, 27694533958986ull},
+    {1152921504605847553ull, 0ull, 105031879276246ull}, {1152921504605618177ull, 0ull, 157253107066567ull},
+    {1152921504604979201ull, 0ull, 76334773615457ull}, {1152921504604766209ull, 0ull, 14852029848402ull},
+    {1152921504604635137ull, 0ull, 93806574463579ull}, {1152921504602505217ull, 0ull, 217691047434989ull},
+    {1152921504601980929ull, 0ull, 112510666220977ull}, {1152921504601915393ull, 0ull, 12114078003698ull},
+    {1152921504601784321ull, 0ull, 4580624056246ull}, {1152921504600309761ull, 0ull, 135029094688496ull},
+    {1152921504600260609ull, 0ull, 120773065591640ull}, {1152921504600145921ull, 0ull, 1663825873988ull}};
 }  // namespace
 
 FheParams FheParams::drop_last_limb() const {
@@ -52,9 +62,11 @@ FheParams FheParams::n4096_l4() {
     for (int i = 0; i < 4; ++i) { p.moduli.push_back(kPrimes60[i][0]); p.psi.push_back(kPrimes60[i][1]); }
     return p;
 }
-FheParams FheParams::n8192_l6() {
+FheParams FheParams::n8192_l6() { return n8192(6); }
+FheParams FheParams::n8192(size_t n_limbs) {
+    if (n_limbs == 0 || n_limbs > kChainPrimes) throw Exception(ErrorCode::INVALID_ARGUMENT, "FheParams::n8192: 1..20 limbs");
     FheParams p{13, {}, {}};
-    for (int i = 0; i < 6; ++i) { p.moduli.push_back(kPrimes60[i][0]); p.psi.push_back(kPrimes60[i][2]); }
+    for (size_t i = 0; i < n_limbs; ++i) { p.moduli.push_back(kPrimes60[i][0]); p.psi.push_back(kPrimes60[i][2]); }
     return p;
 }
 
@@ -332,8 +344,8 @@ ExactMultiplier::ExactMultiplier(const Context& work_ctx, const Context& level_c
     const FheParams &pw = work_ctx.params(), &pl = level_ctx.params();
     impl_->work = &work_ctx; impl_->level = &level_ctx; impl_->t = plain_modulus;
     impl_->ll = pl.n_limbs(); impl_->L = pw.n_limbs(); impl_->n = pw.n();
-    if (pl.log2_n != pw.log2_n || impl_->ll == 0 || impl_->ll >= impl_->L || impl_->ll > 4 || work_ctx.device_id() != level_ctx.device_id() || plain_modulus < 2)
-        throw Exception(ErrorCode::INVALID_ARGUMENT, "ExactMultiplier: the level context must hold the first 1..4 limbs of the work context (same ring degree and device)");
+    if (pl.log2_n != pw.log2_n || impl_->ll == 0 || impl_->ll >= impl_->L || impl_->ll > 9 || impl_->L > 20 || impl_->L - impl_->ll > 10 || work_ctx.device_id() != level_ctx.device_id() || plain_modulus < 2)
+        throw Exception(ErrorCode::INVALID_ARGUMENT, "ExactMultiplier: the level context must hold the first 1..9 limbs of the work context, which has at most 20 and at most 10 beyond the level (same ring degree and device)");
     for (size_t i = 0; i < impl_->ll; ++i)
         if (pl.moduli[i] != pw.moduli[i]) throw Exception(ErrorCode::INVALID_ARGUMENT, "ExactMultiplier: the level's moduli must be the first moduli of the work context");
     double lq = 0, lQ = 0, lW = 0;

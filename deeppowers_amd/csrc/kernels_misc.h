@@ -14,10 +14,6 @@ namespace dpfhe {
 // ------------------------------------------------------------------------------------------------
 enum DyOp { DY_MUL = 0, DY_MUL_ADD = 1, DY_ADD = 2, DY_SUB = 3, DY_NEG = 4 };
 
-struct __attribute__((aligned(16))) U64x2 {
-    u64 a, b;
-};
-
 template <class Arith, int OP>
 __device__ __forceinline__ u64 dy_apply(u64 a, u64 b, u64 acc, const LimbConst& lc) {
     if (OP == DY_MUL) return Arith::mul_var(a, b, lc);
@@ -633,95 +629,8 @@ __global__ __launch_bounds__(256) void lift_qp_kernel(u64* out, const u64* in, c
     *reinterpret_cast<U64x2*>(out + (poly * n_limbs + limb) * n + w0) = r;
 }
 
-// ------------------------------------------------------------------------------------------------
-// Round 4 (towards configs[4] with a non-linear layer): EXACT base extension between limb ranges of one context, and the
-// scale-and-round of an exact (BFV-style) ciphertext multiply.  Per coefficient, from the residues x_i mod q_i of the source limbs:
-//   mixed-radix (Garner) digits  v_0 = x_0,  v_k = ((x_k - v_0) q_0^-1 - v_1) q_1^-1 ... mod q_k,   X = v_0 + q_0 (v_1 + q_1 (v_2 + ...)) in [0, Qs);
-//   centred: X > floor(Qs / 2) (compared digit by digit from the top) means the represented integer is X - Qs;
-//   MODE 0 (extend):      out_j = X mod p_j                                   for every destination limb j
-//   MODE 1 (scale-round): the sources are mul * x_i (the input times a small multiplier, e.g. the plaintext modulus t), the input also
-//                         holds the destination limbs, and  out_j = (mul x_j - X) Qs^-1 mod p_j  =  round(mul x / Qs) mod p_j  exactly.
-// At most 4 source limbs (240 bits) - the ciphertext modulus of the level a multiply runs at.  One thread per pair of words.
-// ------------------------------------------------------------------------------------------------
-constexpr int kBxMaxSrc = 4, kBxMaxDst = 8;
-struct BaseExtArgs {
-    int n_src, n_dst;
-    int src_limb[kBxMaxSrc], dst_limb[kBxMaxDst];   // indices into the context's limb constants
-    u64 inv[kBxMaxSrc][kBxMaxSrc];                  // inv[i][k] = q_i^-1 mod q_k, i < k (source limbs)
-    u64 half[kBxMaxSrc];                            // mixed-radix digits of floor(Qs / 2)
-    u64 q_mod[kBxMaxSrc][kBxMaxDst];                // q_i mod p_j
-    u64 Q_mod[kBxMaxDst];                           // Qs mod p_j
-    u64 Q_inv[kBxMaxDst];                           // Qs^-1 mod p_j              (MODE 1)
-    u64 mul_src[kBxMaxSrc], mul_dst[kBxMaxDst];     // the multiplier mod q_i / mod p_j (MODE 1)
-};
-template <class Arith>
-__device__ __forceinline__ u64 bx_canon(u64 v, const LimbConst& lc) {   // any word -> [0, q)
-    if constexpr (Arith::kFold) return FoldArith::canon(v, lc);
-    else return ShoupArith::mul_var(v, 1, lc);
-}
-template <class Arith, int MODE>
-__global__ __launch_bounds__(256) void base_extend_kernel(u64* __restrict__ out, size_t out_stride, const u64* __restrict__ in, size_t in_stride,
-                                                          size_t in_dst_off /* MODE 1: word offset of the destination limbs inside an input item */,
-                                                          BaseExtArgs a, const LimbConst* __restrict__ lcs, int n, int chunks) {
-    const int chunk = (int)(blockIdx.x % chunks);
-    const size_t p = blockIdx.x / chunks;
-    const int w0 = chunk * 512 + threadIdx.x * 2;
-    if (w0 >= n) return;
-    const u64* src = in + p * in_stride + w0;
-    u64 v[kBxMaxSrc][2];
-#pragma unroll
-    for (int k = 0; k < kBxMaxSrc; ++k) {
-        if (k >= a.n_src) break;
-        const LimbConst lck = lcs[a.src_limb[k]];
-        const U64x2 xv = *reinterpret_cast<const U64x2*>(src + (size_t)k * n);
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            u64 t = h ? xv.b : xv.a;
-            if (MODE == 1) t = Arith::mul_var(t, a.mul_src[k], lck);
-#pragma unroll
-            for (int i = 0; i < kBxMaxSrc; ++i) {
-                if (i >= k) break;
-                t = Arith::mul_var(sub_mod(t, bx_canon<Arith>(v[i][h], lck), lck.q), a.inv[i][k], lck);
-            }
-            v[k][h] = t;
-        }
-    }
-    bool neg[2];
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {   // X > floor(Qs / 2): the top-most differing digit decides
-        bool gt = false, decided = false;
-#pragma unroll
-        for (int k = kBxMaxSrc - 1; k >= 0; --k) {
-            if (k >= a.n_src) continue;
-            if (!decided && v[k][h] != a.half[k]) { gt = v[k][h] > a.half[k]; decided = true; }
-        }
-        neg[h] = gt;
-    }
-    u64* dst = out + p * out_stride + w0;
-#pragma unroll
-    for (int j = 0; j < kBxMaxDst; ++j) {
-        if (j >= a.n_dst) break;
-        const LimbConst lcj = lcs[a.dst_limb[j]];
-        U64x2 r;
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            u64 acc = bx_canon<Arith>(v[a.n_src - 1][h], lcj);
-#pragma unroll
-            for (int k = kBxMaxSrc - 2; k >= 0; --k) {
-                if (k >= a.n_src - 1) continue;
-                acc = add_mod(Arith::mul_var(acc, a.q_mod[k][j], lcj), bx_canon<Arith>(v[k][h], lcj), lcj.q);
-            }
-            if (neg[h]) acc = sub_mod(acc, a.Q_mod[j], lcj.q);
-            (h ? r.b : r.a) = acc;
-        }
-        if (MODE == 1) {
-            const U64x2 xv = *reinterpret_cast<const U64x2*>(in + p * in_stride + in_dst_off + (size_t)j * n + w0);
-            r.a = Arith::mul_var(sub_mod(Arith::mul_var(xv.a, a.mul_dst[j], lcj), r.a, lcj.q), a.Q_inv[j], lcj);
-            r.b = Arith::mul_var(sub_mod(Arith::mul_var(xv.b, a.mul_dst[j], lcj), r.b, lcj.q), a.Q_inv[j], lcj);
-        }
-        *reinterpret_cast<U64x2*>(dst + (size_t)j * n) = r;
-    }
-}
+// (the exact base extension / scale-and-round kernels live in kernels_bx.h: one kernel per source-limb count, compiled in their own
+// translation units k_bx_fold.hip / k_bx_shoup.hip)
 
 // ------------------------------------------------------------------------------------------------
 // N3, round 4: the baby-step pass of the double-hoisted packed products as a STREAM (replaces kernels.h hoisted_qp_kernel, whose one

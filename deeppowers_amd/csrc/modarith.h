@@ -275,4 +275,9 @@ DPF_HD u64 add_mod(u64 a, u64 b, u64 q) { return csub(a + b, q); }
 DPF_HD u64 sub_mod(u64 a, u64 b, u64 q) { return a >= b ? a - b : a + q - b; }
 DPF_HD u64 neg_mod(u64 a, u64 q) { return a ? q - a : 0; }
 
+// two words moved as one 16-byte access
+struct __attribute__((aligned(16))) U64x2 {
+    u64 a, b;
+};
+
 }  // namespace dpfhe

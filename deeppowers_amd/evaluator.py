@@ -495,8 +495,8 @@ class Evaluator:
         fused dpfhe_ct_mul (THE METRIC OP) on all limbs, dpfhe_scale_round (x t / q on the workspace limbs), dpfhe_base_extend back."""
         p = self.ctx.params
         L, ll = p.n_limbs, level_limbs
-        if a.shape != b.shape or a.dim() != 4 or a.shape[1] != 2 or a.shape[2] != ll or not (0 < ll < L and ll <= 4):
-            raise _cabi.DpfheError(2000, "multiply_exact: [batch][2][level_limbs][N] operands, 0 < level_limbs <= min(4, L - 1)")
+        if a.shape != b.shape or a.dim() != 4 or a.shape[1] != 2 or a.shape[2] != ll or not (0 < ll < L and ll <= 9):
+            raise _cabi.DpfheError(2000, "multiply_exact: [batch][2][level_limbs][N] operands, 0 < level_limbs <= min(9, L - 1)")
         # workspace check (exactness): log2 Q - 1 > log2(N) + log2(t) + 2 log2(q) + 1
         import math
         lq = sum(math.log2(m) for m in p.moduli[:ll])

@@ -86,6 +86,12 @@ class FheParams:
         """configs[4] sizes: N=8192, 6 x 60-bit limbs."""
         return FheParams(13, tuple(p[0] for p in PRIMES_60), tuple(p[2] for p in PRIMES_60))
 
+    @staticmethod
+    def n8192(n_limbs: int) -> "FheParams":
+        """N=8192 on the first n_limbs primes of the same descending chain (n8192(6) == n8192_l6()): deeper levels and the workspaces of
+        exact multiplies at higher levels (include/deeppowers/fhe.hpp FheParams::n8192 tabulates the first 20)."""
+        return ntt_primes(13, n_limbs)
+
 
 # ---- building other parameter sets ---------------------------------------------------------------------------------
 def is_prime(n: int) -> bool:

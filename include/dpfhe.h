@@ -207,12 +207,12 @@ int dpfhe_rescale_bsgs(dpfhe_ctx* ctx_ext, uint64_t* d_out2, const uint64_t* d_i
 
 /* -- round 4 (what an EXACT ciphertext x ciphertext multiply needs around dpfhe_ct_mul): limb ranges of one context ------------
  * dpfhe_base_extend: per coefficient, the integer X in (-Qs/2, Qs/2] whose residues modulo the source limbs [src_limb0, src_limb0 + n_src)
- *   are given (Qs their product, n_src <= 4) is reduced modulo the destination limbs [dst_limb0, dst_limb0 + n_dst) (n_dst <= 8; the ranges may
+ *   are given (Qs their product, n_src <= 10) is reduced modulo the destination limbs [dst_limb0, dst_limb0 + n_dst) (n_dst <= 20; the ranges may
  *   overlap - a destination limb that is also a source limb gets its own residue back).  Exact (mixed-radix reconstruction), not approximate.
  *   d_in: item p's source residues at d_in + (p * in_stride_limbs + i) * N, i < n_src;  d_out: item p's results at d_out + (p * out_stride_limbs + j) * N.
  * dpfhe_scale_round: d_in [n_polys][L][N] holds ALL limbs of the context;  d_out (item stride out_stride_limbs) receives, on the kept limbs
  *   [keep_limb0, keep_limb0 + n_keep),  round(multiplier * X / Qd)  where X is the (centred) integer the L limbs represent and Qd the product of the
- *   dropped limbs [drop_limb0, drop_limb0 + n_drop) (n_drop <= 4, disjoint from the kept ones) - exact as long as |multiplier * X| < Q / 2.
+ *   dropped limbs [drop_limb0, drop_limb0 + n_drop) (n_drop <= 10, disjoint from the kept ones) - exact as long as |multiplier * X| < Q / 2.
  *   With multiplier = the plaintext modulus t and Qd = the operands' ciphertext modulus this is the scale-and-round of a BFV-style multiply:
  *   extend both operands to the whole context, dpfhe_ct_mul there, dpfhe_scale_round, dpfhe_base_extend back (Evaluator::multiply_exact). */
 int dpfhe_base_extend(dpfhe_ctx* ctx, uint64_t* d_out, size_t out_stride_limbs, const uint64_t* d_in, size_t in_stride_limbs, uint32_t src_limb0, uint32_t n_src,

@@ -652,14 +652,14 @@ static uint64_t powmod_(uint64_t b, uint64_t e, uint64_t q) { uint64_t r = 1; b 
 void orc_base_extend(const orc_ctx* c, int mode, uint64_t* out, size_t out_stride_limbs, const uint64_t* in, size_t in_stride_limbs, uint32_t src0, uint32_t ns,
                      uint32_t dst0, uint32_t nd, uint64_t mul, size_t n_polys) {
     const size_t n = (size_t)1 << c->log2n;
-    uint64_t q[4], p[8], inv[4][4], half[4];
+    uint64_t q[10], p[20], inv[10][10], half[10];
     for (uint32_t i = 0; i < ns; ++i) q[i] = c->limb[src0 + i].q;
     for (uint32_t j = 0; j < nd; ++j) p[j] = c->limb[dst0 + j].q;
     for (uint32_t i = 0; i < ns; ++i) for (uint32_t k = i + 1; k < ns; ++k) inv[i][k] = powmod_(q[i] % q[k], q[k] - 2, q[k]);
     { u128 carry = 0; for (int k = (int)ns - 1; k >= 0; --k) { u128 cur = carry * q[k] + (q[k] - 1); half[k] = (uint64_t)(cur / 2); carry = cur & 1; } }
     for (size_t pi = 0; pi < n_polys; ++pi)
         for (size_t w = 0; w < n; ++w) {
-            uint64_t v[4];
+            uint64_t v[10];
             for (uint32_t k = 0; k < ns; ++k) {
                 uint64_t t = in[(pi * in_stride_limbs + (mode ? src0 : 0) + k) * n + w];
                 if (mode) t = mulmod_(t, mul % q[k], q[k]);

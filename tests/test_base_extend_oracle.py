@@ -4,20 +4,30 @@ the integer negacyclic product."""
 import numpy as np
 import pytest
 
-from deeppowers_amd.params import PRIMES_60, FheParams
+from deeppowers_amd.params import FheParams, ntt_primes
 from oracle import pyoracle as po
 from oracle.cbind import Oracle
 
 
 def params(log2n, limbs):
+    """the first `limbs` primes of the N = 8192 chain (FheParams.n8192) on a small ring"""
     n = 1 << log2n
-    qs = [PRIMES_60[i][0] for i in range(limbs)]
-    return FheParams(log2n, tuple(qs), tuple(pow(PRIMES_60[i][2], 8192 // n, PRIMES_60[i][0]) for i in range(limbs)))
+    big = ntt_primes(13, limbs)
+    return FheParams(log2n, big.moduli, tuple(pow(s, 8192 // n, q) for s, q in zip(big.psi, big.moduli)))
 
 
 @pytest.mark.parametrize("ns,src0,dst0,nd", [(1, 0, 0, 5), (2, 0, 0, 5), (3, 2, 0, 2), (4, 1, 0, 5), (2, 3, 1, 2)])
 def test_base_extend_equals_the_big_integer_definition(ns, src0, dst0, nd):
-    p = params(8, 5)
+    check_base_extend(params(8, 5), ns, src0, dst0, nd)
+
+
+@pytest.mark.parametrize("ns,src0,dst0,nd", [(5, 0, 0, 11), (6, 5, 0, 5), (10, 0, 0, 20), (7, 8, 1, 7), (10, 9, 0, 9)])
+def test_base_extend_at_the_limb_counts_of_a_multiply_on_a_deep_level(ns, src0, dst0, nd):
+    """up to 10 source and 20 destination limbs (a multiply at a five-limb level extends 5 -> 11 and comes back 6 -> 5)"""
+    check_base_extend(params(8, 20), ns, src0, dst0, nd)
+
+
+def check_base_extend(p, ns, src0, dst0, nd):
     orc = Oracle.from_params(p)
     rng = np.random.default_rng(5)
     src = list(p.moduli[src0:src0 + ns])
@@ -35,13 +45,26 @@ def test_base_extend_equals_the_big_integer_definition(ns, src0, dst0, nd):
 
 @pytest.mark.parametrize("drop0,nd,keep0,nk,mul", [(0, 2, 2, 3, 65537), (4, 1, 0, 4, 1), (1, 3, 4, 1, 12289), (0, 4, 4, 1, 3)])
 def test_scale_round_equals_the_big_integer_definition(drop0, nd, keep0, nk, mul):
-    p = params(8, 5)
+    check_scale_round(params(8, 5), drop0, nd, keep0, nk, mul)
+
+
+@pytest.mark.parametrize("drop0,nd,keep0,nk,mul", [(0, 5, 5, 6, 65537), (0, 9, 9, 10, 65537), (10, 10, 0, 8, 3)])
+def test_scale_round_at_the_limb_counts_of_a_multiply_on_a_deep_level(drop0, nd, keep0, nk, mul):
+    check_scale_round(params(8, max(drop0 + nd, keep0 + nk)), drop0, nd, keep0, nk, mul)
+
+
+def check_scale_round(p, drop0, nd, keep0, nk, mul):
     orc = Oracle.from_params(p)
     rng = np.random.default_rng(6)
     Q = int(np.prod([int(q) for q in p.moduli], dtype=object))
     # integers small enough that mul * X stays centred in Q (the entry's precondition), incl. negatives and exact multiples of the divisor
     Qd = int(np.prod([int(q) for q in p.moduli[drop0:drop0 + nd]], dtype=object))
-    vals = [int(rng.integers(0, 2**62)) * int(rng.integers(0, 2**62)) * int(rng.integers(0, 2**62)) * int(rng.integers(0, 2**62)) % (Q // (4 * mul)) for _ in range(2 * p.n)]
+    def big():   # uniform-ish below Q / (4 mul)
+        v = 0
+        for _ in range(p.n_limbs):
+            v = (v << 62) | int(rng.integers(0, 2**62))
+        return v % (Q // (4 * mul))
+    vals = [big() for _ in range(2 * p.n)]
     vals[:6] = [0, Qd, -Qd, Qd // 2, Qd // 2 + 1, -(Qd // 2) - 1]
     vals = [v if i % 2 else -v for i, v in enumerate(vals)]
     x = np.array([[[v % q for v in vals[b * p.n:(b + 1) * p.n]] for q in p.moduli] for b in range(2)], dtype=np.uint64)   # [2][L][N]

@@ -30,7 +30,7 @@ def build_example(name="encrypted_multiply"):
 
 
 def test_example_compiles():
-    assert all(os.path.exists(build_example(e)) for e in ("encrypted_multiply", "bench_ct_mul", "encrypted_linear", "encrypted_gpt2_linear", "encrypted_gpt2_ffn", "encrypted_gpt2_ffn_act", "encrypted_gpt2_block_act",
+    assert all(os.path.exists(build_example(e)) for e in ("encrypted_multiply", "bench_ct_mul", "encrypted_linear", "encrypted_gpt2_linear", "encrypted_gpt2_ffn", "encrypted_gpt2_ffn_act", "encrypted_gpt2_block_act", "encrypted_gpt2_stack",
                                                           "encrypted_gpt2_block", "sharded_ct_mul", "sharded_ffn"))
 
 
@@ -131,6 +131,22 @@ def test_example_whole_block_with_activation(mode):
     d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
     b = d["budget_bits"]
     assert d["correct"] is True and len(b) == 8 and b[0] > b[1] > b[2] > b[3] > b[4] > 0 and b[5] > b[6] > b[7] > 20, b
+
+
+@pytest.mark.gpu
+def test_example_two_blocks_on_a_modulus_chain():
+    """configs[4] as a forward pass, DEEPER than one block: two blocks with the square activation chained on seven data limbs (420 bits); the limb
+    count of every level is planned from a budget model (no secret key involved) and falls 7 -> 2 over the twelve levels; the first block's
+    activation is an exact multiply at a five- or six-limb level (11 / 13-limb workspace); BOTH blocks' outputs decrypt to the plaintext forward."""
+    import json
+    out = subprocess.run([build_example("encrypted_gpt2_stack"), "2", "1", "json"], capture_output=True, text=True, timeout=1500)
+    assert out.returncode == 0 and out.stdout.strip().endswith("OK"), out.stdout[-1500:] + out.stderr[-500:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
+    assert d["correct"] is True and d["blocks"] == 2 and d["correct_blocks"] == 2 and d["ct_ct_multiplies_per_token"] == 2, d
+    b = d["budget_bits"]
+    lv = [int(v) for v in d["limbs_per_level"].replace("|", " ").split()]
+    assert len(b) == 12 and all(x > y for x, y in zip(b, b[1:])) and b[-1] > 10, b
+    assert len(lv) == 12 and lv[0] == 7 and lv[-1] == 2 and all(x >= y for x, y in zip(lv, lv[1:])), lv
 
 
 @pytest.mark.gpu

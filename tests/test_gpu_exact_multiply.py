@@ -9,15 +9,16 @@ torch = pytest.importorskip("torch")
 
 from deeppowers_amd import _cabi  # noqa: E402
 from deeppowers_amd.evaluator import Context, Evaluator, to_device, to_host  # noqa: E402
-from deeppowers_amd.params import PRIMES_60, FheParams  # noqa: E402
+from deeppowers_amd.params import FheParams, ntt_primes  # noqa: E402
 from oracle import pyoracle as po  # noqa: E402
 from oracle.cbind import Oracle  # noqa: E402
 
 
 def fold_params(log2n, limbs):
+    """the first `limbs` primes of the N = 8192 chain (FheParams.n8192), on ring degree 2^log2n"""
     n = 1 << log2n
-    qs = [PRIMES_60[i][0] for i in range(limbs)]
-    return FheParams(log2n, tuple(qs), tuple(pow(PRIMES_60[i][2], 8192 // n, PRIMES_60[i][0]) for i in range(limbs)))
+    big = ntt_primes(13, limbs)
+    return FheParams(log2n, big.moduli, tuple(pow(s, 8192 // n, q) for s, q in zip(big.psi, big.moduli)))
 
 
 def generic_params(log2n):
@@ -58,9 +59,49 @@ def test_base_extend_and_scale_round_bit_exact(make, log2n):
     # argument checks
     t = to_device(np.zeros((1, 5, n), np.uint64), ctx.device)
     with pytest.raises(_cabi.DpfheError):
-        ev.base_extend(t, 1, 0, 5)                      # 5 source limbs
+        ev.base_extend(t, 1, 0, 5)                      # source limbs 1 .. 5 of a five-limb context
     with pytest.raises(_cabi.DpfheError):
         ev.scale_round(t, 0, 2, 1, 3, 3)                # kept limbs overlap the dropped ones
+    ctx.close()
+
+
+@pytest.mark.parametrize("log2n", [13, 10])
+def test_deep_level_limb_counts_bit_exact(log2n):
+    """What a multiply at a FIVE-limb level needs (examples/encrypted_gpt2_stack.cpp: the first block of a two-block stack): extension 5 -> 11
+    limbs, scale-and-round dropping 5 and keeping 6, extension back 6 -> 5 - and the entries' limits, 10 source and 20 destination limbs - each
+    against the oracle; then the whole multiply_exact at that level against the oracle's pipeline."""
+    p = fold_params(log2n, 20)
+    orc, ctx = Oracle.from_params(p), Context(p, 0)
+    ev = Evaluator(ctx)
+    rng = np.random.default_rng(21)
+    n = p.n
+    for ns, src0, dst0, nd in ((5, 0, 0, 11), (6, 5, 0, 5), (10, 0, 0, 20), (7, 8, 1, 7), (10, 9, 0, 9)):
+        src = p.moduli[src0:src0 + ns]
+        x = np.stack([rng.integers(0, q, (3, n), dtype=np.uint64) for q in src], axis=1)
+        x[0, :, : n // 2] = np.array(src, np.uint64)[:, None] - np.uint64(1)
+        Qs = int(np.prod([int(q) for q in src], dtype=object))
+        for k, val in enumerate((Qs // 2, Qs // 2 + 1, Qs // 2 - 1, 0)):
+            x[1, :, k] = [val % q for q in src]
+        got = to_host(ev.base_extend(to_device(x, ctx.device), src0, dst0, nd))
+        assert np.array_equal(got, orc.base_extend(x, src0, dst0, nd)), (ns, src0, dst0, nd)
+    x = np.stack([rng.integers(0, q, (2, n), dtype=np.uint64) for q in p.moduli], axis=1)        # any residues: the integer is what they represent
+    for drop0, ndrop, keep0, nkeep, mul in ((0, 5, 5, 6, 65537), (0, 9, 9, 10, 65537), (10, 10, 0, 8, 1)):
+        got = to_host(ev.scale_round(to_device(x, ctx.device), drop0, ndrop, keep0, nkeep, mul))
+        assert np.array_equal(got, orc.scale_round(x, drop0, ndrop, keep0, nkeep, mul)), (drop0, ndrop, keep0, nkeep, mul)
+    with pytest.raises(_cabi.DpfheError):
+        ev.base_extend(to_device(np.zeros((1, 11, n), np.uint64), ctx.device), 0, 0, 4)           # 11 source limbs
+    ctx.close()
+    p = fold_params(log2n, 11)
+    orc, ctx = Oracle.from_params(p), Context(p, 0)
+    ev = Evaluator(ctx)
+    ll, t = 5, 65537
+    a = np.stack([rng.integers(0, q, (2, 2, n), dtype=np.uint64) for q in p.moduli[:ll]], axis=2)   # [2][2][ll][N]
+    b = np.stack([rng.integers(0, q, (2, 2, n), dtype=np.uint64) for q in p.moduli[:ll]], axis=2)
+    got = to_host(ev.multiply_exact(to_device(a, ctx.device), to_device(b, ctx.device), ll, t))
+    A, B = orc.base_extend(a, 0, 0, 11), orc.base_extend(b, 0, 0, 11)
+    T = orc.ct_mul(np.ascontiguousarray(A), np.ascontiguousarray(B), threads=0)
+    want = orc.base_extend(orc.scale_round(T, 0, ll, ll, 11 - ll, t), ll, 0, ll)
+    assert got.shape == (2, 3, ll, n) and np.array_equal(got, want)
     ctx.close()
 
 
