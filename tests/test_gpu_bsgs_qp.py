@@ -4,7 +4,7 @@ generic (Shoup) primes, with more than one 64-element launch group and several t
 import numpy as np
 import pytest
 
-from deeppowers_amd.params import FheParams, PRIMES_60
+from deeppowers_amd.params import FheParams, PRIMES_60, ntt_primes
 from oracle import pyoracle as po
 from oracle.cbind import Oracle
 
@@ -26,10 +26,12 @@ def _params(name):
         return FheParams(12, tuple(x[0] for x in PRIMES_60[:3]), tuple(x[1] for x in PRIMES_60[:3]))     # 2 data limbs + P
     if name == "n4096_l6":
         return FheParams(12, tuple(x[0] for x in PRIMES_60[:6]), tuple(x[1] for x in PRIMES_60[:6]))     # 5 data limbs + P: relin_shared_kernel
+    if name == "n8192_l10":   # 9 data limbs + P: the digit counts of a deep modulus chain (examples/encrypted_gpt2_stack.cpp) - loop-form baby steps with
+        return ntt_primes(13, 10)   # their periodic lazy folds, per-component hoisted rotations, more lazily added products per key switch
     return FheParams(13, tuple(x[0] for x in PRIMES_60[:4]), tuple(x[2] for x in PRIMES_60[:4]))         # 3 data limbs + P
 
 
-@pytest.mark.parametrize("name", ["mixed", "n4096", "n8192"])
+@pytest.mark.parametrize("name", ["mixed", "n4096", "n8192", "n8192_l10"])
 def test_rotate_hoisted_qp_bit_exact(name):
     from deeppowers_amd.evaluator import Ciphertext, Context, Evaluator, to_device, to_host
     pe = _params(name)
@@ -80,7 +82,7 @@ def test_ntt_inverse_galois_bit_exact(name):
     ctx.close()
 
 
-@pytest.mark.parametrize("name", ["mixed", "n4096", "n4096_l6", "n8192"])
+@pytest.mark.parametrize("name", ["mixed", "n4096", "n4096_l6", "n8192", "n8192_l10"])
 def test_switch_key_qp_bit_exact(name):
     from deeppowers_amd.evaluator import Ciphertext, Context, Evaluator, to_device, to_host
     pe = _params(name)
@@ -100,7 +102,7 @@ def test_switch_key_qp_bit_exact(name):
     ctx.close()
 
 
-@pytest.mark.parametrize("name", ["mixed", "n8192"])
+@pytest.mark.parametrize("name", ["mixed", "n8192", "n8192_l10"])
 def test_rescale_bsgs_and_the_whole_deferred_sum(name):
     """dpfhe_rescale_bsgs == round(x / P) + addends (oracle composition); and the deferred giant-step sum
          rescale_bsgs(INTT(sum_i switch_key_qp(rot_i)), rot)  decrypts like  rot_0 + sum_i keyswitch_hybrid(rot_i):

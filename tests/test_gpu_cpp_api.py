@@ -23,6 +23,23 @@ def test_cpp_facade_compiles_and_links():
     assert os.path.exists(build_cpp_test())
 
 
+def test_cpp_prime_chain_is_the_python_generators(tmp_path):
+    """CPU: FheParams::n8192(20) (the tabulated N = 8192 chain the multi-block example and its multiply workspaces are built on) equals
+    params.ntt_primes(13, 20) - largest primes below 2^60 that are 1 mod 2N, smallest primitive 2N-th roots - and its first six are the pinned ones."""
+    from deeppowers_amd.params import FheParams, ntt_primes
+    src = tmp_path / "chain.cpp"
+    src.write_text('#include <cstdio>\n#include <deeppowers/fhe.hpp>\nint main() { auto p = deeppowers::fhe::FheParams::n8192(20);\n'
+                   'for (size_t i = 0; i < p.n_limbs(); ++i) std::printf("%llu %llu\\n", (unsigned long long)p.moduli[i], (unsigned long long)p.psi[i]); }\n')
+    lib = os.path.join(ROOT, "deeppowers_amd")
+    exe = str(tmp_path / "chain")
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-I" + os.path.join(ROOT, "include"), str(src), "-o", exe, "-L" + lib, "-ldpfhe_api", "-ldpfhe_hip",
+                           "-L/opt/rocm/lib", "-lamdhip64", f"-Wl,-rpath,{lib}", "-Wl,-rpath,/opt/rocm/lib"])
+    got = [tuple(int(v) for v in l.split()) for l in subprocess.run([exe], capture_output=True, text=True, check=True).stdout.splitlines()]
+    want = ntt_primes(13, 20)
+    assert got == list(zip(want.moduli, want.psi))
+    assert tuple(q for q, _ in got[:6]) == FheParams.n8192_l6().moduli and FheParams.n8192(6) == FheParams.n8192_l6()
+
+
 def build_example(name="encrypted_multiply"):
     """examples/Makefile (what __graft_entry__.build() runs): rebuilt only when the source or the library changed"""
     subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "examples"), name])
