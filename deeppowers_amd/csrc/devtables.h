@@ -19,7 +19,6 @@ struct DevTables {
     const typename Arith::Tw* inv;          // [L][N]  psi^-brv(i)
     const typename Arith::Tw* fwd4;
     const typename Arith::Tw* inv4;
-    const typename Arith::Tw* fwd3;         // forward table in the 8-words-per-thread layout (N = 8192 FoldArith contexts: relin_kernel MODE 4 A/B), else null
     // split transform (N > 16384): fwd / inv / last then hold one N2-point table per (limb, block) - [L][n_sub][N2] and
     // [L][n_sub] - and the first log2(n_sub) stages run in ntt_top_kernel with these workgroup-uniform twiddles
     const typename Arith::Tw* top_fwd;      // [L][n_sub]  psi^brv(i), entry m + i of the full table, i < n_sub

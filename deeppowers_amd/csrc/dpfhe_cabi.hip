@@ -261,7 +261,7 @@ extern "C" int dpfhe_ctx_create(dpfhe_ctx** out, uint32_t log2_n, uint32_t n_lim
     const size_t tab = L * n * tw_sz;
     const size_t o_lc = 0, o_fwd4 = up(o_lc + L * sizeof(LimbConst)), o_inv4 = up(o_fwd4 + tab),
                  o_fwd = two_geo ? up(o_inv4 + tab) : o_fwd4, o_inv = two_geo ? up(o_fwd + tab) : o_inv4,
-                 o_fwd3 = up(o_inv + tab), o_last = up(o_fwd3 + (log2_n == 13 && fold ? tab : 0)), o_top_fwd = up(o_last + L * n_sub * 2 * tw_sz), o_top_inv = up(o_top_fwd + L * n_sub * tw_sz),
+                 o_last = up(o_inv + tab), o_top_fwd = up(o_last + L * n_sub * 2 * tw_sz), o_top_inv = up(o_top_fwd + L * n_sub * tw_sz),
                  o_top_last = up(o_top_inv + L * n_sub * tw_sz), o_resc = up(o_top_last + L * 2 * tw_sz), total = up(o_resc + L * sizeof(RescaleConst));
     std::vector<unsigned char> blob(total, 0);
     auto fill = [&](auto tw_tag) {
@@ -281,7 +281,6 @@ extern "C" int dpfhe_ctx_create(dpfhe_ctx** out, uint32_t log2_n, uint32_t n_lim
                     pack(ht[l].rp, (int)log2_n, loge, (geo ? o_fwd : o_fwd4) + l * n * tw_sz);
                     pack(ht[l].irp, (int)log2_n, loge, (geo ? o_inv : o_inv4) + l * n * tw_sz);
                 }
-                if (log2_n == 13 && fold) pack(ht[l].rp, 13, 3, o_fwd3 + l * n * tw_sz);
                 lasts[l] = InvLast<Tw>{h_make_tw<Tw>(ht[l].w_last, q), h_make_tw<Tw>(ht[l].lc.ninv, q)};
             } else {
                 for (size_t r = 0; r < n_sub; ++r) {
@@ -329,7 +328,6 @@ extern "C" int dpfhe_ctx_create(dpfhe_ctx** out, uint32_t log2_n, uint32_t n_lim
         c->foldt.inv = reinterpret_cast<const TwFold*>(d + o_inv);
         c->foldt.fwd4 = reinterpret_cast<const TwFold*>(d + o_fwd4);
         c->foldt.inv4 = reinterpret_cast<const TwFold*>(d + o_inv4);
-        c->foldt.fwd3 = log2_n == 13 ? reinterpret_cast<const TwFold*>(d + o_fwd3) : nullptr;
         c->foldt.last = reinterpret_cast<const InvLast<TwFold>*>(d + o_last);
         c->foldt.top_fwd = reinterpret_cast<const TwFold*>(d + o_top_fwd);
         c->foldt.top_inv = reinterpret_cast<const TwFold*>(d + o_top_inv);
@@ -342,7 +340,6 @@ extern "C" int dpfhe_ctx_create(dpfhe_ctx** out, uint32_t log2_n, uint32_t n_lim
         c->shoup.inv = reinterpret_cast<const TwShoup*>(d + o_inv);
         c->shoup.fwd4 = reinterpret_cast<const TwShoup*>(d + o_fwd4);
         c->shoup.inv4 = reinterpret_cast<const TwShoup*>(d + o_inv4);
-        c->shoup.fwd3 = nullptr;
         c->shoup.last = reinterpret_cast<const InvLast<TwShoup>*>(d + o_last);
         c->shoup.top_fwd = reinterpret_cast<const TwShoup*>(d + o_top_fwd);
         c->shoup.top_inv = reinterpret_cast<const TwShoup*>(d + o_top_inv);

@@ -770,11 +770,11 @@ __device__ __forceinline__ u64 canon_any(u64 v, const LimbConst& lc) {  // any v
 //         c2 (MODE 2, 3-component input) or c1 (MODE 3, 2-component input) and writes t = sum_j d_j (.) key_j to a work
 //         buffer [batch][2][L][N] with nothing added back; dpfhe's rescale-add pass then divides by P and adds (c0, c1).
 template <class Arith, int LOGN, int LOGE, int MODE>
-__global__ __launch_bounds__(1 << (LOGN - LOGE), (Arith::kFold ? (LOGE == 3 ? 4 : 2) : 1)) void relin_kernel(u64* __restrict__ out2, const u64* __restrict__ in3,
+__global__ __launch_bounds__(1 << (LOGN - LOGE), (Arith::kFold ? 2 : 1)) void relin_kernel(u64* __restrict__ out2, const u64* __restrict__ in3,
                                                                        const u64* __restrict__ evk, size_t key_stride, unsigned key_group,
                                                                        unsigned n_outer, DevTables<Arith> tb) {
     typedef NttBody<Arith, LOGN, LOGE> B;
-    static_assert(LOGE == kFusedLoge || (LOGE == 3 && LOGN == 13 && MODE == 4), "fused twiddle layout (DevTables::fwd4 / inv4), or the forward-only 8-words-per-thread table (fwd3)");
+    static_assert(LOGE == kFusedLoge, "the fused kernels read the fused twiddle layout (DevTables::fwd4 / inv4)");
     constexpr int E = B::E, N = B::G::N;
     __shared__ __attribute__((aligned(16))) u64 lds[B::G::lds_words()];
     int tid = threadIdx.x;
@@ -819,7 +819,7 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE), (Arith::kFold ? (LOGE == 3 ? 4 
 #pragma unroll
         for (int k = 0; k < E; ++k) x[k] = canon_any<Arith>(x[k], lc);   // [c2]_{q_j} mod q_i
         if (j > 0) lds_barrier();
-        FwdChain<B, 0>::template run<false>(tid, x, lds, (LOGE == kFusedLoge ? tb.fwd4 : tb.fwd3) + (size_t)limb * N, lc);
+        FwdChain<B, 0>::template run<false>(tid, x, lds, tb.fwd4 + (size_t)limb * N, lc);
         const u64* k0 = evk + (((size_t)j * 2 + 0) * L + limb) * N;      // key polynomials, NTT domain (window-0 mapping)
         const u64* k1 = evk + (((size_t)j * 2 + 1) * L + limb) * N;
         if (Arith::kFold) {

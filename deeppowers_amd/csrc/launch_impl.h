@@ -189,14 +189,6 @@ int launch_relin(int log2n, int mode, u64* out2, const u64* in3, const u64* evk,
         grid = ((n_keys + 7u) / 8u) * 8u * (unsigned)tb.n_limbs * kg;
         n_outer |= kRelinRotMajor;
     }
-    // N = 8192, giant-step terms (MODE 4): 8 words per thread - 1024 threads, 4 waves per SIMD in ONE workgroup per CU instead of 2 (A/B: DPFHE_RELIN13_LOGE3=1)
-    if constexpr (Arith::kFold) {
-        static const bool loge3 = [] { const char* e = std::getenv("DPFHE_RELIN13_LOGE3"); return e && e[0] == '1'; }();
-        if (loge3 && log2n == 13 && mode == 4 && tb.fwd3) {
-            hipLaunchKernelGGL((relin_kernel<Arith, 13, 3, 4>), dim3(grid), dim3(Geo<13, 3>::T), 0, s, out2, in3, evk, key_stride, kg, n_outer, tb);
-            return 0;
-        }
-    }
 #define RL_ONE(LN, M)                                                                                                                                    \
     if constexpr (DPFHE_RELIN_SHARED && Arith::kFold && LN >= 10 && LN <= 12) {                                                                          \
         if (n_digits >= 4 && n_digits <= 7) {                                                                                                            \
