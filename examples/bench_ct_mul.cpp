@@ -37,14 +37,15 @@ int main(int argc, char** argv) {
         b.copy_from_host(host.data());
         for (int i = 0; i < 3; ++i) ev.multiply(a, b, c);
         ctx.synchronize();
+        auto hip = [](hipError_t e, const char* what) { if (e != hipSuccess) { std::fprintf(stderr, "%s: %s\n", what, hipGetErrorString(e)); std::exit(3); } };
         hipEvent_t e0, e1;
-        hipEventCreate(&e0); hipEventCreate(&e1);
-        hipEventRecord(e0, nullptr);
+        hip(hipEventCreate(&e0), "hipEventCreate"); hip(hipEventCreate(&e1), "hipEventCreate");
+        hip(hipEventRecord(e0, nullptr), "hipEventRecord");
         for (int i = 0; i < steps; ++i) ev.multiply(a, b, c);
-        hipEventRecord(e1, nullptr);
-        hipEventSynchronize(e1);
+        hip(hipEventRecord(e1, nullptr), "hipEventRecord");
+        hip(hipEventSynchronize(e1), "hipEventSynchronize");
         float ms = 0;
-        hipEventElapsedTime(&ms, e0, e1);
+        hip(hipEventElapsedTime(&ms, e0, e1), "hipEventElapsedTime");
         const double per_s = (double)batch * steps / (ms * 1e-3);
         std::printf("{\"metric\": \"ciphertext-mul/s (N=4096, 4 RNS limbs)\", \"host\": \"c++\", \"batch\": %zu, \"steps\": %d, "
                     "\"ms_per_step\": %.3f, \"value\": %.1f, \"algorithmic_GBps\": %.1f}\n",
