@@ -1058,6 +1058,8 @@ extern "C" int dpfhe_matvec_plain(dpfhe_ctx* c, uint64_t* d_y, const uint64_t* d
 #endif
         // a W beyond the 256 MiB Infinity Cache is a read-once stream (every tile goes to exactly one workgroup here): non-temporal loads
         const bool ntw = DPFHE_MATVEC_NTW && rows * cols * ((size_t)c->n_limbs << c->log2n) * sizeof(u64) > ((size_t)256 << 20);
+        // (the branch-free FULL form of the kernel, which the multi-right-hand-side product takes, measured SLOWER here: 1412 against 1258 us on configs[2] -
+        // this launch streams 6 GiB of W from HBM with two right-hand-side polynomials per workgroup and lives on memory-level parallelism, not on issue slots)
         if (ntw) hipLaunchKernelGGL((matvec_fold_kernel<RT, 2, WPT, true>), dim3((unsigned)blocks), dim3(256), 0, s, d_y, d_W, d_x, c->foldt.lc, (int)c->n_limbs, n, chunks, rows,
                                     cols, (size_t)2, 1u, (unsigned)(rtiles * slabs));
         else hipLaunchKernelGGL((matvec_fold_kernel<RT, 2, WPT>), dim3((unsigned)blocks), dim3(256), 0, s, d_y, d_W, d_x, c->foldt.lc, (int)c->n_limbs, n, chunks, rows, cols,
@@ -1092,14 +1094,22 @@ extern "C" int dpfhe_matvec_plain_multi(dpfhe_ctx* c, uint64_t* d_y, const uint6
     // HBM by every group), see DESIGN.md for the XCD-grouped launch.
     const size_t pairs = n_rhs / 2;
     if (c->fold) {   // split-at-bit-30 column accumulators (kernels_misc.h matvec_fold_kernel), same grouping and block-id layout
+#ifndef DPFHE_MATVEC_FULL
+#define DPFHE_MATVEC_FULL 1
+#endif
 #define MVF_LAUNCH(RT, C, WPT, GROUPS, XS, YS)                                                                                                          \
     {                                                                                                                                                    \
         const int chunks = (n + 256 * (WPT) - 1) / (256 * (WPT));                                                                                        \
         const size_t slabs = c->n_limbs * (size_t)chunks, rtiles = (rows + RT - 1) / RT, tiles = rtiles * slabs;                                         \
         const size_t blocks = ((slabs + 7) / 8) * 8 * rtiles * (GROUPS);                                                                                 \
         if (blocks > kMaxGrid) return fail(DPFHE_INVALID_ARGUMENT, what, "too many rows for one launch");                                             \
-        hipLaunchKernelGGL((matvec_fold_kernel<RT, C, WPT, false, DPFHE_MATVEC_WD>), dim3((unsigned)blocks), dim3(256), 0, s, YS, d_W, XS, c->foldt.lc, (int)c->n_limbs, n, chunks, rows, cols, \
-                           n_rhs * 2, (unsigned)(GROUPS), (unsigned)tiles);                                                                              \
+        /* whole row tiles and whole periods (a packed layer's products): the branch-free form, see kernels_misc.h */                                    \
+        if (DPFHE_MATVEC_FULL && rows % (RT) == 0 && cols % FoldArith::kDot30Period == 0)                                                                \
+            hipLaunchKernelGGL((matvec_fold_kernel<RT, C, WPT, false, DPFHE_MATVEC_WD, true>), dim3((unsigned)blocks), dim3(256), 0, s, YS, d_W, XS, c->foldt.lc, (int)c->n_limbs, n, chunks, rows, \
+                               cols, n_rhs * 2, (unsigned)(GROUPS), (unsigned)tiles);                                                                    \
+        else                                                                                                                                             \
+            hipLaunchKernelGGL((matvec_fold_kernel<RT, C, WPT, false, DPFHE_MATVEC_WD>), dim3((unsigned)blocks), dim3(256), 0, s, YS, d_W, XS, c->foldt.lc, (int)c->n_limbs, n, chunks, rows, cols, \
+                               n_rhs * 2, (unsigned)(GROUPS), (unsigned)tiles);                                                                          \
     }
         if (pairs) {
             MVF_LAUNCH(DPFHE_MATVEC_RT4, 4, DPFHE_MATVEC_WPT4, pairs, d_x, d_y)

@@ -366,7 +366,16 @@ __device__ __forceinline__ WordVec<WPT> load_words(const u64* p, bool in_range) 
 // WD: how many columns AHEAD the W words are requested (a register ring of WD x RT words; WD divides the period).  The W stream is the one
 // operand that comes from HBM (one workgroup group reads each tile once), x comes from L2: round 4 measured ~3.6 us from issue to first word for
 // an HBM burst under load, against ~0.5 us of products per column - one column of lookahead cannot cover it.
-template <int RT, int C, int WPT, bool NTW = false, int WD = 1>
+// FULL: rows is a multiple of RT and cols a multiple of the period (what a packed layer's products are) - no row predicate on the W loads and no
+// ragged last period, i.e. NO control flow inside the period: its 8 columns are one basic block, the double-buffered operands are renamed at
+// compile time and the loads of column j + 1 are waited for where column j + 1 first uses them.  With the checks in place every column was its
+// own block that ended in register copies of the next operands behind s_waitcnt vmcnt(0): the one-column lookahead the source asks for
+// did not exist in the binary.
+#ifndef DPFHE_MATVEC_FULL_DEPTH
+#define DPFHE_MATVEC_FULL_DEPTH 1
+#endif
+constexpr int kMatvecFullDepth = DPFHE_MATVEC_FULL_DEPTH;   // columns of lookahead of the FULL form (both operands)
+template <int RT, int C, int WPT, bool NTW = false, int WD = 1, bool FULL = false>
 __global__ __launch_bounds__(256) void matvec_fold_kernel(u64* y, const u64* W, const u64* x, const LimbConst* lcs, int n_limbs, int n,
                                                           int chunks, size_t rows, size_t cols, size_t polys_per_col, unsigned n_groups,
                                                           unsigned n_tiles) {
@@ -390,7 +399,10 @@ __global__ __launch_bounds__(256) void matvec_fold_kernel(u64* y, const u64* W, 
     // uniform bases (scalar registers, scalar adds) + one 32-bit lane offset: no per-lane 64-bit address arithmetic
     const u64* const wu = W + (row0 * cols * L + limb) * n;
     const u64* const xu = x + (size_t)limb * n;
-    auto ld_w = [&](int r, size_t j) { return load_words<WPT, NTW>(&(wu + (r * rstride + j * wstride))[w0], row0 + r < rows); };
+    // (uniform 64-bit base) + (32-bit BYTE offset of the lane): the shape the global_load "saddr" form takes - base in scalar registers, one
+    // 32-bit vector offset shared by every load of the thread; indexing the u64 pointer with w0 instead makes hipcc scale in 64 bits per lane
+    // (one v_lshl_add_u64 and a 64-bit vector address per load: 12 % of the kernel's vector instructions)
+    auto ld_w = [&](int r, size_t j) { return load_words<WPT, NTW>(&(wu + (r * rstride + j * wstride))[w0], FULL || row0 + r < rows); };
     auto ld_x = [&](int c, size_t j) { return *reinterpret_cast<const V*>(&(xu + (j * xstride + (size_t)c * L * n))[w0]); };
     u64 run[RT][C][WPT];   // folded running words (reduced); the first products of every period chain onto them
 #pragma unroll
@@ -399,6 +411,78 @@ __global__ __launch_bounds__(256) void matvec_fold_kernel(u64* y, const u64* W, 
         for (int c = 0; c < C; ++c)
 #pragma unroll
             for (int k = 0; k < WPT; ++k) run[r][c][k] = 0;
+    if constexpr (FULL) {
+        // Both operands of column j + FD are requested at the top of column j into a register ring of FD columns, and a scheduling barrier
+        // closes every column: without it the scheduler pulls the (cheap) splits of the next column's operands up into the current one and
+        // the wait for them with it - half a column of lookahead instead of FD columns.
+        constexpr int FD = kMatvecFullDepth;
+        static_assert(P % FD == 0, "the operand ring must divide the period");
+        // Every load of the thread is (uniform 64-bit base) + (ONE 32-bit byte offset of the lane).  Written as pointer arithmetic hipcc folds the lane part
+        // into a 64-bit vector base and adds the uniform part per load (one v_lshl_add_u64 and an address register pair each: 12 % of the kernel's vector
+        // instructions); a raw buffer load takes the base in scalar registers (the descriptor, rebuilt per load by the scalar unit - W may exceed a 32-bit
+        // offset) and the lane offset as is.
+        const unsigned b0 = w0 * 8u;
+        auto bld = [&](const u64* uniform) {
+            V r;
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<u64*>(uniform), 0, 0x7fffffff, 0x00020000);
+            if constexpr (WPT == 1) {
+                typedef unsigned v2u __attribute__((ext_vector_type(2)));
+                const v2u t = __builtin_amdgcn_raw_buffer_load_b64(rs, (int)b0, 0, NTW ? 2 : 0);
+                r.v[0] = ((u64)t.y << 32) | t.x;
+            } else {
+                typedef unsigned v4u __attribute__((ext_vector_type(4)));
+                const v4u t = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)b0, 0, NTW ? 2 : 0);
+                r.v[0] = ((u64)t.y << 32) | t.x; r.v[1] = ((u64)t.w << 32) | t.z;
+            }
+            return r;
+        };
+        auto ld_w = [&](int r, size_t j) { return bld(wu + (r * rstride + j * wstride)); };
+        auto ld_x = [&](int c, size_t j) { return bld(xu + (j * xstride + (size_t)c * L * n)); };
+        V wr[FD][RT], xr[FD][C];
+#pragma unroll
+        for (int d = 0; d < FD; ++d) {
+            const size_t jd = (size_t)d < cols ? (size_t)d : cols - 1;
+#pragma unroll
+            for (int r = 0; r < RT; ++r) wr[d][r] = ld_w(r, jd);
+#pragma unroll
+            for (int c = 0; c < C; ++c) xr[d][c] = ld_x(c, jd);
+        }
+        for (size_t j0 = 0; j0 < cols; j0 += P) {
+            FoldArith::Dot30 acc[RT][C][WPT];
+#pragma unroll
+            for (int u = 0; u < P; ++u) {
+                const size_t j = j0 + u, jp = j + FD < cols ? j + FD : cols - 1;
+                V w[RT], xv[C];
+#pragma unroll
+                for (int r = 0; r < RT; ++r) { w[r] = wr[u % FD][r]; wr[u % FD][r] = ld_w(r, jp); }
+#pragma unroll
+                for (int c = 0; c < C; ++c) { xv[c] = xr[u % FD][c]; xr[u % FD][c] = ld_x(c, jp); }
+                __builtin_amdgcn_sched_barrier(0);   // ... and the requests stay up here (the scheduler otherwise sinks them to the end of the column to save registers)
+#pragma unroll
+                for (int k = 0; k < WPT; ++k) {
+                    H wh[RT], xh[C];
+#pragma unroll
+                    for (int r = 0; r < RT; ++r) wh[r] = FoldArith::split30(w[r].v[k]);
+#pragma unroll
+                    for (int c = 0; c < C; ++c) xh[c] = FoldArith::split30(xv[c].v[k]);
+#pragma unroll
+                    for (int c = 0; c < C; ++c)
+#pragma unroll
+                        for (int r = 0; r < RT; ++r) {
+                            if (u == 0) acc[r][c][k] = FoldArith::Dot30{run[r][c][k], 0, 0};
+                            FoldArith::dot30_mac(acc[r][c][k], wh[r], xh[c]);
+                        }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int r = 0; r < RT; ++r)
+#pragma unroll
+                for (int c = 0; c < C; ++c)
+#pragma unroll
+                    for (int k = 0; k < WPT; ++k) run[r][c][k] = FoldArith::dot30_fold(acc[r][c][k], 0, lc);
+        }
+    } else {
     static_assert(WD >= 1 && FoldArith::kDot30Period % WD == 0, "the W ring must divide the period");
     V wq[WD][RT], xv[C];
 #pragma unroll
@@ -414,9 +498,11 @@ __global__ __launch_bounds__(256) void matvec_fold_kernel(u64* y, const u64* W, 
 #pragma unroll
         for (int u = 0; u < P; ++u) {
             const size_t j = j0 + u;
-            if (j >= cols) {   // ragged last period: nothing to add (uniform branch)
-                if (u == 0) break;
-                continue;
+            if constexpr (!FULL) {
+                if (j >= cols) {   // ragged last period: nothing to add (uniform branch)
+                    if (u == 0) break;
+                    continue;
+                }
             }
             const size_t jn = j + 1 < cols ? j + 1 : j, jw = j + WD < cols ? j + WD : cols - 1;
             V w[RT], xn[C];
@@ -449,9 +535,10 @@ __global__ __launch_bounds__(256) void matvec_fold_kernel(u64* y, const u64* W, 
 #pragma unroll
                 for (int k = 0; k < WPT; ++k) run[r][c][k] = FoldArith::dot30_fold(acc[r][c][k], 0, lc);
     }
+    }
 #pragma unroll
     for (int r = 0; r < RT; ++r) {
-        if (row0 + r >= rows) break;
+        if (!FULL && row0 + r >= rows) break;
 #pragma unroll
         for (int c = 0; c < C; ++c) {
             V o;

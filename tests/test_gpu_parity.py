@@ -345,12 +345,17 @@ def test_matvec_plain_vs_oracle(rigs, name, rows, cols):
 
 def test_matvec_plain_multi_rhs_vs_oracle(rigs):
     """dpfhe_matvec_plain_multi: [cols][n_rhs] right-hand sides against one oracle matvec per right-hand side; n_rhs = 7 exercises
-    the 4 + 2 + 1 grouping, ragged row counts the tile tails."""
+    the 4 + 2 + 1 grouping, ragged row counts the tile tails.  Whole row tiles and whole 8-column periods (8 x 16, 4 x 8, 16 x 64 - the shape
+    of a packed layer's products - and 12 x 24 with an odd right-hand-side count) take the branch-free form of the kernel (raw buffer loads, operands
+    requested a column ahead); the 16 x 64 case carries q - 1 in every word of two rows and two columns: the lazy columns at their largest."""
     r = rigs("n4096")
     L, n = r.p.n_limbs, r.p.n
-    for rows, cols, n_rhs in ((5, 3, 7), (8, 16, 4), (3, 2, 2), (2, 5, 1)):
+    qm1 = (np.array(r.p.moduli, np.uint64) - np.uint64(1))[:, None]
+    for rows, cols, n_rhs in ((5, 3, 7), (8, 16, 4), (3, 2, 2), (2, 5, 1), (4, 8, 2), (16, 64, 8), (12, 24, 5)):
         W = r.orc.fill(rows * cols, 11).reshape(rows, cols, L, n)
         x = r.orc.fill(cols * n_rhs * 2, 12).reshape(cols, n_rhs, 2, L, n)
+        if rows == 16:
+            W[3, :], W[:, 5], x[:, 1], x[7] = qm1, qm1, qm1, qm1
         got = to_host(r.ev.matvec_plain_multi(Plaintext(r.dev(W), True), r.dev(x), n_rhs))
         for t in range(n_rhs):
             want = r.orc.matvec_plain(W.ravel(), np.ascontiguousarray(x[:, t]).ravel(), rows, cols, threads=0)
