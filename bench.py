@@ -300,7 +300,7 @@ def digest_other(o):
     if pl:
         e = {"all_correct": pl.get("all_correct")}
         if pl.get("layers"):
-            e["ms_per_token"] = {f"{l.get('layer', '?')}@{l.get('tokens', '?')}": r3(l.get("ms_per_token")) for l in pl["layers"]}
+            e["ms_per_token"] = {f"{l.get('layer', '?')}@{l.get('tokens_per_apply', l.get('tokens', '?'))}": r3(l.get("ms_per_token")) for l in pl["layers"]}
         for blk in ("ffn_block", "transformer_block", "activated_ffn", "activated_block", "activated_stack"):
             if isinstance(pl.get(blk), dict):
                 e[blk] = {x: pl[blk].get(x) for x in ("ms_per_token", "ms_per_token_per_block", "correct", "blocks", "correct_blocks", "data_limbs", "tokens", "error", "budget_bits",
