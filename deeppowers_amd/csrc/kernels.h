@@ -769,10 +769,10 @@ __device__ __forceinline__ u64 canon_any(u64 v, const LimbConst& lc) {  // any v
 //         lives on the first Ld = L - 1 limbs; the kernel runs for all L limbs (including P), takes the Ld digits from
 //         c2 (MODE 2, 3-component input) or c1 (MODE 3, 2-component input) and writes t = sum_j d_j (.) key_j to a work
 //         buffer [batch][2][L][N] with nothing added back; dpfhe's rescale-add pass then divides by P and adds (c0, c1).
-template <class Arith, int LOGN, int LOGE, int MODE>
+template <class Arith, int LOGN, int LOGE, int MODE, bool TRACE = false>
 __global__ __launch_bounds__(1 << (LOGN - LOGE), (Arith::kFold ? 2 : 1)) void relin_kernel(u64* __restrict__ out2, const u64* __restrict__ in3,
                                                                        const u64* __restrict__ evk, size_t key_stride, unsigned key_group,
-                                                                       unsigned n_outer, DevTables<Arith> tb) {
+                                                                       unsigned n_outer, DevTables<Arith> tb, u64* trace = nullptr) {
     typedef NttBody<Arith, LOGN, LOGE> B;
     static_assert(LOGE == kFusedLoge, "the fused kernels read the fused twiddle layout (DevTables::fwd4 / inv4)");
     constexpr int E = B::E, N = B::G::N;
@@ -811,15 +811,32 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE), (Arith::kFold ? 2 : 1)) void re
 #pragma unroll
     for (int k = 0; k < E; ++k) acc0[k] = acc1[k] = 0;
     int lazy_terms = 0;
+    // TRACE (diagnostic builds only, tools/relin_trace.py): per workgroup, where the digit loop spends its time - sums over the digits of
+    // [digit words arrived, transform done, first key tile arrived, its products done, second key tile arrived, its products done]
+    const u64 tr_start = trace_stamp<TRACE>((u64)tid);
+    u64 tr_sum[6] = {0, 0, 0, 0, 0, 0};
 #pragma unroll 1
     for (int j = 0; j < Ld; ++j) {
         asm volatile("" : "+v"(tid));
         u64 x[E];
+        const u64 tr0 = trace_stamp<TRACE>((u64)tid);
         B::load_top(tid, x, c2 + (size_t)j * N);
 #pragma unroll
         for (int k = 0; k < E; ++k) x[k] = canon_any<Arith>(x[k], lc);   // [c2]_{q_j} mod q_i
+        u64 tr_dep = 0;
+        if constexpr (TRACE) {
+#pragma unroll
+            for (int k = 0; k < E; ++k) tr_dep |= x[k];
+        }
+        const u64 tr1 = trace_stamp<TRACE>(tr_dep);
         if (j > 0) lds_barrier();
         FwdChain<B, 0>::template run<false>(tid, x, lds, tb.fwd4 + (size_t)limb * N, lc);
+        if constexpr (TRACE) {
+            tr_dep = 0;
+#pragma unroll
+            for (int k = 0; k < E; ++k) tr_dep |= x[k];
+        }
+        const u64 tr2 = trace_stamp<TRACE>(tr_dep);
         const u64* k0 = evk + (((size_t)j * 2 + 0) * L + limb) * N;      // key polynomials, NTT domain (window-0 mapping)
         const u64* k1 = evk + (((size_t)j * 2 + 1) * L + limb) * N;
         if (Arith::kFold) {
@@ -839,14 +856,51 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE), (Arith::kFold ? 2 : 1)) void re
             // faster (N = 8192: -7 %), in registers otherwise (N = 4096: the LDS path is 5 % slower at 2 waves per SIMD)
             constexpr bool kLdsKeys = B::kLdsIO && LOGN >= 13;
             if constexpr (kLdsKeys) B::load_bot_lds(tid, e, k0, lds); else B::load_bot(tid, e, k0);
+            u64 tr_d = 0;
+            if constexpr (TRACE) {
+#pragma unroll
+                for (int k = 0; k < E; ++k) tr_d |= e[k];
+            }
+            const u64 tr3 = trace_stamp<TRACE>(tr_d);
 #pragma unroll
             for (int k = 0; k < E; ++k)
                 acc0[k] = Arith::kFold ? acc0[k] + FoldArith::mul60(x[k], e[k], (u32)lc.d) : add_mod(acc0[k], ShoupArith::mul_var(x[k], e[k], lc), lc.q);
+            if constexpr (TRACE) {
+                tr_d = 0;
+#pragma unroll
+                for (int k = 0; k < E; ++k) tr_d |= acc0[k];
+            }
+            const u64 tr4 = trace_stamp<TRACE>(tr_d);
             asm volatile("" ::: "memory");
             if constexpr (kLdsKeys) B::load_bot_lds(tid, e, k1, lds); else B::load_bot(tid, e, k1);
+            if constexpr (TRACE) {
+                tr_d = 0;
+#pragma unroll
+                for (int k = 0; k < E; ++k) tr_d |= e[k];
+            }
+            const u64 tr5 = trace_stamp<TRACE>(tr_d);
 #pragma unroll
             for (int k = 0; k < E; ++k)
                 acc1[k] = Arith::kFold ? acc1[k] + FoldArith::mul60(x[k], e[k], (u32)lc.d) : add_mod(acc1[k], ShoupArith::mul_var(x[k], e[k], lc), lc.q);
+            if constexpr (TRACE) {
+                tr_d = 0;
+#pragma unroll
+                for (int k = 0; k < E; ++k) tr_d |= acc1[k];
+                const u64 tr6 = trace_stamp<TRACE>(tr_d);
+                tr_sum[0] += tr1 - tr0; tr_sum[1] += tr2 - tr1; tr_sum[2] += tr3 - tr2; tr_sum[3] += tr4 - tr3; tr_sum[4] += tr5 - tr4; tr_sum[5] += tr6 - tr5;
+            }
+        }
+    }
+    if constexpr (TRACE) {
+        u64 tr_d = 0;
+#pragma unroll
+        for (int k = 0; k < E; ++k) tr_d |= acc1[k];
+        const u64 tr_end = trace_stamp<TRACE>(tr_d);
+        if (tid == 0 && trace) {
+            u64* t = trace + (size_t)blockIdx.x * 8;
+            t[0] = tr_start; t[1] = tr_end;
+#pragma unroll
+            for (int i = 0; i < 6; ++i) t[2 + i] = tr_sum[i];
         }
     }
     if (Arith::kFold) {

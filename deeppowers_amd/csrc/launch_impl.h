@@ -166,6 +166,10 @@ int launch_ct_mul_trace(int log2n, u64* out3, const u64* a2, const u64* b2, size
     }
 }
 
+#ifdef DPFHE_RELIN_TRACE
+inline u64* g_relin_trace = nullptr;
+inline unsigned g_relin_trace_blocks = 0;
+#endif
 template <class Arith>
 int launch_relin(int log2n, int mode, u64* out2, const u64* in3, const u64* evk, size_t key_stride, unsigned key_group, size_t blocks,
                  const DevTables<Arith>& tb, hipStream_t s) {
@@ -189,6 +193,16 @@ int launch_relin(int log2n, int mode, u64* out2, const u64* in3, const u64* evk,
         grid = ((n_keys + 7u) / 8u) * 8u * (unsigned)tb.n_limbs * kg;
         n_outer |= kRelinRotMajor;
     }
+#ifdef DPFHE_RELIN_TRACE   // diagnostic builds only (tools/ab_variant.sh reltrace -DDPFHE_RELIN_TRACE; tools/relin_trace.py reads the buffer back)
+    if constexpr (Arith::kFold) {
+        if (log2n == 13 && mode == 4) {
+            if (!g_relin_trace) { if (hipMalloc(&g_relin_trace, sizeof(u64) * 8 * 65536) != hipSuccess) return -1; }
+            g_relin_trace_blocks = grid;
+            hipLaunchKernelGGL((relin_kernel<Arith, 13, kFusedLoge, 4, true>), dim3(grid), dim3(Geo<13, kFusedLoge>::T), 0, s, out2, in3, evk, key_stride, kg, n_outer, tb, g_relin_trace);
+            return 0;
+        }
+    }
+#endif
 #define RL_ONE(LN, M)                                                                                                                                    \
     if constexpr (DPFHE_RELIN_SHARED && Arith::kFold && LN >= 10 && LN <= 12) {                                                                          \
         if (n_digits >= 4 && n_digits <= 7) {                                                                                                            \
