@@ -476,11 +476,13 @@ __global__ __launch_bounds__(256) void matvec_fold_kernel(u64* y, const u64* W, 
                 __builtin_amdgcn_sched_barrier(0);
             }
 #pragma unroll
-            for (int r = 0; r < RT; ++r)
+            for (int r = 0; r < RT; ++r) {
 #pragma unroll
                 for (int c = 0; c < C; ++c)
 #pragma unroll
-                    for (int k = 0; k < WPT; ++k) run[r][c][k] = FoldArith::dot30_fold(acc[r][c][k], 0, lc);
+                    for (int k = 0; k < WPT; ++k) run[r][c][k] = FoldArith::dot30_fold0(acc[r][c][k], lc);
+                __builtin_amdgcn_sched_barrier(0);   // one row of folds at a time: interleaving all sixteen costs ten more registers (and the third wave per SIMD)
+            }
         }
     } else {
     static_assert(WD >= 1 && FoldArith::kDot30Period % WD == 0, "the W ring must divide the period");

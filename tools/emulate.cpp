@@ -316,7 +316,7 @@ extern "C" u64 emu_dot30(u64 q, const u64* a, const u64* b, size_t n) {
     int since = 0;
     for (size_t i = 0; i < n; ++i) {
         FoldArith::dot30_mac(acc, FoldArith::split30(a[i]), FoldArith::split30(b[i]));
-        if (++since == FoldArith::kDot30Period) { acc = FoldArith::Dot30{FoldArith::dot30_fold(acc, 0, lc), 0, 0}; since = 0; }
+        if (++since == FoldArith::kDot30Period) { acc = FoldArith::Dot30{FoldArith::dot30_fold0(acc, lc), 0, 0}; since = 0; }
     }
-    return FoldArith::canon_small(since ? FoldArith::dot30_fold(acc, 0, lc) : acc.s0, lc);
+    return FoldArith::canon_small(since ? FoldArith::dot30_fold0(acc, lc) : acc.s0, lc);
 }
