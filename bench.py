@@ -14,8 +14,11 @@ other keys, so everything a reader of that record needs is inside those three; f
   roofline.ntt - BASELINE configs[1] (the metric's second half): forward / inverse NTT fraction of HBM peak (region-bracketed medians
                  and the 2 s windows), against the copy kernel, with board power / cap / shader clock over the windows.
   roofline.regime - what kind of box this is: CU count, compute / memory partition, clocks (rocm-smi), the multiply's stall share.
-  config.autotune - which form of the fused multiply ran, and every measurement behind the choice (probe at context creation,
-                 dpfhe_ctx_autotune on 8192-pair-sized scratch, three timed steps per form).
+  config.autotune - which form of the fused multiply ran, and every measurement behind the choice (dpfhe_ctx_autotune on
+                 8192-pair-sized scratch - the explicit opt-in; context creation measures nothing -, three timed steps per form).
+  roofline.* scalars - the driver's record keeps only SCALARS of `roofline`: ntt_fwd_frac / ntt_inv_frac (configs[1], the metric's second
+                 half), their 2 s windows, copy_frac, board_w / cap_w / sclk_mhz, the N = 8192 fractions, the generic-prime (Shoup)
+                 figures and autotune_chosen sit there as plain numbers next to the nested objects.
   ntt          - BASELINE configs[1] (batch = 1024 RNS polys x 4 limbs, N=4096): forward / inverse NTT
                  kernel time and fraction of HBM peak (2*N*8 algorithmic bytes per residue polynomial).
   sustained    - >= 2 s of back-to-back forward / inverse NTT launches (configs[1] in place, and 1 GiB out of place) and of the
@@ -330,7 +333,7 @@ def main():
                     help="all-gather through the library's own communicator (dpfhe_comm_*, RCCL behind the C ABI) instead of torch.distributed")
     ap.add_argument("--sustained-seconds", type=float, default=2.0, help="length of each sustained NTT / copy window (0 = skip the block)")
     ap.add_argument("--skip-other", action="store_true", help="skip the other_configs block (profiling runs: every launch is serialised under rocprofv3)")
-    ap.add_argument("--ct-mul-form", default="auto", choices=["auto", "quad", "dual", "single", "quadpf", "quad2"],
+    ap.add_argument("--ct-mul-form", default="auto", choices=["auto", "quad", "dual"],
                     help="form of the fused multiply: auto = measured on this box (library probe + three timed steps per form), or forced")
     ap.add_argument("--no-live-traffic", action="store_true", help="do not profile the multiply's HBM traffic with rocprofv3 after the timed region (roofline.traffic then quotes the committed profile)")
     ap.add_argument("--dry-run", action="store_true", help="CPU + gloo: walk the multi-rank host path (collectives, barriers, report) without kernels")
@@ -364,7 +367,7 @@ def main():
     ctx = Context(params, local_rank)
     ev = Evaluator(ctx)
     dev = ctx.device
-    autotune = {"at_ctx_create": ctx.tune_info()}   # dpfhe_ctx_create's own bounded probe (include/dpfhe.h "A0, continued")
+    autotune = {"at_ctx_create": ctx.tune_info()}   # dpfhe_ctx_create measures nothing: the default form (include/dpfhe.h "A0, continued")
 
     # synthetic inputs: uniform residues, generated on the device, resident in HBM before timing
     g = torch.Generator(device=dev).manual_seed(1000 + rank)
@@ -945,7 +948,7 @@ def main():
         # `frac` keeps the contract's meaning (algorithmic bytes / launch time / HBM peak); the kernel's real bound is VALU issue,
         # so both fractions are first-class: frac_hbm (= frac) and frac_alu (butterflies/s over the register-only ceiling).
         "roofline": {
-            "kernel": {"quad": "ct_mul_quad_kernel<FoldArith,12,4>", "dual": "ct_mul_dual_kernel<FoldArith,12,4,false>", "single": "ct_mul_kernel<FoldArith,12,4,false,false>", "quadpf": "ct_mul_quad_kernel<FoldArith,12,4,false,true> (operands of the workgroup 96 ids ahead requested into L2)", "quad2": "ct_mul_quad2_kernel<FoldArith,12,4> (two pairs per workgroup, the second pair's operands requested during the first pair's last inverse phase)"}.get(autotune.get("chosen"), "ct_mul_quad_kernel<FoldArith,12,4>"),
+            "kernel": {"quad": "ct_mul_quad_kernel<FoldArith,12,4>", "dual": "ct_mul_dual_kernel<FoldArith,12,4,false>"}.get(autotune.get("chosen"), "ct_mul_quad_kernel<FoldArith,12,4>"),
             "bound": "valu", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
             "frac": achieved / HBM_PEAK, "frac_hbm": achieved / HBM_PEAK, "frac_alu": (bfly_per_s / alu_peak) if alu_peak else None,
             "traffic": traffic,
@@ -971,6 +974,7 @@ def main():
         "allgather_us": {"median": gather_us[len(gather_us) // 2], "min": gather_us[0], "max": gather_us[-1]} if (world > 1 or comm is not None or dist.is_initialized()) else None,
     }
 
+    result["roofline"]["autotune_chosen"] = autotune.get("chosen") or autotune["at_ctx_create"].get("chosen")
     rates = [B * args.steps / e for e in per_rank_elapsed]
     result["per_rank_ct_mul_per_s"] = {"min": min(rates), "max": max(rates), "ranks": len(rates)}
     detail = {}
@@ -995,6 +999,13 @@ def main():
                                   "fwd_1GiB_out_of_place_frac": sustained_result["ntt_fwd_1GiB_out_of_place"]["frac_of_hbm_peak"],
                                   "inv_1GiB_out_of_place_frac": sustained_result["ntt_inv_1GiB_out_of_place"]["frac_of_hbm_peak"]}
         result["roofline"]["ntt"] = nv
+        # ... and as SCALARS of `roofline` (the driver's parsed record drops nested objects)
+        rf = result["roofline"]
+        rf.update({"ntt_fwd_frac": nv["fwd_frac"], "ntt_inv_frac": nv["inv_frac"], "ntt_fwd_us": nv["fwd_us"], "ntt_inv_us": nv["inv_us"], "copy_frac": nv["device_copy_frac"]})
+        if "sustained_2s" in nv:
+            s2 = nv["sustained_2s"]
+            rf.update({"ntt_sustained_fwd_frac": s2["fwd_frac"], "ntt_sustained_inv_frac": s2["inv_frac"], "copy_sustained_frac": s2["copy_frac"],
+                       "board_w": s2["board_w"], "cap_w": s2["cap_w"], "sclk_mhz": s2["sclk_mhz"]})
         detail["ntt"] = ntt_result
     if sustained_result is not None:
         detail["sustained"] = sustained_result
@@ -1007,6 +1018,10 @@ def main():
     if other_result is not None:
         detail["other_configs"] = other_result
         result["other_configs"] = digest_other(other_result)
+        c5 = other_result.get("n8192_l6")
+        if c5:
+            result["roofline"].update({"n8192_ntt_fwd_frac": c5["ntt_fwd"]["frac_of_hbm_peak"], "n8192_ntt_inv_frac": c5["ntt_inv"]["frac_of_hbm_peak"],
+                                       "n8192_ct_mul_frac": c5["ct_mul"]["frac_of_hbm_peak"]})
     # the reduced result of the last step equals a recomputation of the same sequence on the main stream (every rank checks,
     # rank 0 reports; at N>1 the recomputation repeats the all-gather, so all ranks must take part)
     chk = ev.reduce_sum(Ciphertext(out), stream=main)

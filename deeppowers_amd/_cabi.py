@@ -15,6 +15,7 @@ SYMBOLS = {
     "dpfhe_ctx_log2n": ([C.c_void_p], C.c_uint32),
     "dpfhe_ctx_limbs": ([C.c_void_p], C.c_uint32),
     "dpfhe_ctx_uses_fold": ([C.c_void_p], C.c_int),
+    "dpfhe_ctx_set_scratch_limit": ([C.c_void_p, C.c_size_t], C.c_int),
     "dpfhe_ctx_autotune": ([C.c_void_p, _U64P, C.c_size_t, C.c_uint32, C.c_void_p], C.c_int),
     "dpfhe_ctx_tune_info": ([C.c_void_p, C.c_void_p], C.c_int),
     "dpfhe_ctx_set_ct_mul_variant": ([C.c_void_p, C.c_int], C.c_int),
@@ -68,7 +69,7 @@ class TuneInfo(C.Structure):
                 ("probe_reps", C.c_uint32), ("probe_us", C.c_float * 8)]
 
 
-TUNE_SOURCES = ("default", "probe at dpfhe_ctx_create", "dpfhe_ctx_autotune", "forced")
+TUNE_SOURCES = ("default", "cached dpfhe_ctx_autotune of this shape", "dpfhe_ctx_autotune", "forced")
 
 
 class DpfheError(RuntimeError):

@@ -86,21 +86,25 @@ struct dpfhe_ctx {
     // given until the context goes - the default pool hands its memory back at every synchronisation and pays the mapping again
     hipMemPool_t scratch_pool = nullptr;
     std::mutex scratch_mutex;
-    // which form of the fused multiply dpfhe_ct_mul(flags = 0) launches (launch.h CtMulVariant): the default of the ring degree until a
-    // probe (dpfhe_ctx_create / dpfhe_ctx_autotune), DPFHE_CTMUL_VARIANT or dpfhe_ctx_set_ct_mul_variant says otherwise.  All forms give the same words.
+    // which form of the fused multiply dpfhe_ct_mul(flags = 0) launches (launch.h CtMulVariant): the default of the ring degree until
+    // dpfhe_ctx_autotune or dpfhe_ctx_set_ct_mul_variant says otherwise.  Both forms give the same words.
     std::atomic<int> ct_mul_variant{0};
-    dpfhe_tune_info tune{};
+    dpfhe_tune_info tune{};           // guarded by tune_mutex (the launch path reads ct_mul_variant only)
+    mutable std::mutex tune_mutex;
+    size_t scratch_limit_words = (size_t)1024 << 17;   // slice size of the composed large-ring operations (dpfhe_ctx_set_scratch_limit)
 };
 
 
 // ------------------------------------------------------------------------------------------------
 // Variant choice of the fused multiply (the reference sketches this class of mechanism as an auto-tuner:
-// /root/reference/src/core/inference/auto_tuner.hpp:26-64).  The three forms move the same bytes and give the same words; which is
-// fastest depends on how well the box hides memory latency behind two waves per SIMD, so the choice is MEASURED:
-// `reps` back-to-back launches per form over `pairs` synthetic ciphertext pairs, two passes in opposite orders, best pass per form;
-// a non-default form is taken only when it is at least 3 % faster than the default.
+// /root/reference/src/core/inference/auto_tuner.hpp:26-64).  The two forms move the same bytes and give the same words.
+// dpfhe_ctx_create NEVER measures: it takes the ring degree's default form (or what an earlier EXPLICIT dpfhe_ctx_autotune on the same
+// (device, log2 N, L) found - a process-wide cache), allocates nothing besides the tables and launches nothing (round 5: the constructor-time
+// probe of round 4 cost 256 MiB and 30 launches per context to confirm a default that won on every box measured).
+// dpfhe_ctx_autotune, on CALLER scratch: `reps` back-to-back launches per form over `pairs` synthetic ciphertext pairs, two passes in opposite
+// orders, best pass per form; a non-default form is taken only when it is at least 3 % faster than the default.
 // ------------------------------------------------------------------------------------------------
-static const char* const kCtMulVariantNames[kCtMulVariants] = {"quad", "dual", "single", "quadpf", "quad2"};
+static const char* const kCtMulVariantNames[kCtMulVariants] = {"quad", "dual"};
 static const float kTuneMargin = 0.97f;
 
 __global__ __launch_bounds__(256) void tune_fill_kernel(u64* __restrict__ p, size_t n) {
@@ -111,6 +115,14 @@ __global__ __launch_bounds__(256) void tune_fill_kernel(u64* __restrict__ p, siz
 static bool ct_mul_variant_compiled(const dpfhe_ctx* c, int v) {
     return c->fold && (c->log2n == 12 || c->log2n == 13) && v >= 0 && v < kCtMulVariants;
 }
+
+// process-wide results of explicit probes, keyed (device, log2 N, L): a later context of the same shape starts from them
+struct TuneKey {
+    int device; uint32_t log2n, n_limbs;
+    bool operator==(const TuneKey& o) const { return device == o.device && log2n == o.log2n && n_limbs == o.n_limbs; }
+};
+static std::mutex g_tune_cache_mutex;
+static std::vector<std::pair<TuneKey, dpfhe_tune_info>> g_tune_cache;
 
 // probes on `s`; synchronises it.  us[v] < 0: not available.  Returns a hipError_t.
 static hipError_t probe_ct_mul(dpfhe_ctx* c, u64* work, size_t pairs, unsigned reps, hipStream_t s, float us[kCtMulVariants]) {
@@ -141,51 +153,46 @@ static hipError_t probe_ct_mul(dpfhe_ctx* c, u64* work, size_t pairs, unsigned r
     return err;
 }
 
-static void adopt_probe(dpfhe_ctx* c, const float us[kCtMulVariants], size_t pairs, unsigned reps, int source) {
+static void adopt_probe(dpfhe_ctx* c, const float us[kCtMulVariants], size_t pairs, unsigned reps) {
     const int def = ct_mul_default_variant((int)c->log2n);
     int best = def;
     for (int v = 0; v < kCtMulVariants; ++v)
         if (us[v] > 0 && us[def] > 0 && us[v] < kTuneMargin * us[def] && (best == def || us[v] < us[best])) best = v;
-    c->tune.n_variants = kCtMulVariants;
-    c->tune.source = source;
-    c->tune.probe_pairs = (uint32_t)pairs;
-    c->tune.probe_reps = reps;
-    for (int v = 0; v < kCtMulVariants; ++v) c->tune.probe_us[v] = us[v];
-    c->tune.chosen = best;
-    c->ct_mul_variant.store(best);
+    dpfhe_tune_info t{};
+    t.n_variants = kCtMulVariants;
+    t.source = DPFHE_TUNE_EXPLICIT;
+    t.probe_pairs = (uint32_t)pairs;
+    t.probe_reps = reps;
+    for (int v = 0; v < 8; ++v) t.probe_us[v] = v < kCtMulVariants ? us[v] : -1.0f;
+    t.chosen = best;
+    {
+        std::lock_guard<std::mutex> lk(c->tune_mutex);
+        c->tune = t;
+        c->ct_mul_variant.store(best);
+    }
+    const TuneKey key{c->device, c->log2n, c->n_limbs};
+    std::lock_guard<std::mutex> lk(g_tune_cache_mutex);
+    for (auto& e : g_tune_cache)
+        if (e.first == key) { e.second = t; return; }
+    g_tune_cache.emplace_back(key, t);
 }
 
-// at context creation: a bounded probe on transient device memory (<= 256 MiB, freed before returning; a failure keeps the default)
+// at context creation: the default form, or the cached result of an explicit probe of this shape on this device.  No device work.
 static void tune_at_create(dpfhe_ctx* c) {
     const int def = ct_mul_default_variant((int)c->log2n);
-    c->ct_mul_variant.store(def);
-    c->tune = dpfhe_tune_info{};
-    c->tune.chosen = def;
-    c->tune.n_variants = ct_mul_variant_compiled(c, def) ? kCtMulVariants : 0;
-    for (int v = 0; v < 8; ++v) c->tune.probe_us[v] = -1.0f;
-    if (!ct_mul_variant_compiled(c, def)) return;
-    if (const char* f = std::getenv("DPFHE_CTMUL_VARIANT")) {
-        for (int v = 0; v < kCtMulVariants; ++v)
-            if (!std::strcmp(f, kCtMulVariantNames[v])) { c->ct_mul_variant.store(v); c->tune.chosen = v; c->tune.source = DPFHE_TUNE_FORCED; return; }
+    dpfhe_tune_info t{};
+    t.chosen = def;
+    t.source = DPFHE_TUNE_DEFAULT;
+    t.n_variants = ct_mul_variant_compiled(c, def) ? kCtMulVariants : 0;
+    for (int v = 0; v < 8; ++v) t.probe_us[v] = -1.0f;
+    if (t.n_variants) {
+        const TuneKey key{c->device, c->log2n, c->n_limbs};
+        std::lock_guard<std::mutex> lk(g_tune_cache_mutex);
+        for (const auto& e : g_tune_cache)
+            if (e.first == key) { t = e.second; t.source = DPFHE_TUNE_CACHED; break; }
     }
-    const char* e = std::getenv("DPFHE_AUTOTUNE");
-    if (e && e[0] == '0') return;
-    const size_t poly = (size_t)c->n_limbs << c->log2n;
-    size_t pairs = ((size_t)256 << 20) / (7 * poly * sizeof(u64));
-    const size_t cap = (size_t)(8 * c->n_cu) / c->n_limbs;           // four generations of two workgroups per CU are plenty
-    if (pairs > cap) pairs = cap;
-    if (pairs == 0) return;
-    u64* work = nullptr;
-    if (hipMalloc(&work, 7 * pairs * poly * sizeof(u64)) != hipSuccess) { (void)hipGetLastError(); return; }
-    hipStream_t s = nullptr;
-    if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) == hipSuccess) {
-        float us[kCtMulVariants];
-        if (probe_ct_mul(c, work, pairs, 3, s, us) == hipSuccess) adopt_probe(c, us, pairs, 3, DPFHE_TUNE_AT_CREATE);
-        else (void)hipGetLastError();
-        (void)hipStreamSynchronize(s);
-        (void)hipStreamDestroy(s);
-    }
-    (void)hipFree(work);
+    c->tune = t;
+    c->ct_mul_variant.store(t.chosen);
 }
 
 extern "C" int dpfhe_ctx_autotune(dpfhe_ctx* c, uint64_t* d_work, size_t work_words, uint32_t reps, void* stream) {
@@ -198,11 +205,12 @@ extern "C" int dpfhe_ctx_autotune(dpfhe_ctx* c, uint64_t* d_work, size_t work_wo
     DPFHE_ON_DEVICE(c, "dpfhe_ctx_autotune");
     float us[kCtMulVariants];
     HIP_TRY(probe_ct_mul(c, d_work, pairs, reps, static_cast<hipStream_t>(stream), us));
-    adopt_probe(c, us, pairs, reps, DPFHE_TUNE_EXPLICIT);
+    adopt_probe(c, us, pairs, reps);
     return DPFHE_SUCCESS;
 }
 extern "C" int dpfhe_ctx_tune_info(const dpfhe_ctx* c, dpfhe_tune_info* out) {
     if (!c || !out) return fail(DPFHE_INVALID_ARGUMENT, "dpfhe_ctx_tune_info", "null argument");
+    std::lock_guard<std::mutex> lk(c->tune_mutex);
     *out = c->tune;
     out->chosen = c->ct_mul_variant.load();
     return DPFHE_SUCCESS;
@@ -210,6 +218,7 @@ extern "C" int dpfhe_ctx_tune_info(const dpfhe_ctx* c, dpfhe_tune_info* out) {
 extern "C" int dpfhe_ctx_set_ct_mul_variant(dpfhe_ctx* c, int variant) {
     if (!c) return fail(DPFHE_INVALID_ARGUMENT, "dpfhe_ctx_set_ct_mul_variant", "null context");
     if (!ct_mul_variant_compiled(c, variant)) return fail(DPFHE_INVALID_ARGUMENT, "dpfhe_ctx_set_ct_mul_variant", "this context has no such form of the fused multiply");
+    std::lock_guard<std::mutex> lk(c->tune_mutex);
     c->ct_mul_variant.store(variant);
     c->tune.chosen = variant;
     c->tune.source = DPFHE_TUNE_FORCED;
@@ -347,7 +356,7 @@ extern "C" int dpfhe_ctx_create(dpfhe_ctx** out, uint32_t log2_n, uint32_t n_lim
         c->shoup.n_sub = (int)n_sub;
         c->shoup.n_limbs = (int)n_limbs;
     }
-    tune_at_create(c);   // picks the form of the fused multiply for this box (bounded probe; DPFHE_AUTOTUNE=0 skips it)
+    tune_at_create(c);   // default form of the fused multiply, or a cached explicit probe of this shape: no device work
     (void)hipSetDevice(prev);
     *out = c;
     return DPFHE_SUCCESS;
@@ -358,6 +367,12 @@ extern "C" int dpfhe_ctx_destroy(dpfhe_ctx* c) {
     if (c->d_blob) (void)hipFree(c->d_blob);
     if (c->scratch_pool) (void)hipMemPoolDestroy(c->scratch_pool);
     delete c;
+    return DPFHE_SUCCESS;
+}
+extern "C" int dpfhe_ctx_set_scratch_limit(dpfhe_ctx* c, size_t mib) {
+    if (!c) return fail(DPFHE_INVALID_ARGUMENT, "dpfhe_ctx_set_scratch_limit", "null context");
+    if (mib == 0 || mib > ((size_t)1 << 20)) return fail(DPFHE_INVALID_ARGUMENT, "dpfhe_ctx_set_scratch_limit", "limit must be in [1 MiB, 1 TiB]");
+    c->scratch_limit_words = mib << 17;
     return DPFHE_SUCCESS;
 }
 extern "C" uint32_t dpfhe_ctx_log2n(const dpfhe_ctx* c) { return c ? c->log2n : 0; }
@@ -545,22 +560,14 @@ static int key_switch_composed_slice(dpfhe_ctx* c, uint64_t* d_out2, const uint6
     return check_launch("add-back kernel launch");
 }
 
-// Large batches go through in slices whose scratch stays below scratch_words() (the slices run back to back on the caller's stream and reuse
+// Large batches go through in slices whose scratch stays below the context's scratch limit (the slices run back to back on the caller's stream and reuse
 // the pool's block): the scratch of a composed operation is 4 (multiply) or L^2 / 2 (key switch) times its input.
-static size_t scratch_words() {   // 1 GiB unless DPFHE_SCRATCH_MIB says otherwise (read once)
-    static const size_t words = [] {
-        const char* e = std::getenv("DPFHE_SCRATCH_MIB");
-        const long mib = e ? std::atol(e) : 0;
-        return (size_t)(mib > 0 ? mib : 1024) << 17;
-    }();
-    return words;
-}
-static size_t slice_items(size_t batch, size_t scratch_words_per_item) {
-    const size_t fit = scratch_words() / scratch_words_per_item;
+static size_t slice_items(const dpfhe_ctx* c, size_t batch, size_t scratch_words_per_item) {   // 1 GiB of scratch unless dpfhe_ctx_set_scratch_limit said otherwise
+    const size_t fit = c->scratch_limit_words / scratch_words_per_item;
     return fit == 0 ? 1 : (fit < batch ? fit : batch);
 }
 static int ct_mul_composed(dpfhe_ctx* c, uint64_t* d_out3, const uint64_t* d_a2, const uint64_t* d_b2, size_t batch, uint32_t flags, hipStream_t s) {
-    const size_t poly = (size_t)c->n_limbs << c->log2n, per = slice_items(batch, 4 * poly);
+    const size_t poly = (size_t)c->n_limbs << c->log2n, per = slice_items(c, batch, 4 * poly);
     for (size_t i = 0; i < batch; i += per) {
         const size_t m = batch - i < per ? batch - i : per;
         if (int rc = ct_mul_composed_slice(c, d_out3 + i * 3 * poly, d_a2 + i * 2 * poly, d_b2 + i * 2 * poly, m, flags, s)) return rc;
@@ -569,7 +576,7 @@ static int ct_mul_composed(dpfhe_ctx* c, uint64_t* d_out3, const uint64_t* d_a2,
 }
 static int key_switch_composed(dpfhe_ctx* c, uint64_t* d_out2, const uint64_t* d_in, int in_comps, int add_mask, const uint64_t* d_evk, size_t batch,
                                hipStream_t s, const char* what) {
-    const size_t poly = (size_t)c->n_limbs << c->log2n, per = slice_items(batch, c->n_limbs * poly);
+    const size_t poly = (size_t)c->n_limbs << c->log2n, per = slice_items(c, batch, c->n_limbs * poly);
     for (size_t i = 0; i < batch; i += per) {
         const size_t m = batch - i < per ? batch - i : per;
         if (int rc = key_switch_composed_slice(c, d_out2 + i * 2 * poly, d_in + i * (size_t)in_comps * poly, in_comps, add_mask, d_evk, m, s, what)) return rc;
@@ -928,8 +935,7 @@ extern "C" int dpfhe_rotate_hoisted_qp(dpfhe_ctx* c, uint64_t* d_out_qp, const u
             QpElts ge{};
             for (size_t i = 0; i < cnt; ++i) ge.v[i] = galois_elts[first + i];
             // (pairs per thread: 2 measured best at 8 tokens - 291 us against 300 with 1 and 329 with 4 -, 1 is 5 % ahead at one token: profiles/r04_ab_baby_steps.txt)
-            static const bool upfront = [] { const char* e = std::getenv("DPFHE_QP_UPFRONT"); return !(e && e[0] == '0'); }();   // A/B: DPFHE_QP_UPFRONT=0 keeps the loop form
-            if (c->fold && upfront && Ld >= 1 && Ld <= 6) {   // every segment of the workgroup requested up front (one pair of words per thread)
+            if (c->fold && Ld >= 1 && Ld <= 6) {   // every segment of the workgroup requested up front (one pair of words per thread)
                 const size_t grid1 = qp_stream_grid((int)c->log2n, (int)L, cnt, T, 1);
                 if (grid1 > kMaxGrid) return fail(DPFHE_INVALID_ARGUMENT, what, "batch too large for one launch");
 #define QPU(LD) case LD: hipLaunchKernelGGL((hoisted_qp_upfront_kernel<LD>), dim3((unsigned)grid1), dim3(256), 0, s, dst, d_digits, d_in_ntt, d_keys + first * key_words, key_words, ge, \
@@ -1202,7 +1208,7 @@ static int base_extend_common(dpfhe_ctx* c, int mode, uint64_t* d_out, size_t ou
     if (!c) return fail(DPFHE_INVALID_ARGUMENT, what, "null context");
     if (n_polys == 0) return DPFHE_SUCCESS;
     const uint32_t L = c->n_limbs;
-    if (ns == 0 || ns > (uint32_t)kBxMaxSrc || nd == 0 || nd > (uint32_t)kBxMaxDst || src0 + ns > L || dst0 + nd > L)
+    if (ns == 0 || ns > (uint32_t)kBxMaxSrc || nd == 0 || nd > (uint32_t)kBxMaxDst || src0 > L || ns > L - src0 || dst0 > L || nd > L - dst0)   /* no 32-bit wrap-around */
         return fail(DPFHE_INVALID_ARGUMENT, what, "1..10 source limbs and 1..20 destination limbs inside the context");
     if (mode == 1 && !(dst0 >= src0 + ns || dst0 + nd <= src0)) return fail(DPFHE_INVALID_ARGUMENT, what, "the dropped limbs and the kept limbs must be disjoint");
     if (!d_out || !d_in || misaligned(d_out) || misaligned(d_in) || out_stride_limbs < nd || in_stride_limbs < ns) return fail(DPFHE_INVALID_ARGUMENT, what, "null or misaligned buffer, or an item stride shorter than its limbs");

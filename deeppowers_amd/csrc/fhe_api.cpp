@@ -95,7 +95,7 @@ void* Context::handle() const { return impl_->h; }
 Context::TuneInfo Context::tune_info() const {
     dpfhe_tune_info t{};
     check(dpfhe_ctx_tune_info(impl_->h, &t), "dpfhe_ctx_tune_info");
-    static const char* const src[] = {"default", "probe at dpfhe_ctx_create", "dpfhe_ctx_autotune", "forced"};
+    static const char* const src[] = {"default", "cached dpfhe_ctx_autotune of this shape", "dpfhe_ctx_autotune", "forced"};
     TuneInfo r;
     r.chosen = dpfhe_ct_mul_variant_name(t.chosen);
     r.source = (t.source >= 0 && t.source < 4) ? src[t.source] : "?";
@@ -344,8 +344,8 @@ ExactMultiplier::ExactMultiplier(const Context& work_ctx, const Context& level_c
     const FheParams &pw = work_ctx.params(), &pl = level_ctx.params();
     impl_->work = &work_ctx; impl_->level = &level_ctx; impl_->t = plain_modulus;
     impl_->ll = pl.n_limbs(); impl_->L = pw.n_limbs(); impl_->n = pw.n();
-    if (pl.log2_n != pw.log2_n || impl_->ll == 0 || impl_->ll >= impl_->L || impl_->ll > 9 || impl_->L > 20 || impl_->L - impl_->ll > 10 || work_ctx.device_id() != level_ctx.device_id() || plain_modulus < 2)
-        throw Exception(ErrorCode::INVALID_ARGUMENT, "ExactMultiplier: the level context must hold the first 1..9 limbs of the work context, which has at most 20 and at most 10 beyond the level (same ring degree and device)");
+    if (pl.log2_n != pw.log2_n || impl_->ll == 0 || impl_->ll >= impl_->L || impl_->ll > (work_ctx.uses_fold() ? 9u : 8u) || impl_->L > 20 || impl_->L - impl_->ll > (work_ctx.uses_fold() ? 10u : 8u) || work_ctx.device_id() != level_ctx.device_id() || plain_modulus < 2)
+        throw Exception(ErrorCode::INVALID_ARGUMENT, "ExactMultiplier: the level context must hold the first 1..9 limbs (1..8 with generic primes) of the work context, which has at most 20 and at most 10 (generic primes: 8) beyond the level (same ring degree and device)");
     for (size_t i = 0; i < impl_->ll; ++i)
         if (pl.moduli[i] != pw.moduli[i]) throw Exception(ErrorCode::INVALID_ARGUMENT, "ExactMultiplier: the level's moduli must be the first moduli of the work context");
     double lq = 0, lQ = 0, lW = 0;

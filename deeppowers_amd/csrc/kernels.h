@@ -225,23 +225,17 @@ struct InvChain2 {
 };
 
 // Three inverse transforms of one limb on two LDS buffers (x | y, then z reuses buffer 0), one set of twiddle fetches.
-// `at_last_phase` runs when the LAST phase (the top window: workgroup-uniform twiddles in scalar registers) is about to start: the ~60 vector
-// registers of the per-thread twiddles are free from there on, which is where a caller can have the next operands requested (ct_mul_quad2_kernel).
-struct NoHook { __device__ __forceinline__ void operator()() const {} };
 template <class B, int P, int IN>
 struct InvChain3 {
     typedef typename B::TwRegs TwRegs;
-    template <class Hook = NoHook>
     static __device__ __forceinline__ void run(int tid, u64 (&x)[B::E], u64 (&y)[B::E], u64 (&z)[B::E], u64* lds0, u64* lds1, const typename B::Tw* tw,
-                                               const InvLast<typename B::Tw>& last, const LimbConst& lc, Hook&& at_last_phase = Hook()) {
+                                               const InvLast<typename B::Tw>& last, const LimbConst& lc) {
         TwRegs twr;
         B::template load_tw<P, false>(tid, tw, twr);
-        run_with(tid, x, y, z, lds0, lds1, tw, last, lc, twr, at_last_phase);
+        run_with(tid, x, y, z, lds0, lds1, tw, last, lc, twr);
     }
-    template <class Hook>
     static __device__ __forceinline__ void run_with(int tid, u64 (&x)[B::E], u64 (&y)[B::E], u64 (&z)[B::E], u64* lds0, u64* lds1,
-                                                    const typename B::Tw* tw, const InvLast<typename B::Tw>& last, const LimbConst& lc, const TwRegs& twr, Hook&& at_last_phase) {
-        if constexpr (P == 0) at_last_phase();
+                                                    const typename B::Tw* tw, const InvLast<typename B::Tw>& last, const LimbConst& lc, const TwRegs& twr) {
         B::template inv_phase_r<P, IN>(x, twr, last.w_last, last.w_ninv, lc);
         if constexpr (P > 0) {
             exch_sync_before_write<typename B::G, P - 1, false>();
@@ -258,7 +252,7 @@ struct InvChain3 {
             B::template lds_write<P - 1, P, false>(tid, z, lds0);
             exch_sync_after_write<typename B::G, P - 1>();
             B::template lds_read<P - 1, P - 1, false>(tid, z, lds0);
-            InvChain3<B, P - 1, IN>::run_with(tid, x, y, z, lds0, lds1, tw, last, lc, nxt, at_last_phase);
+            InvChain3<B, P - 1, IN>::run_with(tid, x, y, z, lds0, lds1, tw, last, lc, nxt);
         } else {
             B::template inv_phase_r<P, IN>(y, twr, last.w_last, last.w_ninv, lc);
             B::template inv_phase_r<P, IN>(z, twr, last.w_last, last.w_ninv, lc);
@@ -574,26 +568,9 @@ __device__ __forceinline__ u64 trace_stamp(u64 dep) {
     if constexpr (TRACE) asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) : "v"(dep) : "memory");
     return t;
 }
-// PF (the "quadpf" form): every workgroup also REQUESTS the four operand polynomials of the workgroup `pf_dist` ids ahead (same
-// limb, same XCD: pf_dist is a multiple of 8 and of L) with loads whose results are thrown away - they land in that XCD's L2 about when
-// the later workgroup starts, so its first operand word comes from L2 instead of HBM.  The workgroup timeline (tools/ctmul_trace.py)
-// shows ~11 % of a workgroup's life spent waiting for that word, with two waves per SIMD to cover it.  No extra HBM traffic when the
-// prefetch hits its window; the untracked loads only make the compiler's own vmcnt waits conservative (returns are in order).
-typedef unsigned v4u32 __attribute__((ext_vector_type(4)));
-template <int N_WORDS, int T>
-__device__ __forceinline__ void prefetch_poly_l2(const u64* g, int tid) {
-    constexpr int kLoads = N_WORDS * 8 / (T * 16);     // 16 bytes per lane per load
-#pragma unroll
-    for (int r = 0; r < kLoads; ++r) {
-        v4u32 sink;
-        const u64* base = g + (size_t)r * T * 2;       // workgroup-uniform: an SGPR pair, the lane offset stays one 32-bit register
-        asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(sink) : "v"((unsigned)tid * 16u), "s"(base) : "memory");
-    }
-}
-template <class Arith, int LOGN, int LOGE, bool TRACE = false, bool PF = false>
+template <class Arith, int LOGN, int LOGE, bool TRACE = false>
 __global__ __launch_bounds__(1 << (LOGN - LOGE), 2) void ct_mul_quad_kernel(u64* __restrict__ out3, const u64* __restrict__ a2,
-                                                                         const u64* __restrict__ b2, DevTables<Arith> tb, u64* __restrict__ trace = nullptr,
-                                                                         unsigned pf_dist = 0) {
+                                                                         const u64* __restrict__ b2, DevTables<Arith> tb, u64* __restrict__ trace = nullptr) {
     typedef NttBody<Arith, LOGN, LOGE> B;
     static_assert(Arith::kFold && LOGE == kFusedLoge, "FoldArith, fused twiddle layout");
     constexpr int E = B::E, N = B::G::N, W = B::G::lds_words();
@@ -618,16 +595,6 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE), 2) void ct_mul_quad_kernel(u64*
     B::template load_top<true>(tid, z, src_a + cstride);
     B::template load_top<true>(tid, w, src_b + cstride);
     const u64 ts_i = trace_stamp<TRACE>((u64)tid);                              // all 64 loads are issued
-    if constexpr (PF) {
-        const size_t ahead = (size_t)blockIdx.x + pf_dist;
-        if (ahead < gridDim.x) {    // (pf_dist % L == 0: the same limb, pf_dist / L pairs further)
-            const size_t off = (size_t)(pf_dist / (unsigned)L) * 2 * cstride;
-            prefetch_poly_l2<N, B::G::T>(src_a + off, tid);
-            prefetch_poly_l2<N, B::G::T>(src_b + off, tid);
-            prefetch_poly_l2<N, B::G::T>(src_a + off + cstride, tid);
-            prefetch_poly_l2<N, B::G::T>(src_b + off + cstride, tid);
-        }
-    }
     const u64 ts1 = trace_stamp<TRACE>(x[0]);
     const u64 ts_xl = trace_stamp<TRACE>(x[E - 1]);                             // the whole first operand has arrived
     FwdChain4<B, 0>::run(tid, x, y, z, w, lds, lds + W, tb.fwd4 + (size_t)limb * N, lc);
@@ -667,81 +634,6 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE), 2) void ct_mul_quad_kernel(u64*
             t[8] = ts_p; t[9] = ts_x; t[10] = ts_i; t[11] = ts_xl;
         }
     }
-}
-
-// "quad2": the quad form over TWO consecutive pairs per workgroup, STRAIGHT-LINE (no loop: a loop edge makes hipcc's wait-count pass give up and
-// wait for every outstanding memory operation before every twiddle use - DESIGN.md section 5, the looped form ran 2.2 x slower).  The second pair's
-// a0, b0 and a1 are requested when the first pair's LAST inverse phase starts (into the registers the per-thread twiddles leave free there), its b1
-// when the second pair starts: of the two first-operand waits of the two pairs (10 % of a workgroup's life each) the second one is gone.
-template <class Arith, int LOGN, int LOGE>
-__global__ __launch_bounds__(1 << (LOGN - LOGE), 2) void ct_mul_quad2_kernel(u64* __restrict__ out3, const u64* __restrict__ a2,
-                                                                           const u64* __restrict__ b2, DevTables<Arith> tb, unsigned batch) {
-    typedef NttBody<Arith, LOGN, LOGE> B;
-    static_assert(Arith::kFold && LOGE == kFusedLoge, "FoldArith, fused twiddle layout");
-    constexpr int E = B::E, N = B::G::N, W = B::G::lds_words();
-    __shared__ __attribute__((aligned(16))) u64 lds[2 * W];
-    int tid = threadIdx.x;
-    const size_t L = (size_t)tb.n_limbs;
-    const int limb = (int)(blockIdx.x % L);
-    const size_t first = (size_t)(blockIdx.x / L) * 2;
-    const bool two = first + 1 < batch;           // workgroup-uniform: the last workgroup of an odd batch has one pair
-    const LimbConst lc = tb.lc[limb];
-    const size_t cstride = L * N;
-    const InvLast<typename B::Tw> last = tb.last[limb];
-    constexpr int kInvIn = 2 * kMulB;
-    const u64* src_a = a2 + ((first * 2) * L + limb) * N;
-    const u64* src_b = b2 + ((first * 2) * L + limb) * N;
-    u64* dst = out3 + ((first * 3) * L + limb) * N;
-    const typename B::Tw* twf = tb.fwd4 + (size_t)limb * N;
-    const typename B::Tw* twi = tb.inv4 + (size_t)limb * N;
-    u64 x[E], y[E], z[E], w[E], xn[E], yn[E], zn[E];
-    B::template load_top<true>(tid, x, src_a);
-    B::template load_top<true>(tid, y, src_b);
-    B::template load_top<true>(tid, z, src_a + cstride);
-    B::template load_top<true>(tid, w, src_b + cstride);
-    auto product = [&](u64 (&x_)[E], u64 (&y_)[E], u64 (&z_)[E], u64 (&w_)[E]) {
-        B::fwd_reduce_partner(y_, lc);
-        B::fwd_reduce_partner(w_, lc);
-#pragma unroll
-        for (int k = 0; k < E; ++k) {
-            const u64 a0 = x_[k], b0 = y_[k], a1 = z_[k], b1 = w_[k];
-            x_[k] = FoldArith::mul60(a0, b0, (u32)lc.d);
-            y_[k] = FoldArith::mul60(a0, b1, (u32)lc.d) + FoldArith::mul60(a1, b0, (u32)lc.d);
-            z_[k] = FoldArith::mul60(a1, b1, (u32)lc.d);
-        }
-    };
-    auto finish = [&](u64 (&x_)[E], u64 (&y_)[E], u64 (&z_)[E], u64* d) {
-        B::inv_canon(x_, lc);
-        B::template store_top<DPFHE_CTMUL_NT_STORE != 0>(tid, x_, d);
-        B::inv_canon(y_, lc);
-        B::template store_top<DPFHE_CTMUL_NT_STORE != 0>(tid, y_, d + cstride);
-        B::inv_canon(z_, lc);
-        B::template store_top<DPFHE_CTMUL_NT_STORE != 0>(tid, z_, d + 2 * cstride);
-    };
-    // ---- pair 0
-    FwdChain4<B, 0>::run(tid, x, y, z, w, lds, lds + W, twf, lc);
-    product(x, y, z, w);
-    asm volatile("" : "+v"(tid));
-    // the next pair's a0, b0, a1 are requested when the LAST inverse phase starts (a third of the inverse transforms + the stores ahead of their
-    // use: more than the 3.6 us a first operand word takes), into the registers the per-thread twiddles have just left
-    InvChain3<B, B::NPH - 1, kInvIn>::run(tid, x, y, z, lds, lds + W, twi, last, lc, [&]() {
-        if (two) {
-            B::template load_top<true>(tid, xn, src_a + 2 * cstride);
-            B::template load_top<true>(tid, yn, src_b + 2 * cstride);
-            B::template load_top<true>(tid, zn, src_a + 3 * cstride);
-        }
-    });
-    finish(x, y, z, dst);
-    if (!two) return;
-    // ---- pair 1 (its first three operands are already in flight or in registers)
-    asm volatile("" : "+v"(tid));   // keeps the twiddle fetches of the two pairs apart (see ct_mul_kernel)
-    B::template load_top<true>(tid, w, src_b + 3 * cstride);
-    lds_barrier();                  // pair 0's last exchange was read across waves; pair 1's first one writes across them
-    FwdChain4<B, 0>::run(tid, xn, yn, zn, w, lds, lds + W, twf, lc);
-    product(xn, yn, zn, w);
-    asm volatile("" : "+v"(tid));
-    InvChain3<B, B::NPH - 1, kInvIn>::run(tid, xn, yn, zn, lds, lds + W, twi, last, lc);
-    finish(xn, yn, zn, dst + 3 * cstride);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -34,7 +34,8 @@ template <class Arith>
 int launch_ct_mul(int log2n, unsigned flags, u64* out3, const u64* a2, const u64* b2, size_t blocks, const DevTables<Arith>& tb, hipStream_t s);
 
 // named forms of the fused multiply (launch_impl.h launch_ct_mul_variant; instantiated in k_ctmul_var.hip)
-enum CtMulVariant { kCtMulQuad = 0, kCtMulDual = 1, kCtMulSingle = 2, kCtMulQuadPf = 3, kCtMulQuad2 = 4, kCtMulVariants = 5 };
+// (round 5: the single-transform, prefetching and two-pair forms never won on any of 19 boxes - profiles/r04_box_fingerprints.txt - and are gone)
+enum CtMulVariant { kCtMulQuad = 0, kCtMulDual = 1, kCtMulVariants = 2 };
 constexpr int ct_mul_default_variant(int log2n) { return log2n <= 12 ? kCtMulQuad : kCtMulDual; }   // what launch_ct_mul runs for flags = 0
 template <class Arith>
 int launch_ct_mul_variant(int log2n, int variant, u64* out3, const u64* a2, const u64* b2, size_t blocks, const DevTables<Arith>& tb, hipStream_t s);

@@ -119,17 +119,8 @@ int launch_ct_mul(int log2n, unsigned flags, u64* out3, const u64* a2, const u64
     }
 }
 
-// how many workgroup ids ahead the "quadpf" form prefetches: a multiple of 8 (same XCD) and of L (same limb), 96 by default (two operand
-// round trips at the measured 3.6 us first-word latency; 16 ... 192 measured, profiles/r04_ab_quadpf.txt); DPFHE_CTMUL_PF_DIST overrides (A/B runs)
-inline unsigned pf_distance(int n_limbs) {
-    static const unsigned want = [] { const char* e = std::getenv("DPFHE_CTMUL_PF_DIST"); const int n = e ? std::atoi(e) : 0; return n > 0 ? (unsigned)n : 96u; }();
-    unsigned lcm = 8u;
-    while (lcm % (unsigned)n_limbs) lcm += 8u;
-    const unsigned d = (want + lcm - 1) / lcm * lcm;
-    return d ? d : lcm;
-}
 // The fused multiply in a NAMED form (coefficient domain in and out, FoldArith, N = 4096 / 8192): what dpfhe_ctx_autotune probes and
-// what a context then launches.  kCtMulQuad / kCtMulDual / kCtMulSingle differ in how many transforms share twiddle fetches and LDS
+// what a context then launches.  kCtMulQuad / kCtMulDual differ in how many transforms share twiddle fetches and LDS
 // buffers (kernels.h), not in results (bit-identical) or HBM traffic (7 residue polynomials per limb).  -1: not compiled for this ring.
 template <class Arith>
 int launch_ct_mul_variant(int log2n, int variant, u64* out3, const u64* a2, const u64* b2, size_t blocks, const DevTables<Arith>& tb, hipStream_t s) {
@@ -139,12 +130,6 @@ int launch_ct_mul_variant(int log2n, int variant, u64* out3, const u64* a2, cons
     case LN:                                                                                                                                          \
         if (variant == kCtMulQuad) hipLaunchKernelGGL((ct_mul_quad_kernel<Arith, LN, kFusedLoge>), dim3((unsigned)blocks), dim3(Geo<LN, kFusedLoge>::T), 0, s, out3, a2, b2, tb, (u64*)nullptr); \
         else if (variant == kCtMulDual) hipLaunchKernelGGL((ct_mul_dual_kernel<Arith, LN, kFusedLoge, false>), dim3((unsigned)blocks), dim3(Geo<LN, kFusedLoge>::T), 0, s, out3, a2, b2, tb); \
-        else if (variant == kCtMulSingle) hipLaunchKernelGGL((ct_mul_kernel<Arith, LN, kFusedLoge, false, false>), dim3((unsigned)blocks), dim3(Geo<LN, kFusedLoge>::T), 0, s, out3, a2, b2, tb); \
-        else if (variant == kCtMulQuadPf) hipLaunchKernelGGL((ct_mul_quad_kernel<Arith, LN, kFusedLoge, false, true>), dim3((unsigned)blocks), dim3(Geo<LN, kFusedLoge>::T), 0, s, out3, a2, b2, tb, (u64*)nullptr, pf_distance(tb.n_limbs)); \
-        else if (variant == kCtMulQuad2) {                                                                                                            \
-            const unsigned batch = (unsigned)(blocks / (size_t)tb.n_limbs);                                                                           \
-            hipLaunchKernelGGL((ct_mul_quad2_kernel<Arith, LN, kFusedLoge>), dim3(((batch + 1u) / 2u) * (unsigned)tb.n_limbs), dim3(Geo<LN, kFusedLoge>::T), 0, s, out3, a2, b2, tb, batch); \
-        }                                                                                                                                             \
         else return -1;                                                                                                                               \
         return 0
         switch (log2n) {

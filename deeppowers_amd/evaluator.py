@@ -87,6 +87,10 @@ class Context:
             raise _cabi.DpfheError(2000, f"unknown form {name!r}")
         _cabi.check(self._lib.dpfhe_ctx_set_ct_mul_variant(self._h, names.index(name)), "dpfhe_ctx_set_ct_mul_variant")
 
+    def set_scratch_limit(self, mib: int):
+        """Slice size (MiB of scratch) of the composed large-ring operations (log2_n >= 14); a set-up call."""
+        _cabi.check(self._lib.dpfhe_ctx_set_scratch_limit(self._h, int(mib)), "dpfhe_ctx_set_scratch_limit")
+
     def close(self):
         if getattr(self, "_h", None):
             self._lib.dpfhe_ctx_destroy(self._h)
@@ -495,8 +499,11 @@ class Evaluator:
         fused dpfhe_ct_mul (THE METRIC OP) on all limbs, dpfhe_scale_round (x t / q on the workspace limbs), dpfhe_base_extend back."""
         p = self.ctx.params
         L, ll = p.n_limbs, level_limbs
-        if a.shape != b.shape or a.dim() != 4 or a.shape[1] != 2 or a.shape[2] != ll or not (0 < ll < L and ll <= 9):
-            raise _cabi.DpfheError(2000, "multiply_exact: [batch][2][level_limbs][N] operands, 0 < level_limbs <= min(9, L - 1)")
+        # the limits of dpfhe_base_extend / dpfhe_scale_round (base_ext.h kBxMaxSrc = 10, kBxMaxDst = 20, kBxMaxSrcGeneric = 8), checked BEFORE anything is
+        # enqueued (ExactMultiplier's constructor in fhe_api.cpp makes the same checks)
+        max_src = 9 if self.ctx.uses_fold else 8
+        if a.shape != b.shape or a.dim() != 4 or a.shape[1] != 2 or a.shape[2] != ll or not (0 < ll < L and ll <= max_src and L <= 20 and L - ll <= (10 if self.ctx.uses_fold else 8)):
+            raise _cabi.DpfheError(2000, "multiply_exact: [batch][2][level_limbs][N] operands, 0 < level_limbs <= min(9, L - 1) (8 with generic primes), L <= 20, L - level_limbs <= 10 (8)")
         # workspace check (exactness): log2 Q - 1 > log2(N) + log2(t) + 2 log2(q) + 1
         import math
         lq = sum(math.log2(m) for m in p.moduli[:ll])

@@ -66,10 +66,10 @@ public:
     bool uses_fold() const;
     void* handle() const;  // dpfhe_ctx*
     void synchronize() const;
-    // Which form of the fused multiply Evaluator::multiply launches on this box (include/dpfhe.h "A0, continued": measured once at
-    // construction, in the spirit of the reference's AutoTuner, src/core/inference/auto_tuner.hpp:26-64).  All forms give the same words.
+    // Which form of the fused multiply Evaluator::multiply launches (include/dpfhe.h "A0, continued": the ring degree's default; autotune()
+    // is the explicit opt-in measurement, in the spirit of the reference's AutoTuner, src/core/inference/auto_tuner.hpp:26-64).  Both forms give the same words.
     struct TuneInfo {
-        std::string chosen, source;                                // e.g. "quad", "probe at dpfhe_ctx_create"
+        std::string chosen, source;                                // e.g. "quad", "default"
         std::vector<std::pair<std::string, float>> probe_us;       // microseconds per probe launch of each measured form
         unsigned probe_pairs = 0, probe_reps = 0;
     };

@@ -28,8 +28,8 @@
  *     BASELINE configuration) they never allocate either: all scratch is caller-provided (d_work / d_digits / ... arguments).  The ONE
  *     exception is spelled out at dpfhe_ctx_create below: at log2_n >= 14 dpfhe_ct_mul, dpfhe_relinearize, dpfhe_switch_key and the two
  *     single-key hybrid entries take their scratch from a stream-ordered pool owned by the context (no synchronisation, no host allocation;
- *     the pool keeps its memory until dpfhe_ctx_destroy).  dpfhe_ctx_create / dpfhe_ctx_autotune / dpfhe_comm_create are set-up calls: they
- *     allocate, run device work and synchronise.  After set-up a dpfhe_ctx is immutable: concurrent calls from different host threads on
+ *     the pool keeps its memory until dpfhe_ctx_destroy).  dpfhe_ctx_create (uploads the tables: one allocation, one copy, no kernel), dpfhe_ctx_autotune
+ *     (times kernels on caller scratch) and dpfhe_comm_create are set-up calls: they may allocate and synchronise.  After set-up a dpfhe_ctx is immutable: concurrent calls from different host threads on
  *     different streams are allowed.
  *   - No C++ types and no exceptions cross this boundary.
  */
@@ -63,29 +63,31 @@ enum { DPFHE_IN_NTT = 1u, DPFHE_OUT_NTT = 2u };
  * log2_n in [8, 16] (N > 16384 runs a two-kernel split transform; the fused ct x ct / key-switch kernels stop at 13: above it dpfhe_ct_mul,
  * dpfhe_relinearize and dpfhe_switch_key compose the batched transforms with one-pass streaming kernels and take their scratch from the
  * stream-ordered allocator (a memory pool of the context's own, on the caller's stream; kept until dpfhe_ctx_destroy; large batches run in slices of at most
- * 1 GiB of scratch, or DPFHE_SCRATCH_MIB MiB when that environment variable is set); so do the single-key hybrid entries dpfhe_relinearize_hybrid / dpfhe_switch_key_hybrid; the batched, hoisted and grouped rotation entries return
+ * 1 GiB of scratch, or what dpfhe_ctx_set_scratch_limit said); so do the single-key hybrid entries dpfhe_relinearize_hybrid / dpfhe_switch_key_hybrid; the batched, hoisted and grouped rotation entries return
  * DPFHE_INVALID_STATE there); n_limbs >= 1; moduli[i] prime < 2^60 with q = 1 (mod 2N); psi[i] a primitive
  * 2N-th root of unity mod q_i (psi^N = -1).  Builds twiddle / Shoup / Barrett tables on device_id. */
 int dpfhe_ctx_create(dpfhe_ctx** out, uint32_t log2_n, uint32_t n_limbs, const uint64_t* moduli,
                      const uint64_t* psi, int device_id);
 int dpfhe_ctx_destroy(dpfhe_ctx* ctx);
+/* set-up call (before the context is shared between threads): the composed large-ring operations (log2_n >= 14) slice their batches so that
+ * one slice's scratch stays below `mib` MiB (default 1024).  The library reads NO environment variable. */
+int dpfhe_ctx_set_scratch_limit(dpfhe_ctx* ctx, size_t mib);
 uint32_t dpfhe_ctx_log2n(const dpfhe_ctx* ctx);
 uint32_t dpfhe_ctx_limbs(const dpfhe_ctx* ctx);
 /* 1 if every limb is of the form 2^60 - d, d < 2^24, and the fold-reduction kernels are in use */
 int dpfhe_ctx_uses_fold(const dpfhe_ctx* ctx);
 
 /* -- A0, continued: which FORM of the fused multiply a context launches -------------------------------------------------
- * dpfhe_ct_mul(flags = 0) has five forms at N = 4096 / 8192 on fold-reduction contexts - "quad" (all four forward and all three inverse
- * transforms of a workgroup share twiddle fetches), "dual" (transforms in pairs), "single" (one at a time, half the LDS), "quadpf" (quad,
- * each workgroup also requesting the operands of a workgroup 96 ids ahead into its XCD's L2), "quad2" (quad over two consecutive pairs per
- * workgroup, straight-line, the second pair's operands requested during the first pair's last inverse phase) - with identical results and identical HBM traffic; which is fastest depends on the box (how well two waves per SIMD hide its memory latency).
- * dpfhe_ctx_create measures them once (three launches each, twice, on <= 256 MiB of transient device memory it frees again: the only
- * device work and the only allocation besides the tables) and keeps the default unless another form is >= 3 % faster.
- * Environment: DPFHE_AUTOTUNE=0 skips the probe; DPFHE_CTMUL_VARIANT=quad|dual|single|quadpf|quad2 forces a form.
- * dpfhe_ctx_autotune repeats the measurement on CALLER-provided scratch (work_words >= 7 L N; pairs = work_words / (7 L N) synthetic
- * ciphertext pairs; contents are overwritten; synchronises `stream`).  It changes the context: call it before the context is shared
- * between threads.  Other contexts (generic primes, other ring degrees) have one form; both calls are no-ops there. */
-enum { DPFHE_TUNE_DEFAULT = 0, DPFHE_TUNE_AT_CREATE = 1, DPFHE_TUNE_EXPLICIT = 2, DPFHE_TUNE_FORCED = 3 };
+ * dpfhe_ct_mul(flags = 0) has two forms at N = 4096 / 8192 on fold-reduction contexts - "quad" (all four forward and all three inverse
+ * transforms of a workgroup share twiddle fetches; the default at N = 4096) and "dual" (transforms in pairs; the default at N = 8192) -
+ * with identical results and identical HBM traffic.
+ * dpfhe_ctx_create takes the default (or the result an earlier dpfhe_ctx_autotune in this process found for the same device, log2_n and
+ * n_limbs): it measures nothing, launches nothing and allocates nothing besides the tables.
+ * dpfhe_ctx_autotune is the explicit opt-in: it times both forms on CALLER-provided scratch (work_words >= 7 L N; pairs = work_words /
+ * (7 L N) synthetic ciphertext pairs; contents are overwritten; synchronises `stream`) and keeps the default unless the other form is
+ * >= 3 % faster.  It changes the context: call it before the context is shared between threads.  Other contexts (generic primes, other
+ * ring degrees) have one form; the call is a no-op there. */
+enum { DPFHE_TUNE_DEFAULT = 0, DPFHE_TUNE_CACHED = 1, DPFHE_TUNE_EXPLICIT = 2, DPFHE_TUNE_FORCED = 3 };
 typedef struct dpfhe_tune_info {
     int32_t chosen;        /* form in use (index for dpfhe_ct_mul_variant_name) */
     int32_t n_variants;    /* forms this context can run (0: one form, nothing measured) */

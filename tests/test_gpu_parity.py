@@ -263,8 +263,9 @@ def test_ct_mul_vs_oracle_all_domains(rigs, name):
 
 @pytest.mark.parametrize("name", ["n4096", "n8192", "fold12x3", "shoup12", "fold11"])
 def test_every_form_of_the_fused_multiply_is_bit_exact_and_tunable(rigs, name):
-    """include/dpfhe.h "A0, continued": quad / dual / single give the same words as the oracle; the probe at context creation and
-    dpfhe_ctx_autotune on caller scratch report their measurements and leave a usable choice; contexts with one form say so."""
+    """include/dpfhe.h "A0, continued": quad / dual give the same words as the oracle; context creation measures nothing (default form, no
+    probe times); dpfhe_ctx_autotune on caller scratch reports its measurements, leaves a usable choice and seeds the process-wide cache that
+    a later context of the same shape starts from; contexts with one form say so."""
     r = rigs(name)
     L, n = r.p.n_limbs, r.p.n
     info = r.ctx.tune_info()
@@ -273,10 +274,12 @@ def test_every_form_of_the_fused_multiply_is_bit_exact_and_tunable(rigs, name):
         with pytest.raises(_cabi.DpfheError):
             r.ctx.set_ct_mul_variant("dual")
         return
-    forms = ("quad", "dual", "single", "quadpf", "quad2")
+    forms = ("quad", "dual")
+    default = "quad" if r.p.log2_n == 12 else "dual"
     assert info["n_variants"] == len(forms) and info["chosen"] in forms
-    assert info["source"] == "probe at dpfhe_ctx_create" and set(info["probe_us"]) == set(forms) and all(v > 0 for v in info["probe_us"].values())
-    batch = 29   # odd: the two-pair form's last workgroup has one pair; the prefetching form reaches 96 workgroup ids ahead: some workgroups have a successor there, the last ones do not
+    # a context built before any explicit probe of its shape says "default"; one built after it (another test's rig, this test re-run) says "cached"
+    assert (info["source"] == "default" and info["chosen"] == default and info["probe_us"] == {}) or info["source"].startswith("cached")
+    batch = 29
     a = r.orc.fill(batch * 2, 33).reshape(batch, 2, L, n)
     b = r.orc.fill(batch * 2, 34).reshape(batch, 2, L, n)
     qs = np.array(r.p.moduli, np.uint64)[None, :, None]
@@ -296,9 +299,14 @@ def test_every_form_of_the_fused_multiply_is_bit_exact_and_tunable(rigs, name):
         info = r.ctx.autotune(work, reps=2)
         assert info["source"] == "dpfhe_ctx_autotune" and info["probe_pairs"] == 64 and info["probe_reps"] == 2 and len(info["probe_us"]) == len(forms)
         best = min(info["probe_us"], key=info["probe_us"].get)
-        default = "quad" if r.p.log2_n == 12 else "dual"
         assert info["chosen"] in (best, default)          # the default stays unless another form is >= 3 % faster
         assert np.array_equal(to_host(r.ev.multiply(A, Bc).data), want)
+        second = Context(r.p, r.ctx.device_id)            # same (device, log2 N, L): starts from the cached probe, launches nothing
+        try:
+            i2 = second.tune_info()
+            assert i2["source"].startswith("cached") and i2["chosen"] == info["chosen"] and i2["probe_us"] == info["probe_us"]
+        finally:
+            second.close()
         with pytest.raises(_cabi.DpfheError):
             r.ctx.autotune(work[:100])
     finally:
@@ -577,8 +585,10 @@ def test_bench_distributed_path_world_size_one():
     assert 0 < nv["fwd_frac"] < 1 and 0 < nv["inv_frac"] < 1 and nv["round_trip_exact"] is True and "sustained_2s" in nv
     lt = d["roofline"]["traffic_live"]   # measured by rocprofv3 in this very run (or an error string when the box has no profiler): never silently absent
     assert lt is not None and ("error" in lt or 0.99 < lt["hbm_bytes_per_ct_mul"] / lt["algorithmic_bytes_per_ct_mul"] < 1.02), lt
-    assert at["chosen"] in ("quad", "dual", "single", "quadpf", "quad2") and set(at["step_probe_ms"]) == {"quad", "dual", "single", "quadpf", "quad2"} and at["at_ctx_create"]["probe_us"]
-    assert at["chosen"].replace("quadpf", "quad").replace("quad2", "quad") in d["roofline"]["kernel"].replace("ct_mul_kernel", "single") and "regime" in d["roofline"] and len(line) < 12000
+    assert at["chosen"] in ("quad", "dual") and set(at["step_probe_ms"]) == {"quad", "dual"} and at["at_ctx_create"]["source"] == "default" and at["at_ctx_create"]["probe_us"] == {}
+    assert at["chosen"] in d["roofline"]["kernel"] and "regime" in d["roofline"] and len(line) < 12000
+    rf = d["roofline"]   # the metric's second half as SCALARS (the driver's record keeps scalars of `roofline` only)
+    assert rf["autotune_chosen"] == at["chosen"] and rf["ntt_fwd_frac"] == nv["fwd_frac"] and rf["ntt_inv_frac"] == nv["inv_frac"] and rf["ntt_fwd_us"] > 0 and 0 < rf["copy_frac"] < 1
     # the same launch with the library's own communicator as the transport
     out = subprocess.run(cmd[:-1] + ["--no-cpu-baseline", "--native-comm", "--no-live-traffic"], capture_output=True, text=True, timeout=600, env=env, cwd=root)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
@@ -653,9 +663,9 @@ def test_large_rings_multiply_and_key_switch_composed_behind_the_c_abi(rigs, nam
 
 
 def test_large_ring_batches_are_sliced_to_bound_the_scratch():
-    """The composed operations above N = 8192 take their scratch in slices (1 GiB by default): with DPFHE_SCRATCH_MIB = 2 a batch of 5
+    """The composed operations above N = 8192 take their scratch in slices (1 GiB by default): with dpfhe_ctx_set_scratch_limit(2 MiB) a batch of 5
     items at N = 16384 runs as 5 (multiply: 1.5 MiB of scratch per item) and 3 (key switch: 1.1 MiB) slices - same words as the oracle.
-    The variable is read once per process, hence the child."""
+    Run in a child so that the context's memory pool goes with the process."""
     code = r"""
 import numpy as np, torch
 from deeppowers_amd.evaluator import Ciphertext, Context, Evaluator, to_device, to_host
@@ -664,7 +674,7 @@ from oracle import pyoracle as po
 from oracle.cbind import Oracle
 qs = [PRIMES_60[i][0] for i in (1, 2, 4)]
 p = FheParams(14, tuple(qs), tuple(po.min_primitive_2n_root(16384, q) for q in qs))
-ctx = Context(p, 0); ev = Evaluator(ctx); orc = Oracle.from_params(p)
+ctx = Context(p, 0); ctx.set_scratch_limit(2); ev = Evaluator(ctx); orc = Oracle.from_params(p)
 L, n = p.n_limbs, p.n
 ah, bh = orc.fill(10, 1).reshape(5, 2, L, n), orc.fill(10, 2).reshape(5, 2, L, n)
 want = orc.ct_mul(ah, bh, threads=0)
@@ -677,6 +687,6 @@ print("SLICED-OK")
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, DPFHE_SCRATCH_MIB="2", PYTHONPATH=root)
+    env = dict(os.environ, PYTHONPATH=root)
     run = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env, cwd=root)
     assert run.returncode == 0 and "SLICED-OK" in run.stdout, run.stdout + run.stderr

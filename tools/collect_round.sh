@@ -36,7 +36,7 @@ packed)
     echo "pmc packed pass $i rc=$? ($set)"; rm -rf $OUT/pmcp$i
   done ;;
 pmc)
-  export DPFHE_AUTOTUNE=0   # the counter runs time the DEFAULT forms only: the probe's launches of the other forms would share kernel names with the measured ones
+  # (round 5: contexts no longer probe at creation, so the counter runs see the default forms only without any switch)
   # the metric kernel and the NTT kernels at BASELINE configs[1] / configs[3] sizes (tools/ntt_bench.py <ntt polys> <ct_mul pairs>), one counter set per run
   i=0
   for set in "GRBM_GUI_ACTIVE FETCH_SIZE" "GRBM_GUI_ACTIVE WRITE_SIZE" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAVES" "SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU"; do

@@ -61,7 +61,7 @@ def main():
         print(json.dumps({"error": "rocprofv3 not on PATH"}))
         return
     form = sys.argv[1] if len(sys.argv) > 1 else ""
-    env = dict(os.environ, TMPDIR="/tmp", DPFHE_AUTOTUNE="0", DPFHE_LIVE_FORM=form)
+    env = dict(os.environ, TMPDIR="/tmp", DPFHE_LIVE_FORM=form)
     out = {"pairs": PAIRS, "form": form or "default"}
     for counter in ("FETCH_SIZE", "WRITE_SIZE"):
         d = tempfile.mkdtemp(prefix="dpfhe_pmc_", dir="/tmp")

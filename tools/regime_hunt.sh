@@ -22,7 +22,7 @@ if [ "$(cat $OUT/slow)" = "1" ]; then
              "TCP_TCC_READ_REQ_LATENCY_sum TCP_TCC_READ_REQ_sum TCP_TCC_WRITE_REQ_LATENCY_sum TCP_TCC_WRITE_REQ_sum" \
              "TCP_UTCL1_TRANSLATION_MISS_sum TCP_UTCL1_TRANSLATION_HIT_sum TCP_UTCL1_REQUEST_sum TCP_PENDING_STALL_CYCLES_sum"; do
     i=$((i+1))
-    DPFHE_AUTOTUNE=0 timeout 200 rocprofv3 --pmc $set --kernel-trace -d $OUT/pmc$i -o pmc -- python tools/ntt_bench.py 1024 8192 > $OUT/pmc$i.log 2>&1
+    timeout 200 rocprofv3 --pmc $set --kernel-trace -d $OUT/pmc$i -o pmc -- python tools/ntt_bench.py 1024 8192 > $OUT/pmc$i.log 2>&1
     f=$(db $OUT/pmc$i); [ -n "$f" ] && python tools/pmc_summary.py $f "ct_mul" > $OUT/pmc_lat_pass$i.txt 2>&1; grep -A9 "ct_mul_quad" $OUT/pmc_lat_pass$i.txt | head -10; rm -rf $OUT/pmc$i
   done
   timeout 300 python bench.py --skip-other --no-cpu-baseline > $OUT/bench_lean.json 2> $OUT/bench.err; tail -c 400 $OUT/bench_lean.json
