@@ -25,6 +25,12 @@ struct DevTables {
     const typename Arith::Tw* top_inv;      // [L][n_sub]  psi^-brv(i)
     const InvLast<typename Arith::Tw>* top_last;  // [L]   last inverse stage with N^-1 folded in
     int n_sub;                              // 1: single-kernel transform
+    // N = 8192 in "halves" form (ntt_halves.h; null at other ring degrees): per limb the two 4096-point sub-tree tables (roots 2 and 3 of the
+    // N = 8192 table) in the (12, 4) kernel layout, the column stage's twiddle psi^brv(1), and the inverse column stage with N^-1 folded in
+    const typename Arith::Tw* hfwd;         // [L][2][4096]
+    const typename Arith::Tw* hinv;         // [L][2][4096]
+    const typename Arith::Tw* htop_fwd;     // [L]
+    const InvLast<typename Arith::Tw>* htop_last;  // [L]  {psi^-brv(1) N^-1, N^-1}
     const InvLast<typename Arith::Tw>* last;  // [L]
     const LimbConst* lc;                    // [L]
     int n_limbs;

@@ -271,7 +271,11 @@ extern "C" int dpfhe_ctx_create(dpfhe_ctx** out, uint32_t log2_n, uint32_t n_lim
     const size_t o_lc = 0, o_fwd4 = up(o_lc + L * sizeof(LimbConst)), o_inv4 = up(o_fwd4 + tab),
                  o_fwd = two_geo ? up(o_inv4 + tab) : o_fwd4, o_inv = two_geo ? up(o_fwd + tab) : o_inv4,
                  o_last = up(o_inv + tab), o_top_fwd = up(o_last + L * n_sub * 2 * tw_sz), o_top_inv = up(o_top_fwd + L * n_sub * tw_sz),
-                 o_top_last = up(o_top_inv + L * n_sub * tw_sz), o_resc = up(o_top_last + L * 2 * tw_sz), total = up(o_resc + L * sizeof(RescaleConst));
+                 o_top_last = up(o_top_inv + L * n_sub * tw_sz), o_resc = up(o_top_last + L * 2 * tw_sz);
+    // N = 8192: the "halves" tables next to the one-piece ones (ntt_halves.h; the fused kernels keep the one-piece layout)
+    const bool halves = log2_n == 13;
+    const size_t o_hfwd = up(o_resc + L * sizeof(RescaleConst)), o_hinv = halves ? up(o_hfwd + tab) : o_hfwd, o_htop_fwd = halves ? up(o_hinv + tab) : o_hfwd,
+                 o_htop_last = halves ? up(o_htop_fwd + L * tw_sz) : o_hfwd, total = halves ? up(o_htop_last + L * 2 * tw_sz) : o_hfwd;
     std::vector<unsigned char> blob(total, 0);
     auto fill = [&](auto tw_tag) {
         typedef decltype(tw_tag) Tw;
@@ -291,6 +295,14 @@ extern "C" int dpfhe_ctx_create(dpfhe_ctx** out, uint32_t log2_n, uint32_t n_lim
                     pack(ht[l].irp, (int)log2_n, loge, (geo ? o_inv : o_inv4) + l * n * tw_sz);
                 }
                 lasts[l] = InvLast<Tw>{h_make_tw<Tw>(ht[l].w_last, q), h_make_tw<Tw>(ht[l].lc.ninv, q)};
+                if (halves) {
+                    for (size_t r = 0; r < 2; ++r) {
+                        pack(subtree_table(ht[l].rp, 13, 1, r), 12, 4, o_hfwd + (l * 2 + r) * (n / 2) * tw_sz);
+                        pack(subtree_table(ht[l].irp, 13, 1, r), 12, 4, o_hinv + (l * 2 + r) * (n / 2) * tw_sz);
+                    }
+                    reinterpret_cast<Tw*>(&blob[o_htop_fwd])[l] = h_make_tw<Tw>(ht[l].rp[1], q);
+                    reinterpret_cast<InvLast<Tw>*>(&blob[o_htop_last])[l] = lasts[l];   // the column stage IS the one-piece transform's last stage
+                }
             } else {
                 for (size_t r = 0; r < n_sub; ++r) {
                     const std::vector<u64> f = subtree_table(ht[l].rp, (int)log2_n, log_n1, r), v = subtree_table(ht[l].irp, (int)log2_n, log_n1, r);
@@ -343,6 +355,10 @@ extern "C" int dpfhe_ctx_create(dpfhe_ctx** out, uint32_t log2_n, uint32_t n_lim
         c->foldt.top_last = reinterpret_cast<const InvLast<TwFold>*>(d + o_top_last);
         c->foldt.n_sub = (int)n_sub;
         c->foldt.n_limbs = (int)n_limbs;
+        if (halves) {
+            c->foldt.hfwd = reinterpret_cast<const TwFold*>(d + o_hfwd); c->foldt.hinv = reinterpret_cast<const TwFold*>(d + o_hinv);
+            c->foldt.htop_fwd = reinterpret_cast<const TwFold*>(d + o_htop_fwd); c->foldt.htop_last = reinterpret_cast<const InvLast<TwFold>*>(d + o_htop_last);
+        }
     } else {
         c->shoup.lc = reinterpret_cast<const LimbConst*>(d + o_lc);
         c->shoup.fwd = reinterpret_cast<const TwShoup*>(d + o_fwd);
@@ -355,6 +371,10 @@ extern "C" int dpfhe_ctx_create(dpfhe_ctx** out, uint32_t log2_n, uint32_t n_lim
         c->shoup.top_last = reinterpret_cast<const InvLast<TwShoup>*>(d + o_top_last);
         c->shoup.n_sub = (int)n_sub;
         c->shoup.n_limbs = (int)n_limbs;
+        if (halves) {
+            c->shoup.hfwd = reinterpret_cast<const TwShoup*>(d + o_hfwd); c->shoup.hinv = reinterpret_cast<const TwShoup*>(d + o_hinv);
+            c->shoup.htop_fwd = reinterpret_cast<const TwShoup*>(d + o_htop_fwd); c->shoup.htop_last = reinterpret_cast<const InvLast<TwShoup>*>(d + o_htop_last);
+        }
     }
     tune_at_create(c);   // default form of the fused multiply, or a cached explicit probe of this shape: no device work
     (void)hipSetDevice(prev);

@@ -3,6 +3,7 @@
 #include <cstdlib>
 
 #include "kernels.h"
+#include "kernels_halves.h"
 #include "launch.h"
 
 namespace dpfhe {
@@ -64,6 +65,19 @@ int launch_ntt(int log2n, bool inverse, u64* out, const u64* in, size_t npolys, 
     // batches whose input + output cannot stay in the 256 MiB Infinity Cache stream around it (FoldArith, the two production ring degrees)
     const size_t touched = (npolys << log2n) * sizeof(u64) * (out == in ? 1 : 2);
     const bool nt = Arith::kFold && (log2n == 12 || log2n == 13) && touched > ((size_t)256 << 20);
+#ifndef DPFHE_NTT13_HALVES
+#define DPFHE_NTT13_HALVES 1   // N = 8192: 256-thread workgroups, column stage in registers + two 4096-point sub-transforms (kernels_halves.h)
+#endif
+    if (DPFHE_NTT13_HALVES && log2n == 13 && tb.hfwd) {
+        if (inverse) {
+            if (nt && Arith::kFold) hipLaunchKernelGGL((ntt_inv_halves_kernel<Arith, Arith::kFold>), dim3((unsigned)npolys), dim3(256), 0, s, out, in, tb);
+            else hipLaunchKernelGGL((ntt_inv_halves_kernel<Arith, false>), dim3((unsigned)npolys), dim3(256), 0, s, out, in, tb);
+        } else {
+            if (nt && Arith::kFold) hipLaunchKernelGGL((ntt_fwd_halves_kernel<Arith, Arith::kFold>), dim3((unsigned)npolys), dim3(256), 0, s, out, in, tb);
+            else hipLaunchKernelGGL((ntt_fwd_halves_kernel<Arith, false>), dim3((unsigned)npolys), dim3(256), 0, s, out, in, tb);
+        }
+        return 0;
+    }
 #define NTT_CASE(LN, LE)                                                                                                              \
     if constexpr (Arith::kFold && (LN == 12 || LN == 13)) {                                                                           \
         if (nt) {                                                                                                                     \

@@ -183,9 +183,11 @@ struct GsPlan {  // one Gentleman-Sande phase on E local elements, up to LOGE st
     int out_bound;
 };
 
-// lb0 = local bit of the first stage, r stages (local bits ascending), every input < in_bound
+// lb0 = local bit of the first stage, r stages (local bits ascending), every input < in_bound.
+// last_all_mul: the phase ends with the transform's LAST stage, whose sums are multiplied by N^-1 too - by a twiddle product (ninv_shift = 0:
+// generic primes, bound kTwB) or by FoldArith::mul_ninv's exact division by 2^ninv_shift (result < q + s / 2^ninv_shift + 1 for a sum s).
 template <int LOGE>
-constexpr GsPlan<LOGE> make_gs_plan(int lb0, int r, int in_bound, int out_bound, bool last_all_mul) {
+constexpr GsPlan<LOGE> make_gs_plan(int lb0, int r, int in_bound, int out_bound, bool last_all_mul, int ninv_shift = 0) {
     GsPlan<LOGE> p{};
     constexpr int E = 1 << LOGE;
     int bnd[E] = {};
@@ -205,7 +207,8 @@ constexpr GsPlan<LOGE> make_gs_plan(int lb0, int r, int in_bound, int out_bound,
             }
             p.off[u][k] = offq;
             const bool final_stage = last_all_mul && (u == r - 1);
-            bnd[k] = final_stage ? kTwB : bx + by;   // last inverse stage multiplies x' by N^-1 too
+            // last inverse stage multiplies x' by N^-1 too: a twiddle product, or the exact division (x' < q + (a + b) / N + 1)
+            bnd[k] = !final_stage ? bx + by : (ninv_shift ? kUnit + ((bx + by) >> ninv_shift) + 2 : kTwB);
             bnd[k | bit] = kTwB;
         }
     }
@@ -267,7 +270,11 @@ constexpr CtfPlan<LOGE> make_ctf_plan(int lb_top, int r, int in_bound, int out_c
 // ------------------------------------------------------------------------------------------------
 // per-thread transform body
 // ------------------------------------------------------------------------------------------------
-template <class Arith, int LOGN, int LOGE>
+// SUB = 1: the body runs as one HALF of a 2N-point transform whose column stage (the first forward / last inverse radix-2 stage) the caller
+// runs in registers (ntt_halves.h): forward inputs arrive lazy (< kCtfMid q/1024, the column stage's differences) instead of canonical, and the
+// inverse leaves out N^-1 and hands over words below kSubInvOut q/1024 (the caller's column stage multiplies by (2N)^-1).
+constexpr int kSubInvOut = 7 * kUnit;   // lo + hi < 14 q: the column stage's sum fits mul_ninv's precondition, its difference + 7 q a 64-bit word
+template <class Arith, int LOGN, int LOGE, int SUB = 0>
 struct NttBody {
     typedef Geo<LOGN, LOGE> G;
     typedef typename Arith::Tw Tw;
@@ -563,7 +570,7 @@ struct NttBody {
     template <int P>
     static constexpr CtfPlan<LOGE> ctf_plan() {
         constexpr Phase ph = G::phase(P);
-        int in = kUnit;
+        int in = SUB ? kCtfMid : kUnit;
         for (int i = 0; i < P; ++i) {   // hand-over bound of the previous phase
             const Phase pi = G::phase(i);
             in = make_ctf_plan<LOGE>(pi.b - pi.c + pi.r - 1, pi.r, in, kCtfMid).out_bound;
@@ -646,7 +653,8 @@ struct NttBody {
     template <int P, int IN>
     static constexpr GsPlan<LOGE> gs_plan() {
         constexpr Phase ph = G::phase(P);
-        return make_gs_plan<LOGE>(ph.b - ph.c, ph.r, (P == NPH - 1) ? IN : kGsMid, (P == 0) ? kLimit : kGsMid, P == 0);
+        if (SUB) return make_gs_plan<LOGE>(ph.b - ph.c, ph.r, (P == NPH - 1) ? IN : kGsMid, (P == 0) ? kSubInvOut : kGsMid, false);
+        return make_gs_plan<LOGE>(ph.b - ph.c, ph.r, (P == NPH - 1) ? IN : kGsMid, (P == 0) ? kLimit : kGsMid, P == 0, Arith::kFold ? LOGN : 0);
     }
 
     template <int P, int IN>
@@ -658,7 +666,7 @@ struct NttBody {
         for (int u = 0; u < ph.r; ++u) {
             const int pos = ph.b + u;
             const int lb = pos - ph.c;
-            const bool last = (pos == LOGN - 1);
+            const bool last = (pos == LOGN - 1) && !SUB;   // SUB: the caller's column stage is the last one
 #pragma clang loop unroll(full)
             for (int k = 0; k < E; ++k) {
                 if (k & (1 << lb)) continue;
@@ -696,7 +704,9 @@ struct NttBody {
         load_tw<P, false>(tid, tw, twr);
         inv_phase_r<P, IN>(x, twr, w_last, w_ninv, lc);
     }
-    // inverse output (all words are outputs of the last-stage multiplies, < 2q) -> canonical
+    // inverse output (all words are outputs of the last stage: twiddle products < 2^60 + 13 d and exact divisions < q + 2^(64 - LOGN) + 1, both
+    // inside canon_small's precondition r < 1.5 * 2^60 - the static plan carries the real bound, checked here) -> canonical
+    static_assert(!Arith::kFold || SUB || (kWord >> LOGN) + 2 <= kUnit / 2, "the exact division's output (make_gs_plan: kUnit + (sum >> LOGN) + 2) must fit canon_small");
     static DPF_HD void inv_canon(u64 (&x)[E], const LimbConst& lc) {
 #pragma clang loop unroll(full)
         for (int k = 0; k < E; ++k) x[k] = Arith::kFold ? FoldArith::canon_small(x[k], lc) : csub(x[k], lc.q);

@@ -21,7 +21,7 @@ U = C.POINTER(C.c_uint64)
 def emu():
     so = os.path.join(ROOT, "tools", "libemu.so")
     src = os.path.join(ROOT, "tools", "emulate.cpp")
-    deps = [src] + [os.path.join(ROOT, "deeppowers_amd", "csrc", f) for f in ("ntt_core.h", "ntt_top.h", "modarith.h", "tables.h")]
+    deps = [src] + [os.path.join(ROOT, "deeppowers_amd", "csrc", f) for f in ("ntt_core.h", "ntt_top.h", "ntt_halves.h", "modarith.h", "tables.h")]
     if not os.path.exists(so) or any(os.path.getmtime(d) > os.path.getmtime(so) for d in deps):
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-o", so, src])
     lib = C.CDLL(so)
@@ -125,6 +125,29 @@ def test_emulated_split_transform_matches_oracle(emu, ln, arith):
             out = np.zeros_like(a)
             rc = emu.emu_ntt_split(arith, ln, inv, q, psi, a.ctypes.data_as(U), out.ctypes.data_as(U))
             assert rc == 0 and np.array_equal(out, ref(a))
+    assert emu.emu_overflows() == before, "lazy arithmetic wrapped around 2^64"
+
+
+@pytest.mark.parametrize("arith", [0, 1], ids=["shoup", "fold"])
+def test_emulated_halves_transform_matches_oracle(emu, arith):
+    """N = 8192 as a register column stage + two 4096-point sub-transforms through one LDS buffer (ntt_halves.h, the 256-thread kernels of
+    kernels_halves.h) == the oracle's one-piece transform, worst-case residues included, no 64-bit wrap of the lazy arithmetic."""
+    n = 8192
+    emu.emu_ntt_halves.argtypes = [C.c_int, C.c_int, C.c_uint64, C.c_uint64, U, U]
+    emu.emu_ntt_halves.restype = C.c_int
+    before = emu.emu_overflows()
+    for limb in (0, 2, 5):
+        q, psi = PRIMES_60[limb][0], PRIMES_60[limb][2]
+        orc = Oracle(13, [q], [psi])
+        pats = [orc.fill(1, 177 + limb).ravel().copy(), np.full(n, q - 1, np.uint64), np.zeros(n, np.uint64),
+                np.where(np.arange(n) % 2 == 0, q - 1, 0).astype(np.uint64), np.where(np.arange(n) < n // 2, q - 1, 1).astype(np.uint64),
+                np.where(np.arange(n) < n // 2, 0, q - 1).astype(np.uint64)]
+        for a in pats:
+            a = np.ascontiguousarray(a, dtype=np.uint64)
+            for inv, ref in ((0, orc.ntt_fwd), (1, orc.ntt_inv)):
+                out = np.zeros_like(a)
+                rc = emu.emu_ntt_halves(arith, inv, q, psi, a.ctypes.data_as(U), out.ctypes.data_as(U))
+                assert rc == 0 and np.array_equal(out, ref(a)), (limb, inv)
     assert emu.emu_overflows() == before, "lazy arithmetic wrapped around 2^64"
 
 

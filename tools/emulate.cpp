@@ -9,6 +9,7 @@
 #include <vector>
 
 #include "../deeppowers_amd/csrc/ntt_core.h"
+#include "../deeppowers_amd/csrc/ntt_halves.h"
 #include "../deeppowers_amd/csrc/ntt_top.h"
 #include "../deeppowers_amd/csrc/tables.h"
 
@@ -237,6 +238,54 @@ extern "C" int emu_ntt_split(int arith, int log2n, int inverse, u64 q, u64 psi, 
     if (log2n == 15) return arith ? emu_split<FoldArith, 3>(inverse, q, psi, in, out) : emu_split<ShoupArith, 3>(inverse, q, psi, in, out);
     if (log2n == 16) return arith ? emu_split<FoldArith, 4>(inverse, q, psi, in, out) : emu_split<ShoupArith, 4>(inverse, q, psi, in, out);
     return -1;
+}
+
+// N = 8192 as a column stage in registers + two 4096-point sub-transforms through ONE LDS buffer (ntt_halves.h; kernels_halves.h runs
+// exactly these steps on the device): 256 emulated threads hold lo / hi, the sub-transforms run on the tables dpfhe_ctx_create builds
+// for them (tables.h subtree_table, roots 2 and 3 of the N = 8192 table).
+template <class Arith>
+static int emu_halves(int inverse, u64 q, u64 psi, const u64* in, u64* out) {
+    typedef Halves13<Arith> H;
+    typedef typename H::B B;
+    typedef typename Arith::Tw Tw;
+    HostLimbTables t;
+    int rc = build_limb_tables(H::LOGN, q, psi, t);
+    if (rc) return rc;
+    if (Arith::kFold && !fold_eligible(q)) return 2000;
+    constexpr int E = B::E, T = B::T, N2 = H::N2;
+    std::vector<u64> lo((size_t)T * E), hi((size_t)T * E), lds(B::G::lds_words(), 0xDEADBEEFDEADBEEFull);
+    auto X = [&](std::vector<u64>& r, int tid) -> u64(&)[E] { return *reinterpret_cast<u64(*)[E]>(&r[(size_t)tid * E]); };
+    std::vector<Tw> tw[2];
+    for (size_t r = 0; r < 2; ++r) {
+        const std::vector<u64> words = subtree_table(inverse ? t.irp : t.rp, H::LOGN, 1, r);
+        tw[r].resize(words.size());
+        for (size_t i = 0; i < words.size(); ++i) tw[r][i] = h_make_tw<Tw>(words[i], q);
+        permute_window0(tw[r], H::LOGN2, H::LOGE, B::G::kPermStages);
+    }
+    if (!inverse) {
+        const Tw wtop = h_make_tw<Tw>(t.rp[1], q);
+        for (int tid = 0; tid < T; ++tid) { B::load_top(tid, X(lo, tid), in); B::load_top(tid, X(hi, tid), in + N2); H::fwd_column(X(lo, tid), X(hi, tid), wtop, t.lc); }
+        FwdSteps<B, 0>::run(lo, lds, tw[0].data(), t.lc);
+        for (int tid = 0; tid < T; ++tid) { B::fwd_canon(X(lo, tid), t.lc); B::store_bot(tid, X(lo, tid), out); }
+        FwdSteps<B, 0>::run(hi, lds, tw[1].data(), t.lc);
+        for (int tid = 0; tid < T; ++tid) { B::fwd_canon(X(hi, tid), t.lc); B::store_bot(tid, X(hi, tid), out + N2); }
+    } else {
+        const InvLast<Tw> last{h_make_tw<Tw>(t.w_last, q), h_make_tw<Tw>(t.lc.ninv, q)};
+        const Tw unused = h_make_tw<Tw>(1, q);
+        for (int tid = 0; tid < T; ++tid) B::load_bot(tid, X(lo, tid), in);
+        InvSteps<B, B::NPH - 1, kUnit>::run(lo, lds, tw[0].data(), unused, unused, t.lc);
+        for (int tid = 0; tid < T; ++tid) B::load_bot(tid, X(hi, tid), in + N2);
+        InvSteps<B, B::NPH - 1, kUnit>::run(hi, lds, tw[1].data(), unused, unused, t.lc);
+        for (int tid = 0; tid < T; ++tid) {
+            H::inv_column(X(lo, tid), X(hi, tid), last, t.lc);
+            B::inv_canon(X(lo, tid), t.lc); B::inv_canon(X(hi, tid), t.lc);
+            B::store_top(tid, X(lo, tid), out); B::store_top(tid, X(hi, tid), out + N2);
+        }
+    }
+    return 0;
+}
+extern "C" int emu_ntt_halves(int arith, int inverse, u64 q, u64 psi, const u64* in, u64* out) {
+    return arith ? emu_halves<FoldArith>(inverse, q, psi, in, out) : emu_halves<ShoupArith>(inverse, q, psi, in, out);
 }
 
 // The fused ct x ct kernels' lazy FoldArith data path (kernels.h ct_mul_kernel / ct_mul_dual_kernel - the paired kernel computes
