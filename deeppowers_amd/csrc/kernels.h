@@ -665,7 +665,9 @@ template <class Arith, int LOGN, int LOGE, int MODE, bool TRACE = false>
 __global__ __launch_bounds__(1 << (LOGN - LOGE), (Arith::kFold ? 2 : 1)) void relin_kernel(u64* __restrict__ out2, const u64* __restrict__ in3,
                                                                        const u64* __restrict__ evk, size_t key_stride, unsigned key_group,
                                                                        unsigned n_outer, DevTables<Arith> tb, u64* trace = nullptr) {
-    typedef NttBody<Arith, LOGN, LOGE> B;
+    // the digits are residues of ANOTHER limb: any word below 2^60.  FoldArith's forward transform takes them as they are (NttBody FWD_IN = kRedB: the first
+    // stage's fused multiply-add reduces its addend for free - 7 instructions per word less than canonicalising first); generic primes canonicalise.
+    typedef NttBody<Arith, LOGN, LOGE, 0, Arith::kFold ? kRedB : kUnit> B;
     static_assert(LOGE == kFusedLoge, "the fused kernels read the fused twiddle layout (DevTables::fwd4 / inv4)");
     constexpr int E = B::E, N = B::G::N;
     __shared__ __attribute__((aligned(16))) u64 lds[B::G::lds_words()];
@@ -713,8 +715,10 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE), (Arith::kFold ? 2 : 1)) void re
         u64 x[E];
         const u64 tr0 = trace_stamp<TRACE>((u64)tid);
         B::load_top(tid, x, c2 + (size_t)j * N);
+        if constexpr (!Arith::kFold) {
 #pragma unroll
-        for (int k = 0; k < E; ++k) x[k] = canon_any<Arith>(x[k], lc);   // [c2]_{q_j} mod q_i
+            for (int k = 0; k < E; ++k) x[k] = canon_any<Arith>(x[k], lc);   // [c2]_{q_j} mod q_i
+        }
         u64 tr_dep = 0;
         if constexpr (TRACE) {
 #pragma unroll
@@ -850,7 +854,7 @@ template <class Arith, int LOGN, int LOGE, int MODE>
 __global__ __launch_bounds__(1 << (LOGN - LOGE), 2) void relin_shared_kernel(u64* __restrict__ out2, const u64* __restrict__ in3,
                                                                            const u64* __restrict__ evk, size_t key_stride, unsigned key_group,
                                                                            unsigned n_outer, DevTables<Arith> tb) {
-    typedef NttBody<Arith, LOGN, LOGE> B;
+    typedef NttBody<Arith, LOGN, LOGE, 0, kRedB> B;   // digits enter the forward transforms as they are (< 2^60): relin_kernel
     static_assert(Arith::kFold && LOGE == kFusedLoge, "FoldArith, fused twiddle layout");
     constexpr int E = B::E, N = B::G::N, W = B::G::lds_words();
     __shared__ __attribute__((aligned(16))) u64 lds[2 * W];
@@ -887,11 +891,7 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE), 2) void relin_shared_kernel(u64
     const typename B::Tw* const twf = tb.fwd4 + (size_t)limb * N;
     static_assert(7 * kMulB + kRedB <= kWord, "seven lazily added products must fit a 64-bit word");
     u64 acc0[E], acc1[E];
-    auto digit = [&](u64 (&x)[E], int j) {
-        B::load_top(tid, x, c2 + (size_t)j * N);
-#pragma unroll
-        for (int k = 0; k < E; ++k) x[k] = FoldArith::canon(x[k], lc);   // [c]_{q_j} mod q_i
-    };
+    auto digit = [&](u64 (&x)[E], int j) { B::load_top(tid, x, c2 + (size_t)j * N); };   // [c]_{q_j}: reduced mod q_i by the transform's first stage
     auto mac = [&](const u64 (&d)[E], int j, bool first) {   // one key polynomial at a time
         u64 e[E];
         B::load_bot(tid, e, evk + (((size_t)j * 2 + 0) * L + limb) * N);

@@ -25,6 +25,13 @@ constexpr int split_log_n1(int log2n) { return log2n > 14 ? log2n - kSplitLog2N2
 #define DPFHE_FUSED_LOGE 4   // words-per-thread exponent of the fused kernels (tools/ab_variant.sh builds -DDPFHE_FUSED_LOGE=3 for A/B runs)
 #endif
 constexpr int kFusedLoge = DPFHE_FUSED_LOGE;
+// N = 8192 on the N = 4096 body ("halves": ntt_halves.h, kernels_halves.h - a register column stage + two 4096-point sub-transforms through one LDS
+// buffer, 256-thread workgroups).  MEASURED NEGATIVE in round 5 (profiles/r05_halves_*.txt: batched forward transform 6 % slower, inverse equal, giant-step
+// key inner products 3 % slower than the 512-thread kernels, bit-identical): not built into the library.  -DDPFHE_N13_HALVES=1 (tools/ab_variant.sh) builds the
+// kernels and their tables for A/B runs; tests/test_emulated_kernels.py keeps the arithmetic proven on the CPU either way.
+#ifndef DPFHE_N13_HALVES
+#define DPFHE_N13_HALVES 0
+#endif
 constexpr int kMaxGaloisBatch = 64;   // Galois elements travel as kernel arguments, this many per launch
 
 // return 0, or -1 when log2n has no compiled geometry.  Launch errors are left in hipGetLastError().

@@ -3,8 +3,10 @@
 #include <cstdlib>
 
 #include "kernels.h"
-#include "kernels_halves.h"
 #include "launch.h"
+#if DPFHE_N13_HALVES
+#include "kernels_halves.h"
+#endif
 
 namespace dpfhe {
 
@@ -65,10 +67,8 @@ int launch_ntt(int log2n, bool inverse, u64* out, const u64* in, size_t npolys, 
     // batches whose input + output cannot stay in the 256 MiB Infinity Cache stream around it (FoldArith, the two production ring degrees)
     const size_t touched = (npolys << log2n) * sizeof(u64) * (out == in ? 1 : 2);
     const bool nt = Arith::kFold && (log2n == 12 || log2n == 13) && touched > ((size_t)256 << 20);
-#ifndef DPFHE_NTT13_HALVES
-#define DPFHE_NTT13_HALVES 1   // N = 8192: 256-thread workgroups, column stage in registers + two 4096-point sub-transforms (kernels_halves.h)
-#endif
-    if (DPFHE_NTT13_HALVES && log2n == 13 && tb.hfwd) {
+#if DPFHE_N13_HALVES   // A/B builds only (launch.h)
+    if (log2n == 13 && tb.hfwd) {
         if (inverse) {
             if (nt && Arith::kFold) hipLaunchKernelGGL((ntt_inv_halves_kernel<Arith, Arith::kFold>), dim3((unsigned)npolys), dim3(256), 0, s, out, in, tb);
             else hipLaunchKernelGGL((ntt_inv_halves_kernel<Arith, false>), dim3((unsigned)npolys), dim3(256), 0, s, out, in, tb);
@@ -78,6 +78,7 @@ int launch_ntt(int log2n, bool inverse, u64* out, const u64* in, size_t npolys, 
         }
         return 0;
     }
+#endif
 #define NTT_CASE(LN, LE)                                                                                                              \
     if constexpr (Arith::kFold && (LN == 12 || LN == 13)) {                                                                           \
         if (nt) {                                                                                                                     \
@@ -192,6 +193,21 @@ int launch_relin(int log2n, int mode, u64* out2, const u64* in3, const u64* evk,
         grid = ((n_keys + 7u) / 8u) * 8u * (unsigned)tb.n_limbs * kg;
         n_outer |= kRelinRotMajor;
     }
+#if DPFHE_N13_HALVES   // A/B builds only (launch.h): one 256-thread workgroup per (item, limb, half of the NTT domain) - kernels_halves.h relin_half_kernel
+    if (log2n == 13 && mode == 4 && tb.hfwd) {
+        const unsigned VL = 2u * (unsigned)tb.n_limbs;
+        const size_t vblocks = blocks * 2;
+        unsigned h_outer = (kg > 1 && vblocks % ((size_t)kg * VL) == 0) ? (unsigned)(vblocks / kg) : 0u;
+        unsigned h_grid = h_outer ? ((h_outer + 7u) / 8u) * 8u * kg : (unsigned)vblocks;
+        if (DPFHE_RELIN_KEY_MAJOR && h_outer && h_outer / VL >= 8u) {
+            const unsigned n_keys = h_outer / VL;
+            h_grid = ((n_keys + 7u) / 8u) * 8u * VL * kg;
+            h_outer |= kRelinRotMajor;
+        }
+        hipLaunchKernelGGL((relin_half_kernel<Arith>), dim3(h_grid), dim3(256), 0, s, out2, in3, evk, key_stride, kg, h_outer, tb);
+        return 0;
+    }
+#endif
 #ifdef DPFHE_RELIN_TRACE   // diagnostic builds only (tools/ab_variant.sh reltrace -DDPFHE_RELIN_TRACE; tools/relin_trace.py reads the buffer back)
     if constexpr (Arith::kFold) {
         if (log2n == 13 && mode == 4) {

@@ -274,11 +274,14 @@ constexpr CtfPlan<LOGE> make_ctf_plan(int lb_top, int r, int in_bound, int out_c
 // runs in registers (ntt_halves.h): forward inputs arrive lazy (< kCtfMid q/1024, the column stage's differences) instead of canonical, and the
 // inverse leaves out N^-1 and hands over words below kSubInvOut q/1024 (the caller's column stage multiplies by (2N)^-1).
 constexpr int kSubInvOut = 7 * kUnit;   // lo + hi < 14 q: the column stage's sum fits mul_ninv's precondition, its difference + 7 q a 64-bit word
-template <class Arith, int LOGN, int LOGE, int SUB = 0>
+// FWD_IN: static bound (q/1024) of every word the FORWARD transform is given.  kUnit = canonical residues; kRedB = any residue below 2^60 (a word that is
+// canonical for ANOTHER limb of a FoldArith context - the digits of a key switch: the first stage's fused multiply-add reduces it for free).
+template <class Arith, int LOGN, int LOGE, int SUB = 0, int FWD_IN = (SUB ? kCtfMid : kUnit)>
 struct NttBody {
     typedef Geo<LOGN, LOGE> G;
     typedef typename Arith::Tw Tw;
     static constexpr int E = G::E, T = G::T, NPH = G::NPH;
+    static_assert(FWD_IN >= kUnit && FWD_IN <= kCtfMid && (!SUB || FWD_IN == kCtfMid), "forward input bound: canonical ... the phase hand-over bound");
 
     // ---------------- global <-> registers ----------------
     // window-top mapping (forward input / inverse output): word j = k*T + tid, 8 B per lane, coalesced
@@ -570,7 +573,7 @@ struct NttBody {
     template <int P>
     static constexpr CtfPlan<LOGE> ctf_plan() {
         constexpr Phase ph = G::phase(P);
-        int in = SUB ? kCtfMid : kUnit;
+        int in = FWD_IN;
         for (int i = 0; i < P; ++i) {   // hand-over bound of the previous phase
             const Phase pi = G::phase(i);
             in = make_ctf_plan<LOGE>(pi.b - pi.c + pi.r - 1, pi.r, in, kCtfMid).out_bound;

@@ -93,6 +93,14 @@ class FheParams:
         return ntt_primes(13, n_limbs)
 
 
+    @staticmethod
+    def generic_n4096_l4() -> "FheParams":
+        """N=4096 on four GENERIC primes (the largest primes = 1 mod 8192 below 2^59, 2^50, 2^40, 2^33; none of the 2^60 - d shape): the library's
+        generic-prime arithmetic (Harvey/Shoup butterflies, 128-bit Barrett products) at the headline shape - bench.py other_configs.shoup_n4096_l4."""
+        qs = tuple(ntt_primes(12, 1, bits).moduli[0] for bits in (59, 50, 40, 33))
+        return FheParams(12, qs, tuple(min_primitive_2n_root(4096, q) for q in qs))
+
+
 # ---- building other parameter sets ---------------------------------------------------------------------------------
 def is_prime(n: int) -> bool:
     """Deterministic Miller-Rabin for n < 3.3e24 (the first 13 primes as witnesses)."""

@@ -151,6 +151,30 @@ def test_emulated_halves_transform_matches_oracle(emu, arith):
     assert emu.emu_overflows() == before, "lazy arithmetic wrapped around 2^64"
 
 
+@pytest.mark.parametrize("ln", [8, 10, 12, 13])
+def test_emulated_forward_transform_of_words_below_2_60(emu, ln):
+    """The key-switch kernels hand the digits (residues of ANOTHER limb: any word < 2^60) to the forward transform without canonicalising them
+    (NttBody FWD_IN = kRedB): same result as the oracle's transform of the reduced words, no 64-bit wrap, no broken multiply-add precondition."""
+    n = 1 << ln
+    emu.emu_ntt_fwd_any60.argtypes = [C.c_int, C.c_uint64, C.c_uint64, U, U]
+    emu.emu_ntt_fwd_any60.restype = C.c_int
+    before = emu.emu_overflows()
+    rng = np.random.default_rng(ln)
+    for limb in (0, 3, 5):
+        q = PRIMES_60[limb][0]
+        psi = pow(PRIMES_60[limb][2], 8192 // n, q)
+        orc = Oracle(ln, [q], [psi])
+        top = (1 << 60) - 1
+        pats = [np.full(n, top, np.uint64), rng.integers(0, 1 << 60, n, dtype=np.uint64), np.where(np.arange(n) % 2 == 0, top, q).astype(np.uint64),
+                np.where(np.arange(n) < n // 2, top, 0).astype(np.uint64), np.where(np.arange(n) < n // 2, q - 1, top).astype(np.uint64)]
+        for a in pats:
+            a = np.ascontiguousarray(a, dtype=np.uint64)
+            out = np.zeros_like(a)
+            assert emu.emu_ntt_fwd_any60(ln, q, psi, a.ctypes.data_as(U), out.ctypes.data_as(U)) == 0
+            assert np.array_equal(out, orc.ntt_fwd(np.ascontiguousarray(a % np.uint64(q))))
+    assert emu.emu_overflows() == before, "lazy arithmetic wrapped around 2^64"
+
+
 def test_dot30_column_accumulators_match_128_bit_arithmetic(emu):
     """The FoldArith matvec kernels accumulate products of canonical residues in three 64-bit columns (operands split at bit 30)
     and fold every 8 terms: same result as exact integer arithmetic, no 64-bit wrap, for random and worst-case operands."""

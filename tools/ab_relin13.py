@@ -8,6 +8,9 @@ import numpy as np
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import deeppowers_amd._cabi as _cabi  # noqa: E402
+if os.environ.get("DPFHE_AB_LIB"):  # A/B experiments: time another build of the library (tool only)
+    _cabi.LIB_PATH = os.path.abspath(os.environ["DPFHE_AB_LIB"])
 from deeppowers_amd.evaluator import Ciphertext, Context, Evaluator  # noqa: E402
 from deeppowers_amd.params import FheParams  # noqa: E402
 
@@ -33,4 +36,4 @@ for rep in range(5):
     e1.record()
     torch.cuda.synchronize()
     ts.append(e0.elapsed_time(e1) * 1e3 / 20)
-print(f"RELIN13 loge3={os.environ.get('DPFHE_RELIN13_LOGE3', '0')}  us per call (5 x 20): {' '.join(f'{t:.1f}' for t in ts)}  median {np.median(ts):.1f}  checksum {chk:x}")
+print(f"RELIN13 {os.path.basename(os.environ.get('DPFHE_AB_LIB', 'HEAD')):14s} us per call (5 x 20): {' '.join(f'{t:.1f}' for t in ts)}  median {np.median(ts):.1f}  checksum {chk:x}")

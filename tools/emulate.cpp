@@ -240,6 +240,33 @@ extern "C" int emu_ntt_split(int arith, int log2n, int inverse, u64 q, u64 psi, 
     return -1;
 }
 
+// Forward transform of words that are only known to be below 2^60 (the digits of a key switch are canonical for ANOTHER limb): NttBody's
+// FWD_IN = kRedB plans, which relin_kernel / relin_shared_kernel rely on to skip the canonicalisation.  FoldArith only.
+template <int LOGN, int LOGE>
+static int emu_fwd_any60(u64 q, u64 psi, const u64* in, u64* out) {
+    typedef NttBody<FoldArith, LOGN, LOGE, 0, kRedB> B;
+    HostLimbTables t;
+    int rc = build_limb_tables(LOGN, q, psi, t);
+    if (rc) return rc;
+    if (!fold_eligible(q)) return 2000;
+    constexpr int E = B::E, T = B::T;
+    std::vector<u64> regs((size_t)T * E), lds(B::G::lds_words(), 0xDEADBEEFDEADBEEFull);
+    auto X = [&](int tid) -> u64(&)[E] { return *reinterpret_cast<u64(*)[E]>(&regs[(size_t)tid * E]); };
+    auto tw = TwTab<FoldArith>::make(t.rp, t.rp_sh, q);
+    permute_window0(tw, LOGN, LOGE, B::G::kPermStages);
+    for (int tid = 0; tid < T; ++tid) B::load_top(tid, X(tid), in);
+    FwdSteps<B, 0>::run(regs, lds, tw.data(), t.lc);
+    for (int tid = 0; tid < T; ++tid) { B::fwd_canon(X(tid), t.lc); B::store_bot(tid, X(tid), out); }
+    return 0;
+}
+extern "C" int emu_ntt_fwd_any60(int log2n, u64 q, u64 psi, const u64* in, u64* out) {
+    if (log2n == 8) return emu_fwd_any60<8, 4>(q, psi, in, out);
+    if (log2n == 10) return emu_fwd_any60<10, 4>(q, psi, in, out);
+    if (log2n == 12) return emu_fwd_any60<12, 4>(q, psi, in, out);
+    if (log2n == 13) return emu_fwd_any60<13, 4>(q, psi, in, out);
+    return -1;
+}
+
 // N = 8192 as a column stage in registers + two 4096-point sub-transforms through ONE LDS buffer (ntt_halves.h; kernels_halves.h runs
 // exactly these steps on the device): 256 emulated threads hold lo / hi, the sub-transforms run on the tables dpfhe_ctx_create builds
 // for them (tables.h subtree_table, roots 2 and 3 of the N = 8192 table).
