@@ -299,6 +299,10 @@ def digest_other(o):
         c5 = o["n8192_l6"]
         d["n8192_l6"] = {"ntt_fwd_frac": r3(c5["ntt_fwd"]["frac_of_hbm_peak"]), "ntt_inv_frac": r3(c5["ntt_inv"]["frac_of_hbm_peak"]),
                          "ct_mul_per_s": round(c5["ct_mul"]["per_s"]), "ct_mul_frac": r3(c5["ct_mul"]["frac_of_hbm_peak"])}
+    if isinstance(o.get("shoup_n4096_l4"), dict) and "ct_mul" in o["shoup_n4096_l4"]:
+        sg = o["shoup_n4096_l4"]
+        d["shoup_n4096_l4"] = {"ntt_fwd_frac": r3(sg["ntt_fwd"]["frac_of_hbm_peak"]), "ntt_inv_frac": r3(sg["ntt_inv"]["frac_of_hbm_peak"]), "ct_mul_per_s": round(sg["ct_mul"]["per_s"]),
+                               "ct_mul_frac": r3(sg["ct_mul"]["frac_of_hbm_peak"]), "fold_over_shoup_ct_mul": r3(sg["fold_over_shoup_ct_mul"])}
     pl = o.get("packed_linear") or {}
     if pl:
         e = {"all_correct": pl.get("all_correct")}
@@ -689,6 +693,35 @@ def main():
         other["n8192_l6"] = c5
         del a5, b5, o5, x5, y5
         ctx5.close()
+        # the GENERIC-PRIME arithmetic (ShoupArith) at the headline shape: N=4096, four primes of 59 / 50 / 40 / 33 bits (none 2^60 - d), configs[1]'s
+        # 1024 RNS polynomials and configs[3]'s 8192-pair shard - what a chain of mixed-width limbs pays against the fold primes
+        try:
+            pg = FheParams.generic_n4096_l4()
+            ctxg = Context(pg, local_rank)
+            evg = Evaluator(ctxg)
+            qg = torch.tensor(pg.moduli, dtype=torch.int64, device=dev)
+            xg = torch.randint(0, 2**62, (1024, L, N), generator=g, dtype=torch.int64, device=dev) % qg.view(1, L, 1)
+            yg = torch.empty_like(xg)
+            sg = {"workload": "generic primes (59/50/40/33 bits, Harvey/Shoup butterflies + 128-bit Barrett products): N=4096, L=4; NTT on 1024 RNS polys (configs[1]), "
+                              "fused multiply on 8192 pairs (configs[3]'s shard)", "moduli_bits": [int(m).bit_length() for m in pg.moduli], "uses_fold": ctxg.uses_fold}
+            for name, fn in (("ntt_fwd", evg.ntt_forward), ("ntt_inv", evg.ntt_inverse)):
+                t = timed(lambda: fn(xg, out=yg), 10)
+                nbytes = 2 * N * 8 * 1024 * L
+                sg[name] = {"median_us": t * 1e6, "GBps": nbytes / t / 1e9, "frac_of_hbm_peak": nbytes / t / HBM_PEAK}
+            del xg, yg
+            ag = Ciphertext(torch.randint(0, 2**62, (B, 2, L, N), generator=g, dtype=torch.int64, device=dev) % qg.view(1, 1, L, 1))
+            bg = Ciphertext(torch.randint(0, 2**62, (B, 2, L, N), generator=g, dtype=torch.int64, device=dev) % qg.view(1, 1, L, 1))
+            og = outs[0].view(-1)[: B * 3 * L * N].view(B, 3, L, N)
+            t = timed(lambda: evg.multiply(ag, bg, out=og), 5)
+            sg["ct_mul"] = {"pairs": B, "median_us": t * 1e6, "per_s": B / t, "frac_of_hbm_peak": 7 * L * N * 8 * B / t / HBM_PEAK}
+            t = timed(lambda: ev.multiply(a, b, out=og), 5)     # the fold arm, same launch shape, same moment
+            sg["fold_ct_mul_per_s_same_moment"] = B / t
+            sg["fold_over_shoup_ct_mul"] = sg["fold_ct_mul_per_s_same_moment"] / sg["ct_mul"]["per_s"]
+            other["shoup_n4096_l4"] = sg
+            del ag, bg
+            ctxg.close()
+        except Exception as e:
+            other["shoup_n4096_l4"] = {"error": repr(e)[:200]}
         # N3: one token through the reference's dense-layer shapes under encryption, slot-packed, through the C++
         # operator API (examples/encrypted_gpt2_linear.cpp: PackedLinear at N=8192, 5 data limbs + special prime); the program
         # decrypts every result and compares it with W x mod t
@@ -1022,6 +1055,11 @@ def main():
         if c5:
             result["roofline"].update({"n8192_ntt_fwd_frac": c5["ntt_fwd"]["frac_of_hbm_peak"], "n8192_ntt_inv_frac": c5["ntt_inv"]["frac_of_hbm_peak"],
                                        "n8192_ct_mul_frac": c5["ct_mul"]["frac_of_hbm_peak"]})
+        sg = other_result.get("shoup_n4096_l4") or {}
+        if "ct_mul" in sg:
+            result["roofline"].update({"shoup_ntt_fwd_frac": sg["ntt_fwd"]["frac_of_hbm_peak"], "shoup_ntt_inv_frac": sg["ntt_inv"]["frac_of_hbm_peak"],
+                                       "shoup_ct_mul_per_s": sg["ct_mul"]["per_s"], "shoup_ct_mul_frac": sg["ct_mul"]["frac_of_hbm_peak"],
+                                       "fold_over_shoup_ct_mul": sg["fold_over_shoup_ct_mul"]})
     # the reduced result of the last step equals a recomputation of the same sequence on the main stream (every rank checks,
     # rank 0 reports; at N>1 the recomputation repeats the all-gather, so all ranks must take part)
     chk = ev.reduce_sum(Ciphertext(out), stream=main)

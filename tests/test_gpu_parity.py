@@ -454,6 +454,31 @@ def test_ct_mul_large_batch_checksum_of_checksums(rigs):
     assert np.array_equal(to_host(c.data), want)
 
 
+def test_generic_primes_full_size_whole_buffer_oracle():
+    """The generic-prime arithmetic (Harvey/Shoup butterflies, 128-bit Barrett products) at the headline shape - N = 4096, four primes of 59 / 50 / 40 / 33
+    bits, none of the 2^60 - d form (bench.py other_configs.shoup_n4096_l4): configs[1]'s 1024 RNS polynomials through both transforms and 2048
+    ciphertext pairs through the fused multiply, EVERY output word against the oracle; round trip and canonical range on the device."""
+    p = FheParams.generic_n4096_l4()
+    r = Rig(p)
+    try:
+        assert not r.ctx.uses_fold and [q.bit_length() for q in p.moduli] == [59, 50, 40, 33]
+        L, n = 4, 4096
+        g = torch.Generator(device="cpu").manual_seed(23)
+        q = torch.tensor(p.moduli, dtype=torch.int64)
+        x = (torch.randint(0, 2**62, (1024, L, n), generator=g, dtype=torch.int64) % q.view(1, L, 1)).to(r.ctx.device)
+        X = r.ev.ntt_forward(x)
+        assert torch.equal(r.ev.ntt_inverse(X), x) and int(X.min()) >= 0 and bool((X < q.view(1, L, 1).to(X.device)).all())
+        assert np.array_equal(to_host(X), r.orc.ntt_fwd(to_host(x), threads=0))
+        assert np.array_equal(to_host(r.ev.ntt_inverse(x)), r.orc.ntt_inv(to_host(x), threads=0))
+        batch = 2048
+        a = (torch.randint(0, 2**62, (batch, 2, L, n), generator=g, dtype=torch.int64) % q.view(1, 1, L, 1)).to(r.ctx.device)
+        b = (torch.randint(0, 2**62, (batch, 2, L, n), generator=g, dtype=torch.int64) % q.view(1, 1, L, 1)).to(r.ctx.device)
+        c = r.ev.multiply(Ciphertext(a), Ciphertext(b))
+        assert np.array_equal(to_host(c.data), r.orc.ct_mul(to_host(a), to_host(b), threads=0))
+    finally:
+        r.ctx.close()
+
+
 def test_config4_per_gpu_shard_full_size_through_the_bench_step(rigs):
     """BASELINE configs[3], one GPU's share: 8192 ct-muls at N=4096 / L=4 through deeppowers_amd.sharding.ShardedMultiplyReduce
     - the very object bench.py times (multiply on the main stream, shard-local reduce -> all-gather -> final sum on the side
