@@ -84,7 +84,8 @@ struct dpfhe_ctx {
     DevTables<FoldArith> foldt{};
     // scratch of the composed large-ring operations: a pool of this context's own (created on first use) that keeps what it has been
     // given until the context goes - the default pool hands its memory back at every synchronisation and pays the mapping again
-    hipMemPool_t scratch_pool = nullptr;
+    struct ScratchArena { hipStream_t stream; u64* p; size_t words; };
+    std::vector<ScratchArena> scratch_arenas;   // one per stream that ever ran a composed operation (StreamScratch below)
     std::mutex scratch_mutex;
     // which form of the fused multiply dpfhe_ct_mul(flags = 0) launches (launch.h CtMulVariant): the default of the ring degree until
     // dpfhe_ctx_autotune or dpfhe_ctx_set_ct_mul_variant says otherwise.  Both forms give the same words.
@@ -385,7 +386,7 @@ extern "C" int dpfhe_ctx_create(dpfhe_ctx** out, uint32_t log2_n, uint32_t n_lim
 extern "C" int dpfhe_ctx_destroy(dpfhe_ctx* c) {
     if (!c) return DPFHE_SUCCESS;
     if (c->d_blob) (void)hipFree(c->d_blob);
-    if (c->scratch_pool) (void)hipMemPoolDestroy(c->scratch_pool);
+    for (auto& a : c->scratch_arenas) if (a.p) (void)hipFree(a.p);
     delete c;
     return DPFHE_SUCCESS;
 }
@@ -507,31 +508,39 @@ extern "C" int dpfhe_multiply_plain(dpfhe_ctx* c, uint64_t* o, const uint64_t* a
 // stream: no synchronisation, the memory returns to the context's pool when the stream gets there).
 static const uint32_t kFusedMaxLog2N = 13;
 
+// Scratch of the composed large-ring operations: one ARENA per (context, stream), a plain hipMalloc made the first time that stream runs a
+// composed operation and grown (hipStreamSynchronize of that stream + hipFree + hipMalloc) only when a larger slice than ever before arrives;
+// kept until dpfhe_ctx_destroy.  Work on one stream is ordered, so consecutive calls share their stream's arena without a fence; different
+// streams never share one.  Steady state: no allocation, no synchronisation.
+// (Rounds 2-4 took the scratch from a stream-ordered memory pool - hipMallocFromPoolAsync / hipFreeAsync.  Round 5 found blocks of tens of MiB from
+// that pool giving wrong results and millisecond allocation times in a process without PyTorch - the C++ programs; tools/gpu_r05_f.sh -, while the
+// same calls under PyTorch were exact: the arena has no such dependence on the runtime's allocator state.)
 struct StreamScratch {
     u64* p = nullptr;
     dpfhe_ctx* c;
     hipStream_t s;
     StreamScratch(dpfhe_ctx* ctx, hipStream_t st) : c(ctx), s(st) {}
     int alloc(size_t words, const char* what) {
-        {
-            std::lock_guard<std::mutex> lock(c->scratch_mutex);
-            if (!c->scratch_pool) {
-                hipMemPoolProps props = {};
-                props.allocType = hipMemAllocationTypePinned;
-                props.handleTypes = hipMemHandleTypeNone;
-                props.location.type = hipMemLocationTypeDevice;
-                props.location.id = c->device;
-                hipError_t e = hipMemPoolCreate(&c->scratch_pool, &props);
-                if (e != hipSuccess) { c->scratch_pool = nullptr; (void)hipGetLastError(); return fail(DPFHE_DEVICE_ERROR, what, hipGetErrorString(e)); }
-                uint64_t keep = ~0ull;
-                (void)hipMemPoolSetAttribute(c->scratch_pool, hipMemPoolAttrReleaseThreshold, &keep);
-            }
+        std::lock_guard<std::mutex> lock(c->scratch_mutex);
+        dpfhe_ctx::ScratchArena* arena = nullptr;
+        for (auto& a : c->scratch_arenas) if (a.stream == s) arena = &a;
+        if (arena && arena->words >= words) { p = arena->p; return DPFHE_SUCCESS; }
+        if (arena && arena->p) {   // growth: the stream's earlier launches may still be using the old block
+            hipError_t e = hipStreamSynchronize(s);
+            if (e != hipSuccess) return fail(DPFHE_DEVICE_ERROR, what, hipGetErrorString(e));
+            (void)hipFree(arena->p);
+            arena->p = nullptr; arena->words = 0;
         }
-        hipError_t e = hipMallocFromPoolAsync(reinterpret_cast<void**>(&p), words * sizeof(u64), c->scratch_pool, s);
-        if (e != hipSuccess) { p = nullptr; (void)hipGetLastError(); return fail(DPFHE_OUT_OF_MEMORY, what, hipGetErrorString(e)); }
+        const size_t gran = (size_t)1 << 21;                                    // 16 MiB steps
+        const size_t want = (words + gran - 1) / gran * gran;
+        u64* q = nullptr;
+        hipError_t e = hipMalloc(reinterpret_cast<void**>(&q), want * sizeof(u64));
+        if (e != hipSuccess) { (void)hipGetLastError(); return fail(DPFHE_OUT_OF_MEMORY, what, hipGetErrorString(e)); }
+        if (arena) { arena->p = q; arena->words = want; }
+        else c->scratch_arenas.push_back(dpfhe_ctx::ScratchArena{s, q, want});
+        p = q;
         return DPFHE_SUCCESS;
     }
-    ~StreamScratch() { if (p) (void)hipFreeAsync(p, s); }
 };
 
 static int ct_mul_composed_slice(dpfhe_ctx* c, uint64_t* d_out3, const uint64_t* d_a2, const uint64_t* d_b2, size_t batch, uint32_t flags, hipStream_t s) {
@@ -701,6 +710,36 @@ extern "C" int dpfhe_rescale(dpfhe_ctx* c, uint64_t* d_out, const uint64_t* d_in
     return check_launch("rescale kernel launch");
 }
 
+// Above N = 8192 (no fused key-switch kernel): out[item][2][L][N] (NTT domain over Q P) = sum_j NTT(lift(digit_j of item)) (.) key_j, the digits being the Ld
+// limbs of one component (`comp0`: component pointer of item 0, items `item_stride` words apart), keys per item group (key_stride / key_group as in
+// launch_relin; 0 / 1 = one key).  Composed from lift_digits_kernel, the batched forward transform and key_inner_product_kernel; scratch from the
+// context's pool, batch sliced so that a slice's Ld L N words per item stay below the scratch limit.
+static int key_products_composed(dpfhe_ctx* c, uint64_t* d_out_qp, const uint64_t* comp0, size_t item_stride, const uint64_t* d_keys, size_t key_stride, unsigned key_group,
+                                 size_t batch, hipStream_t s, const char* what) {
+    const size_t L = c->n_limbs, Ld = L - 1;
+    const int n = 1 << c->log2n, ch = n / 512;
+    const LimbConst* lc = c->fold ? c->foldt.lc : c->shoup.lc;
+    const size_t per = slice_items(c, batch, Ld * L * (size_t)n);
+    for (size_t i0 = 0; i0 < batch; i0 += per) {
+        const size_t m = batch - i0 < per ? batch - i0 : per;
+        const size_t lift_grid = m * Ld * L * (size_t)ch;
+        if (lift_grid > kMaxGrid || !ntt_grid_fits(c, m * Ld * L)) return fail(DPFHE_INVALID_ARGUMENT, what, "batch too large for one launch (lower the scratch limit)");
+        StreamScratch ws(c, s);
+        if (int rc = ws.alloc(m * Ld * L * n, what)) return rc;
+        const u64* comp = comp0 + i0 * item_stride;
+        if (c->fold) hipLaunchKernelGGL((lift_digits_kernel<FoldArith>), dim3((unsigned)lift_grid), dim3(256), 0, s, ws.p, comp, item_stride, lc, (int)L, n, ch);
+        else hipLaunchKernelGGL((lift_digits_kernel<ShoupArith>), dim3((unsigned)lift_grid), dim3(256), 0, s, ws.p, comp, item_stride, lc, (int)L, n, ch);
+        if (int rc = check_launch("digit lift kernel launch")) return rc;
+        if (int rc = ntt_launch(c, false, ws.p, ws.p, m * Ld * L, s)) return rc;
+        const unsigned grid = (unsigned)(m * L * (size_t)ch);
+        u64* o = d_out_qp + i0 * 2 * L * n;
+        if (c->fold) hipLaunchKernelGGL((key_inner_product_kernel<FoldArith>), dim3(grid), dim3(256), 0, s, o, ws.p, d_keys, lc, (int)Ld, (int)L, n, ch, key_stride, key_group, (unsigned)i0);
+        else hipLaunchKernelGGL((key_inner_product_kernel<ShoupArith>), dim3(grid), dim3(256), 0, s, o, ws.p, d_keys, lc, (int)Ld, (int)L, n, ch, key_stride, key_group, (unsigned)i0);
+        if (int rc = check_launch("key inner product kernel launch")) return rc;
+    }
+    return DPFHE_SUCCESS;
+}
+
 // hybrid key switching = inner product over all L limbs (relin_kernel MODE 2/3) + divide by the special prime and add (c0, c1)
 static int hybrid_entry(dpfhe_ctx* c, const char* what, int in_comps, uint64_t* d_out2, const uint64_t* d_in, const uint64_t* d_key,
                         uint64_t* d_work, size_t batch, void* stream, size_t key_stride = 0, unsigned key_group = 1) {
@@ -724,23 +763,10 @@ static int hybrid_entry(dpfhe_ctx* c, const char* what, int in_comps, uint64_t* 
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int mode = in_comps == 3 ? 2 : 3;
     if (c->log2n > kFusedMaxLog2N) {
-        // no fused kernel: digits lifted to Q P -> one batched transform -> inner products with the key -> batched inverse into `work`
-        if (key_stride != 0 || key_group > 1) return fail(DPFHE_INVALID_STATE, what, "per-item keys are not available above N = 8192");
-        const int ch = n / 512;
-        const size_t lift_grid = batch * Ld * L * (size_t)ch;
-        if (lift_grid > kMaxGrid || !ntt_grid_fits(c, batch * Ld * L)) return fail(DPFHE_INVALID_ARGUMENT, what, "batch too large for one launch");
-        StreamScratch ws(c, s);
-        if (int rc = ws.alloc(batch * Ld * L * n, what)) return rc;
-        const LimbConst* lc = c->fold ? c->foldt.lc : c->shoup.lc;
-        const u64* comp = d_in + (size_t)(in_comps - 1) * Ld * n;
-        if (c->fold) hipLaunchKernelGGL((lift_digits_kernel<FoldArith>), dim3((unsigned)lift_grid), dim3(256), 0, s, ws.p, comp, (size_t)in_comps * Ld * n, lc, (int)L, n, ch);
-        else hipLaunchKernelGGL((lift_digits_kernel<ShoupArith>), dim3((unsigned)lift_grid), dim3(256), 0, s, ws.p, comp, (size_t)in_comps * Ld * n, lc, (int)L, n, ch);
-        if (int rc = check_launch("digit lift kernel launch")) return rc;
-        if (int rc = ntt_launch(c, false, ws.p, ws.p, batch * Ld * L, s)) return rc;
-        const unsigned grid = (unsigned)(batch * L * (size_t)ch);
-        if (c->fold) hipLaunchKernelGGL((key_inner_product_kernel<FoldArith>), dim3(grid), dim3(256), 0, s, d_work, ws.p, d_key, lc, (int)Ld, (int)L, n, ch);
-        else hipLaunchKernelGGL((key_inner_product_kernel<ShoupArith>), dim3(grid), dim3(256), 0, s, d_work, ws.p, d_key, lc, (int)Ld, (int)L, n, ch);
-        if (int rc = check_launch("key inner product kernel launch")) return rc;
+        // no fused kernel: digits lifted to Q P -> one batched transform -> inner products with the key(s) -> batched inverse into `work`;
+        // in slices whose scratch (Ld L N words per item) stays below the context's limit
+        if (int rc = key_products_composed(c, d_work, d_in + (size_t)(in_comps - 1) * Ld * n, (size_t)in_comps * Ld * n, d_key, key_stride, (unsigned)kg, batch, s, what)) return rc;
+        if (!ntt_grid_fits(c, batch * 2 * L)) return fail(DPFHE_INVALID_ARGUMENT, what, "batch too large for one launch");
         if (int rc = ntt_launch(c, true, d_work, d_work, batch * 2 * L, s)) return rc;
     } else {
         const int rc = c->fold ? launch_relin<FoldArith>((int)c->log2n, mode, d_work, d_in, d_key, key_stride, key_group, blocks, c->foldt, s)
@@ -901,7 +927,7 @@ extern "C" int dpfhe_rotate_hoisted_qp(dpfhe_ctx* c, uint64_t* d_out_qp, const u
     const char* what = "dpfhe_rotate_hoisted_qp";
     if (!c) return fail(DPFHE_INVALID_ARGUMENT, what, "null context");
     if (c->n_limbs < 2) return fail(DPFHE_INVALID_STATE, what, "the extended context needs at least one data limb and the special prime");
-    if (c->log2n > (uint32_t)kMaxFusedLog2N) return fail(DPFHE_INVALID_STATE, what, "no fused kernel geometry for this log2_n");
+    if (c->log2n > 14) return fail(DPFHE_INVALID_STATE, what, "available up to N = 16384 (the stream kernels and the single-kernel transforms)");
     if (n_items == 0) return DPFHE_SUCCESS;
     if (!d_out_qp || !d_in2 || (batch && (!galois_elts || !d_keys)) || !d_in_ntt || !d_digits || misaligned(d_out_qp) || misaligned(d_in2) || misaligned(d_keys) ||
         misaligned(d_in_ntt) || misaligned(d_digits))
@@ -1016,6 +1042,8 @@ extern "C" int dpfhe_switch_key_qp(dpfhe_ctx* c, uint64_t* d_out_qp, const uint6
     DPFHE_ON_DEVICE(c, what);
     hipStream_t s = static_cast<hipStream_t>(stream);
     const size_t key_words = Ld * 2 * L * (size_t)n;
+    if (c->log2n > kFusedMaxLog2N)   // composed from the batched transform (round 5): the digits of c1, lifted and transformed, times the group's key
+        return key_products_composed(c, d_out_qp, d_in2 + Ld * (size_t)n, 2 * Ld * (size_t)n, d_keys, key_words, (unsigned)group, batch, s, what);
     const int rc = c->fold ? launch_relin<FoldArith>((int)c->log2n, 4, d_out_qp, d_in2, d_keys, key_words, (unsigned)group, blocks, c->foldt, s)
                            : launch_relin<ShoupArith>((int)c->log2n, 4, d_out_qp, d_in2, d_keys, key_words, (unsigned)group, blocks, c->shoup, s);
     if (rc) return fail(DPFHE_INVALID_STATE, what, "no kernel geometry for this log2_n");

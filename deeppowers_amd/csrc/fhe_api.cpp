@@ -48,6 +48,12 @@ const uint64_t kPrimes60[kChainPrimes][3] = {
     {1152921504601980929ull, 0ull, 112510666220977ull}, {1152921504601915393ull, 0ull, 12114078003698ull},
     {1152921504601784321ull, 0ull, 4580624056246ull}, {1152921504600309761ull, 0ull, 135029094688496ull},
     {1152921504600260609ull, 0ull, 120773065591640ull}, {1152921504600145921ull, 0ull, 1663825873988ull}};
+// the 8 largest primes below 2^60 that are 1 mod 2^15 (deeppowers_amd/params.py ntt_primes(14, 8)): {q, smallest primitive 32768-th root}
+constexpr size_t kChainPrimes14 = 8;
+const uint64_t kPrimes60N14[kChainPrimes14][2] = {
+    {1152921504606748673ull, 62213374832584ull}, {1152921504606683137ull, 212089012217363ull}, {1152921504606584833ull, 92166579128688ull},
+    {1152921504605962241ull, 74756755228070ull}, {1152921504604979201ull, 52069629205452ull}, {1152921504600260609ull, 27543819356734ull},
+    {1152921504599080961ull, 92056553354496ull}, {1152921504598720513ull, 89492317149395ull}};
 }  // namespace
 
 FheParams FheParams::drop_last_limb() const {
@@ -67,6 +73,13 @@ FheParams FheParams::n8192(size_t n_limbs) {
     if (n_limbs == 0 || n_limbs > kChainPrimes) throw Exception(ErrorCode::INVALID_ARGUMENT, "FheParams::n8192: 1..20 limbs");
     FheParams p{13, {}, {}};
     for (size_t i = 0; i < n_limbs; ++i) { p.moduli.push_back(kPrimes60[i][0]); p.psi.push_back(kPrimes60[i][2]); }
+    return p;
+}
+
+FheParams FheParams::n16384(size_t n_limbs) {
+    if (n_limbs == 0 || n_limbs > kChainPrimes14) throw Exception(ErrorCode::INVALID_ARGUMENT, "FheParams::n16384: 1..8 limbs");
+    FheParams p{14, {}, {}};
+    for (size_t i = 0; i < n_limbs; ++i) { p.moduli.push_back(kPrimes60N14[i][0]); p.psi.push_back(kPrimes60N14[i][1]); }
     return p;
 }
 

@@ -54,18 +54,21 @@ __global__ __launch_bounds__(256) void lift_rns_digits_kernel(u64* __restrict__ 
     *reinterpret_cast<U64x2*>(out + ((item * n_limbs + digit) * n_limbs + limb) * n + w0) = r;
 }
 
-// acc[item][c][i] = sum_{j < n_digits} x[item][j][i] (.) evk[j][c][i], c = 0, 1 (NTT domain; x: [batch][n_digits][L][N], evk: [n_digits][2][L][N],
-// one key for the whole batch: its tiles are re-read from L2).  acc: [batch][2][L][N].  n_digits = L (RNS-digit keys) or L - 1 (hybrid keys: the
-// last limb is the special prime, the sum is divided by it afterwards).
+// acc[item][c][i] = sum_{j < n_digits} x[item][j][i] (.) evk[j][c][i], c = 0, 1 (NTT domain; x: [batch][n_digits][L][N], evk: [n_digits][2][L][N];
+// its tiles are re-read from L2).  acc: [batch][2][L][N].  n_digits = L (RNS-digit keys) or L - 1 (hybrid keys: the last limb is the special prime,
+// the sum is divided by it afterwards).  Per-item keys (round 5: the batched rotations and the giant steps of a packed layer above N = 8192):
+// item i of this launch uses the key at evk + ((item0 + i) / key_group) * key_stride; key_stride = 0 is one key for the whole batch.
 template <class Arith>
 __global__ __launch_bounds__(256) void key_inner_product_kernel(u64* __restrict__ acc, const u64* __restrict__ x, const u64* __restrict__ evk, const LimbConst* lcs,
-                                                                int n_digits, int n_limbs, int n, int chunks) {
+                                                                int n_digits, int n_limbs, int n, int chunks, size_t key_stride = 0, unsigned key_group = 1,
+                                                                unsigned item0 = 0) {
     const int chunk = (int)(blockIdx.x % chunks);
     const int limb = (int)((blockIdx.x / chunks) % n_limbs);
     const size_t item = blockIdx.x / chunks / n_limbs;
     const int w0 = chunk * 512 + threadIdx.x * 2;
     if (w0 >= n) return;
     const LimbConst lc = lcs[limb];
+    evk += ((item + item0) / key_group) * key_stride;
     U64x2 s0{0, 0}, s1{0, 0};
 #pragma unroll 2
     for (int j = 0; j < n_digits; ++j) {

@@ -3,7 +3,9 @@
 // Z_65537 by the diagonal method with baby-step / giant-step rotations (deeppowers::fhe::PackedLinear).
 // The layer shapes are the reference's matmul sites (/root/reference/src/core/execution/models/gpt_model.cpp:793 QKV 768 -> 2304,
 // :848 FFN 768 -> 3072 -> 768, :883 logits 768 -> 50257; hidden_size 768, vocab 50257 at execution/model.hpp:47-50).
-//   usage: encrypted_gpt2_linear [layer = all | square | qkv | ffn_up | ffn_down | lm_head | <out>x<in>] [reps = 2] [json | text] [tokens = 1]
+//   usage: encrypted_gpt2_linear [layer = all | square | qkv | ffn_up | ffn_down | lm_head | <out>x<in>] [reps = 2] [json | text] [tokens = 1] [log2_n = 13 | 14]
+// log2_n = 14: the same layer at N = 16384 on six primes that are 1 mod 2^15 (round 5: the packed pipeline's rotations above N = 8192 are composed
+// from the batched transforms; a 360-bit modulus under key switching at N = 16384 is inside the 128-bit-security budget of 438 bits).
 // Prints one line per layer; with a third argument "json" the lines are JSON objects (bench.py other_configs.packed_linear).
 // tokens > 1: that many encrypted hidden states go through the layer in ONE application (keys and diagonals read once).
 #include <chrono>
@@ -24,6 +26,8 @@ int main(int argc, char** argv) {
     const int reps = argc > 2 ? std::atoi(argv[2]) : 2;
     const bool json = argc > 3 && !std::strcmp(argv[3], "json");
     const size_t T = argc > 4 ? (size_t)std::atol(argv[4]) : 1;
+    const int log2n = argc > 5 ? std::atoi(argv[5]) : 13;
+    if (log2n != 13 && log2n != 14) { std::fprintf(stderr, "log2_n must be 13 or 14\n"); return 1; }
     std::vector<Shape> shapes;
     const Shape known[] = {{"square", 768, 768}, {"qkv", 2304, 768}, {"ffn_up", 3072, 768}, {"ffn_down", 768, 3072}, {"lm_head", 50257, 768}};
     for (const Shape& k : known)
@@ -34,7 +38,7 @@ int main(int argc, char** argv) {
         else { std::fprintf(stderr, "unknown layer '%s'\n", which.c_str()); return 1; }
     }
     try {
-        FheParams p = FheParams::n8192_l6();
+        FheParams p = log2n == 14 ? FheParams::n16384(6) : FheParams::n8192_l6();
         const uint64_t special = p.moduli.back(), special_psi = p.psi.back();
         p.moduli.pop_back(); p.psi.pop_back();
         const size_t n = p.n();
@@ -85,9 +89,9 @@ int main(int argc, char** argv) {
                 for (size_t r = 0; r < sh.out; ++r) bad += y[r] != want[tk * sh.out + r];
             }
             if (json)
-                std::printf("{\"layer\": \"%s\", \"out_dim\": %zu, \"in_dim\": %zu, \"log2_n\": 13, \"data_limbs\": %zu, \"plain_modulus\": %llu, \"baby_steps\": %zu, "
+                std::printf("{\"layer\": \"%s\", \"out_dim\": %zu, \"in_dim\": %zu, \"log2_n\": %d, \"data_limbs\": %zu, \"plain_modulus\": %llu, \"baby_steps\": %zu, "
                             "\"giant_steps\": %zu, \"output_ciphertexts\": %zu, \"key_switches\": %zu, \"tokens_per_apply\": %zu, \"setup_s\": %.2f, \"ms_per_token\": %.3f, \"correct\": %s}\n",
-                            sh.name, sh.out, sh.in, p.n_limbs(), (unsigned long long)t, layer.baby_steps(), layer.giant_steps(), outs, layer.key_switches_per_apply(), T,
+                            sh.name, sh.out, sh.in, log2n, p.n_limbs(), (unsigned long long)t, layer.baby_steps(), layer.giant_steps(), outs, layer.key_switches_per_apply(), T,
                             setup_s, apply_ms, bad ? "false" : "true");
             else
                 std::printf("%-8s %5zu <- %4zu: period %zu, %zu baby x %zu giant steps, %zu output ciphertext(s), %zu key switches, %zu token(s) per apply; setup %.2f s, apply %.3f ms per token: %s\n",

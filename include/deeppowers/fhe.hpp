@@ -50,6 +50,7 @@ struct FheParams {
     static FheParams config1();     // N=1024, one 30-bit limb       (BASELINE.json configs[0])
     static FheParams n4096_l4();    // N=4096, 4 x 60-bit limbs      (configs[1..3], the metric)
     static FheParams n8192_l6();    // N=8192, 6 x 60-bit limbs      (configs[4] sizes)
+    static FheParams n16384(size_t n_limbs);  // N=16384, the first n_limbs (<= 8) primes below 2^60 that are 1 mod 2^15: a ring with room for a security margin
     static FheParams n8192(size_t n_limbs);   // N=8192, the first n_limbs (<= 20) primes of the same descending chain: deeper levels, multiply workspaces
 };
 

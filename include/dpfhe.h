@@ -27,8 +27,9 @@
  *   - `stream` is a hipStream_t (NULL = the null stream).  Compute calls only enqueue work and never synchronise.  At log2_n <= 13 (every
  *     BASELINE configuration) they never allocate either: all scratch is caller-provided (d_work / d_digits / ... arguments).  The ONE
  *     exception is spelled out at dpfhe_ctx_create below: at log2_n >= 14 dpfhe_ct_mul, dpfhe_relinearize, dpfhe_switch_key and the two
- *     single-key hybrid entries take their scratch from a stream-ordered pool owned by the context (no synchronisation, no host allocation;
- *     the pool keeps its memory until dpfhe_ctx_destroy).  dpfhe_ctx_create (uploads the tables: one allocation, one copy, no kernel), dpfhe_ctx_autotune
+ *     hybrid entries take their scratch from an arena the context keeps PER STREAM: allocated (hipMalloc) the first time that stream runs such an
+ *     operation, grown - after synchronising that stream only - when a larger slice than ever before arrives, kept until dpfhe_ctx_destroy; in steady
+ *     state they neither allocate nor synchronise.  dpfhe_ctx_create (uploads the tables: one allocation, one copy, no kernel), dpfhe_ctx_autotune
  *     (times kernels on caller scratch) and dpfhe_comm_create are set-up calls: they may allocate and synchronise.  After set-up a dpfhe_ctx is immutable: concurrent calls from different host threads on
  *     different streams are allowed.
  *   - No C++ types and no exceptions cross this boundary.
@@ -62,9 +63,10 @@ enum { DPFHE_IN_NTT = 1u, DPFHE_OUT_NTT = 2u };
 /* -- A0: context ----------------------------------------------------------------------------------
  * log2_n in [8, 16] (N > 16384 runs a two-kernel split transform; the fused ct x ct / key-switch kernels stop at 13: above it dpfhe_ct_mul,
  * dpfhe_relinearize and dpfhe_switch_key compose the batched transforms with one-pass streaming kernels and take their scratch from the
- * stream-ordered allocator (a memory pool of the context's own, on the caller's stream; kept until dpfhe_ctx_destroy; large batches run in slices of at most
- * 1 GiB of scratch, or what dpfhe_ctx_set_scratch_limit said); so do the single-key hybrid entries dpfhe_relinearize_hybrid / dpfhe_switch_key_hybrid; the batched, hoisted and grouped rotation entries return
- * DPFHE_INVALID_STATE there); n_limbs >= 1; moduli[i] prime < 2^60 with q = 1 (mod 2N); psi[i] a primitive
+ * context's scratch arena of the caller's stream (see "Conventions"; kept until dpfhe_ctx_destroy; large batches run in slices of at most
+ * 1 GiB of scratch, or what dpfhe_ctx_set_scratch_limit said); so do the hybrid entries - dpfhe_relinearize_hybrid / dpfhe_switch_key_hybrid, and since round 5 the per-item-key ones:
+ * dpfhe_rotate_hybrid_batch / dpfhe_rotate_hybrid_grouped and dpfhe_switch_key_qp; dpfhe_rotate_hoisted_qp and dpfhe_ntt_inv_galois run up to log2_n = 14
+ * (the whole packed-layer pipeline at N = 16384); dpfhe_rotate_hybrid_hoisted returns DPFHE_INVALID_STATE above 13); n_limbs >= 1; moduli[i] prime < 2^60 with q = 1 (mod 2N); psi[i] a primitive
  * 2N-th root of unity mod q_i (psi^N = -1).  Builds twiddle / Shoup / Barrett tables on device_id. */
 int dpfhe_ctx_create(dpfhe_ctx** out, uint32_t log2_n, uint32_t n_limbs, const uint64_t* moduli,
                      const uint64_t* psi, int device_id);

@@ -26,12 +26,15 @@ def _params(name):
         return FheParams(12, tuple(x[0] for x in PRIMES_60[:3]), tuple(x[1] for x in PRIMES_60[:3]))     # 2 data limbs + P
     if name == "n4096_l6":
         return FheParams(12, tuple(x[0] for x in PRIMES_60[:6]), tuple(x[1] for x in PRIMES_60[:6]))     # 5 data limbs + P: relin_shared_kernel
+    if name == "fold14":      # N = 16384: 2 data limbs + P on the pinned primes that are 1 mod 32768 - the stages composed from the batched transforms (round 5)
+        qs = tuple(PRIMES_60[i][0] for i in (1, 2, 4))
+        return FheParams(14, qs, tuple(po.min_primitive_2n_root(16384, q) for q in qs))
     if name == "n8192_l10":   # 9 data limbs + P: the digit counts of a deep modulus chain (examples/encrypted_gpt2_stack.cpp) - loop-form baby steps with
         return ntt_primes(13, 10)   # their periodic lazy folds, per-component hoisted rotations, more lazily added products per key switch
     return FheParams(13, tuple(x[0] for x in PRIMES_60[:4]), tuple(x[2] for x in PRIMES_60[:4]))         # 3 data limbs + P
 
 
-@pytest.mark.parametrize("name", ["mixed", "n4096", "n8192", "n8192_l10"])
+@pytest.mark.parametrize("name", ["mixed", "n4096", "n8192", "n8192_l10", "fold14"])
 def test_rotate_hoisted_qp_bit_exact(name):
     from deeppowers_amd.evaluator import Ciphertext, Context, Evaluator, to_device, to_host
     pe = _params(name)
@@ -58,7 +61,7 @@ def test_rotate_hoisted_qp_bit_exact(name):
     ctx.close()
 
 
-@pytest.mark.parametrize("name", ["mixed", "n4096", "n8192"])
+@pytest.mark.parametrize("name", ["mixed", "n4096", "n8192", "fold14"])
 def test_ntt_inverse_galois_bit_exact(name):
     """sigma_g applied as a gather in the NTT domain + inverse transform == inverse transform + coefficient-domain automorphism;
     in place and out of place; 70 elements (two launch groups), several RNS polynomials per element."""
@@ -82,7 +85,7 @@ def test_ntt_inverse_galois_bit_exact(name):
     ctx.close()
 
 
-@pytest.mark.parametrize("name", ["mixed", "n4096", "n4096_l6", "n8192", "n8192_l10"])
+@pytest.mark.parametrize("name", ["mixed", "n4096", "n4096_l6", "n8192", "n8192_l10", "fold14"])
 def test_switch_key_qp_bit_exact(name):
     from deeppowers_amd.evaluator import Ciphertext, Context, Evaluator, to_device, to_host
     pe = _params(name)
@@ -102,7 +105,7 @@ def test_switch_key_qp_bit_exact(name):
     ctx.close()
 
 
-@pytest.mark.parametrize("name", ["mixed", "n8192", "n8192_l10"])
+@pytest.mark.parametrize("name", ["mixed", "n8192", "n8192_l10", "fold14"])
 def test_rescale_bsgs_and_the_whole_deferred_sum(name):
     """dpfhe_rescale_bsgs == round(x / P) + addends (oracle composition); and the deferred giant-step sum
          rescale_bsgs(INTT(sum_i switch_key_qp(rot_i)), rot)  decrypts like  rot_0 + sum_i keyswitch_hybrid(rot_i):

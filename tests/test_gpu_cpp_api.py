@@ -75,6 +75,18 @@ def test_example_encrypted_gpt2_layers_eight_tokens_per_launch():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("layer,tokens", [("qkv", 1), ("qkv", 8), ("ffn_down", 2)])
+def test_example_encrypted_gpt2_layers_at_n16384(layer, tokens):
+    """Round 5: the same layers at N = 16384 (six primes that are 1 mod 2^15: a 360-bit modulus under key switching, inside the 438-bit budget of 128-bit
+    security at this ring degree).  No fused key-switch kernel exists there: the baby steps run on the stream kernels and the batched transforms, the giant
+    steps' per-key inner products (dpfhe_switch_key_qp) and the fold rotations (dpfhe_rotate_hybrid_grouped) are composed from lift + batched transform +
+    key_inner_product_kernel with one key per item group, scratch from the context's per-stream arena - in a process WITHOUT PyTorch (the regression case
+    for the arena: a stream-ordered pool gave wrong words here).  Every token's decrypted result must equal W x mod t."""
+    out = subprocess.run([build_example("encrypted_gpt2_linear"), layer, "1", "text", str(tokens), "14"], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0 and "OK" in out.stdout and "MISMATCH" not in out.stdout and f"{tokens} token(s)" in out.stdout, out.stdout + out.stderr
+
+
+@pytest.mark.gpu
 def test_example_encrypted_gpt2_lm_head_tile():
     """gpt_model.cpp:883 logits: 768 -> 50257 is 7 output ciphertexts sharing the baby steps; a 3-ciphertext tile (768 -> 20000)
     runs here, the full head in examples/encrypted_gpt2_linear lm_head (2.3 GB of diagonals, ~1 min of host-side encoding)."""

@@ -466,13 +466,18 @@ def test_hybrid_key_switching_bit_exact_vs_oracle(name):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", ["n4096", "n8192"])
+@pytest.mark.parametrize("name", ["n4096", "n8192", "fold14"])
 def test_gpu_batched_rotations_bit_exact(name):
     """dpfhe_rotate_hybrid_batch == per-item automorphism + hybrid key switch of the oracle, for one shared input and for
-    one input per item (70 items: more than one 64-element launch group)."""
+    one input per item (70 items: more than one 64-element launch group).  fold14: N = 16384, where the key switch is composed from the
+    batched transforms with one key per item (round 5)."""
     from deeppowers_amd.evaluator import Ciphertext, Context, Evaluator, to_device, to_host
     if name == "n4096":
         pe = FheParams(12, tuple(x[0] for x in PRIMES_60[:3]), tuple(x[1] for x in PRIMES_60[:3]))     # 2 data limbs + P
+    elif name == "fold14":
+        from oracle import pyoracle as po
+        qs = tuple(PRIMES_60[i][0] for i in (1, 2, 4))
+        pe = FheParams(14, qs, tuple(po.min_primitive_2n_root(16384, q) for q in qs))
     else:
         pe = FheParams(13, tuple(x[0] for x in PRIMES_60[:3]), tuple(x[2] for x in PRIMES_60[:3]))
     orc = Oracle.from_params(pe)
