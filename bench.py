@@ -308,9 +308,10 @@ def digest_other(o):
         e = {"all_correct": pl.get("all_correct")}
         if pl.get("layers"):
             e["ms_per_token"] = {f"{l.get('layer', '?')}@{l.get('tokens_per_apply', l.get('tokens', '?'))}": r3(l.get("ms_per_token")) for l in pl["layers"]}
-        for blk in ("ffn_block", "transformer_block", "activated_ffn", "activated_block", "activated_stack"):
+        for blk in ("ffn_block", "transformer_block", "activated_ffn", "activated_block", "activated_block_n16384", "activated_stack"):
             if isinstance(pl.get(blk), dict):
-                e[blk] = {x: pl[blk].get(x) for x in ("ms_per_token", "ms_per_token_per_block", "correct", "blocks", "correct_blocks", "data_limbs", "tokens", "error", "budget_bits",
+                e[blk] = {x: pl[blk].get(x) for x in ("ms_per_token", "ms_per_token_per_block", "correct", "blocks", "correct_blocks", "data_limbs", "tokens", "error", "budget_bits", "log2_n",
+                                                      "modulus_bits_under_key_switching", "he_standard_128bit_budget_bits",
                                                       "levels", "limbs_per_level") if pl[blk].get(x) is not None}
         ks = pl.get("kernels") or {}
         if ks.get("stages"):
@@ -766,6 +767,11 @@ def main():
             run = subprocess.run([example("encrypted_gpt2_block_act"), "8", "2", "json", "ladder"], capture_output=True, text=True, timeout=600)   # modulus 5 / 4 / 3 / 2 limbs inside the block
             got = [json.loads(l) for l in run.stdout.splitlines() if l.startswith("{")]
             other["packed_linear"]["activated_block"] = got[0] if got and run.returncode == 0 else {"error": (run.stdout + run.stderr)[-300:]}
+            # ... and the same block on a ring with a SECURITY MARGIN (round 5): N = 16384, six primes = 1 mod 2^15 - 360 bits under key switching against the
+            # 438 bits of 128-bit security there; no fused kernel above N = 8192: every key switch and the multiply composed from the batched transforms
+            run = subprocess.run([example("encrypted_gpt2_block_act"), "8", "2", "json", "ladder", "14"], capture_output=True, text=True, timeout=600)
+            got = [json.loads(l) for l in run.stdout.splitlines() if l.startswith("{")]
+            other["packed_linear"]["activated_block_n16384"] = got[0] if got and run.returncode == 0 else {"error": (run.stdout + run.stderr)[-300:]}
             # ... and THREE such blocks in a row on ten data limbs (600 bits), the limb count of every level planned from a budget model and falling
             # 10 -> 2 over the 18 levels, the activations as exact multiplies at eight-, five- and two-limb levels; every block's output decrypted
             # and compared (examples/encrypted_gpt2_stack.cpp; gpt_model.cpp:626-672, the layer loop)

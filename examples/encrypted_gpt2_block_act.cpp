@@ -6,13 +6,19 @@
 // to two limbs, the activation is an EXACT ciphertext x ciphertext multiply (ExactMultiplier: the fused tensor-product kernel, i.e. the
 // metric op, inside the forward) + relinearisation, and W_down and the residual run on two limbs.  Every stage is decrypted and compared
 // with the plaintext computation; the noise budget is reported after every stage (six levels: qkv, the v mask, W_o, W_up, the square, W_down).
-//   usage: encrypted_gpt2_block_act [tokens = 4] [reps = 2] [json | text] [ladder]
+//   usage: encrypted_gpt2_block_act [tokens = 4] [reps = 2] [json | text] [ladder | flat] [log2_n = 13 | 14]
+// STAND-INS (what this is not): x^2 for GELU, no LayerNorm, attention = v (exact at one position only), ONE of the reference's 12 blocks, no LM head.
+// SECURITY: at N = 8192 the 360-bit modulus under key switching is far beyond the 218 bits the Homomorphic Encryption Standard allows at 128-bit security
+// (ternary secret, sigma = 3.2): that ring is BASELINE configs[4]'s, a performance shape, not a deployable parameter set.  log2_n = 14 runs the same block
+// on six primes = 1 mod 2^15 at N = 16384, where 360 bits are inside the 438-bit budget of 128-bit security (the key switches and the multiply are then
+// composed from the batched transforms: slower per token, but a parameter set with a margin).
 // `ladder`: the modulus falls WITH the noise budget inside the block: qkv on 5 limbs, the v hand-over and W_o on 4, W_up on 3, the square and W_down on 2.
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <memory>
+#include <utility>
 #include <vector>
 
 #include <deeppowers/fhe.hpp>
@@ -41,9 +47,11 @@ int main(int argc, char** argv) {
     // "ladder": the modulus falls WITH the budget - qkv on 5 limbs, the v hand-over and W_o on 4, W_up on 3, the square and W_down on 2 (a layer's
     // cost goes with digits x limbs: 30 / 20 / 12 / 6 instead of 30 / 30 / 30 / 6); default: the attention half and W_up all on 5 limbs
     const bool ladder = argc > 4 && !std::strcmp(argv[4], "ladder");
+    const int log2n = argc > 5 ? std::atoi(argv[5]) : 13;
+    if (log2n != 13 && log2n != 14) { std::fprintf(stderr, "log2_n must be 13 or 14\n"); return 1; }
     const int lv_attn = ladder ? 4 : 5, lv_up = ladder ? 3 : 5;
     try {
-        FheParams p5 = FheParams::n8192_l6();
+        FheParams p5 = log2n == 14 ? FheParams::n16384(6) : FheParams::n8192_l6();
         const uint64_t special = p5.moduli.back(), special_psi = p5.psi.back();
         p5.moduli.pop_back(); p5.psi.pop_back();
         FheParams pl[6];
@@ -89,6 +97,10 @@ int main(int argc, char** argv) {
         PackedSelect take_v(*ctx[lv_attn], *be[lv_attn], *hks[lv_attn], 2 * D, D, lo.input_period());
         const uint32_t row_swap = (uint32_t)(2 * n - 1);
         hks[lv_up]->add_galois_element(row_swap);
+        // W_up leaves its 3072 outputs in slots 0 .. 3071 of row 0; W_down reads its input replicated with period 4096 over BOTH slot rows.  The row swap
+        // fills row 1; a row longer than that period (N = 16384: 8192 slots) also needs the copies inside the row: one more rotation per doubling
+        std::vector<uint32_t> spread;
+        for (size_t sft = ldown.input_period(); sft < n / 2; sft <<= 1) { spread.push_back(be[lv_up]->galois_element(-(int)sft)); hks[lv_up]->add_galois_element(spread.back()); }
         const double setup_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
 
         std::vector<uint64_t> slots(n);
@@ -123,7 +135,13 @@ int main(int argc, char** argv) {
             lup.apply(h1_l, cu);                                           // W_up h1                                                            (gpt_model.cpp:848)
             hks[lv_up]->apply_galois_many(cu, swaps, cus);
             ev[lv_up]->add(cu, cus, cur);                                  // W_down's input packing
-            u2 = &down(cur, lv_up, 2, lad_a);                              // modulus switch to two limbs
+            Ciphertext *packed = &cur, *spare = &cu;
+            for (uint32_t e : spread) {                                    // (N = 16384 only: the period-4096 copies inside a slot row)
+                hks[lv_up]->apply_galois_many(*packed, std::vector<uint32_t>(T, e), cus);
+                ev[lv_up]->add(*packed, cus, *spare);
+                std::swap(packed, spare);
+            }
+            u2 = &down(*packed, lv_up, 2, lad_a);                          // modulus switch to two limbs
             mul.multiply(*u2, *u2, sq3);                                   // the activation (exact multiply around the fused ct x ct kernel)
             hks[2]->relinearize(sq3, sq);
             ldown.apply(sq, cdn);                                          // W_down on two limbs
@@ -165,10 +183,10 @@ int main(int argc, char** argv) {
         char levels[96];
         std::snprintf(levels, sizeof levels, "qkv 5, v + W_o %d, W_up %d, square + W_down 2 limbs", lv_attn, lv_up);
         if (json)
-            std::printf("{\"block\": \"transformer_block_square_activation\", \"hidden\": %zu, \"inner\": %zu, \"log2_n\": 13, \"levels\": \"%s\", "
+            std::printf("{\"block\": \"transformer_block_square_activation\", \"hidden\": %zu, \"inner\": %zu, \"log2_n\": %d, \"modulus_bits_under_key_switching\": 360, \"he_standard_128bit_budget_bits\": %d, \"levels\": \"%s\", "
                         "\"plain_modulus\": %llu, \"tokens\": %zu, \"key_switches_per_token\": %zu, \"ct_ct_multiplies_per_token\": 1, \"setup_s\": %.2f, \"ms_per_token\": %.3f, "
                         "\"budget_bits\": [%.0f, %.0f, %.0f, %.0f, %.0f, %.0f, %.0f, %.0f], \"correct\": %s}\n",
-                        D, H, levels, (unsigned long long)TM, T, ks, setup_s, ms_per_token, b[0], b[1], b[2], b[3], b[4], b[5], b[6], b[7], ok ? "true" : "false");
+                        D, H, log2n, log2n == 14 ? 438 : 218, levels, (unsigned long long)TM, T, ks, setup_s, ms_per_token, b[0], b[1], b[2], b[3], b[4], b[5], b[6], b[7], ok ? "true" : "false");
         else
             std::printf("transformer block with a square activation (%s), %zu token(s) per application, %zu key switches + one ct x ct multiply per token; setup %.2f s, %.3f ms per token\n"
                         "  noise budget (bits): fresh %.0f -> qkv %.0f -> v hand-over %.0f -> h1 %.0f -> W_up hand-over %.0f -> 2 limbs %.0f -> squared %.0f -> h2 %.0f\n"

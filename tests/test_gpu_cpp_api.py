@@ -163,6 +163,20 @@ def test_example_whole_block_with_activation(mode):
 
 
 @pytest.mark.gpu
+def test_example_whole_block_with_activation_on_a_128_bit_secure_ring():
+    """Round 5: the same block at N = 16384 on six primes = 1 mod 2^15 - 360 bits under key switching, inside the 438 bits the Homomorphic Encryption
+    Standard allows at 128-bit security for this ring degree (ternary secret, sigma 3.2) - with every key switch and the multiply composed from the
+    batched transforms (no fused kernel above N = 8192): h1, the activation and h2 decrypt to the plaintext forward."""
+    import json
+    out = subprocess.run([build_example("encrypted_gpt2_block_act"), "2", "1", "json", "ladder", "14"], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0 and out.stdout.strip().endswith("OK"), out.stdout[-1500:] + out.stderr[-500:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
+    b = d["budget_bits"]
+    assert d["correct"] is True and d["log2_n"] == 14 and d["modulus_bits_under_key_switching"] <= d["he_standard_128bit_budget_bits"] == 438
+    assert len(b) == 8 and b[0] > b[1] > b[2] > b[3] > b[4] > 0 and b[5] > b[6] > b[7] > 20, b
+
+
+@pytest.mark.gpu
 def test_example_two_blocks_on_a_modulus_chain():
     """configs[4] as a forward pass, DEEPER than one block: two blocks with the square activation chained on seven data limbs (420 bits); the limb
     count of every level is planned from a budget model (no secret key involved) and falls 7 -> 2 over the twelve levels; the first block's

@@ -105,6 +105,31 @@ def test_deep_level_limb_counts_bit_exact(log2n):
     ctx.close()
 
 
+def test_multiply_exact_at_n16384_equals_the_oracle_pipeline():
+    """Round 5: the exact multiply at N = 16384 (five primes = 1 mod 2^15, ciphertexts at the two-limb level: examples/encrypted_gpt2_block_act ... 14),
+    where the tensor product is composed from the batched transforms: base extension, multiply, scale-and-round and the extension back, each and
+    together, word for word against the oracle."""
+    p = ntt_primes(14, 5)
+    orc, ctx = Oracle.from_params(p), Context(p, 0)
+    ev = Evaluator(ctx)
+    rng = np.random.default_rng(14)
+    ll, t, n = 2, 65537, p.n
+    a = np.stack([rng.integers(0, q, (3, 2, n), dtype=np.uint64) for q in p.moduli[:ll]], axis=2)   # [3][2][ll][N]
+    b = np.stack([rng.integers(0, q, (3, 2, n), dtype=np.uint64) for q in p.moduli[:ll]], axis=2)
+    A, B = orc.base_extend(a, 0, 0, 5), orc.base_extend(b, 0, 0, 5)
+    assert np.array_equal(to_host(ev.base_extend(to_device(a, ctx.device), 0, 0, 5)), A)
+    T = orc.ct_mul(np.ascontiguousarray(A), np.ascontiguousarray(B), threads=0)
+    W = orc.scale_round(T, 0, ll, ll, 5 - ll, t)
+    assert np.array_equal(to_host(ev.scale_round(to_device(T, ctx.device), 0, ll, ll, 5 - ll, t)), W)
+    want = orc.base_extend(W, ll, 0, ll)
+    got = to_host(ev.multiply_exact(to_device(a, ctx.device), to_device(b, ctx.device), ll, t))
+    assert got.shape == (3, 3, ll, n) and np.array_equal(got, want)
+    sq = to_host(ev.multiply_exact(to_device(a, ctx.device), to_device(a, ctx.device), ll, t))      # (squaring shares one extension: the activation's shape)
+    Ts = orc.ct_mul(np.ascontiguousarray(A), np.ascontiguousarray(A), threads=0)
+    assert np.array_equal(sq, orc.base_extend(orc.scale_round(Ts, 0, ll, ll, 5 - ll, t), ll, 0, ll))
+    ctx.close()
+
+
 def test_multiply_exact_equals_the_oracle_pipeline_and_decrypts_to_the_product():
     """N = 8192, five 60-bit limbs, ciphertexts at the two-limb level, t = 65537 (the configuration of the activated FFN example): the GPU
     pipeline equals the oracle's word for word; on a small ring the result decrypts to m1 * m2 mod (X^N + 1, t) under a toy BFV scheme."""
