@@ -15,6 +15,9 @@
 // hand-overs, the gather a device copy), which is what runs on the single-GPU test box.
 //
 //   usage: encrypted_gpt2_block [tokens = 8] [reps = 2] [json | text] [ranks = 0] [layers = 1]
+// STAND-INS: the block's LINEAR skeleton only - no activation, no LayerNorm, attention = v (exact at one position only); 1-4 of the reference's 12 blocks.
+// SECURITY: N = 8192, 360 bits under key switching against the 218 bits of 128-bit security at that ring (Homomorphic Encryption Standard): BASELINE configs[4]'s
+// performance shape, not a deployable parameter set.
 #define __HIP_PLATFORM_AMD__ 1
 #include <hip/hip_runtime_api.h>
 #include <sys/wait.h>

@@ -7,6 +7,9 @@
 // next one on the device (one row-swap rotation + add), the result of the second layer is already a valid input again (the residual
 // is a plain ciphertext add), and the noise of two chained plaintext products + 2 x 62 key switches stays far below the budget.
 //   usage: encrypted_gpt2_ffn [tokens = 4] [reps = 3] [json | text]
+// WHAT THIS IS NOT: only the FFN's two dense layers with the residual (x + W_down (W_up x)) - no activation at all, no LayerNorm.
+// SECURITY: N = 8192 with 5 data primes + special prime = 360 bits under key switching; 128-bit security at N = 8192 allows 218 (Homomorphic Encryption
+// Standard, ternary secret, sigma 3.2).  BASELINE configs[4]'s performance shape, not a deployable parameter set (encrypted_gpt2_linear / _block_act ... 14 run N = 16384).
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>

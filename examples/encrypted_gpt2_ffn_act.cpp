@@ -8,6 +8,9 @@
 //     shrinks with the modulus), the square, the relinearisation and W_down run there - three limbs of work per layer less;
 //   * the noise budget after every stage (Decryptor::noise_budget_bits).
 //   usage: encrypted_gpt2_ffn_act [tokens = 4] [reps = 2] [json | text]
+// STAND-INS: x^2 for GELU, no LayerNorm; one FFN block, no attention.
+// SECURITY: N = 8192, 360 bits under key switching against the 218 bits of 128-bit security at that ring (Homomorphic Encryption Standard): a performance shape,
+// not a deployable parameter set - encrypted_gpt2_block_act ... 14 runs the whole activated block at N = 16384 (360 of 438 bits).
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>

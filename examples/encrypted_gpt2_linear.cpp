@@ -4,6 +4,8 @@
 // The layer shapes are the reference's matmul sites (/root/reference/src/core/execution/models/gpt_model.cpp:793 QKV 768 -> 2304,
 // :848 FFN 768 -> 3072 -> 768, :883 logits 768 -> 50257; hidden_size 768, vocab 50257 at execution/model.hpp:47-50).
 //   usage: encrypted_gpt2_linear [layer = all | square | qkv | ffn_up | ffn_down | lm_head | <out>x<in>] [reps = 2] [json | text] [tokens = 1] [log2_n = 13 | 14]
+// WHAT THIS IS: single dense layers (matrix x encrypted vector over Z_65537), nothing else of the model.  SECURITY: at the default N = 8192 the 360-bit modulus
+// under key switching is beyond the 218 bits of 128-bit security at that ring (Homomorphic Encryption Standard): a performance shape (BASELINE configs[4]).
 // log2_n = 14: the same layer at N = 16384 on six primes that are 1 mod 2^15 (round 5: the packed pipeline's rotations above N = 8192 are composed
 // from the batched transforms; a 360-bit modulus under key switching at N = 16384 is inside the 128-bit-security budget of 438 bits).
 // Prints one line per layer; with a third argument "json" the lines are JSON objects (bench.py other_configs.packed_linear).

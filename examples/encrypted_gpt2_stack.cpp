@@ -10,6 +10,10 @@
 // at that point (five limbs in the first of two blocks: an eleven-limb workspace).  Every block's output is decrypted and compared with the
 // plaintext forward; the budget is read after every level.
 //   usage: encrypted_gpt2_stack [tokens = 4] [reps = 1] [json | text] [data_limbs = 7] [blocks = 0: as many as the budget model allows]
+// STAND-INS: x^2 for GELU, no LayerNorm, attention = v (exact at one position only), at most 3 of the reference's 12 blocks, no LM head.
+// SECURITY: NONE TO SPEAK OF - N = 8192 with 7 ... 20 data primes + special prime is 480 ... 1260 bits under key switching against the 218 bits of 128-bit security
+// at that ring (Homomorphic Encryption Standard).  This program demonstrates the budget arithmetic of a deep chain (limb count per level planned from a noise model,
+// exact multiplies at several levels), not a deployable forward pass; a chain this long needs N >= 32768.
 #include <algorithm>
 #include <chrono>
 #include <cstdio>
