@@ -23,7 +23,7 @@ other keys, so everything a reader of that record needs is inside those three; f
                  kernel time and fraction of HBM peak (2*N*8 algorithmic bytes per residue polynomial).
   sustained    - >= 2 s of back-to-back forward / inverse NTT launches (configs[1] in place, and 1 GiB out of place) and of the
                  library's plain copy kernel, each with board power / cap / shader clock sampled over THAT window: the
-                 driver-visible evidence for what bounds the transforms.
+                 driver-visible evidence for what bounds the transforms (MEASUREMENTS.md section 5).
   cpu_baseline - the CPU oracle ("port": reference has no CPU evaluator) timed on
                  this host's cores on a bounded sample of the same workload (rank 0, N=1 only).
 
@@ -50,7 +50,7 @@ HBM_PEAK = 8.0e12  # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
 
 class PowerSampler(threading.Thread):
     """Reads power1_average|power1_input, power1_cap and freq1_input (sclk) of one HIP device from sysfs every 2 ms.  The
-    transforms run at the board's power cap (profiles/*_power_probe.txt); the bench line carries the evidence."""
+    transforms run at the board's power cap (MEASUREMENTS.md section 5, profiles/*_power_probe.txt); the bench line carries the evidence."""
 
     def __init__(self, device):
         super().__init__(daemon=True)
@@ -95,7 +95,7 @@ class PowerSampler(threading.Thread):
 
 def box_regime(device_index):
     """rank 0, outside the timed region: what rocm-smi says about this GPU (partition modes, clock levels, power cap).  The pool's
-    boxes differ in how the fused multiply runs; the record names the box it was measured on."""
+    boxes differ in how the fused multiply runs (MEASUREMENTS.md section 5); the record names the box it was measured on."""
     import subprocess
     out = {}
     try:
@@ -819,7 +819,7 @@ def main():
         except Exception as e:   # a secondary block must not take the headline metric down with it
             other_result.setdefault("packed_linear", {})["kernels"] = {"error": repr(e)[:300]}
     # every rank runs the windows whatever N is (no collective inside; rank 0 reports): the timed region below is shorter than the power
-    # manager's memory, so what ran before it decides which regime it sees - the same history for every N
+    # manager's memory, so what ran before it decides which regime it sees (MEASUREMENTS.md section 5) - the same history for every N
     sustained_result = measure_sustained(args.sustained_seconds) if args.sustained_seconds > 0 else None
 
     def tune_form():
@@ -1004,7 +1004,7 @@ def main():
             "alu": {"unit": "butterflies/s", "achieved": bfly_per_s, "peak": alu_peak, "peak_clock_mhz": alu_clock,
                     "frac": (bfly_per_s / alu_peak) if alu_peak else None,
                     "peak_source": (alu_src + ": register-only radix-2 butterflies (the kernels' 12-instruction fused butterfly), 8 workgroups per CU, shader clock measured inside the kernel") if alu_src else None,
-                    "note": "7 transforms x L limbs x (N/2) log2 N butterflies per ct-mul.  Not in the peak: the dyadic products, canonicalisation, addressing (~15 % of the kernel's VALU instructions) and the clock the chip sustains under HBM load (1.9-2.1 GHz against the loop's 2.3 GHz) - see DESIGN.md section 5"},
+                    "note": "7 transforms x L limbs x (N/2) log2 N butterflies per ct-mul.  Not in the peak: the dyadic products, canonicalisation, addressing (~15 % of the kernel's VALU instructions) and the clock the chip sustains under HBM load (1.9-2.1 GHz against the loop's 2.3 GHz) - see MEASUREMENTS.md section 5"},
         },
         # "report compute-only and end-to-end": `value` is end-to-end (multiply + shard-local reduce +
         # all-gather + final sum); this is the multiply kernel alone, timed inside the same overlapped steps

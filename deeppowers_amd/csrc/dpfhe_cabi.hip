@@ -1145,7 +1145,7 @@ extern "C" int dpfhe_matvec_plain_multi(dpfhe_ctx* c, uint64_t* d_y, const uint6
     // the groups of a W tile on the same XCD (kernels_misc.h), an odd last right-hand side in a second launch.  x / y are
     // [cols | rows][n_rhs][2][L][N]: a group is a strided slice, so the kernels take the full stride.  Measured on the 32 x 32 x
     // 1024-diagonal matvec of a packed GPT-2 layer, per token: 86 us single; 8 tokens: 75 us with one launch per group (W re-read from
-    // HBM by every group), see DESIGN.md for the XCD-grouped launch.
+    // HBM by every group), see MEASUREMENTS.md for the XCD-grouped launch.
     const size_t pairs = n_rhs / 2;
     if (c->fold) {   // split-at-bit-30 column accumulators (kernels_misc.h matvec_fold_kernel), same grouping and block-id layout
 #ifndef DPFHE_MATVEC_FULL

@@ -263,11 +263,11 @@ struct InvChain3 {
 // ------------------------------------------------------------------------------------------------
 // A1 / A2: batched NTT, one workgroup per residue polynomial (4 resident per CU at N=4096; the hardware
 // dispatcher keeps the generations de-phased - persistent workgroups with prefetch, up-front twiddle fetch and
-// staggered starts were all measured slower).
+// staggered starts were all measured slower, MEASUREMENTS.md section 5).
 // ------------------------------------------------------------------------------------------------
 // NT: non-temporal global accesses, chosen by the launcher for batches whose input + output exceed the 256 MiB Infinity Cache (a
 // stream that cannot stay there gains from not allocating in it - the plain copy kernel goes from 5.7 to 6.25 TB/s -, while
-// configs[1]'s 128 MiB, which DO stay, measured 6 % slower with them: DESIGN.md section 5).
+// configs[1]'s 128 MiB, which DO stay, measured 6 % slower with them: MEASUREMENTS.md section 5).
 template <class Arith, int LOGN, int LOGE, bool NT = false>
 __global__ __launch_bounds__(1 << (LOGN - LOGE)) void ntt_fwd_kernel(u64* __restrict__ out, const u64* __restrict__ in,
                                                                       DevTables<Arith> tb) {

@@ -1,4 +1,4 @@
-"""Where a workgroup of the fused multiply spends its life (tool; diagnostics of the "memory-parked" regime).
+"""Where a workgroup of the fused multiply spends its life (tool; diagnostics of the "memory-parked" regime, MEASUREMENTS.md section 5).
 
 Launches dpfhe_debug_ct_mul_trace (the quad form with s_memrealtime stamps at its milestones, one record per workgroup) over `pairs`
 ciphertext pairs at N=4096 / L=4 and prints, per segment, median / p10 / p90 microseconds over all workgroups of the steady state:

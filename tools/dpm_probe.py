@@ -1,4 +1,4 @@
-"""Which clock domain differs between the two regimes of the multiply?  (tool)
+"""Which clock domain differs between the two regimes of the multiply (MEASUREMENTS.md section 5)?  (tool)
 Phases of ~2 s each: the bench step from a rested chip, a 1 GiB copy loop, the bench step again; a sampler thread reads the `*`-marked level
 of every pp_dpm_* file of the device and the hwmon power / sclk every 10 ms.  Prints, per phase, the step time and the mean of each clock."""
 import glob, os, re, sys, threading, time

@@ -2,7 +2,7 @@
 
 A sampler thread reads the amdgpu hwmon files (power1_average / power1_input, power1_cap, freq1_input) every 20 ms while the main
 thread keeps ~2 s of launches queued per phase; `rocm-smi` is only used for the one-off static dump.  Output: one line per phase
-with the mean / max of the samples taken while the queue was full.  This is the evidence for DESIGN.md section 5's statement that
+with the mean / max of the samples taken while the queue was full.  This is the evidence for MEASUREMENTS.md section 5's statement that
 the transforms run at a power-limited clock: the board sits at its cap and the clock settles below nominal.
 """
 import glob, os, subprocess, sys, threading, time

@@ -1,6 +1,6 @@
 #!/bin/bash
 # One fingerprint of this box (the multiply alone, the workgroup timeline); if it is a SLOW-regime box (quad form above 3.25 ms per 8192 pairs,
-# DESIGN.md section 5) collect what round 3 lacked there: every form side by side, the timeline, memory-latency / TLB counters, partition modes.
+# MEASUREMENTS.md section 5) collect what round 3 lacked there: every form side by side, the timeline, memory-latency / TLB counters, partition modes.
 OUT=gpurun_out/hunt_$(date +%H%M%S); mkdir -p $OUT; export TMPDIR=/tmp
 db() { find $1 -name "*.db" | head -1; }
 timeout 200 python tools/ctmul_trace.py 8192 json 2>/dev/null | grep "^{" > $OUT/trace.json
