@@ -105,3 +105,26 @@ def test_no_kernel_spills_to_scratch(lib):
                     bad.append((name, int(m.group(1))))
     assert seen > 50, "resource-usage remarks missing from the build logs"
     assert not bad, f"kernels with scratch: {bad[:5]}"
+
+
+def test_library_sources_read_no_environment_variable():
+    """Round 5: a library's behaviour does not depend on its environment - the only getenv left in the product sources is the split-sweep switch of the
+    packed layers, compiled in only under -DDPFHE_EXPERIMENTS."""
+    import glob
+    hits = []
+    for path in glob.glob(os.path.join(ROOT, "deeppowers_amd", "csrc", "*")) + glob.glob(os.path.join(ROOT, "include", "**", "*.h*"), recursive=True):
+        if not os.path.isfile(path) or path.endswith((".o", ".so", ".log")):
+            continue
+        lines = open(path, errors="replace").read().split("\n")
+        for i, l in enumerate(lines):
+            if "getenv(" in l and not l.lstrip().startswith("//"):
+                guarded = any("#ifdef DPFHE_EXPERIMENTS" in p for p in lines[max(0, i - 3):i])
+                if not guarded:
+                    hits.append(f"{os.path.basename(path)}:{i + 1}")
+    assert not hits, hits
+
+
+def test_design_md_stays_readable():
+    """DESIGN.md is the design, MEASUREMENTS.md the history: the former stays under 300 lines with no line over 200 characters."""
+    lines = open(os.path.join(ROOT, "DESIGN.md")).read().split("\n")
+    assert len(lines) <= 300 and max(len(l) for l in lines) <= 200
