@@ -860,7 +860,7 @@ extern "C" int dpfhe_rotate_hybrid_hoisted(dpfhe_ctx* c, uint64_t* d_out2, const
     const char* what = "dpfhe_rotate_hybrid_hoisted";
     if (!c) return fail(DPFHE_INVALID_ARGUMENT, what, "null context");
     if (c->n_limbs < 2) return fail(DPFHE_INVALID_STATE, what, "the extended context needs at least one data limb and the special prime");
-    if (c->log2n > (uint32_t)kMaxFusedLog2N) return fail(DPFHE_INVALID_STATE, what, "no fused kernel geometry for this log2_n");
+    if (c->log2n > 14) return fail(DPFHE_INVALID_STATE, what, "available up to N = 16384");
     if (batch == 0 || n_items == 0) return DPFHE_SUCCESS;
     if (!d_out2 || !d_in2 || !galois_elts || !d_keys || !d_work || !d_rotated0 || !d_digits || misaligned(d_out2) || misaligned(d_in2) || misaligned(d_keys) ||
         misaligned(d_work) || misaligned(d_rotated0) || misaligned(d_digits))
@@ -877,6 +877,32 @@ extern "C" int dpfhe_rotate_hybrid_hoisted(dpfhe_ctx* c, uint64_t* d_out2, const
         return fail(DPFHE_INVALID_ARGUMENT, what, "buffers must not overlap");
     const size_t key_words = Ld * 2 * L * (size_t)n;
     const int chunks = (n + 511) / 512;
+    if (c->log2n > (uint32_t)kMaxFusedLog2N) {
+        // N = 16384 (round 5): no fused hoisted kernel - the deferred-division pipeline instead: dpfhe_rotate_hoisted_qp gives, per rotation and item,
+        // P sigma_g(ct) + its key-switching term in the NTT domain over Q P; one inverse transform and the division by P per term finish it (the same words:
+        // tests/test_rlwe_semantics.py).  Scratch (the Q P terms + the transformed inputs) from the stream's arena, rotations in slices under the scratch limit;
+        // d_work / d_rotated0 are not used on this path.
+        const size_t item_qp = T * 2 * L * (size_t)n, fit = c->scratch_limit_words / item_qp;
+        const size_t per = fit > 2 ? (fit - 2 < batch ? fit - 2 : batch) : 1;     // (+ block 0 and the transformed inputs)
+        for (size_t r0 = 0; r0 < batch; r0 += per) {
+            const size_t m = batch - r0 < per ? batch - r0 : per;
+            if (m * T * 2 * Ld * (size_t)chunks > kMaxGrid || !ntt_grid_fits(c, m * T * 2 * L)) return fail(DPFHE_INVALID_ARGUMENT, what, "batch too large for one launch (lower the scratch limit)");
+            StreamScratch ws(c, static_cast<hipStream_t>(stream));
+            if (int rc = ws.alloc((m + 1) * item_qp + in_words, what)) return rc;
+            u64* qp = ws.p;
+            u64* in_ntt = qp + (m + 1) * item_qp;
+            if (int rc = dpfhe_rotate_hoisted_qp(c, qp, d_in2, T, galois_elts + r0, d_keys + r0 * key_words, in_ntt, d_digits, m, stream)) return rc;
+            DPFHE_ON_DEVICE(c, what);
+            hipStream_t s = static_cast<hipStream_t>(stream);
+            if (int rc = ntt_launch(c, true, qp + item_qp, qp + item_qp, m * T * 2 * L, s)) return rc;
+            const size_t rblocks = m * T * 2 * Ld * (size_t)chunks;
+            u64* o = d_out2 + r0 * T * 2 * Ld * n;
+            if (c->fold) hipLaunchKernelGGL((rescale_kernel<FoldArith>), dim3((unsigned)rblocks), dim3(256), 0, s, o, qp + item_qp, (const u64*)nullptr, 0, 0, c->foldt.lc, c->d_rescale, (int)L, n, chunks);
+            else hipLaunchKernelGGL((rescale_kernel<ShoupArith>), dim3((unsigned)rblocks), dim3(256), 0, s, o, qp + item_qp, (const u64*)nullptr, 0, 0, c->shoup.lc, c->d_rescale, (int)L, n, chunks);
+            if (int rc = check_launch("hoisted rescale launch")) return rc;
+        }
+        return DPFHE_SUCCESS;
+    }
     // (the key-switch launch pads its (rotation, limb[, component]) tiles to a multiple of 8 per token: launch_impl.h launch_hoisted_ks)
     if (total * 2 * Ld * (size_t)chunks > kMaxGrid || (total * L * 2 + 8 * T) > kMaxGrid || T * Ld * L * (size_t)chunks > kMaxGrid)
         return fail(DPFHE_INVALID_ARGUMENT, what, "batch too large for one launch");

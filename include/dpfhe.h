@@ -66,7 +66,8 @@ enum { DPFHE_IN_NTT = 1u, DPFHE_OUT_NTT = 2u };
  * context's scratch arena of the caller's stream (see "Conventions"; kept until dpfhe_ctx_destroy; large batches run in slices of at most
  * 1 GiB of scratch, or what dpfhe_ctx_set_scratch_limit said); so do the hybrid entries - dpfhe_relinearize_hybrid / dpfhe_switch_key_hybrid, and since round 5 the per-item-key ones:
  * dpfhe_rotate_hybrid_batch / dpfhe_rotate_hybrid_grouped and dpfhe_switch_key_qp; dpfhe_rotate_hoisted_qp and dpfhe_ntt_inv_galois run up to log2_n = 14
- * (the whole packed-layer pipeline at N = 16384); dpfhe_rotate_hybrid_hoisted returns DPFHE_INVALID_STATE above 13); n_limbs >= 1; moduli[i] prime < 2^60 with q = 1 (mod 2N); psi[i] a primitive
+ * (the whole packed-layer pipeline at N = 16384), and so does dpfhe_rotate_hybrid_hoisted (there: the deferred-division pipeline + one inverse transform
+ * and division by P per rotation, scratch from the arena)); n_limbs >= 1; moduli[i] prime < 2^60 with q = 1 (mod 2N); psi[i] a primitive
  * 2N-th root of unity mod q_i (psi^N = -1).  Builds twiddle / Shoup / Barrett tables on device_id. */
 int dpfhe_ctx_create(dpfhe_ctx** out, uint32_t log2_n, uint32_t n_limbs, const uint64_t* moduli,
                      const uint64_t* psi, int device_id);

@@ -500,7 +500,7 @@ def test_gpu_batched_rotations_bit_exact(name):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", ["n4096", "n8192"])
+@pytest.mark.parametrize("name", ["n4096", "n8192", "fold14"])
 def test_gpu_hoisted_rotations_bit_exact(name):
     """dpfhe_rotate_hybrid_hoisted == the oracle's hoisted restatement (lift the digits, THEN rotate), for 5 and for 70 rotations of
     one ciphertext (more than one 64-element launch group); and it differs from the non-hoisted path only by a valid
@@ -508,6 +508,10 @@ def test_gpu_hoisted_rotations_bit_exact(name):
     from deeppowers_amd.evaluator import Ciphertext, Context, Evaluator, to_device, to_host
     if name == "n4096":
         pe = FheParams(12, tuple(x[0] for x in PRIMES_60[:3]), tuple(x[1] for x in PRIMES_60[:3]))     # 2 data limbs + P
+    elif name == "fold14":   # N = 16384 (round 5): composed from dpfhe_rotate_hoisted_qp + inverse transform + division by P
+        from oracle import pyoracle as po
+        qs = tuple(PRIMES_60[i][0] for i in (1, 2, 4))
+        pe = FheParams(14, qs, tuple(po.min_primitive_2n_root(16384, q) for q in qs))
     else:
         pe = FheParams(13, tuple(x[0] for x in PRIMES_60[:4]), tuple(x[2] for x in PRIMES_60[:4]))     # 3 data limbs + P
     orc = Oracle.from_params(pe)
