@@ -1,6 +1,7 @@
 #!/bin/bash
 # round 5, GPU call B: the giant-step key inner products (relin MODE 4, N = 8192) as one 256-thread workgroup per (item, limb, half) against the
 # 512-thread kernel, same box, alternated; parity of everything on the packed pipeline; counters of both forms of the batched N = 8192 transforms.
+# (arms as built at that commit: HEAD = halves kernels ON (today: -DDPFHE_N13_HALVES=1), var_base.so = the shipped 512-thread kernels, var_r3.so = -DDPFHE_RELIN_HALF_OCC=3)
 OUT=gpurun_out/r05b; mkdir -p $OUT
 export TMPDIR=/tmp
 timeout 900 python -m pytest tests/test_gpu_bsgs_qp.py tests/test_rlwe_semantics.py tests/test_gpu_cpp_api.py -x -q -p no:cacheprovider -m gpu 2>&1 | tail -5 | tee $OUT/pytest_subset.txt
