@@ -127,6 +127,8 @@ void Context::synchronize() const {
     hip_check(hipDeviceSynchronize(), "hipDeviceSynchronize");
 }
 
+void Context::set_scratch_limit(size_t mib) { check(dpfhe_ctx_set_scratch_limit(impl_->h, mib), "dpfhe_ctx_set_scratch_limit"); }
+
 // ---- PolyBuffer -----------------------------------------------------------------------------------------
 class PolyBuffer::Impl {
 public:

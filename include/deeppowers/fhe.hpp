@@ -67,6 +67,8 @@ public:
     bool uses_fold() const;
     void* handle() const;  // dpfhe_ctx*
     void synchronize() const;
+    // set-up call: slice size (MiB of scratch) of the operations composed from the batched transforms at N >= 16384 (dpfhe_ctx_set_scratch_limit; default 1024)
+    void set_scratch_limit(size_t mib);
     // Which form of the fused multiply Evaluator::multiply launches (include/dpfhe.h "A0, continued": the ring degree's default; autotune()
     // is the explicit opt-in measurement, in the spirit of the reference's AutoTuner, src/core/inference/auto_tuner.hpp:26-64).  Both forms give the same words.
     struct TuneInfo {
