@@ -274,7 +274,7 @@ extern "C" int dpfhe_ctx_create(dpfhe_ctx** out, uint32_t log2_n, uint32_t n_lim
                  o_last = up(o_inv + tab), o_top_fwd = up(o_last + L * n_sub * 2 * tw_sz), o_top_inv = up(o_top_fwd + L * n_sub * tw_sz),
                  o_top_last = up(o_top_inv + L * n_sub * tw_sz), o_resc = up(o_top_last + L * 2 * tw_sz);
     // N = 8192: the "halves" tables next to the one-piece ones (ntt_halves.h; the fused kernels keep the one-piece layout)
-    const bool halves = DPFHE_N13_HALVES && log2_n == 13;   // A/B builds only (launch.h)
+    const bool halves = (DPFHE_N13_HALVES || DPFHE_RELIN13_HALVES) && log2_n == 13 && fold;   // the halves tables (launch.h): large batched transforms at N = 8192
     const size_t o_hfwd = up(o_resc + L * sizeof(RescaleConst)), o_hinv = halves ? up(o_hfwd + tab) : o_hfwd, o_htop_fwd = halves ? up(o_hinv + tab) : o_hfwd,
                  o_htop_last = halves ? up(o_htop_fwd + L * tw_sz) : o_hfwd, total = halves ? up(o_htop_last + L * 2 * tw_sz) : o_hfwd;
     std::vector<unsigned char> blob(total, 0);

@@ -1,7 +1,7 @@
 // kernels_halves.h - the N = 8192 kernels on the N = 4096 body (device code; included by launch_impl.h).
 //
-// SURVEY.md section 8(a) A1/A2 (batched transforms) and N1/N3 (the key-switch inner products of the packed layers) at BASELINE
-// configs[4]'s ring degree; no reference counterpart (section 0).  ntt_halves.h has the arithmetic: one radix-2 column stage in
+// SURVEY.md section 8(a) A1/A2 (batched transforms: in the library for batches of >= kHalvesMinPolys residue polynomials, launch.h) and N1/N3 (the key-switch
+// inner products of the packed layers: an A/B build) at BASELINE configs[4]'s ring degree; no reference counterpart (section 0).  ntt_halves.h has the arithmetic: one radix-2 column stage in
 // registers, then the two independent 4096-point sub-transforms one after the other through ONE 38 KiB LDS buffer, 256 threads
 // (4 waves) per workgroup - so that three to four workgroups share a CU and de-phase, where Geo<13, 4>'s 512-thread workgroups sit
 // two (batched) or one (fused) to a CU behind 8-wave barriers.
@@ -87,6 +87,7 @@ __global__ __launch_bounds__(256, DPFHE_HALVES_OCC) void ntt_inv_halves_kernel(u
     B::template store_top<NT>(tid, hi, out + p * N + N2);
 }
 
+#if DPFHE_RELIN13_HALVES   // A/B builds only: measured 3 % slower than relin_kernel<..., 13, 4, MODE 4> (profiles/r05_halves_relin_ab.txt)
 // ------------------------------------------------------------------------------------------------
 // N3: the giant-step key inner products of a packed layer (relin_kernel MODE 4: digits of c1 -> forward transforms -> multiply-accumulate
 // with the two key polynomials, result LEFT in the NTT domain over Q P) with one workgroup per (item, limb, HALF of the NTT domain).
@@ -204,5 +205,7 @@ __global__ __launch_bounds__(256, DPFHE_RELIN_HALF_OCC) void relin_half_kernel(u
         B::store_bot(tid, acc1, o1);
     }
 }
+
+#endif
 
 }  // namespace dpfhe

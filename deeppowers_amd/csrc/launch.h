@@ -26,12 +26,17 @@ constexpr int split_log_n1(int log2n) { return log2n > 14 ? log2n - kSplitLog2N2
 #endif
 constexpr int kFusedLoge = DPFHE_FUSED_LOGE;
 // N = 8192 on the N = 4096 body ("halves": ntt_halves.h, kernels_halves.h - a register column stage + two 4096-point sub-transforms through one LDS
-// buffer, 256-thread workgroups).  MEASURED NEGATIVE in round 5 (profiles/r05_halves_*.txt: batched forward transform 6 % slower, inverse equal, giant-step
-// key inner products 3 % slower than the 512-thread kernels, bit-identical): not built into the library.  -DDPFHE_N13_HALVES=1 (tools/ab_variant.sh) builds the
-// kernels and their tables for A/B runs; tests/test_emulated_kernels.py keeps the arithmetic proven on the CPU either way.
+// buffer, 256-thread workgroups, three to a CU).  Round 5, measured (profiles/r05_ntt13_batch_sweep.txt, r05_ntt_workgroup_timelines.txt, r05_halves_*.txt):
+//  * batched transforms: 2.5-9 % FASTER than the 512-thread kernels from 384 RNS polynomials (2304 workgroups) up - the 512-thread kernel keeps only 1.7 of
+//    its 2 workgroups per CU resident -, 4 % slower at 256 and below (two lockstep generations): launch_ntt picks the form by batch size, FoldArith contexts;
+//  * giant-step key inner products as one workgroup per (item, limb, half): 3 % slower at the packed layers' size - A/B builds only (-DDPFHE_RELIN13_HALVES=1).
 #ifndef DPFHE_N13_HALVES
-#define DPFHE_N13_HALVES 0
+#define DPFHE_N13_HALVES 1
 #endif
+#ifndef DPFHE_RELIN13_HALVES
+#define DPFHE_RELIN13_HALVES 0
+#endif
+constexpr size_t kHalvesMinPolys = 2304;   // residue polynomials per launch from which the halves form of the N = 8192 transforms wins (measured crossover: 1536 loses, 2304 wins)
 constexpr int kMaxGaloisBatch = 64;   // Galois elements travel as kernel arguments, this many per launch
 
 // return 0, or -1 when log2n has no compiled geometry.  Launch errors are left in hipGetLastError().

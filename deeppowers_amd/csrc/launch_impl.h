@@ -4,8 +4,11 @@
 
 #include "kernels.h"
 #include "launch.h"
-#if DPFHE_N13_HALVES
+#if DPFHE_N13_HALVES || DPFHE_RELIN13_HALVES
 #include "kernels_halves.h"
+#endif
+#ifdef DPFHE_NTT_TRACE   // diagnostic builds only
+#include "kernels_trace.h"
 #endif
 
 namespace dpfhe {
@@ -67,8 +70,23 @@ int launch_ntt(int log2n, bool inverse, u64* out, const u64* in, size_t npolys, 
     // batches whose input + output cannot stay in the 256 MiB Infinity Cache stream around it (FoldArith, the two production ring degrees)
     const size_t touched = (npolys << log2n) * sizeof(u64) * (out == in ? 1 : 2);
     const bool nt = Arith::kFold && (log2n == 12 || log2n == 13) && touched > ((size_t)256 << 20);
-#if DPFHE_N13_HALVES   // A/B builds only (launch.h)
-    if (log2n == 13 && tb.hfwd) {
+#ifdef DPFHE_NTT_TRACE   // diagnostic builds only: the forward transform at N = 4096 / 8192 with per-workgroup timestamps (kernels_trace.h, tools/ntt_trace.py)
+    if constexpr (Arith::kFold) {
+        if (!inverse && (log2n == 12 || log2n == 13) && npolys <= 65536) {
+            if (!g_ntt_trace) { if (hipMalloc(&g_ntt_trace, sizeof(u64) * 8 * 65536) != hipSuccess) return -1; }
+            g_ntt_trace_blocks = (unsigned)npolys;
+#if DPFHE_N13_HALVES
+            if (log2n == 13 && tb.hfwd && (npolys >= kHalvesMinPolys || DPFHE_NTT_TRACE > 1)) { hipLaunchKernelGGL((ntt_fwd_halves_trace_kernel<Arith>), dim3((unsigned)npolys), dim3(256), 0, s, out, in, tb, g_ntt_trace); return 0; }
+#endif
+            if (log2n == 12) hipLaunchKernelGGL((ntt_fwd_trace_kernel<Arith, 12, 4>), dim3((unsigned)npolys), dim3(Geo<12, 4>::T), 0, s, out, in, tb, g_ntt_trace);
+            else hipLaunchKernelGGL((ntt_fwd_trace_kernel<Arith, 13, 4>), dim3((unsigned)npolys), dim3(Geo<13, 4>::T), 0, s, out, in, tb, g_ntt_trace);
+            return 0;
+        }
+    }
+#endif
+#if DPFHE_N13_HALVES   // N = 8192, large batches, FoldArith: 256-thread workgroups on the N = 4096 body (launch.h)
+    if constexpr (Arith::kFold) {
+    if (log2n == 13 && tb.hfwd && npolys >= kHalvesMinPolys) {
         if (inverse) {
             if (nt && Arith::kFold) hipLaunchKernelGGL((ntt_inv_halves_kernel<Arith, Arith::kFold>), dim3((unsigned)npolys), dim3(256), 0, s, out, in, tb);
             else hipLaunchKernelGGL((ntt_inv_halves_kernel<Arith, false>), dim3((unsigned)npolys), dim3(256), 0, s, out, in, tb);
@@ -77,6 +95,7 @@ int launch_ntt(int log2n, bool inverse, u64* out, const u64* in, size_t npolys, 
             else hipLaunchKernelGGL((ntt_fwd_halves_kernel<Arith, false>), dim3((unsigned)npolys), dim3(256), 0, s, out, in, tb);
         }
         return 0;
+    }
     }
 #endif
 #define NTT_CASE(LN, LE)                                                                                                              \
@@ -193,7 +212,7 @@ int launch_relin(int log2n, int mode, u64* out2, const u64* in3, const u64* evk,
         grid = ((n_keys + 7u) / 8u) * 8u * (unsigned)tb.n_limbs * kg;
         n_outer |= kRelinRotMajor;
     }
-#if DPFHE_N13_HALVES   // A/B builds only (launch.h): one 256-thread workgroup per (item, limb, half of the NTT domain) - kernels_halves.h relin_half_kernel
+#if DPFHE_RELIN13_HALVES   // A/B builds only (launch.h): one 256-thread workgroup per (item, limb, half of the NTT domain) - kernels_halves.h relin_half_kernel
     if (log2n == 13 && mode == 4 && tb.hfwd) {
         const unsigned VL = 2u * (unsigned)tb.n_limbs;
         const size_t vblocks = blocks * 2;
