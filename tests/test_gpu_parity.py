@@ -598,6 +598,35 @@ def test_streams_and_concurrent_contexts(rigs):
     assert np.array_equal(to_host(d1), want) and np.array_equal(to_host(d2), want)
 
 
+def test_composed_large_ring_operations_on_two_streams_keep_their_scratch_apart(rigs):
+    """N = 16384: the composed multiply and key switch take their scratch from an arena the context keeps PER STREAM (round 5; a stream-ordered pool before).
+    Two streams issue them interleaved, several times, with different batch sizes (the second call on a stream makes its arena grow): every result equals
+    the oracle's - a shared arena, or a growth that frees a block another stream still uses, would corrupt one of them."""
+    r = rigs("fold14")
+    L, n = r.p.n_limbs, r.p.n
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    cases = []
+    for i, batch in enumerate((2, 5, 3, 7)):
+        a = r.orc.fill(batch * 2, 300 + i).reshape(batch, 2, L, n)
+        b = r.orc.fill(batch * 2, 400 + i).reshape(batch, 2, L, n)
+        cases.append((a, b, r.orc.ct_mul(np.ascontiguousarray(a), np.ascontiguousarray(b), threads=0)))
+    evk = r.orc.fill(L * 2, 7).reshape(L, 2, L, n)
+    devk = r.dev(evk)
+    dev = [(Ciphertext(r.dev(a)), Ciphertext(r.dev(b))) for a, b, _ in cases]
+    torch.cuda.synchronize()
+    outs = []
+    for rep in range(2):
+        for i, (A, Bc) in enumerate(dev):
+            st = s1 if i % 2 == 0 else s2
+            c = r.ev.multiply(A, Bc, stream=st)
+            outs.append((i, c, r.ev.relinearize(c, devk, stream=st)))
+    torch.cuda.synchronize()
+    for i, c, rl in outs:
+        want = cases[i][2]
+        assert np.array_equal(to_host(c.data), want), i
+        assert np.array_equal(to_host(rl.data), r.orc.relinearize(want, evk, threads=0)), i
+
+
 def test_rccl_allgather_world_size_one(rigs):
     import ctypes as C
     r = rigs("n4096")
