@@ -15,6 +15,7 @@ SYMBOLS = {
     "dpfhe_ctx_log2n": ([C.c_void_p], C.c_uint32),
     "dpfhe_ctx_limbs": ([C.c_void_p], C.c_uint32),
     "dpfhe_ctx_uses_fold": ([C.c_void_p], C.c_int),
+    "dpfhe_ctx_limb_class": ([C.c_void_p, C.c_uint32], C.c_int),
     "dpfhe_ctx_set_scratch_limit": ([C.c_void_p, C.c_size_t], C.c_int),
     "dpfhe_ctx_autotune": ([C.c_void_p, _U64P, C.c_size_t, C.c_uint32, C.c_void_p], C.c_int),
     "dpfhe_ctx_tune_info": ([C.c_void_p, C.c_void_p], C.c_int),

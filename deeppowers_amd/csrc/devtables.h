@@ -34,6 +34,24 @@ struct DevTables {
     const InvLast<typename Arith::Tw>* last;  // [L]
     const LimbConst* lc;                    // [L]
     int n_limbs;
+    // Per-limb arithmetic classes (round 6, dpfhe_cabi.hip): a launch may cover only SOME limbs of the context - those whose primes this policy
+    // serves.  n_active = 0: all n_limbs limbs (the uniform contexts; block b works on limb b mod n_limbs).  Otherwise block b works on item
+    // b / n_active and limb (active_map >> 4 (b mod n_active)) & 15; tables and data stay indexed by the limb's number in the context
+    // (n_limbs = the stride), so a class's tables simply leave the other limbs' slots unused.  Contexts of more than 16 limbs are uniform.
+    int n_active;
+    unsigned long long active_map;
 };
+
+// (item, limb) of a workgroup of the transform / fused-multiply kernels; `blk` = blockIdx.x
+template <class TB>
+DPF_HD void block_item_limb(const TB& tb, size_t blk, size_t& item, int& limb) {
+    if (tb.n_active) {
+        item = blk / (unsigned)tb.n_active;
+        limb = (int)((tb.active_map >> (4u * (unsigned)(blk % (unsigned)tb.n_active))) & 15u);
+    } else {
+        item = blk / (unsigned)tb.n_limbs;
+        limb = (int)(blk % (unsigned)tb.n_limbs);
+    }
+}
 
 }  // namespace dpfhe

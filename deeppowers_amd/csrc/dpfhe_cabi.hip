@@ -82,6 +82,17 @@ struct dpfhe_ctx {
     const RescaleConst* d_rescale = nullptr;
     DevTables<ShoupArith> shoup{};
     DevTables<FoldArith> foldt{};
+    // Round 6 - per-limb arithmetic classes.  A context whose limbs are not ALL of the pinned 2^60 - d shape used to run every limb on the
+    // generic (Harvey / Shoup) kernels.  Now each limb gets the fastest policy its prime admits (tables.h limb_class) for the batched transforms and
+    // the fused multiply: one launch per class present, each over that class's limbs only (devtables.h DevTables::n_active / active_map).  The
+    // generic tables above stay complete (every limb), so the key-switching kernels of such a context run as before.
+    // `classes` is set when L <= 16, 8 <= log2 N <= 14 and at least one limb has a faster class than the context-wide policy.
+    bool classes = false;
+    unsigned char limb_cls[16] = {};                  // LimbClass of limb i
+    void* class_blob[kLimbClasses] = {};              // device tables of the Fold / F64 / FoldScaled classes (the Shoup class reads `shoup`)
+    DevTables<FoldArith> cls_fold{};
+    DevTables<F64Arith> cls_f64{};
+    DevTables<FoldScaledArith> cls_fscaled{};
     // scratch of the composed large-ring operations: a pool of this context's own (created on first use) that keeps what it has been
     // given until the context goes - the default pool hands its memory back at every synchronisation and pays the mapping again
     struct ScratchArena { hipStream_t stream; u64* p; size_t words; };
@@ -230,6 +241,59 @@ extern "C" const char* dpfhe_ct_mul_variant_name(int variant) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// Tables of one arithmetic class of a non-uniform context (round 6): LimbConst[L] | fwd4 | inv4 | (fwd | inv when the batched transforms use another
+// layout) | last[L], slots indexed by the limb's number in the context, only the class's limbs filled.  Single-kernel transforms only (log2 N <= 14).
+template <class Arith, class MakeTw>
+static hipError_t build_class_tables(int log2n, const std::vector<HostLimbTables>& ht, LimbClass cls, const unsigned char* limb_cls, MakeTw make_tw,
+                                     DevTables<Arith>& tb, void** blob_out) {
+    typedef typename Arith::Tw Tw;
+    const size_t L = ht.size(), n = (size_t)1 << log2n;
+    auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    const int loge_ntt = ntt_loge(log2n);
+    const bool two_geo = loge_ntt != kFusedLoge;
+    const size_t tab = L * n * sizeof(Tw);
+    const size_t o_lc = 0, o_fwd4 = up(L * sizeof(LimbConst)), o_inv4 = up(o_fwd4 + tab), o_fwd = two_geo ? up(o_inv4 + tab) : o_fwd4,
+                 o_inv = two_geo ? up(o_fwd + tab) : o_inv4, o_last = up(o_inv + tab), total = up(o_last + L * sizeof(InvLast<Tw>));
+    std::vector<unsigned char> blob(total, 0);
+    int n_active = 0;
+    unsigned long long map = 0;
+    for (size_t l = 0; l < L; ++l) {
+        if (limb_cls[l] != (unsigned char)cls) continue;
+        map |= (unsigned long long)l << (4 * n_active++);
+        const u64 q = ht[l].lc.q;
+        const LimbConst lc = limb_const_of_class(ht[l].lc, cls);
+        std::memcpy(&blob[o_lc + l * sizeof(LimbConst)], &lc, sizeof(LimbConst));
+        auto pack = [&](const std::vector<u64>& words, int loge, size_t off) {
+            std::vector<Tw> t(words.size());
+            for (size_t i = 0; i < words.size(); ++i) t[i] = make_tw(words[i], q);
+            permute_window0(t, log2n, loge, geo_perm_stages(log2n, loge));
+            std::memcpy(&blob[off], t.data(), t.size() * sizeof(Tw));
+        };
+        for (int geo = 0; geo < (two_geo ? 2 : 1); ++geo) {
+            const int loge = geo ? loge_ntt : kFusedLoge;
+            pack(ht[l].rp, loge, (geo ? o_fwd : o_fwd4) + l * n * sizeof(Tw));
+            pack(ht[l].irp, loge, (geo ? o_inv : o_inv4) + l * n * sizeof(Tw));
+        }
+        reinterpret_cast<InvLast<Tw>*>(&blob[o_last])[l] = InvLast<Tw>{make_tw(ht[l].w_last, q), make_tw(ht[l].lc.ninv, q)};
+    }
+    void* d = nullptr;
+    hipError_t e = hipMalloc(&d, total);
+    if (e == hipSuccess) e = hipMemcpy(d, blob.data(), total, hipMemcpyHostToDevice);
+    if (e != hipSuccess) { if (d) (void)hipFree(d); return e; }
+    unsigned char* b = static_cast<unsigned char*>(d);
+    tb = DevTables<Arith>{};
+    tb.lc = reinterpret_cast<const LimbConst*>(b + o_lc);
+    tb.fwd = reinterpret_cast<const Tw*>(b + o_fwd); tb.inv = reinterpret_cast<const Tw*>(b + o_inv);
+    tb.fwd4 = reinterpret_cast<const Tw*>(b + o_fwd4); tb.inv4 = reinterpret_cast<const Tw*>(b + o_inv4);
+    tb.last = reinterpret_cast<const InvLast<Tw>*>(b + o_last);
+    tb.n_sub = 1;
+    tb.n_limbs = (int)L;
+    tb.n_active = n_active;
+    tb.active_map = map;
+    *blob_out = d;
+    return hipSuccess;
+}
+
 extern "C" int dpfhe_ctx_create(dpfhe_ctx** out, uint32_t log2_n, uint32_t n_limbs, const uint64_t* moduli,
                                 const uint64_t* psi, int device_id) {
     if (!out || !moduli || !psi) return fail(DPFHE_INVALID_ARGUMENT, "dpfhe_ctx_create", "null argument");
@@ -377,6 +441,26 @@ extern "C" int dpfhe_ctx_create(dpfhe_ctx** out, uint32_t log2_n, uint32_t n_lim
             c->shoup.htop_fwd = reinterpret_cast<const TwShoup*>(d + o_htop_fwd); c->shoup.htop_last = reinterpret_cast<const InvLast<TwShoup>*>(d + o_htop_last);
         }
     }
+    // per-limb arithmetic classes of a non-uniform context (see dpfhe_ctx::classes)
+    if (!fold && L <= 16 && log2_n >= 8 && log2_n <= 14) {
+        bool any_fast = false;
+        for (size_t l = 0; l < L; ++l) { c->limb_cls[l] = (unsigned char)limb_class(moduli[l]); any_fast = any_fast || c->limb_cls[l] != kClassShoup; }
+        if (any_fast) {
+            auto has = [&](LimbClass k) { for (size_t l = 0; l < L; ++l) if (c->limb_cls[l] == k) return true; return false; };
+            hipError_t ce = hipSuccess;
+            if (has(kClassFold)) ce = build_class_tables<FoldArith>((int)log2_n, ht, kClassFold, c->limb_cls, [](u64 w, u64 q) { return h_tw_fold(w, q); }, c->cls_fold, &c->class_blob[kClassFold]);
+            if (ce == hipSuccess && has(kClassF64)) ce = build_class_tables<F64Arith>((int)log2_n, ht, kClassF64, c->limb_cls, [](u64 w, u64 q) { return h_make_tw<TwF64>(w, q); }, c->cls_f64, &c->class_blob[kClassF64]);
+            if (ce == hipSuccess && has(kClassFoldScaled)) ce = build_class_tables<FoldScaledArith>((int)log2_n, ht, kClassFoldScaled, c->limb_cls, [](u64 w, u64 q) { return h_tw_fold_scaled(w, q, fold_scaled_shift(q)); }, c->cls_fscaled, &c->class_blob[kClassFoldScaled]);
+            if (ce != hipSuccess) {
+                for (void* b : c->class_blob) if (b) (void)hipFree(b);
+                (void)hipFree(c->d_blob);
+                delete c;
+                (void)hipSetDevice(prev);
+                return fail(ce == hipErrorOutOfMemory ? DPFHE_OUT_OF_MEMORY : DPFHE_DEVICE_ERROR, "dpfhe_ctx_create: class table upload", hipGetErrorString(ce));
+            }
+            c->classes = true;
+        }
+    }
     tune_at_create(c);   // default form of the fused multiply, or a cached explicit probe of this shape: no device work
     (void)hipSetDevice(prev);
     *out = c;
@@ -386,6 +470,7 @@ extern "C" int dpfhe_ctx_create(dpfhe_ctx** out, uint32_t log2_n, uint32_t n_lim
 extern "C" int dpfhe_ctx_destroy(dpfhe_ctx* c) {
     if (!c) return DPFHE_SUCCESS;
     if (c->d_blob) (void)hipFree(c->d_blob);
+    for (void* b : c->class_blob) if (b) (void)hipFree(b);
     for (auto& a : c->scratch_arenas) if (a.p) (void)hipFree(a.p);
     delete c;
     return DPFHE_SUCCESS;
@@ -399,6 +484,12 @@ extern "C" int dpfhe_ctx_set_scratch_limit(dpfhe_ctx* c, size_t mib) {
 extern "C" uint32_t dpfhe_ctx_log2n(const dpfhe_ctx* c) { return c ? c->log2n : 0; }
 extern "C" uint32_t dpfhe_ctx_limbs(const dpfhe_ctx* c) { return c ? c->n_limbs : 0; }
 extern "C" int dpfhe_ctx_uses_fold(const dpfhe_ctx* c) { return c && c->fold ? 1 : 0; }
+extern "C" int dpfhe_ctx_limb_class(const dpfhe_ctx* c, uint32_t limb) {
+    if (!c || limb >= c->n_limbs) return -1;
+    if (c->classes) return (int)c->limb_cls[limb];
+    return c->fold ? DPFHE_ARITH_FOLD : DPFHE_ARITH_SHOUP;
+}
+static_assert(DPFHE_ARITH_SHOUP == kClassShoup && DPFHE_ARITH_FOLD == kClassFold && DPFHE_ARITH_F64 == kClassF64 && DPFHE_ARITH_FOLD_SCALED == kClassFoldScaled, "dpfhe.h <-> tables.h");
 
 // ------------------------------------------------------------------------------------------------
 // words per thread of the FoldArith matvec kernels: 2 right-hand-side polynomials per workgroup / 4 (kernels_misc.h matvec_fold_kernel)
@@ -436,11 +527,47 @@ static bool ntt_grid_fits(const dpfhe_ctx* c, size_t npolys) {
     return npolys <= kMaxGrid && widest <= kMaxGrid;
 }
 // arguments validated, device selected by the caller
-static int ntt_launch(dpfhe_ctx* c, bool inverse, uint64_t* out, const uint64_t* in, size_t npolys, hipStream_t s) {
-    const int rc = c->fold ? launch_ntt<FoldArith>((int)c->log2n, inverse, out, in, npolys, c->foldt, s)
-                           : launch_ntt<ShoupArith>((int)c->log2n, inverse, out, in, npolys, c->shoup, s);
+// One launch per arithmetic class present among the first `limbs_used` limbs of a non-uniform context (dpfhe_ctx::classes): `fn(tables)` launches
+// over the class's limbs.  The Shoup class reads the context's complete generic tables through the same active-limb map.
+template <class Fn>
+static int for_each_class(const dpfhe_ctx* c, size_t limbs_used, Fn fn) {
+    auto restrict_to = [&](auto tb, LimbClass k) {
+        int na = 0;
+        unsigned long long map = 0;
+        for (size_t l = 0; l < limbs_used; ++l) if (c->limb_cls[l] == (unsigned char)k) map |= (unsigned long long)l << (4 * na++);
+        tb.n_limbs = (int)limbs_used;
+        tb.n_active = na;
+        tb.active_map = map;
+        return tb;
+    };
+    int rc = 0;
+    { auto tb = restrict_to(c->cls_fold, kClassFold); if (tb.n_active && !rc) rc = fn(tb); }
+    { auto tb = restrict_to(c->cls_f64, kClassF64); if (tb.n_active && !rc) rc = fn(tb); }
+    { auto tb = restrict_to(c->cls_fscaled, kClassFoldScaled); if (tb.n_active && !rc) rc = fn(tb); }
+    { auto tb = restrict_to(c->shoup, kClassShoup); if (tb.n_active && !rc) rc = fn(tb); }
+    return rc;
+}
+
+// batched transform of `items` RNS polynomials over the first `limbs_used` limbs (limbs_used = 0: all); arguments validated, device selected by the caller
+static int ntt_launch_items(dpfhe_ctx* c, bool inverse, uint64_t* out, const uint64_t* in, size_t items, size_t limbs_used, hipStream_t s) {
+    const size_t Lu = limbs_used ? limbs_used : c->n_limbs;
+    int rc;
+    if (c->classes) {
+        rc = for_each_class(c, Lu, [&](const auto& tb) {
+            return launch_ntt((int)c->log2n, inverse, out, in, items * (size_t)tb.n_active, tb, s);
+        });
+    } else if (c->fold) {
+        DevTables<FoldArith> td = c->foldt; td.n_limbs = (int)Lu;
+        rc = launch_ntt<FoldArith>((int)c->log2n, inverse, out, in, items * Lu, td, s);
+    } else {
+        DevTables<ShoupArith> td = c->shoup; td.n_limbs = (int)Lu;
+        rc = launch_ntt<ShoupArith>((int)c->log2n, inverse, out, in, items * Lu, td, s);
+    }
     if (rc) return fail(DPFHE_INVALID_STATE, "ntt", "no kernel geometry for this log2_n");
     return check_launch("ntt kernel launch");
+}
+static int ntt_launch(dpfhe_ctx* c, bool inverse, uint64_t* out, const uint64_t* in, size_t npolys, hipStream_t s) {
+    return ntt_launch_items(c, inverse, out, in, npolys / c->n_limbs, 0, s);
 }
 
 static int ntt_entry(dpfhe_ctx* c, bool inverse, uint64_t* out, const uint64_t* in, size_t n_rns_polys, void* stream) {
@@ -637,8 +764,14 @@ extern "C" int dpfhe_ct_mul(dpfhe_ctx* c, uint64_t* d_out3, const uint64_t* d_a2
             return check_launch("ct_mul kernel launch");
         }
     }
-    const int rc = c->fold ? launch_ct_mul<FoldArith>((int)c->log2n, flags, d_out3, d_a2, d_b2, blocks, c->foldt, s)
-                           : launch_ct_mul<ShoupArith>((int)c->log2n, flags, d_out3, d_a2, d_b2, blocks, c->shoup, s);
+    int rc;
+    if (c->classes && c->log2n <= kFusedMaxLog2N) {   // one launch per arithmetic class of the limbs (dpfhe_ctx::classes)
+        const size_t pairs = blocks / c->n_limbs;
+        rc = for_each_class(c, c->n_limbs, [&](const auto& tb) { return launch_ct_mul((int)c->log2n, flags, d_out3, d_a2, d_b2, pairs * (size_t)tb.n_active, tb, s); });
+    } else {
+        rc = c->fold ? launch_ct_mul<FoldArith>((int)c->log2n, flags, d_out3, d_a2, d_b2, blocks, c->foldt, s)
+                     : launch_ct_mul<ShoupArith>((int)c->log2n, flags, d_out3, d_a2, d_b2, blocks, c->shoup, s);
+    }
     if (rc) return fail(DPFHE_INVALID_STATE, "dpfhe_ct_mul", "no kernel geometry for this log2_n");
     return check_launch("ct_mul kernel launch");
 }

@@ -104,6 +104,7 @@ Context::~Context() {
 const FheParams& Context::params() const { return impl_->params; }
 int Context::device_id() const { return impl_->device_id; }
 bool Context::uses_fold() const { return dpfhe_ctx_uses_fold(impl_->h) != 0; }
+int Context::limb_class(uint32_t limb) const { return dpfhe_ctx_limb_class(impl_->h, limb); }
 void* Context::handle() const { return impl_->h; }
 Context::TuneInfo Context::tune_info() const {
     dpfhe_tune_info t{};

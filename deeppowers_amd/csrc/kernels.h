@@ -274,9 +274,14 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE)) void ntt_fwd_kernel(u64* __rest
     typedef NttBody<Arith, LOGN, LOGE> B;
     __shared__ __attribute__((aligned(16))) u64 lds[B::G::lds_words()];
     const int tid = threadIdx.x;
-    const size_t p = blockIdx.x;             // block p transforms words [p N, (p + 1) N): one polynomial, or one of its n_sub blocks
+    size_t p = blockIdx.x;                   // block p transforms words [p N, (p + 1) N): one polynomial, or one of its n_sub blocks
     const size_t sub = p % (size_t)tb.n_sub;
-    const int limb = (int)((p / (size_t)tb.n_sub) % (size_t)tb.n_limbs);
+    int limb = (int)((p / (size_t)tb.n_sub) % (size_t)tb.n_limbs);
+    if (tb.n_active) {                       // a launch over one arithmetic class of the context's limbs (devtables.h; n_sub = 1)
+        size_t item;
+        block_item_limb(tb, blockIdx.x, item, limb);
+        p = item * (size_t)tb.n_limbs + (size_t)limb;
+    }
     const LimbConst lc = tb.lc[limb];
     const typename B::Tw* tw = tb.fwd + ((size_t)limb * tb.n_sub + sub) * B::G::N;
     u64 x[B::E];
@@ -293,9 +298,14 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE)) void ntt_inv_kernel(u64* __rest
     typedef NttBody<Arith, LOGN, LOGE> B;
     __shared__ __attribute__((aligned(16))) u64 lds[B::G::lds_words()];
     const int tid = threadIdx.x;
-    const size_t p = blockIdx.x;
+    size_t p = blockIdx.x;
     const size_t sub = p % (size_t)tb.n_sub;
-    const int limb = (int)((p / (size_t)tb.n_sub) % (size_t)tb.n_limbs);
+    int limb = (int)((p / (size_t)tb.n_sub) % (size_t)tb.n_limbs);
+    if (tb.n_active) {
+        size_t item;
+        block_item_limb(tb, blockIdx.x, item, limb);
+        p = item * (size_t)tb.n_limbs + (size_t)limb;
+    }
     const LimbConst lc = tb.lc[limb];
     const typename B::Tw* tw = tb.inv + ((size_t)limb * tb.n_sub + sub) * B::G::N;
     const InvLast<typename B::Tw> last = tb.last[(size_t)limb * tb.n_sub + sub];
@@ -378,8 +388,9 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE), (LOGE <= 3 && LOGN - LOGE <= 9)
     __shared__ __attribute__((aligned(16))) u64 lds[(IN_NTT && OUT_NTT) ? 16 : B::G::lds_words()];
     int tid = threadIdx.x;
     const size_t L = (size_t)tb.n_limbs;
-    const size_t bi = blockIdx.x / L;
-    const int limb = (int)(blockIdx.x % L);
+    size_t bi;
+    int limb;
+    block_item_limb(tb, blockIdx.x, bi, limb);
     const LimbConst lc = tb.lc[limb];
     const u64* src_a = a2 + ((bi * 2) * L + limb) * N;  // component c at + c*L*N
     const u64* src_b = b2 + ((bi * 2) * L + limb) * N;
@@ -488,8 +499,9 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE), 2) void ct_mul_dual_kernel(u64*
     __shared__ __attribute__((aligned(16))) u64 lds[2 * W];
     int tid = threadIdx.x;
     const size_t L = (size_t)tb.n_limbs;
-    const size_t bi = blockIdx.x / L;
-    const int limb = (int)(blockIdx.x % L);
+    size_t bi;
+    int limb;
+    block_item_limb(tb, blockIdx.x, bi, limb);
     const LimbConst lc = tb.lc[limb];
     const u64* src_a = a2 + ((bi * 2) * L + limb) * N;
     const u64* src_b = b2 + ((bi * 2) * L + limb) * N;
@@ -578,8 +590,9 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE), 2) void ct_mul_quad_kernel(u64*
     const int tid = threadIdx.x;
     const u64 ts0 = trace_stamp<TRACE>((u64)tid);
     const size_t L = (size_t)tb.n_limbs;
-    const size_t bi = blockIdx.x / L;
-    const int limb = (int)(blockIdx.x % L);
+    size_t bi;
+    int limb;
+    block_item_limb(tb, blockIdx.x, bi, limb);
     const LimbConst lc = tb.lc[limb];
     const u64* src_a = a2 + ((bi * 2) * L + limb) * N;
     const u64* src_b = b2 + ((bi * 2) * L + limb) * N;

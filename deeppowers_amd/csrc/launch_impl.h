@@ -65,8 +65,11 @@ static void launch_ntt_split(bool inverse, u64* out, const u64* in, size_t npoly
 
 template <class Arith>
 int launch_ntt(int log2n, bool inverse, u64* out, const u64* in, size_t npolys, const DevTables<Arith>& tb, hipStream_t s) {
-    if (log2n == 15) { launch_ntt_split<Arith, 3>(inverse, out, in, npolys, tb, s); return 0; }
-    if (log2n == 16) { launch_ntt_split<Arith, 4>(inverse, out, in, npolys, tb, s); return 0; }
+    constexpr bool kClassPolicy = Arith::kF64 || (Arith::kFoldCore && !Arith::kFold);   // round 6's per-limb classes: single-kernel transforms only
+    if constexpr (!kClassPolicy) {
+        if (log2n == 15) { launch_ntt_split<Arith, 3>(inverse, out, in, npolys, tb, s); return 0; }
+        if (log2n == 16) { launch_ntt_split<Arith, 4>(inverse, out, in, npolys, tb, s); return 0; }
+    }
     // batches whose input + output cannot stay in the 256 MiB Infinity Cache stream around it (FoldArith, the two production ring degrees)
     const size_t touched = (npolys << log2n) * sizeof(u64) * (out == in ? 1 : 2);
     const bool nt = Arith::kFold && (log2n == 12 || log2n == 13) && touched > ((size_t)256 << 20);
@@ -86,7 +89,7 @@ int launch_ntt(int log2n, bool inverse, u64* out, const u64* in, size_t npolys, 
 #endif
 #if DPFHE_N13_HALVES   // N = 8192, large batches, FoldArith: 256-thread workgroups on the N = 4096 body (launch.h)
     if constexpr (Arith::kFold) {
-    if (log2n == 13 && tb.hfwd && npolys >= kHalvesMinPolys) {
+    if (log2n == 13 && tb.hfwd && !tb.n_active && npolys >= kHalvesMinPolys) {
         if (inverse) {
             if (nt && Arith::kFold) hipLaunchKernelGGL((ntt_inv_halves_kernel<Arith, Arith::kFold>), dim3((unsigned)npolys), dim3(256), 0, s, out, in, tb);
             else hipLaunchKernelGGL((ntt_inv_halves_kernel<Arith, false>), dim3((unsigned)npolys), dim3(256), 0, s, out, in, tb);

@@ -45,7 +45,7 @@ struct LimbConst {  // one per RNS limb, read through scalar loads (limb index i
     u64 br_hi;      // floor(2^128 / q), high word   (generic Barrett)
     u64 br_lo;      //                   low word
     u64 two64;      // 2^64 mod q
-    u64 pad1;
+    u64 pad1;       // FoldScaledArith: 60 - k, the scaling shift of a 2^k - d0 limb (0 otherwise)
 };
 
 DPF_HD u64 mad32(u32 a, u32 b, u64 c) { return (u64)a * b + c; }
@@ -97,9 +97,15 @@ struct alignas(16) TwFold {
     u64 w, ws;
 };
 
+// Policy flags read by ntt_core.h / the launchers:
+//   kFold      - the pinned 2^60 - d primes: the fused kernels' lazy forms, exact division by N (FoldArith only);
+//   kFoldCore  - fold butterflies and static bound plans inside a transform (FoldArith, FoldScaledArith);
+//   kF64       - residues travel as IEEE doubles inside a transform (F64Arith).
+// ntt_lc(c) is the LimbConst the transform's butterflies see (FoldScaledArith: the scaled modulus).
 struct ShoupArith {
     typedef TwShoup Tw;
-    static constexpr bool kFold = false;
+    static constexpr bool kFold = false, kFoldCore = false, kF64 = false;
+    static DPF_HD const LimbConst& ntt_lc(const LimbConst& c) { return c; }
     // w*y mod q, result in [0, 2q), for ANY y < 2^64 (w < q, wsh = floor(w 2^64/q))
     static DPF_HD u64 mul_tw(u64 y, const Tw& t, const LimbConst& c) {
         u64 hi = mulhi64(y, t.wsh);
@@ -124,7 +130,8 @@ struct ShoupArith {
 
 struct FoldArith {
     typedef TwFold Tw;
-    static constexpr bool kFold = true;
+    static constexpr bool kFold = true, kFoldCore = true, kF64 = false;
+    static DPF_HD const LimbConst& ntt_lc(const LimbConst& c) { return c; }
     // fold of the 124-bit product P = [p0, n0, r0, r1] (little-endian 32-bit words, r = P >> 64 < 2^60):
     // P = xl + xh 2^60  ==  xl + xh d (mod q), twice.  Result < 2^60 + 2^53 (< 2q), typically < q + 2^45.
     static DPF_HD u64 fold124(u32 p0, u32 n0, u64 r, u32 d) {
@@ -285,6 +292,89 @@ struct FoldArith {
         A = mad32((u32)(T >> 28), d, A);
         A = add_hi32(A, (u32)T & 0x0fffffffu);
         return reduce(A, c);
+    }
+};
+
+// -------------------------------------------------------------------------------------------------
+// FoldScaledArith - primes q = 2^k - d0 with 48 <= k < 60 and d0 2^(60-k) < 2^24 (round 6).
+// With s = 2^(60-k) the residue x is carried as s x modulo q' = s q = 2^60 - d, d = d0 s:  s x mod s q = s (x mod q), so the
+// scaled words are an exact image of Z_q, q' has the shape FoldArith wants (2^60 = d mod q', d < 2^24) and every fold
+// reduction, bound plan and butterfly of FoldArith applies unchanged with (q', d).  Twiddles stay UNSCALED (w < q; the
+// companion w 2^32 is taken mod q': tables.h h_tw_fold_scaled), so (s x) w = s (x w): one shift when a word enters a
+// transform, one when it leaves.  N^-1 is a twiddle product (the exact division of FoldArith::mul_ninv needs q' = 1 mod 2N).
+// LimbConst of such a limb: q = the TRUE prime, d = d0 s, pad1 = 60 - k; Barrett constants of the true prime.
+// At the kernels' level the policy is "generic": canonical words of the true prime between transforms (kFold = false).
+struct FoldScaledArith {
+    typedef TwFold Tw;
+    static constexpr bool kFold = false, kFoldCore = true, kF64 = false;
+    static DPF_HD LimbConst ntt_lc(const LimbConst& c) {
+        LimbConst r = c;
+        r.q = c.q << c.pad1;
+        return r;
+    }
+    static DPF_HD u64 enter(u64 x, const LimbConst& c) { return x << c.pad1; }                       // canonical x < q  ->  s x < q'
+    static DPF_HD u64 leave(u64 x, const LimbConst& c) { return x >> c.pad1; }                       // canonical mod q' (a multiple of s)  ->  x
+    static DPF_HD u64 mul_var(u64 a, u64 b, const LimbConst& c) {                                    // canonical a, b < q
+        const u64 r = FoldArith::mul60(a << c.pad1, b, (u32)c.d);                                    // s a b mod q', < q' + 2^53
+        return csub(r, c.q << c.pad1) >> c.pad1;
+    }
+};
+
+// -------------------------------------------------------------------------------------------------
+// F64Arith - primes q < 2^47 (round 6): inside a transform a residue is an IEEE double holding a (signed) integer, and the
+// modular product is the error-free FMA sequence
+//     p = y w;  e = fma(y, w, -p);  h = rint(y (w/q));  r = fma(-h, q, p);  t = r + e            ( = y w - h q exactly )
+// - 6 full-rate FP64 instructions, no integer multiply.  Exactness (|y| < 2^51, 0 <= w < q < 2^47, wq = fl(w / q)):
+//   * y wq differs from y w / q by at most |y| 2^-52 <= 1/2, so |y w / q - h| <= 1 and |t| <= q;
+//   * p and h q are integers and |r| = |t - e| <= q + ulp(p)/2 < 2^53, so the second fma is exact; so is r + e.
+// Butterflies are plain signed additions: a forward (Cooley-Tukey) word grows by at most q per stage, 1 + log2 N <= 16 q <= 2^51
+// at the last stage - no reduction inside a forward transform at all; the inverse (Gentleman-Sande) sums double per stage and are
+// reduced where the static plan (ntt_core.h make_gs_plan, cap 16 q) says so (3 instructions).  The rounding to an integer is the
+// magic-constant addition (fma(y, wq, 1.5 2^52) - 1.5 2^52): no dependence on the rate of v_rndne_f64.
+// At the kernels' level the policy is "generic": canonical u64 words between transforms.
+// LimbConst of such a limb (the array behind DevTables<F64Arith>::lc): q = the prime, ninv / ninv_sh REINTERPRETED as the doubles
+// q and fl(1 / q) (N^-1 reaches the transform as a twiddle), d = 0; Barrett constants as usual.
+struct alignas(16) TwF64 {
+    double w, wq;   // w and fl(w / q)
+};
+struct F64Arith {
+    typedef TwF64 Tw;
+    static constexpr bool kFold = false, kFoldCore = false, kF64 = true;
+    static constexpr int kMaxBits = 47;
+    static DPF_HD const LimbConst& ntt_lc(const LimbConst& c) { return c; }
+    static DPF_HD double f(u64 x) { return __builtin_bit_cast(double, x); }
+    static DPF_HD u64 b(double x) { return __builtin_bit_cast(u64, x); }
+    static DPF_HD double qd(const LimbConst& c) { return f(c.ninv); }
+    static DPF_HD double qinv(const LimbConst& c) { return f(c.ninv_sh); }
+    static constexpr double kTwo52 = 4503599627370496.0, kMagic = 6755399441055744.0;   // 2^52, 1.5 2^52
+    // integer x < 2^52 -> double, and back for an integer-valued 0 <= r < 2^52: two instructions each
+    static DPF_HD double to_f(u64 x) { return f(x | 0x4330000000000000ull) - kTwo52; }
+    static DPF_HD u64 from_f(double r) { return b(r + kTwo52) & 0x000fffffffffffffull; }
+    static DPF_HD double rint_mul(double y, double k) { return __builtin_fma(y, k, kMagic) - kMagic; }   // rint(y k), |y k| < 2^51
+    static DPF_HD double mulmod(double y, double w, double wq, double q) {
+        DPFHE_EMU_ASSERT(y > -2251799813685248.0 && y < 2251799813685248.0);
+        const double p = y * w;
+        const double e = __builtin_fma(y, w, -p);
+        const double h = rint_mul(y, wq);
+        const double r = __builtin_fma(-h, q, p);
+        return r + e;
+    }
+    // any |x| < 2^52  ->  x mod q in [-q/2 - 1, q/2 + 1]
+    static DPF_HD double reduce(double x, double q, double qi) { return __builtin_fma(-rint_mul(x, qi), q, x); }
+    static DPF_HD double canon(double x, double q, double qi) {
+        const double r = reduce(x, q, qi);
+        return r < 0.0 ? r + q : r;
+    }
+    static DPF_HD u64 enter(u64 x, const LimbConst&) { return b(to_f(x)); }
+    static DPF_HD u64 leave(u64 x, const LimbConst& c) { return from_f(canon(f(x), qd(c), qinv(c))); }
+    // a*b mod q, canonical in and out (the dyadic products of the generic fused multiply)
+    static DPF_HD u64 mul_var(u64 a, u64 bb, const LimbConst& c) {
+        const double q = qd(c), qi = qinv(c), x = to_f(a), y = to_f(bb);
+        const double p = x * y;
+        const double e = __builtin_fma(x, y, -p);
+        const double h = rint_mul(p, qi);               // p / q < 2^47: the estimate is within 2^-5 of the quotient
+        const double r = __builtin_fma(-h, q, p) + e;   // in [-q/2 - 1, q/2 + 1]
+        return from_f(r < 0.0 ? r + q : r);
     }
 };
 

@@ -584,11 +584,40 @@ struct NttBody {
     static constexpr int kFwdOutBound = Arith::kFold ? ctf_plan<NPH - 1>().out_bound : 4 * kUnit;
     static_assert(!Arith::kFold || kFwdOutBound <= kLimitPartner, "lazy forward outputs must satisfy mul60's bound");
 
+    // generic policies (FoldScaledArith, F64Arith) convert a canonical word when it enters a transform and back when it leaves (Arith::enter /
+    // Arith::leave); the pinned-prime and Harvey policies work on the words as they are
+    static constexpr bool kConverts = Arith::kF64 || (Arith::kFoldCore && !Arith::kFold);
+    static_assert(!kConverts || !SUB, "the halves form is FoldArith's");
+    static_assert(!Arith::kF64 || LOGN <= 15, "F64Arith: a forward word reaches (1 + log2 N) q <= 16 q <= 2^51 unreduced");
+    static DPF_HD void enter(u64 (&x)[E], const LimbConst& lc) {
+        if constexpr (kConverts) {
+#pragma clang loop unroll(full)
+            for (int k = 0; k < E; ++k) x[k] = Arith::enter(x[k], lc);
+        }
+    }
     template <int P>
-    static DPF_HD void fwd_phase_r(u64 (&x)[E], const TwRegs& twr, const LimbConst& lc) {
+    static DPF_HD void fwd_phase_r(u64 (&x)[E], const TwRegs& twr, const LimbConst& lc_in) {
         constexpr Phase ph = G::phase(P);
+        const auto& lc = Arith::ntt_lc(lc_in);   // FoldScaledArith: the scaled modulus q' = 2^60 - d
+        if constexpr (P == 0) enter(x, lc_in);
         const u64 two_q = 2 * lc.q;
-        if constexpr (Arith::kFold) {
+        if constexpr (Arith::kF64) {
+            const double q = Arith::qd(lc);
+#pragma clang loop unroll(full)
+            for (int u = 0; u < ph.r; ++u) {
+                const int lb = ph.b + ph.r - 1 - u - ph.c;
+#pragma clang loop unroll(full)
+                for (int k = 0; k < E; ++k) {
+                    if (k & (1 << lb)) continue;
+                    const int kk = k | (1 << lb);
+                    const Tw& w = twr[u][k >> (lb + 1)];
+                    const double a = Arith::f(x[k]);
+                    const double t = Arith::mulmod(Arith::f(x[kk]), w.w, w.wq, q);   // |t| <= q: a word grows by at most q per stage
+                    x[k] = Arith::b(a + t);
+                    x[kk] = Arith::b(a - t);
+                }
+            }
+        } else if constexpr (Arith::kFoldCore) {
             constexpr CtfPlan<LOGE> plan = ctf_plan<P>();
 #pragma clang loop unroll(full)
             for (int u = 0; u < ph.r; ++u) {
@@ -629,11 +658,18 @@ struct NttBody {
         fwd_phase_r<P>(x, twr, lc);
     }
     // forward output -> canonical residues
-    static DPF_HD void fwd_canon(u64 (&x)[E], const LimbConst& lc) {
-        if constexpr (Arith::kFold) {
+    static DPF_HD void fwd_canon(u64 (&x)[E], const LimbConst& lc_in) {
+        const auto& lc = Arith::ntt_lc(lc_in);
+        if constexpr (Arith::kF64) {
+#pragma clang loop unroll(full)
+            for (int k = 0; k < E; ++k) x[k] = Arith::leave(x[k], lc);
+        } else if constexpr (Arith::kFoldCore) {
             constexpr CtfPlan<LOGE> plan = ctf_plan<NPH - 1>();   // sums leave the last stage reduced: 4 instructions instead of 7
 #pragma clang loop unroll(full)
-            for (int k = 0; k < E; ++k) x[k] = plan.out[k] <= kRedB ? FoldArith::canon_small(x[k], lc) : FoldArith::canon(x[k], lc);
+            for (int k = 0; k < E; ++k) {
+                x[k] = plan.out[k] <= kRedB ? FoldArith::canon_small(x[k], lc) : FoldArith::canon(x[k], lc);
+                if constexpr (kConverts) x[k] = Arith::leave(x[k], lc_in);
+            }
         } else {
 #pragma clang loop unroll(full)
             for (int k = 0; k < E; ++k) x[k] = csub(csub(x[k], 2 * lc.q), lc.q);
@@ -657,49 +693,89 @@ struct NttBody {
     static constexpr GsPlan<LOGE> gs_plan() {
         constexpr Phase ph = G::phase(P);
         if (SUB) return make_gs_plan<LOGE>(ph.b - ph.c, ph.r, (P == NPH - 1) ? IN : kGsMid, (P == 0) ? kSubInvOut : kGsMid, false);
+        // (F64Arith reads the same plan: bounds are on |x| in units of q / 1024, the cap 16 q <= 2^51 is its product's precondition, a reduction leaves
+        //  |x| <= q / 2 + 1 < kRedB and a product |x| <= q < kTwB; the offsets are not used - doubles are signed)
         return make_gs_plan<LOGE>(ph.b - ph.c, ph.r, (P == NPH - 1) ? IN : kGsMid, (P == 0) ? kLimit : kGsMid, P == 0, Arith::kFold ? LOGN : 0);
     }
 
     template <int P, int IN>
-    static DPF_HD void inv_phase_r(u64 (&x)[E], const TwRegs& twr, const Tw& w_last, const Tw& w_ninv, const LimbConst& lc) {
+    static DPF_HD void inv_phase_r(u64 (&x)[E], const TwRegs& twr, const Tw& w_last, const Tw& w_ninv, const LimbConst& lc_in) {
         constexpr Phase ph = G::phase(P);
         constexpr GsPlan<LOGE> plan = gs_plan<P, IN>();
-        const u64 q = lc.q, two_q = 2 * lc.q;
+        const auto& lc = Arith::ntt_lc(lc_in);
+        if constexpr (P == NPH - 1) enter(x, lc_in);
+        if constexpr (Arith::kF64) {
+            static_assert(IN <= kWord / 2, "F64Arith: the first butterfly's operands must fit the plan's cap");
+            const double q = Arith::qd(lc), qi = Arith::qinv(lc);
 #pragma clang loop unroll(full)
-        for (int u = 0; u < ph.r; ++u) {
-            const int pos = ph.b + u;
-            const int lb = pos - ph.c;
-            const bool last = (pos == LOGN - 1) && !SUB;   // SUB: the caller's column stage is the last one
+            for (int u = 0; u < ph.r; ++u) {
+                const int pos = ph.b + u;
+                const int lb = pos - ph.c;
+                const bool last = (pos == LOGN - 1);
 #pragma clang loop unroll(full)
-            for (int k = 0; k < E; ++k) {
-                if (k & (1 << lb)) continue;
-                const int kk = k | (1 << lb);
-                u64 a = x[k], b = x[kk];
-                u64 s, dlt;
-                if (Arith::kFold) {
-                    if (plan.red[u][k]) a = FoldArith::reduce(a, lc);
-                    if (plan.red[u][kk]) b = FoldArith::reduce(b, lc);
-                    s = chk_add(a, b);
-                    dlt = chk_sub_add(a, b, (u64)plan.off[u][k] * q);
-                } else {  // Harvey: inputs in [0,2q)
-                    s = csub(a + b, two_q);
-                    dlt = a - b + two_q;
-                }
-                if (last) {  // N^-1 folded into the last stage: x' = (a+b) N^-1, y' = (a-b) w N^-1
-                    if constexpr (Arith::kFold) x[k] = FoldArith::mul_ninv(s, lc, LOGN);   // exact division by N: 6 instructions instead of 9
-                    else x[k] = Arith::mul_tw(s, w_ninv, lc);
-                    x[kk] = Arith::mul_tw(dlt, w_last, lc);
-                } else {
-                    x[k] = s;
-                    x[kk] = Arith::mul_tw(dlt, twr[u][k >> (lb + 1)], lc);
+                for (int k = 0; k < E; ++k) {
+                    if (k & (1 << lb)) continue;
+                    const int kk = k | (1 << lb);
+                    double a = Arith::f(x[k]), b = Arith::f(x[kk]);
+                    if (plan.red[u][k]) a = Arith::reduce(a, q, qi);
+                    if (plan.red[u][kk]) b = Arith::reduce(b, q, qi);
+                    const double s = a + b, dlt = a - b;
+                    if (last) {
+                        x[k] = Arith::b(Arith::mulmod(s, w_ninv.w, w_ninv.wq, q));
+                        x[kk] = Arith::b(Arith::mulmod(dlt, w_last.w, w_last.wq, q));
+                    } else {
+                        const Tw& w = twr[u][k >> (lb + 1)];
+                        x[k] = Arith::b(s);
+                        x[kk] = Arith::b(Arith::mulmod(dlt, w.w, w.wq, q));
+                    }
                 }
             }
-        }
-        if (Arith::kFold) {
 #pragma clang loop unroll(full)
             for (int k = 0; k < E; ++k)
-                if (plan.red_end[k]) x[k] = FoldArith::reduce(x[k], lc);
+                if (plan.red_end[k]) x[k] = Arith::b(Arith::reduce(Arith::f(x[k]), q, qi));
+        } else {
+            const u64 q = lc.q, two_q = 2 * lc.q;
+#pragma clang loop unroll(full)
+            for (int u = 0; u < ph.r; ++u) {
+                const int pos = ph.b + u;
+                const int lb = pos - ph.c;
+                const bool last = (pos == LOGN - 1) && !SUB;   // SUB: the caller's column stage is the last one
+#pragma clang loop unroll(full)
+                for (int k = 0; k < E; ++k) {
+                    if (k & (1 << lb)) continue;
+                    const int kk = k | (1 << lb);
+                    u64 a = x[k], b = x[kk];
+                    u64 s, dlt;
+                    if constexpr (Arith::kFoldCore) {
+                        if (plan.red[u][k]) a = FoldArith::reduce(a, lc);
+                        if (plan.red[u][kk]) b = FoldArith::reduce(b, lc);
+                        s = chk_add(a, b);
+                        dlt = chk_sub_add(a, b, (u64)plan.off[u][k] * q);
+                    } else {  // Harvey: inputs in [0,2q)
+                        s = csub(a + b, two_q);
+                        dlt = a - b + two_q;
+                    }
+                    if (last) {  // N^-1 folded into the last stage: x' = (a+b) N^-1, y' = (a-b) w N^-1
+                        if constexpr (Arith::kFold) x[k] = FoldArith::mul_ninv(s, lc, LOGN);   // exact division by N: 6 instructions instead of 9
+                        else x[k] = tw_mul(s, w_ninv, lc);                                     // (scaled limbs: q' is not 1 mod 2N)
+                        x[kk] = tw_mul(dlt, w_last, lc);
+                    } else {
+                        x[k] = s;
+                        x[kk] = tw_mul(dlt, twr[u][k >> (lb + 1)], lc);
+                    }
+                }
+            }
+            if constexpr (Arith::kFoldCore) {
+#pragma clang loop unroll(full)
+                for (int k = 0; k < E; ++k)
+                    if (plan.red_end[k]) x[k] = FoldArith::reduce(x[k], lc);
+            }
         }
+    }
+    // twiddle product of the integer policies (FoldScaledArith runs FoldArith's on the scaled modulus)
+    static DPF_HD u64 tw_mul(u64 y, const Tw& t, const LimbConst& lc) {
+        if constexpr (Arith::kFoldCore) return FoldArith::mul_tw(y, t, lc);
+        else return Arith::mul_tw(y, t, lc);
     }
     template <int P, int IN>
     static DPF_HD void inv_phase(int tid, u64 (&x)[E], const Tw* tw, const Tw& w_last, const Tw& w_ninv, const LimbConst& lc) {
@@ -710,9 +786,16 @@ struct NttBody {
     // inverse output (all words are outputs of the last stage: twiddle products < 2^60 + 13 d and exact divisions < q + 2^(64 - LOGN) + 1, both
     // inside canon_small's precondition r < 1.5 * 2^60 - the static plan carries the real bound, checked here) -> canonical
     static_assert(!Arith::kFold || SUB || (kWord >> LOGN) + 2 <= kUnit / 2, "the exact division's output (make_gs_plan: kUnit + (sum >> LOGN) + 2) must fit canon_small");
-    static DPF_HD void inv_canon(u64 (&x)[E], const LimbConst& lc) {
+    static DPF_HD void inv_canon(u64 (&x)[E], const LimbConst& lc_in) {
+        const auto& lc = Arith::ntt_lc(lc_in);
 #pragma clang loop unroll(full)
-        for (int k = 0; k < E; ++k) x[k] = Arith::kFold ? FoldArith::canon_small(x[k], lc) : csub(x[k], lc.q);
+        for (int k = 0; k < E; ++k) {
+            if constexpr (Arith::kF64) x[k] = Arith::leave(x[k], lc);
+            else if constexpr (Arith::kFoldCore) {
+                x[k] = FoldArith::canon_small(x[k], lc);
+                if constexpr (kConverts) x[k] = Arith::leave(x[k], lc_in);
+            } else x[k] = csub(x[k], lc.q);
+        }
     }
 };
 

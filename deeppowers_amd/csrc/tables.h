@@ -58,6 +58,47 @@ inline TwFold h_tw_fold(u64 w, u64 q) {
 template <class Tw> inline Tw h_make_tw(u64 w, u64 q);
 template <> inline TwFold h_make_tw<TwFold>(u64 w, u64 q) { return h_tw_fold(w, q); }
 template <> inline TwShoup h_make_tw<TwShoup>(u64 w, u64 q) { return TwShoup{w, (u64)(((u128)w << 64) / q)}; }
+// F64Arith: w and the correctly rounded quotient w / q (both exact or within half an ulp: w < q < 2^47 are exact doubles)
+template <> inline TwF64 h_make_tw<TwF64>(u64 w, u64 q) { return TwF64{(double)w, (double)w / (double)q}; }
+
+// ---- per-limb arithmetic classes (round 6): which policy's transform kernels a limb runs on ------------------------------------------
+// kClassFold: the pinned shape 2^60 - d; kClassF64: any prime below 2^47; kClassFoldScaled: 2^k - d0, 48 <= k < 60, d0 2^(60-k) < 2^24;
+// kClassShoup: everything else (50 ... 59-bit primes far from a power of two, 47 ... 49-bit primes).
+enum LimbClass { kClassShoup = 0, kClassFold = 1, kClassF64 = 2, kClassFoldScaled = 3, kLimbClasses = 4 };
+inline int h_bit_length(u64 v) { int b = 0; while (v) { ++b; v >>= 1; } return b; }
+// the scaling shift 60 - k of a FoldScaledArith prime, 0 when q is not one
+inline int fold_scaled_shift(u64 q) {
+    const int k = h_bit_length(q);
+    if (k < 48 || k > 59) return 0;
+    const u64 d0 = (1ull << k) - q;
+    return (d0 << (60 - k)) < (1ull << 24) ? 60 - k : 0;
+}
+inline bool f64_eligible(u64 q) { return q < (1ull << F64Arith::kMaxBits); }
+inline LimbClass limb_class(u64 q) {
+    if (q < (1ull << 60) && ((1ull << 60) - q) < (1ull << 24)) return kClassFold;
+    if (f64_eligible(q)) return kClassF64;
+    if (fold_scaled_shift(q)) return kClassFoldScaled;
+    return kClassShoup;
+}
+// FoldScaledArith twiddle of w (< q): w unscaled, the companion w 2^32 modulo the SCALED modulus q' = q 2^sh (modarith.h)
+inline TwFold h_tw_fold_scaled(u64 w, u64 q, int sh) { return h_tw_fold(w, q << sh); }
+// the LimbConst a class's transform kernels read (modarith.h: FoldScaledArith / F64Arith reinterpret fields); `lc` is build_limb_tables' record
+inline LimbConst limb_const_of_class(const LimbConst& lc, LimbClass cls) {
+    LimbConst c = lc;
+    if (cls == kClassFoldScaled) {
+        const int sh = fold_scaled_shift(lc.q);
+        c.d = ((1ull << (60 - sh)) - lc.q) << sh;
+        c.pad1 = (u64)sh;
+    } else if (cls == kClassF64) {
+        const double qd = (double)lc.q, qi = 1.0 / qd;
+        c.d = 0;
+        c.ninv = __builtin_bit_cast(u64, qd);
+        c.ninv_sh = __builtin_bit_cast(u64, qi);
+    } else if (cls == kClassShoup) {
+        c.d = 0;
+    }
+    return c;
+}
 
 // Split transform (N > 16384, ntt_top.h): after the first log_n1 radix-2 stages the remaining ones act inside blocks of
 // N2 = N >> log_n1 consecutive words, and block r runs an ordinary N2-point merged transform whose twiddles are the

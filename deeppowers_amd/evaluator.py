@@ -60,6 +60,13 @@ class Context:
     def uses_fold(self) -> bool:
         return bool(self._lib.dpfhe_ctx_uses_fold(self._h))
 
+    ARITH_NAMES = ("shoup", "fold", "f64", "fold_scaled")
+
+    @property
+    def limb_classes(self) -> tuple:
+        """per limb, the arithmetic the transforms and the fused multiply run it on (dpfhe_ctx_limb_class): 'shoup' | 'fold' | 'f64' | 'fold_scaled'"""
+        return tuple(self.ARITH_NAMES[self._lib.dpfhe_ctx_limb_class(self._h, i)] for i in range(self.params.n_limbs))
+
     # ---- which form of the fused multiply this context launches (include/dpfhe.h "A0, continued") ----
     def tune_info(self) -> dict:
         """{"chosen": name, "source": ..., "probe_us": {name: us}, "probe_pairs": n, "probe_reps": r}; forms are bit-identical."""

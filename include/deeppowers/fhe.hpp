@@ -65,6 +65,8 @@ public:
     const FheParams& params() const;
     int device_id() const;
     bool uses_fold() const;
+    // arithmetic of limb i in the batched transforms and the fused multiply (dpfhe_ctx_limb_class): 0 Shoup, 1 fold, 2 f64, 3 fold-scaled
+    int limb_class(uint32_t limb) const;
     void* handle() const;  // dpfhe_ctx*
     void synchronize() const;
     // set-up call: slice size (MiB of scratch) of the operations composed from the batched transforms at N >= 16384 (dpfhe_ctx_set_scratch_limit; default 1024)

@@ -1,0 +1,163 @@
+"""-m gpu: the per-limb arithmetic classes (round 6; include/dpfhe.h dpfhe_ctx_limb_class) through the C ABI against the oracle.
+
+A context's limbs no longer share one arithmetic: the batched transforms and the fused multiply run each limb on the fastest policy its prime admits -
+fold (2^60 - d), f64 (any prime below 2^47: doubles inside a transform), fold_scaled (2^k - d0 carried as 2^60 - d), shoup (the rest) - one launch per class
+present.  Results must be the same words whatever the class: every case below compares whole buffers with the oracle (radix-2 Harvey NTT + u128
+schoolbook, a different algorithm from all four)."""
+import numpy as np
+import pytest
+
+from deeppowers_amd.params import FheParams, PRIMES_60, ntt_primes
+from oracle import pyoracle as po
+from oracle.cbind import Oracle
+
+
+def primes_of(log2n, widths):
+    """one prime = 1 mod 2N per requested width, distinct (the j-th largest below 2^w for the j-th request of width w)"""
+    qs, ps, seen = [], [], {}
+    for w in widths:
+        j = seen.get(w, 0)
+        seen[w] = j + 1
+        p = ntt_primes(log2n, j + 1, w)
+        qs.append(p.moduli[j])
+        ps.append(p.psi[j])
+    return FheParams(log2n, tuple(qs), tuple(ps))
+
+
+def expected_class(q):
+    if q < (1 << 60) and (1 << 60) - q < (1 << 24):
+        return "fold"
+    if q < (1 << 47):
+        return "f64"
+    k = q.bit_length()
+    if 48 <= k <= 59 and (((1 << k) - q) << (60 - k)) < (1 << 24):
+        return "fold_scaled"
+    return "shoup"
+
+
+def worst_case(x, qcol, n):
+    """stripes of extreme residues in the first item: q - 1 everywhere in one stretch, alternating q - 1 / 0 in another, the half point in a third"""
+    x[0, ..., : n // 8] = qcol - np.uint64(1)
+    x[0, ..., n // 8: n // 4: 2] = qcol - np.uint64(1)
+    x[0, ..., n // 8 + 1: n // 4: 2] = 0
+    x[0, ..., n // 4: n // 4 + n // 8] = qcol // np.uint64(2)
+    return x
+
+
+CASES = [
+    # (name, log2n, widths)
+    ("f64_30x4", 12, (30, 30, 30, 30)),
+    ("f64_mixed_widths", 12, (20, 31, 40, 46)),
+    ("f64_46x3_n8192", 13, (46, 46, 46)),
+    ("f64_n16384", 14, (36, 45)),
+    ("f64_n256", 8, (30, 46)),
+    ("fscaled_59x4", 12, (59, 59, 59, 59)),
+    ("fscaled_widths", 12, (59, 58, 57, 56)),
+    ("fscaled_n8192", 13, (59, 58)),
+    ("fscaled_n16384", 14, (59, 57)),
+    ("shoup_49x2", 12, (49, 49)),
+    ("all_four_classes", 12, (60, 40, 59, 49)),
+    ("seal_like_60_40_40_60", 12, (60, 40, 40, 60)),
+    ("bench_mixed_59_50_40_33", 12, (59, 50, 40, 33)),
+    ("config1_like_30bit_n1024", 10, (30,)),
+    ("all_four_classes_n8192", 13, (60, 33, 59, 49, 60, 46)),
+    ("all_four_classes_n2048", 11, (49, 60, 45, 58)),
+]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,log2n,widths", CASES, ids=[c[0] for c in CASES])
+def test_limb_classes_transforms_and_fused_multiply_match_the_oracle(name, log2n, widths):
+    from deeppowers_amd.evaluator import Ciphertext, Context, Evaluator, to_device, to_host
+    p = primes_of(log2n, widths)
+    L, n = p.n_limbs, p.n
+    orc = Oracle.from_params(p)
+    ctx = Context(p, 0)
+    ev = Evaluator(ctx)
+    try:
+        want_cls = tuple(expected_class(q) for q in p.moduli)
+        if all(c == "shoup" for c in want_cls) or all(c == "fold" for c in want_cls):
+            assert ctx.limb_classes == want_cls   # uniform contexts report the context-wide policy
+        else:
+            assert ctx.limb_classes == want_cls, (ctx.limb_classes, want_cls)
+        qcol = np.array(p.moduli, np.uint64)[:, None]
+        batch = 5
+        x = worst_case(orc.fill(batch, 4100).reshape(batch, L, n), qcol, n)
+        X = ev.ntt_forward(to_device(x, ctx.device))
+        assert np.array_equal(to_host(X), orc.ntt_fwd(x, threads=0))
+        assert np.array_equal(to_host(ev.ntt_inverse(to_device(x, ctx.device))), orc.ntt_inv(x, threads=0))   # inverse of non-image data
+        assert np.array_equal(to_host(ev.ntt_inverse(X)), x)
+        if log2n <= 13:
+            a = worst_case(orc.fill(batch * 2, 4200).reshape(batch, 2, L, n), qcol, n)
+            b = worst_case(orc.fill(batch * 2, 4300).reshape(batch, 2, L, n), qcol, n)
+            want = orc.ct_mul(a, b, threads=0)
+            A, B = Ciphertext(to_device(a, ctx.device)), Ciphertext(to_device(b, ctx.device))
+            assert np.array_equal(to_host(ev.multiply(A, B).data), want)
+            want_ntt = orc.ntt_fwd(want.reshape(-1, L, n), threads=0).reshape(want.shape)
+            assert np.array_equal(to_host(ev.multiply(A, B, out_ntt=True).data), want_ntt)
+            An = Ciphertext(ev.ntt_forward(A.data.view(-1, L, n)).view(batch, 2, L, n), is_ntt=True)
+            Bn = Ciphertext(ev.ntt_forward(B.data.view(-1, L, n)).view(batch, 2, L, n), is_ntt=True)
+            assert np.array_equal(to_host(ev.multiply(An, Bn, out_ntt=False).data), want)
+            assert np.array_equal(to_host(ev.multiply(An, Bn, out_ntt=True).data), want_ntt)
+    finally:
+        ctx.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("widths", [(30, 30, 30, 30), (59, 50, 40, 33), (59, 59, 58, 58)], ids=["f64", "mixed", "fold_scaled"])
+def test_limb_classes_full_size_whole_buffer_oracle(widths):
+    """BASELINE configs[1]'s batch (1024 RNS polynomials = 4096 residue polynomials, N = 4096) and 1024 ciphertext pairs, every word against the oracle,
+    plus the size-independent properties: round trip, linearity of the transform"""
+    import torch
+    from deeppowers_amd.evaluator import Ciphertext, Context, Evaluator, to_device, to_host
+    p = primes_of(12, widths)
+    L, n = p.n_limbs, p.n
+    orc = Oracle.from_params(p)
+    ctx = Context(p, 0)
+    ev = Evaluator(ctx)
+    try:
+        qcol = np.array(p.moduli, np.uint64)[:, None]
+        x = worst_case(orc.fill(1024, 5100).reshape(1024, L, n), qcol, n)
+        dx = to_device(x, ctx.device)
+        X = ev.ntt_forward(dx)
+        assert np.array_equal(to_host(X), orc.ntt_fwd(x, threads=0))
+        assert torch.equal(ev.ntt_inverse(X), dx)
+        y = orc.fill(1024, 5200).reshape(1024, L, n)
+        s = ((x.astype(object) + y.astype(object)) % qcol.astype(object)).astype(np.uint64)
+        Y, S = ev.ntt_forward(to_device(y, ctx.device)), ev.ntt_forward(to_device(s, ctx.device))
+        assert torch.equal(ev.add_words(X, Y), S)   # NTT(x + y) = NTT(x) + NTT(y)
+        pairs = 1024
+        a = worst_case(orc.fill(pairs * 2, 5300).reshape(pairs, 2, L, n), qcol, n)
+        b = worst_case(orc.fill(pairs * 2, 5400).reshape(pairs, 2, L, n), qcol, n)
+        got = to_host(ev.multiply(Ciphertext(to_device(a, ctx.device)), Ciphertext(to_device(b, ctx.device))).data)
+        assert np.array_equal(got, orc.ct_mul(a, b, threads=0))
+    finally:
+        ctx.close()
+
+
+@pytest.mark.gpu
+def test_key_switching_on_a_context_with_classes_still_matches_the_oracle():
+    """the key-switching kernels of a non-uniform context read its complete generic tables; the transforms and the fused multiply around them run per class"""
+    from deeppowers_amd.evaluator import Ciphertext, Context, Evaluator, to_device, to_host
+    p = primes_of(12, (60, 40, 59, 49))
+    L, n = p.n_limbs, p.n
+    orc = Oracle.from_params(p)
+    ctx = Context(p, 0)
+    ev = Evaluator(ctx)
+    try:
+        assert ctx.limb_classes == ("fold", "f64", "fold_scaled", "shoup")
+        a = orc.fill(6, 6100).reshape(3, 2, L, n)
+        b = orc.fill(6, 6200).reshape(3, 2, L, n)
+        want = orc.ct_mul(a, b, threads=0)
+        c = ev.multiply(Ciphertext(to_device(a, ctx.device)), Ciphertext(to_device(b, ctx.device)))
+        assert np.array_equal(to_host(c.data), want)
+        evk = orc.fill(L * 2, 6300).reshape(L, 2, L, n)
+        assert np.array_equal(to_host(ev.relinearize(c, to_device(evk, ctx.device)).data), orc.relinearize(want, evk, threads=0))
+        Ld = L - 1
+        data = Oracle(p.log2_n, p.moduli[:-1], p.psi[:-1])
+        key = orc.fill(Ld * 2, 6400).reshape(Ld, 2, L, n)
+        ct = data.fill(3 * 3, 6500).reshape(3, 3, Ld, n)
+        got = to_host(ev.keyswitch_hybrid(Ciphertext(to_device(ct, ctx.device)), to_device(key, ctx.device)).data)
+        assert np.array_equal(got, orc.keyswitch_hybrid(ct, key, 3, threads=0))
+    finally:
+        ctx.close()

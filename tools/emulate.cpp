@@ -35,6 +35,33 @@ template <> struct TwTab<FoldArith> {
     static TwFold one(u64 w, u64, u64 q) { return h_tw_fold(w, q); }
 };
 
+// round 6: the per-limb classes' policies (tables.h limb_class).  class_lc() = the LimbConst their transform kernels read.
+template <> struct TwTab<F64Arith> {
+    static std::vector<TwF64> make(const std::vector<u64>& w, const std::vector<u64>&, u64 q) {
+        std::vector<TwF64> v(w.size());
+        for (size_t i = 0; i < w.size(); ++i) v[i] = h_make_tw<TwF64>(w[i], q);
+        return v;
+    }
+    static TwF64 one(u64 w, u64, u64 q) { return h_make_tw<TwF64>(w, q); }
+};
+template <> struct TwTab<FoldScaledArith> {
+    static std::vector<TwFold> make(const std::vector<u64>& w, const std::vector<u64>&, u64 q) {
+        std::vector<TwFold> v(w.size());
+        for (size_t i = 0; i < w.size(); ++i) v[i] = h_tw_fold_scaled(w[i], q, fold_scaled_shift(q));
+        return v;
+    }
+    static TwFold one(u64 w, u64, u64 q) { return h_tw_fold_scaled(w, q, fold_scaled_shift(q)); }
+};
+template <class Arith> static bool class_ok(u64 q) {
+    if (Arith::kFold) return fold_eligible(q);
+    if (Arith::kF64) return f64_eligible(q);
+    if (Arith::kFoldCore) return fold_scaled_shift(q) != 0;
+    return true;
+}
+template <class Arith> static LimbConst class_lc(const LimbConst& lc) {
+    return limb_const_of_class(lc, Arith::kFold ? kClassFold : Arith::kF64 ? kClassF64 : Arith::kFoldCore ? kClassFoldScaled : kClassShoup);
+}
+
 template <class B> static constexpr int E_of() { return B::E; }
 // Exchanges are run the way the kernels synchronise them: the all-to-all exchange as "all threads write, barrier, all
 // threads read"; a wave-local exchange (Geo::exch_wave_local) one WAVE at a time - write then read - in DESCENDING wave
@@ -148,7 +175,9 @@ static int emu(int inverse, u64 q, u64 psi, const u64* in, u64* out) {
     HostLimbTables t;
     int rc = build_limb_tables(LOGN, q, psi, t);
     if (rc) return rc;
-    if (Arith::kFold && !fold_eligible(q)) return 2000;
+    if (!class_ok<Arith>(q)) return 2000;
+    const u64 ninv = t.lc.ninv;     // (F64Arith's LimbConst reuses the field)
+    t.lc = class_lc<Arith>(t.lc);
     constexpr int E = B::E, T = B::T;
     std::vector<u64> regs((size_t)T * E), lds(B::G::lds_words(), 0xDEADBEEFDEADBEEFull);
     auto X = [&](int tid) -> u64(&)[E] { return *reinterpret_cast<u64(*)[E]>(&regs[(size_t)tid * E]); };
@@ -161,7 +190,7 @@ static int emu(int inverse, u64 q, u64 psi, const u64* in, u64* out) {
     } else {
         auto tw = TwTab<Arith>::make(t.irp, t.irp_sh, q);
         permute_window0(tw, LOGN, LOGE, B::G::kPermStages);
-        auto wl = TwTab<Arith>::one(t.w_last, t.w_last_sh, q), wn = TwTab<Arith>::one(t.lc.ninv, t.lc.ninv_sh, q);
+        auto wl = TwTab<Arith>::one(t.w_last, t.w_last_sh, q), wn = TwTab<Arith>::one(ninv, h_shoup(ninv, q), q);
         for (int tid = 0; tid < T; ++tid) B::load_bot(tid, X(tid), in);
         InvSteps<B, B::NPH - 1, kUnit>::run(regs, lds, tw.data(), wl, wn, t.lc);
         for (int tid = 0; tid < T; ++tid) { B::inv_canon(X(tid), t.lc); B::store_top(tid, X(tid), out); }
@@ -169,12 +198,67 @@ static int emu(int inverse, u64 q, u64 psi, const u64* in, u64* out) {
     return 0;
 }
 
-// arith: 0 Shoup, 1 Fold.  `in`/`out` must be 16-byte aligned.  returns 0, 2000 bad args, -1 unsupported geometry
+// arith: 0 Shoup, 1 Fold, 2 F64, 3 FoldScaled (tables.h LimbClass).  `in`/`out` must be 16-byte aligned.  returns 0, 2000 bad args, -1 unsupported geometry
 extern "C" int emu_ntt(int arith, int log2n, int loge, int inverse, u64 q, u64 psi, const u64* in, u64* out) {
 #define CASE(LN, LE)                                                                     \
-    if (log2n == LN && loge == LE)                                                       \
-        return arith ? emu<FoldArith, LN, LE>(inverse, q, psi, in, out) : emu<ShoupArith, LN, LE>(inverse, q, psi, in, out);
+    if (log2n == LN && loge == LE) {                                                     \
+        if (arith == 2) return emu<F64Arith, LN, LE>(inverse, q, psi, in, out);          \
+        if (arith == 3) return emu<FoldScaledArith, LN, LE>(inverse, q, psi, in, out);   \
+        return arith ? emu<FoldArith, LN, LE>(inverse, q, psi, in, out) : emu<ShoupArith, LN, LE>(inverse, q, psi, in, out); \
+    }
     CASE(8, 4) CASE(10, 4) CASE(11, 4) CASE(12, 4) CASE(13, 5) CASE(14, 5) CASE(14, 4) CASE(12, 3) CASE(12, 5) CASE(13, 4) CASE(6, 3)
+#undef CASE
+    return -1;
+}
+
+// The GENERIC fused multiply's data path (kernels.h ct_mul_kernel, policies without lazy products): four forward transforms to canonical
+// words, Arith::mul_var products, three inverse transforms - for the round-6 policies, whose conversions (Arith::enter / leave) sit inside.
+template <class Arith, int LOGN, int LOGE>
+static int emu_ct_mul_generic(u64 q, u64 psi, const u64* a0, const u64* a1, const u64* b0, const u64* b1, u64* out3) {
+    typedef NttBody<Arith, LOGN, LOGE> B;
+    HostLimbTables t;
+    int rc = build_limb_tables(LOGN, q, psi, t);
+    if (rc) return rc;
+    if (!class_ok<Arith>(q)) return 2000;
+    const u64 ninv = t.lc.ninv;
+    const LimbConst lc = class_lc<Arith>(t.lc);
+    constexpr int E = B::E, T = B::T, N = B::G::N;
+    auto twf = TwTab<Arith>::make(t.rp, t.rp_sh, q), twi = TwTab<Arith>::make(t.irp, t.irp_sh, q);
+    permute_window0(twf, LOGN, LOGE, B::G::kPermStages);
+    permute_window0(twi, LOGN, LOGE, B::G::kPermStages);
+    const auto wl = TwTab<Arith>::one(t.w_last, t.w_last_sh, q), wn = TwTab<Arith>::one(ninv, h_shoup(ninv, q), q);
+    std::vector<u64> lds(B::G::lds_words());
+    auto fwd = [&](const u64* src) {
+        std::vector<u64> regs((size_t)T * E);
+        auto X = [&](int tid) -> u64(&)[E] { return *reinterpret_cast<u64(*)[E]>(&regs[(size_t)tid * E]); };
+        for (int tid = 0; tid < T; ++tid) B::load_top(tid, X(tid), src);
+        FwdSteps<B, 0>::run(regs, lds, twf.data(), lc);
+        for (int tid = 0; tid < T; ++tid) B::fwd_canon(X(tid), lc);
+        return regs;
+    };
+    auto inv = [&](std::vector<u64> regs, u64* dst) {
+        auto X = [&](int tid) -> u64(&)[E] { return *reinterpret_cast<u64(*)[E]>(&regs[(size_t)tid * E]); };
+        InvSteps<B, B::NPH - 1, kUnit>::run(regs, lds, twi.data(), wl, wn, lc);
+        for (int tid = 0; tid < T; ++tid) { B::inv_canon(X(tid), lc); B::store_top(tid, X(tid), dst); }
+    };
+    std::vector<u64> S0 = fwd(a0), S1 = fwd(b0), S2 = fwd(b1), S3 = fwd(a1), x((size_t)N);
+    for (int i = 0; i < N; ++i) x[i] = Arith::mul_var(S0[i], S1[i], lc);
+    inv(x, out3);
+    for (int i = 0; i < N; ++i) x[i] = add_mod(Arith::mul_var(S0[i], S2[i], lc), Arith::mul_var(S3[i], S1[i], lc), lc.q);
+    inv(x, out3 + N);
+    for (int i = 0; i < N; ++i) x[i] = Arith::mul_var(S3[i], S2[i], lc);
+    inv(x, out3 + 2 * N);
+    return 0;
+}
+extern "C" int emu_ct_mul_class(int arith, int log2n, u64 q, u64 psi, const u64* a0, const u64* a1, const u64* b0, const u64* b1, u64* out3) {
+#define CASE(LN)                                                                                                              \
+    if (log2n == LN) {                                                                                                        \
+        if (arith == 2) return emu_ct_mul_generic<F64Arith, LN, 4>(q, psi, a0, a1, b0, b1, out3);                             \
+        if (arith == 3) return emu_ct_mul_generic<FoldScaledArith, LN, 4>(q, psi, a0, a1, b0, b1, out3);                      \
+        if (arith == 0) return emu_ct_mul_generic<ShoupArith, LN, 4>(q, psi, a0, a1, b0, b1, out3);                           \
+        return -1;                                                                                                            \
+    }
+    CASE(8) CASE(10) CASE(12) CASE(13)
 #undef CASE
     return -1;
 }
