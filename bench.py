@@ -299,10 +299,11 @@ def digest_other(o):
         c5 = o["n8192_l6"]
         d["n8192_l6"] = {"ntt_fwd_frac": r3(c5["ntt_fwd"]["frac_of_hbm_peak"]), "ntt_inv_frac": r3(c5["ntt_inv"]["frac_of_hbm_peak"]),
                          "ct_mul_per_s": round(c5["ct_mul"]["per_s"]), "ct_mul_frac": r3(c5["ct_mul"]["frac_of_hbm_peak"])}
-    if isinstance(o.get("shoup_n4096_l4"), dict) and "ct_mul" in o["shoup_n4096_l4"]:
-        sg = o["shoup_n4096_l4"]
-        d["shoup_n4096_l4"] = {"ntt_fwd_frac": r3(sg["ntt_fwd"]["frac_of_hbm_peak"]), "ntt_inv_frac": r3(sg["ntt_inv"]["frac_of_hbm_peak"]), "ct_mul_per_s": round(sg["ct_mul"]["per_s"]),
-                               "ct_mul_frac": r3(sg["ct_mul"]["frac_of_hbm_peak"]), "fold_over_shoup_ct_mul": r3(sg["fold_over_shoup_ct_mul"])}
+    for key in ("shoup_n4096_l4", "p31_n4096_l4", "shoup49_n4096_l4"):   # the per-limb arithmetic classes at the headline shape
+        if isinstance(o.get(key), dict) and "ct_mul" in o[key]:
+            sg = o[key]
+            d[key] = {"classes": sg.get("limb_classes"), "ntt_fwd_frac": r3(sg["ntt_fwd"]["frac_of_hbm_peak"]), "ntt_inv_frac": r3(sg["ntt_inv"]["frac_of_hbm_peak"]),
+                      "ct_mul_per_s": round(sg["ct_mul"]["per_s"]), "ct_mul_frac": r3(sg["ct_mul"]["frac_of_hbm_peak"]), "fold_over_this_ct_mul": r3(sg["fold_over_shoup_ct_mul"])}
     pl = o.get("packed_linear") or {}
     if pl:
         e = {"all_correct": pl.get("all_correct")}
@@ -549,6 +550,8 @@ def main():
                "ntt_inv_configs1_in_place": window(lambda: ev.ntt_inverse_(x), b1),
                "ntt_fwd_1GiB_out_of_place": window(lambda: ev.ntt_forward(x2, out=y2), b2),
                "ntt_inv_1GiB_out_of_place": window(lambda: ev.ntt_inverse(x2, out=y2), b2),
+               # the headline kernel itself: >= `seconds` of back-to-back dpfhe_ct_mul launches on this rank's shard (algorithmic bytes 7 L N 8 per pair)
+               "ct_mul_shard": window(lambda: ev.multiply(a, b, out=outs[0]), 7 * L * N * 8 * a.data.shape[0]),
                "note": "each entry: back-to-back launches for >= seconds_per_window, one host sync at the end; power / cap / sclk are hwmon samples of this GPU over "
                        "that window.  frac_of_copy = the entry's algorithmic GB/s over copy_1GiB's (the same run, the same thermal state); configs[1]'s 128 MiB live in the "
                        "Infinity Cache, the 1 GiB entries stream from HBM"}
@@ -694,35 +697,46 @@ def main():
         other["n8192_l6"] = c5
         del a5, b5, o5, x5, y5
         ctx5.close()
-        # the GENERIC-PRIME arithmetic (ShoupArith) at the headline shape: N=4096, four primes of 59 / 50 / 40 / 33 bits (none 2^60 - d), configs[1]'s
-        # 1024 RNS polynomials and configs[3]'s 8192-pair shard - what a chain of mixed-width limbs pays against the fold primes
-        try:
-            pg = FheParams.generic_n4096_l4()
+        # PER-LIMB ARITHMETIC CLASSES (round 6) at the headline shape: N=4096, L=4, configs[1]'s 1024 RNS polynomials and configs[3]'s 8192-pair shard on
+        # parameter sets whose primes are NOT the pinned 2^60 - d ones.  Until round 5 one such limb sent the whole context to the generic (Harvey / Shoup)
+        # kernels; now every limb runs on the fastest policy its prime admits (include/dpfhe.h dpfhe_ctx_limb_class).
+        #   shoup_n4096_l4  : the round-5 line's primes, 59 / 50 / 40 / 33 bits (now fold_scaled, fold_scaled, f64, f64) - name kept for continuity
+        #   p31_n4096_l4    : four 31-bit primes (f64: residues as doubles inside a transform) - the reference's widest integer is INT32 (hal.hpp:27-33)
+        #   shoup49_n4096_l4: four 49-bit primes - too wide for f64, too far from 2^60 for the scaled fold: what still runs on the generic kernels
+        def class_line(pg, what):
             ctxg = Context(pg, local_rank)
             evg = Evaluator(ctxg)
-            qg = torch.tensor(pg.moduli, dtype=torch.int64, device=dev)
-            xg = torch.randint(0, 2**62, (1024, L, N), generator=g, dtype=torch.int64, device=dev) % qg.view(1, L, 1)
-            yg = torch.empty_like(xg)
-            sg = {"workload": "generic primes (59/50/40/33 bits, Harvey/Shoup butterflies + 128-bit Barrett products): N=4096, L=4; NTT on 1024 RNS polys (configs[1]), "
-                              "fused multiply on 8192 pairs (configs[3]'s shard)", "moduli_bits": [int(m).bit_length() for m in pg.moduli], "uses_fold": ctxg.uses_fold}
-            for name, fn in (("ntt_fwd", evg.ntt_forward), ("ntt_inv", evg.ntt_inverse)):
-                t = timed(lambda: fn(xg, out=yg), 10)
-                nbytes = 2 * N * 8 * 1024 * L
-                sg[name] = {"median_us": t * 1e6, "GBps": nbytes / t / 1e9, "frac_of_hbm_peak": nbytes / t / HBM_PEAK}
-            del xg, yg
-            ag = Ciphertext(torch.randint(0, 2**62, (B, 2, L, N), generator=g, dtype=torch.int64, device=dev) % qg.view(1, 1, L, 1))
-            bg = Ciphertext(torch.randint(0, 2**62, (B, 2, L, N), generator=g, dtype=torch.int64, device=dev) % qg.view(1, 1, L, 1))
-            og = outs[0].view(-1)[: B * 3 * L * N].view(B, 3, L, N)
-            t = timed(lambda: evg.multiply(ag, bg, out=og), 5)
-            sg["ct_mul"] = {"pairs": B, "median_us": t * 1e6, "per_s": B / t, "frac_of_hbm_peak": 7 * L * N * 8 * B / t / HBM_PEAK}
-            t = timed(lambda: ev.multiply(a, b, out=og), 5)     # the fold arm, same launch shape, same moment
-            sg["fold_ct_mul_per_s_same_moment"] = B / t
-            sg["fold_over_shoup_ct_mul"] = sg["fold_ct_mul_per_s_same_moment"] / sg["ct_mul"]["per_s"]
-            other["shoup_n4096_l4"] = sg
-            del ag, bg
-            ctxg.close()
-        except Exception as e:
-            other["shoup_n4096_l4"] = {"error": repr(e)[:200]}
+            try:
+                qg = torch.tensor(pg.moduli, dtype=torch.int64, device=dev)
+                xg = torch.randint(0, 2**62, (1024, L, N), generator=g, dtype=torch.int64, device=dev) % qg.view(1, L, 1)
+                yg = torch.empty_like(xg)
+                sg = {"workload": what + ": N=4096, L=4; NTT on 1024 RNS polys (configs[1]), fused multiply on 8192 pairs (configs[3]'s shard)",
+                      "moduli_bits": [int(m).bit_length() for m in pg.moduli], "uses_fold": ctxg.uses_fold, "limb_classes": list(ctxg.limb_classes)}
+                for name, fn in (("ntt_fwd", evg.ntt_forward), ("ntt_inv", evg.ntt_inverse)):
+                    t = timed(lambda: fn(xg, out=yg), 10)
+                    nbytes = 2 * N * 8 * 1024 * L
+                    sg[name] = {"median_us": t * 1e6, "GBps": nbytes / t / 1e9, "frac_of_hbm_peak": nbytes / t / HBM_PEAK}
+                del xg, yg
+                ag = Ciphertext(torch.randint(0, 2**62, (B, 2, L, N), generator=g, dtype=torch.int64, device=dev) % qg.view(1, 1, L, 1))
+                bg = Ciphertext(torch.randint(0, 2**62, (B, 2, L, N), generator=g, dtype=torch.int64, device=dev) % qg.view(1, 1, L, 1))
+                og = outs[0].view(-1)[: B * 3 * L * N].view(B, 3, L, N)
+                t = timed(lambda: evg.multiply(ag, bg, out=og), 5)
+                sg["ct_mul"] = {"pairs": B, "median_us": t * 1e6, "per_s": B / t, "frac_of_hbm_peak": 7 * L * N * 8 * B / t / HBM_PEAK}
+                t = timed(lambda: ev.multiply(a, b, out=og), 5)     # the fold arm, same launch shape, same moment
+                sg["fold_ct_mul_per_s_same_moment"] = B / t
+                sg["fold_over_shoup_ct_mul"] = sg["fold_ct_mul_per_s_same_moment"] / sg["ct_mul"]["per_s"]
+                del ag, bg
+                return sg
+            finally:
+                ctxg.close()
+        from deeppowers_amd.params import ntt_primes
+        for key, mk, what in (("shoup_n4096_l4", FheParams.generic_n4096_l4, "primes of 59/50/40/33 bits, none 2^60 - d (classes: scaled fold x2, f64 x2)"),
+                              ("p31_n4096_l4", lambda: ntt_primes(12, 4, 31), "four 31-bit primes (f64 class: error-free FMA products on doubles)"),
+                              ("shoup49_n4096_l4", lambda: ntt_primes(12, 4, 49), "four 49-bit primes (generic class: Harvey/Shoup butterflies + 128-bit Barrett products)")):
+            try:
+                other[key] = class_line(mk(), what)
+            except Exception as e:
+                other[key] = {"error": repr(e)[:200]}
         # N3: one token through the reference's dense-layer shapes under encryption, slot-packed, through the C++
         # operator API (examples/encrypted_gpt2_linear.cpp: PackedLinear at N=8192, 5 data limbs + special prime); the program
         # decrypts every result and compares it with W x mod t
@@ -1048,6 +1062,11 @@ def main():
         detail["ntt"] = ntt_result
     if sustained_result is not None:
         detail["sustained"] = sustained_result
+        cs = sustained_result.get("ct_mul_shard")
+        if cs:   # the sustained figure of the headline kernel, next to the ntt_sustained_* scalars
+            result["roofline"].update({"ct_mul_sustained_frac": cs["frac_of_hbm_peak"], "ct_mul_sustained_per_s": a.data.shape[0] / (cs["us_per_launch"] * 1e-6),
+                                       "ct_mul_sustained_window_s": cs["window_s"], "ct_mul_sustained_board_w": cs.get("board_w_mean"),
+                                       "ct_mul_sustained_cap_w": cs.get("cap_w"), "ct_mul_sustained_sclk_mhz": cs.get("sclk_mhz_mean")})
     if rank == 0:
         try:   # where a workgroup of the multiply spends its life ON THIS BOX (diagnostic launch after the timed region; include/dpfhe.h dpfhe_debug_ct_mul_trace)
             regime_result["workgroup_timeline_us"] = workgroup_timeline()
@@ -1066,6 +1085,11 @@ def main():
             result["roofline"].update({"shoup_ntt_fwd_frac": sg["ntt_fwd"]["frac_of_hbm_peak"], "shoup_ntt_inv_frac": sg["ntt_inv"]["frac_of_hbm_peak"],
                                        "shoup_ct_mul_per_s": sg["ct_mul"]["per_s"], "shoup_ct_mul_frac": sg["ct_mul"]["frac_of_hbm_peak"],
                                        "fold_over_shoup_ct_mul": sg["fold_over_shoup_ct_mul"]})
+        for key, pre in (("p31_n4096_l4", "p31"), ("shoup49_n4096_l4", "shoup49")):
+            sg = other_result.get(key) or {}
+            if "ct_mul" in sg:
+                result["roofline"].update({pre + "_ntt_fwd_frac": sg["ntt_fwd"]["frac_of_hbm_peak"], pre + "_ntt_inv_frac": sg["ntt_inv"]["frac_of_hbm_peak"],
+                                           pre + "_ct_mul_per_s": sg["ct_mul"]["per_s"], pre + "_ct_mul_frac": sg["ct_mul"]["frac_of_hbm_peak"]})
     # the reduced result of the last step equals a recomputation of the same sequence on the main stream (every rank checks,
     # rank 0 reports; at N>1 the recomputation repeats the all-gather, so all ranks must take part)
     chk = ev.reduce_sum(Ciphertext(out), stream=main)

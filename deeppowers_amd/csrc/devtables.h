@@ -32,6 +32,9 @@ struct DevTables {
     const typename Arith::Tw* htop_fwd;     // [L]
     const InvLast<typename Arith::Tw>* htop_last;  // [L]  {psi^-brv(1) N^-1, N^-1}
     const InvLast<typename Arith::Tw>* last;  // [L]
+    // FoldScaledArith class only: the same with s^-1 = 2^-(60-k) folded in - the last stage of an inverse transform whose input is a PRODUCT of two
+    // scaled words (the fused multiply's lazy tensor step).  Null elsewhere.
+    const InvLast<typename Arith::Tw>* last2;  // [L]
     const LimbConst* lc;                    // [L]
     int n_limbs;
     // Per-limb arithmetic classes (round 6, dpfhe_cabi.hip): a launch may cover only SOME limbs of the context - those whose primes this policy
@@ -53,5 +56,15 @@ DPF_HD void block_item_limb(const TB& tb, size_t blk, size_t& item, int& limb) {
         limb = (int)(blk % (unsigned)tb.n_limbs);
     }
 }
+
+// the batched transforms' view of a context with per-limb arithmetic classes (kernels.h ntt_classes_kernel, dpfhe_cabi.hip mixed_layout)
+struct MixedTables {
+    const void* fwd;            // [L][N] twiddles, slot l in limb l's format, kernel layout of the batched transforms
+    const void* inv;
+    const void* last;           // [L] InvLast
+    const LimbConst* lc;        // [L], each as its class reads it (tables.h limb_const_of_class)
+    int n_limbs;
+    unsigned long long cls_map; // 4 bits per limb: tables.h LimbClass
+};
 
 }  // namespace dpfhe

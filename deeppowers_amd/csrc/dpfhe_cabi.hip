@@ -89,10 +89,13 @@ struct dpfhe_ctx {
     // `classes` is set when L <= 16, 8 <= log2 N <= 14 and at least one limb has a faster class than the context-wide policy.
     bool classes = false;
     unsigned char limb_cls[16] = {};                  // LimbClass of limb i
-    void* class_blob[kLimbClasses] = {};              // device tables of the Fold / F64 / FoldScaled classes (the Shoup class reads `shoup`)
-    DevTables<FoldArith> cls_fold{};
+    unsigned long long cls_map = 0;                   // the same, 4 bits per limb
+    void* class_blob = nullptr;                       // ONE blob of tables whose per-limb slots are in their limb's class format (mixed_layout)
+    DevTables<FoldArith> cls_fold{};                  // typed views of it; the active-limb maps are set per launch (for_each_class)
     DevTables<F64Arith> cls_f64{};
     DevTables<FoldScaledArith> cls_fscaled{};
+    DevTables<ShoupArith> cls_shoup{};
+    MixedTables mixed{};                              // the batched transforms' one-launch view (kernels.h ntt_classes_kernel)
     // scratch of the composed large-ring operations: a pool of this context's own (created on first use) that keeps what it has been
     // given until the context goes - the default pool hands its memory back at every synchronisation and pays the mapping again
     struct ScratchArena { hipStream_t stream; u64* p; size_t words; };
@@ -241,57 +244,54 @@ extern "C" const char* dpfhe_ct_mul_variant_name(int variant) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// Tables of one arithmetic class of a non-uniform context (round 6): LimbConst[L] | fwd4 | inv4 | (fwd | inv when the batched transforms use another
-// layout) | last[L], slots indexed by the limb's number in the context, only the class's limbs filled.  Single-kernel transforms only (log2 N <= 14).
-template <class Arith, class MakeTw>
-static hipError_t build_class_tables(int log2n, const std::vector<HostLimbTables>& ht, LimbClass cls, const unsigned char* limb_cls, MakeTw make_tw,
-                                     DevTables<Arith>& tb, void** blob_out) {
-    typedef typename Arith::Tw Tw;
-    const size_t L = ht.size(), n = (size_t)1 << log2n;
+// Tables of a context with per-limb arithmetic classes (round 6): ONE blob, LimbConst[L] | fwd4 | inv4 | (fwd | inv when the batched transforms use another
+// layout) | last[L] | last2[L], every per-limb slot in the format of that limb's class (all twiddle types are 16 bytes: the strides agree).  The classes'
+// DevTables are typed views of the same blob, each with its own active-limb map.  Single-kernel transforms only (log2 N <= 14).
+static_assert(sizeof(TwShoup) == 16 && sizeof(TwFold) == 16 && sizeof(TwF64) == 16, "the per-limb slots of the mixed tables share one stride");
+struct MixedLayout { size_t o_lc, o_fwd4, o_inv4, o_fwd, o_inv, o_last, o_last2, total; };
+static MixedLayout mixed_layout(int log2n, size_t L) {
     auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
-    const int loge_ntt = ntt_loge(log2n);
-    const bool two_geo = loge_ntt != kFusedLoge;
-    const size_t tab = L * n * sizeof(Tw);
-    const size_t o_lc = 0, o_fwd4 = up(L * sizeof(LimbConst)), o_inv4 = up(o_fwd4 + tab), o_fwd = two_geo ? up(o_inv4 + tab) : o_fwd4,
-                 o_inv = two_geo ? up(o_fwd + tab) : o_inv4, o_last = up(o_inv + tab), total = up(o_last + L * sizeof(InvLast<Tw>));
-    std::vector<unsigned char> blob(total, 0);
-    int n_active = 0;
-    unsigned long long map = 0;
-    for (size_t l = 0; l < L; ++l) {
-        if (limb_cls[l] != (unsigned char)cls) continue;
-        map |= (unsigned long long)l << (4 * n_active++);
-        const u64 q = ht[l].lc.q;
-        const LimbConst lc = limb_const_of_class(ht[l].lc, cls);
-        std::memcpy(&blob[o_lc + l * sizeof(LimbConst)], &lc, sizeof(LimbConst));
-        auto pack = [&](const std::vector<u64>& words, int loge, size_t off) {
-            std::vector<Tw> t(words.size());
-            for (size_t i = 0; i < words.size(); ++i) t[i] = make_tw(words[i], q);
-            permute_window0(t, log2n, loge, geo_perm_stages(log2n, loge));
-            std::memcpy(&blob[off], t.data(), t.size() * sizeof(Tw));
-        };
-        for (int geo = 0; geo < (two_geo ? 2 : 1); ++geo) {
-            const int loge = geo ? loge_ntt : kFusedLoge;
-            pack(ht[l].rp, loge, (geo ? o_fwd : o_fwd4) + l * n * sizeof(Tw));
-            pack(ht[l].irp, loge, (geo ? o_inv : o_inv4) + l * n * sizeof(Tw));
-        }
-        reinterpret_cast<InvLast<Tw>*>(&blob[o_last])[l] = InvLast<Tw>{make_tw(ht[l].w_last, q), make_tw(ht[l].lc.ninv, q)};
-    }
-    void* d = nullptr;
-    hipError_t e = hipMalloc(&d, total);
-    if (e == hipSuccess) e = hipMemcpy(d, blob.data(), total, hipMemcpyHostToDevice);
-    if (e != hipSuccess) { if (d) (void)hipFree(d); return e; }
-    unsigned char* b = static_cast<unsigned char*>(d);
-    tb = DevTables<Arith>{};
-    tb.lc = reinterpret_cast<const LimbConst*>(b + o_lc);
-    tb.fwd = reinterpret_cast<const Tw*>(b + o_fwd); tb.inv = reinterpret_cast<const Tw*>(b + o_inv);
-    tb.fwd4 = reinterpret_cast<const Tw*>(b + o_fwd4); tb.inv4 = reinterpret_cast<const Tw*>(b + o_inv4);
-    tb.last = reinterpret_cast<const InvLast<Tw>*>(b + o_last);
+    const size_t n = (size_t)1 << log2n, tab = L * n * 16;
+    const bool two_geo = ntt_loge(log2n) != kFusedLoge;
+    MixedLayout m;
+    m.o_lc = 0; m.o_fwd4 = up(L * sizeof(LimbConst)); m.o_inv4 = up(m.o_fwd4 + tab);
+    m.o_fwd = two_geo ? up(m.o_inv4 + tab) : m.o_fwd4; m.o_inv = two_geo ? up(m.o_fwd + tab) : m.o_inv4;
+    m.o_last = up(m.o_inv + tab); m.o_last2 = up(m.o_last + L * 32); m.total = up(m.o_last2 + L * 32);
+    return m;
+}
+template <class Tw, class MakeTw>
+static void fill_mixed_limb(std::vector<unsigned char>& blob, const MixedLayout& m, int log2n, size_t l, const HostLimbTables& t, LimbClass cls, MakeTw make_tw) {
+    static_assert(sizeof(Tw) == 16 && sizeof(InvLast<Tw>) == 32, "slot sizes");
+    const size_t n = (size_t)1 << log2n;
+    const u64 q = t.lc.q;
+    const LimbConst lc = limb_const_of_class(t.lc, cls);
+    std::memcpy(&blob[m.o_lc + l * sizeof(LimbConst)], &lc, sizeof(LimbConst));
+    auto pack = [&](const std::vector<u64>& words, int loge, size_t off) {
+        std::vector<Tw> tw(words.size());
+        for (size_t i = 0; i < words.size(); ++i) tw[i] = make_tw(words[i], q);
+        permute_window0(tw, log2n, loge, geo_perm_stages(log2n, loge));
+        std::memcpy(&blob[off], tw.data(), tw.size() * sizeof(Tw));
+    };
+    pack(t.rp, kFusedLoge, m.o_fwd4 + l * n * 16);
+    pack(t.irp, kFusedLoge, m.o_inv4 + l * n * 16);
+    if (m.o_fwd != m.o_fwd4) { pack(t.rp, ntt_loge(log2n), m.o_fwd + l * n * 16); pack(t.irp, ntt_loge(log2n), m.o_inv + l * n * 16); }
+    reinterpret_cast<InvLast<Tw>*>(&blob[m.o_last])[l] = InvLast<Tw>{make_tw(t.w_last, q), make_tw(t.lc.ninv, q)};
+    // products of two scaled words carry s = 2^(60-k) twice: their inverse transform ends on twiddles with s^-1 folded in (DevTables::last2)
+    const u64 sinv = cls == kClassFoldScaled ? h_powmod((1ull << fold_scaled_shift(q)) % q, q - 2, q) : 1;
+    reinterpret_cast<InvLast<Tw>*>(&blob[m.o_last2])[l] = InvLast<Tw>{make_tw(h_mulmod(t.w_last, sinv, q), q), make_tw(h_mulmod(t.lc.ninv, sinv, q), q)};
+}
+template <class Arith>
+static DevTables<Arith> mixed_view(const unsigned char* b, const MixedLayout& m, size_t L) {
+    typedef typename Arith::Tw Tw;
+    DevTables<Arith> tb{};
+    tb.lc = reinterpret_cast<const LimbConst*>(b + m.o_lc);
+    tb.fwd = reinterpret_cast<const Tw*>(b + m.o_fwd); tb.inv = reinterpret_cast<const Tw*>(b + m.o_inv);
+    tb.fwd4 = reinterpret_cast<const Tw*>(b + m.o_fwd4); tb.inv4 = reinterpret_cast<const Tw*>(b + m.o_inv4);
+    tb.last = reinterpret_cast<const InvLast<Tw>*>(b + m.o_last);
+    tb.last2 = reinterpret_cast<const InvLast<Tw>*>(b + m.o_last2);
     tb.n_sub = 1;
     tb.n_limbs = (int)L;
-    tb.n_active = n_active;
-    tb.active_map = map;
-    *blob_out = d;
-    return hipSuccess;
+    return tb;
 }
 
 extern "C" int dpfhe_ctx_create(dpfhe_ctx** out, uint32_t log2_n, uint32_t n_limbs, const uint64_t* moduli,
@@ -446,18 +446,34 @@ extern "C" int dpfhe_ctx_create(dpfhe_ctx** out, uint32_t log2_n, uint32_t n_lim
         bool any_fast = false;
         for (size_t l = 0; l < L; ++l) { c->limb_cls[l] = (unsigned char)limb_class(moduli[l]); any_fast = any_fast || c->limb_cls[l] != kClassShoup; }
         if (any_fast) {
-            auto has = [&](LimbClass k) { for (size_t l = 0; l < L; ++l) if (c->limb_cls[l] == k) return true; return false; };
-            hipError_t ce = hipSuccess;
-            if (has(kClassFold)) ce = build_class_tables<FoldArith>((int)log2_n, ht, kClassFold, c->limb_cls, [](u64 w, u64 q) { return h_tw_fold(w, q); }, c->cls_fold, &c->class_blob[kClassFold]);
-            if (ce == hipSuccess && has(kClassF64)) ce = build_class_tables<F64Arith>((int)log2_n, ht, kClassF64, c->limb_cls, [](u64 w, u64 q) { return h_make_tw<TwF64>(w, q); }, c->cls_f64, &c->class_blob[kClassF64]);
-            if (ce == hipSuccess && has(kClassFoldScaled)) ce = build_class_tables<FoldScaledArith>((int)log2_n, ht, kClassFoldScaled, c->limb_cls, [](u64 w, u64 q) { return h_tw_fold_scaled(w, q, fold_scaled_shift(q)); }, c->cls_fscaled, &c->class_blob[kClassFoldScaled]);
+            const MixedLayout m = mixed_layout((int)log2_n, L);
+            std::vector<unsigned char> mb(m.total, 0);
+            for (size_t l = 0; l < L; ++l) {
+                const LimbClass k = (LimbClass)c->limb_cls[l];
+                c->cls_map |= (unsigned long long)k << (4 * l);
+                if (k == kClassFold) fill_mixed_limb<TwFold>(mb, m, (int)log2_n, l, ht[l], k, [](u64 w, u64 q) { return h_tw_fold(w, q); });
+                else if (k == kClassF64) fill_mixed_limb<TwF64>(mb, m, (int)log2_n, l, ht[l], k, [](u64 w, u64 q) { return h_make_tw<TwF64>(w, q); });
+                else if (k == kClassFoldScaled) fill_mixed_limb<TwFold>(mb, m, (int)log2_n, l, ht[l], k, [](u64 w, u64 q) { return h_tw_fold_scaled(w, q, fold_scaled_shift(q)); });
+                else fill_mixed_limb<TwShoup>(mb, m, (int)log2_n, l, ht[l], k, [](u64 w, u64 q) { return h_make_tw<TwShoup>(w, q); });
+            }
+            hipError_t ce = hipMalloc(&c->class_blob, m.total);
+            if (ce == hipSuccess) ce = hipMemcpy(c->class_blob, mb.data(), m.total, hipMemcpyHostToDevice);
             if (ce != hipSuccess) {
-                for (void* b : c->class_blob) if (b) (void)hipFree(b);
+                if (c->class_blob) (void)hipFree(c->class_blob);
                 (void)hipFree(c->d_blob);
                 delete c;
                 (void)hipSetDevice(prev);
                 return fail(ce == hipErrorOutOfMemory ? DPFHE_OUT_OF_MEMORY : DPFHE_DEVICE_ERROR, "dpfhe_ctx_create: class table upload", hipGetErrorString(ce));
             }
+            const unsigned char* b = static_cast<const unsigned char*>(c->class_blob);
+            c->cls_fold = mixed_view<FoldArith>(b, m, L);
+            c->cls_f64 = mixed_view<F64Arith>(b, m, L);
+            c->cls_fscaled = mixed_view<FoldScaledArith>(b, m, L);
+            c->cls_shoup = mixed_view<ShoupArith>(b, m, L);
+            c->mixed.fwd = b + m.o_fwd; c->mixed.inv = b + m.o_inv; c->mixed.last = b + m.o_last;
+            c->mixed.lc = reinterpret_cast<const LimbConst*>(b + m.o_lc);
+            c->mixed.n_limbs = (int)L;
+            c->mixed.cls_map = c->cls_map;
             c->classes = true;
         }
     }
@@ -470,7 +486,7 @@ extern "C" int dpfhe_ctx_create(dpfhe_ctx** out, uint32_t log2_n, uint32_t n_lim
 extern "C" int dpfhe_ctx_destroy(dpfhe_ctx* c) {
     if (!c) return DPFHE_SUCCESS;
     if (c->d_blob) (void)hipFree(c->d_blob);
-    for (void* b : c->class_blob) if (b) (void)hipFree(b);
+    if (c->class_blob) (void)hipFree(c->class_blob);
     for (auto& a : c->scratch_arenas) if (a.p) (void)hipFree(a.p);
     delete c;
     return DPFHE_SUCCESS;
@@ -528,7 +544,7 @@ static bool ntt_grid_fits(const dpfhe_ctx* c, size_t npolys) {
 }
 // arguments validated, device selected by the caller
 // One launch per arithmetic class present among the first `limbs_used` limbs of a non-uniform context (dpfhe_ctx::classes): `fn(tables)` launches
-// over the class's limbs.  The Shoup class reads the context's complete generic tables through the same active-limb map.
+// over the class's limbs.
 template <class Fn>
 static int for_each_class(const dpfhe_ctx* c, size_t limbs_used, Fn fn) {
     auto restrict_to = [&](auto tb, LimbClass k) {
@@ -544,7 +560,7 @@ static int for_each_class(const dpfhe_ctx* c, size_t limbs_used, Fn fn) {
     { auto tb = restrict_to(c->cls_fold, kClassFold); if (tb.n_active && !rc) rc = fn(tb); }
     { auto tb = restrict_to(c->cls_f64, kClassF64); if (tb.n_active && !rc) rc = fn(tb); }
     { auto tb = restrict_to(c->cls_fscaled, kClassFoldScaled); if (tb.n_active && !rc) rc = fn(tb); }
-    { auto tb = restrict_to(c->shoup, kClassShoup); if (tb.n_active && !rc) rc = fn(tb); }
+    { auto tb = restrict_to(c->cls_shoup, kClassShoup); if (tb.n_active && !rc) rc = fn(tb); }
     return rc;
 }
 
@@ -553,9 +569,18 @@ static int ntt_launch_items(dpfhe_ctx* c, bool inverse, uint64_t* out, const uin
     const size_t Lu = limbs_used ? limbs_used : c->n_limbs;
     int rc;
     if (c->classes) {
-        rc = for_each_class(c, Lu, [&](const auto& tb) {
-            return launch_ntt((int)c->log2n, inverse, out, in, items * (size_t)tb.n_active, tb, s);
-        });
+        // several classes among these limbs: one launch, the class branch inside the kernel.  One class only: that class's own kernel (the merged
+        // kernel carries the register budget of its widest arm: measured 62 against 69 % of HBM peak on an all-f64 context)
+        bool several = false;
+        for (size_t l = 1; l < Lu; ++l) several = several || c->limb_cls[l] != c->limb_cls[0];
+        rc = 1;
+        if (several) {
+            MixedTables mt = c->mixed;
+            mt.n_limbs = (int)Lu;
+            rc = launch_ntt_classes((int)c->log2n, inverse, out, in, items * Lu, mt, s);
+        }
+        if (rc == 1)                                                                   // (one class, or a geometry without the merged kernel)
+            rc = for_each_class(c, Lu, [&](const auto& tb) { return launch_ntt((int)c->log2n, inverse, out, in, items * (size_t)tb.n_active, tb, s); });
     } else if (c->fold) {
         DevTables<FoldArith> td = c->foldt; td.n_limbs = (int)Lu;
         rc = launch_ntt<FoldArith>((int)c->log2n, inverse, out, in, items * Lu, td, s);

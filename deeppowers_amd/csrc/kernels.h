@@ -323,6 +323,62 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE)) void ntt_inv_kernel(u64* __rest
     B::template store_top<NT>(tid, x, out + p * B::G::N);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Round 6: the batched transforms of a context whose limbs run on DIFFERENT arithmetic classes (dpfhe_cabi.hip dpfhe_ctx::classes) in ONE launch.
+// The tables of such a context live in one blob whose per-limb slots are each in their limb's own format (all twiddle types are 16 bytes, so the
+// strides agree); the limb's class is workgroup-uniform, so the kernel branches once, on a scalar, into that class's transform - the same per-thread
+// code as ntt_fwd_kernel / ntt_inv_kernel.  (One launch per class measured 54.7 / 50.6 % of HBM peak on the 59/50/40/33-bit context at configs[1]'s
+// batch, against 69 and 59 % for its two classes alone: two half-size launches each pay their own tail.)
+// ------------------------------------------------------------------------------------------------
+template <class Arith, int LOGN, int LOGE>
+__device__ __forceinline__ void ntt_fwd_block(u64* __restrict__ out, const u64* __restrict__ in, size_t p, int limb, const MixedTables& tb, u64* lds) {
+    typedef NttBody<Arith, LOGN, LOGE> B;
+    const int tid = threadIdx.x;
+    const LimbConst lc = tb.lc[limb];
+    const typename B::Tw* tw = reinterpret_cast<const typename B::Tw*>(tb.fwd) + (size_t)limb * B::G::N;
+    u64 x[B::E];
+    B::load_top(tid, x, in + p * B::G::N);
+    FwdChain<B, 0>::run(tid, x, lds, tw, lc);
+    B::fwd_canon(x, lc);
+    if constexpr (B::kLdsIO) B::store_bot_lds(tid, x, out + p * B::G::N, lds);
+    else B::store_bot(tid, x, out + p * B::G::N);
+}
+template <class Arith, int LOGN, int LOGE>
+__device__ __forceinline__ void ntt_inv_block(u64* __restrict__ out, const u64* __restrict__ in, size_t p, int limb, const MixedTables& tb, u64* lds) {
+    typedef NttBody<Arith, LOGN, LOGE> B;
+    const int tid = threadIdx.x;
+    const LimbConst lc = tb.lc[limb];
+    const typename B::Tw* tw = reinterpret_cast<const typename B::Tw*>(tb.inv) + (size_t)limb * B::G::N;
+    const InvLast<typename B::Tw> last = reinterpret_cast<const InvLast<typename B::Tw>*>(tb.last)[limb];
+    typename B::TwRegs tw_first;
+    B::template load_tw<B::NPH - 1, false>(tid, tw, tw_first);
+    u64 x[B::E];
+    if constexpr (B::kLdsIO) B::load_bot_lds(tid, x, in + p * B::G::N, lds);
+    else B::load_bot(tid, x, in + p * B::G::N);
+    InvChain<B, B::NPH - 1, kUnit>::run_with(tid, x, lds, tw, last, lc, tw_first);
+    B::inv_canon(x, lc);
+    B::store_top(tid, x, out + p * B::G::N);
+}
+// (launch bounds: the occupancy the single-class kernels reach - 4 waves per SIMD - is requested explicitly; left alone the merged kernel takes a few
+//  registers more than its widest arm and drops to 3)
+template <int LOGN, int LOGE, bool FWD>
+__global__ __launch_bounds__(1 << (LOGN - LOGE), (1 << (LOGN - LOGE)) >= 1024 ? 1 : (1 << (LOGN - LOGE)) >= 512 ? 2 : 4) void ntt_classes_kernel(u64* __restrict__ out, const u64* __restrict__ in, MixedTables tb) {
+    __shared__ __attribute__((aligned(16))) u64 lds[Geo<LOGN, LOGE>::lds_words()];
+    const size_t p = blockIdx.x;
+    const int limb = (int)(p % (size_t)tb.n_limbs);
+    const int cls = (int)((tb.cls_map >> (4 * limb)) & 15);
+#define DPFHE_CLS_RUN(A)                                                         \
+    do {                                                                         \
+        if (FWD) ntt_fwd_block<A, LOGN, LOGE>(out, in, p, limb, tb, lds);        \
+        else ntt_inv_block<A, LOGN, LOGE>(out, in, p, limb, tb, lds);            \
+    } while (0)
+    if (cls == 2) DPFHE_CLS_RUN(F64Arith);
+    else if (cls == 3) DPFHE_CLS_RUN(FoldScaledArith);
+    else if (cls == 1) DPFHE_CLS_RUN(FoldArith);
+    else DPFHE_CLS_RUN(ShoupArith);
+#undef DPFHE_CLS_RUN
+}
+
 // N3: inverse NTT of sigma_g applied in the NTT domain.  In forward-output order position p carries the evaluation at
 // psi^(2 brv(p) + 1) and sigma_g: a(X) -> a(X^g) only permutes evaluation points, NTT(sigma_g a)[p] = NTT(a)[p'] with
 // 2 brv(p') + 1 = g (2 brv(p) + 1) mod 2N: the kernel gathers its input words through that permutation (8-byte gathers inside one
@@ -507,9 +563,11 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE), 2) void ct_mul_dual_kernel(u64*
     const u64* src_b = b2 + ((bi * 2) * L + limb) * N;
     u64* dst = out3 + ((bi * 3) * L + limb) * N;
     const size_t cstride = L * N;
-    const InvLast<typename B::Tw> last = tb.last[limb];
-    constexpr bool kLazy = Arith::kFold && !OUT_NTT;
-    constexpr int kInvIn = Arith::kFold ? 2 * kMulB : kUnit;
+    constexpr bool kLazy = B::kLazyProducts && !OUT_NTT;   // products of forward outputs as the transforms left them, straight into the inverse (ntt_core.h prod)
+    typedef NttBody<Arith, LOGN, LOGE, 0, kUnit, kLazy> BI;  // the inverse transforms' body: no entry conversion in front of lazy products
+    constexpr bool kScaledProducts = kLazy && Arith::kFoldCore && !Arith::kFold;   // FoldScaledArith: the products carry the scale twice
+    const InvLast<typename B::Tw> last = kScaledProducts ? tb.last2[limb] : tb.last[limb];
+    constexpr int kInvIn = kLazy ? B::kProdInvIn : kUnit;
     const typename B::Tw* const twf = tb.fwd4 + (size_t)limb * N;
     const typename B::Tw* const twi = tb.inv4 + (size_t)limb * N;
 
@@ -522,8 +580,7 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE), 2) void ct_mul_dual_kernel(u64*
         B::template load_top<true>(tid, y, src_b + (size_t)r * cstride);
         if (r) lds_barrier();           // pass 0's last exchange was wave-local, but pass 1's first write crosses waves
         FwdChain2<B, 0>::run(tid, x, y, lds, lds + W, twf, lc);
-        if (!Arith::kFold) { B::fwd_canon(x, lc); B::fwd_canon(y, lc); }
-        else if constexpr (kLazy) B::fwd_reduce_partner(y, lc);     // of every product below exactly one factor is reduced: b0, b1
+        if constexpr (kLazy) B::prod_partner(y, lc);     // of every product below exactly one factor is reduced: b0, b1
         else { B::fwd_canon(x, lc); B::fwd_canon(y, lc); }
         if (r == 0) {
 #pragma unroll
@@ -532,10 +589,10 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE), 2) void ct_mul_dual_kernel(u64*
 #pragma unroll
             for (int k = 0; k < E; ++k) {
                 const u64 a0 = D0[k], b0 = D1[k];
-                if (kLazy) {
-                    D0[k] = FoldArith::mul60(a0, b0, (u32)lc.d);
-                    D1[k] = FoldArith::mul60(a0, y[k], (u32)lc.d) + FoldArith::mul60(x[k], b0, (u32)lc.d);
-                    D2[k] = FoldArith::mul60(x[k], y[k], (u32)lc.d);
+                if constexpr (kLazy) {
+                    D0[k] = B::prod(a0, b0, lc);
+                    D1[k] = B::prod_add(B::prod(a0, y[k], lc), B::prod(x[k], b0, lc));
+                    D2[k] = B::prod(x[k], y[k], lc);
                 } else {
                     D0[k] = Arith::mul_var(a0, b0, lc);
                     D1[k] = add_mod(Arith::mul_var(a0, y[k], lc), Arith::mul_var(x[k], b0, lc), lc.q);
@@ -552,14 +609,14 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE), 2) void ct_mul_dual_kernel(u64*
         // c0 | c1 side by side, then c2.  Before the single chain: its wave-local writes go to buffer 0, which other waves read
         // in the pair's last exchange
         asm volatile("" : "+v"(tid));
-        InvChain2<B, B::NPH - 1, kInvIn>::run(tid, D0, D1, lds, lds + W, twi, last, lc);
+        InvChain2<BI, B::NPH - 1, kInvIn>::run(tid, D0, D1, lds, lds + W, twi, last, lc);
         B::inv_canon(D0, lc);
         B::template store_top<true>(tid, D0, dst);
         B::inv_canon(D1, lc);
         B::template store_top<true>(tid, D1, dst + cstride);
         asm volatile("" : "+v"(tid));
         lds_barrier();
-        InvChain<B, B::NPH - 1, kInvIn>::run(tid, D2, lds, twi, last, lc);
+        InvChain<BI, B::NPH - 1, kInvIn>::run(tid, D2, lds, twi, last, lc);
         B::inv_canon(D2, lc);
         B::template store_top<true>(tid, D2, dst + 2 * cstride);
     }
@@ -584,7 +641,9 @@ template <class Arith, int LOGN, int LOGE, bool TRACE = false>
 __global__ __launch_bounds__(1 << (LOGN - LOGE), 2) void ct_mul_quad_kernel(u64* __restrict__ out3, const u64* __restrict__ a2,
                                                                          const u64* __restrict__ b2, DevTables<Arith> tb, u64* __restrict__ trace = nullptr) {
     typedef NttBody<Arith, LOGN, LOGE> B;
-    static_assert(Arith::kFold && LOGE == kFusedLoge, "FoldArith, fused twiddle layout");
+    static_assert(B::kLazyProducts && LOGE == kFusedLoge, "a policy with lazy products (ntt_core.h prod), fused twiddle layout");
+    typedef NttBody<Arith, LOGN, LOGE, 0, kUnit, true> BI;   // the inverse transforms' body: their input is the register-resident products
+    constexpr bool kScaledProducts = Arith::kFoldCore && !Arith::kFold;   // FoldScaledArith: the products carry the scale twice
     constexpr int E = B::E, N = B::G::N, W = B::G::lds_words();
     __shared__ __attribute__((aligned(16))) u64 lds[2 * W];
     const int tid = threadIdx.x;
@@ -598,8 +657,8 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE), 2) void ct_mul_quad_kernel(u64*
     const u64* src_b = b2 + ((bi * 2) * L + limb) * N;
     u64* dst = out3 + ((bi * 3) * L + limb) * N;
     const size_t cstride = L * N;
-    const InvLast<typename B::Tw> last = tb.last[limb];
-    constexpr int kInvIn = 2 * kMulB;
+    const InvLast<typename B::Tw> last = kScaledProducts ? tb.last2[limb] : tb.last[limb];
+    constexpr int kInvIn = B::kProdInvIn;
     u64 x[E], y[E], z[E], w[E];
     const u64 ts_p = trace_stamp<TRACE>((u64)(uintptr_t)src_a ^ (u64)lc.q);   // prologue done: kernel arguments and limb constants are in registers
     B::template load_top<true>(tid, x, src_a);
@@ -611,21 +670,21 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE), 2) void ct_mul_quad_kernel(u64*
     const u64 ts1 = trace_stamp<TRACE>(x[0]);
     const u64 ts_xl = trace_stamp<TRACE>(x[E - 1]);                             // the whole first operand has arrived
     FwdChain4<B, 0>::run(tid, x, y, z, w, lds, lds + W, tb.fwd4 + (size_t)limb * N, lc);
-    B::fwd_reduce_partner(y, lc);     // of every product below exactly one factor is reduced: b0, b1
-    B::fwd_reduce_partner(w, lc);
+    B::prod_partner(y, lc);     // of every product below exactly one factor is reduced: b0, b1
+    B::prod_partner(w, lc);
     const u64 ts2 = trace_stamp<TRACE>(w[E - 1]);
 #pragma unroll
     for (int k = 0; k < E; ++k) {
         const u64 a0 = x[k], b0 = y[k], a1 = z[k], b1 = w[k];
-        x[k] = FoldArith::mul60(a0, b0, (u32)lc.d);
-        y[k] = FoldArith::mul60(a0, b1, (u32)lc.d) + FoldArith::mul60(a1, b0, (u32)lc.d);
-        z[k] = FoldArith::mul60(a1, b1, (u32)lc.d);
+        x[k] = B::prod(a0, b0, lc);
+        y[k] = B::prod_add(B::prod(a0, b1, lc), B::prod(a1, b0, lc));
+        z[k] = B::prod(a1, b1, lc);
     }
     const u64 ts3 = trace_stamp<TRACE>(z[E - 1]);
 #ifndef DPFHE_CTMUL_NT_STORE
 #define DPFHE_CTMUL_NT_STORE 1
 #endif
-    InvChain3<B, B::NPH - 1, kInvIn>::run(tid, x, y, z, lds, lds + W, tb.inv4 + (size_t)limb * N, last, lc);
+    InvChain3<BI, B::NPH - 1, kInvIn>::run(tid, x, y, z, lds, lds + W, tb.inv4 + (size_t)limb * N, last, lc);
     const u64 ts4 = trace_stamp<TRACE>(z[E - 1]);
     B::inv_canon(x, lc);
     B::template store_top<DPFHE_CTMUL_NT_STORE != 0>(tid, x, dst);

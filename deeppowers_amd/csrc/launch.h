@@ -45,6 +45,9 @@ int launch_ntt(int log2n, bool inverse, u64* out, const u64* in, size_t npolys, 
 template <class Arith>
 int launch_ct_mul(int log2n, unsigned flags, u64* out3, const u64* a2, const u64* b2, size_t blocks, const DevTables<Arith>& tb, hipStream_t s);
 
+// round 6: the batched transforms of a context with per-limb arithmetic classes, one launch (kernels.h ntt_classes_kernel; k_ntt_classes.hip)
+int launch_ntt_classes(int log2n, bool inverse, u64* out, const u64* in, size_t npolys, const MixedTables& tb, hipStream_t s);
+
 // named forms of the fused multiply (launch_impl.h launch_ct_mul_variant; instantiated in k_ctmul_var.hip)
 // (round 5: the single-transform, prefetching and two-pair forms never won on any of 19 boxes - profiles/r04_box_fingerprints.txt - and are gone)
 enum CtMulVariant { kCtMulQuad = 0, kCtMulDual = 1, kCtMulVariants = 2 };

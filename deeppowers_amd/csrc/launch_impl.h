@@ -135,9 +135,9 @@ static int launch_ct_mul_dom(int log2n, u64* out3, const u64* a2, const u64* b2,
 #define DPFHE_CTMUL_QUAD_MAXLOGN 12   // tools/ab_variant.sh quad13 -DDPFHE_CTMUL_QUAD_MAXLOGN=13 builds the N = 8192 form for A/B runs
 #endif
 #define CT_CASE(LN, LE)                                                                                                                              \
-    if constexpr (DPFHE_CTMUL_QUAD && Arith::kFold && !IN_NTT && !OUT_NTT && LN <= DPFHE_CTMUL_QUAD_MAXLOGN)                                                           \
+    if constexpr (DPFHE_CTMUL_QUAD && Arith::kFoldCore && !IN_NTT && !OUT_NTT && LN <= DPFHE_CTMUL_QUAD_MAXLOGN)   /* (F64Arith's quad form spills: pairs) */           \
         hipLaunchKernelGGL((ct_mul_quad_kernel<Arith, LN, kFusedLoge>), dim3((unsigned)blocks), dim3(Geo<LN, kFusedLoge>::T), 0, s, out3, a2, b2, tb, (u64*)nullptr); \
-    else if constexpr (DPFHE_CTMUL_DUAL && Arith::kFold && !IN_NTT && LN <= DPFHE_CTMUL_DUAL_MAXLOGN)                                                                                          \
+    else if constexpr (DPFHE_CTMUL_DUAL && (Arith::kFoldCore || Arith::kF64) && !IN_NTT && LN <= DPFHE_CTMUL_DUAL_MAXLOGN)                                                                     \
         hipLaunchKernelGGL((ct_mul_dual_kernel<Arith, LN, kFusedLoge, OUT_NTT>), dim3((unsigned)blocks), dim3(Geo<LN, kFusedLoge>::T), 0, s, out3, a2, b2, tb); \
     else                                                                                                                                             \
         hipLaunchKernelGGL((ct_mul_kernel<Arith, LN, kFusedLoge, IN_NTT, OUT_NTT>), dim3((unsigned)blocks), dim3(Geo<LN, kFusedLoge>::T), 0, s, out3, a2, b2, tb)

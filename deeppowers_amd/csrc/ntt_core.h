@@ -276,7 +276,9 @@ constexpr CtfPlan<LOGE> make_ctf_plan(int lb_top, int r, int in_bound, int out_c
 constexpr int kSubInvOut = 7 * kUnit;   // lo + hi < 14 q: the column stage's sum fits mul_ninv's precondition, its difference + 7 q a 64-bit word
 // FWD_IN: static bound (q/1024) of every word the FORWARD transform is given.  kUnit = canonical residues; kRedB = any residue below 2^60 (a word that is
 // canonical for ANOTHER limb of a FoldArith context - the digits of a key switch: the first stage's fused multiply-add reduces it for free).
-template <class Arith, int LOGN, int LOGE, int SUB = 0, int FWD_IN = (SUB ? kCtfMid : kUnit)>
+// RAW_INV: the INVERSE transform's input is already in the policy's internal form (register-resident products of forward outputs in the fused
+// multiply: doubles for F64Arith, scaled words for FoldScaledArith) - no Arith::enter in front of its first stage.
+template <class Arith, int LOGN, int LOGE, int SUB = 0, int FWD_IN = (SUB ? kCtfMid : kUnit), bool RAW_INV = false>
 struct NttBody {
     typedef Geo<LOGN, LOGE> G;
     typedef typename Arith::Tw Tw;
@@ -581,8 +583,8 @@ struct NttBody {
         return make_ctf_plan<LOGE>(ph.b - ph.c + ph.r - 1, ph.r, in, (P == NPH - 1) ? kWord : kCtfMid);
     }
     // bound of every word a forward transform hands to a dyadic product when its output is left lazy
-    static constexpr int kFwdOutBound = Arith::kFold ? ctf_plan<NPH - 1>().out_bound : 4 * kUnit;
-    static_assert(!Arith::kFold || kFwdOutBound <= kLimitPartner, "lazy forward outputs must satisfy mul60's bound");
+    static constexpr int kFwdOutBound = Arith::kFoldCore ? ctf_plan<NPH - 1>().out_bound : Arith::kF64 ? (LOGN + 1) * kUnit : 4 * kUnit;
+    static_assert(!Arith::kFoldCore || kFwdOutBound <= kLimitPartner, "lazy forward outputs must satisfy mul60's bound");
 
     // generic policies (FoldScaledArith, F64Arith) convert a canonical word when it enters a transform and back when it leaves (Arith::enter /
     // Arith::leave); the pinned-prime and Harvey policies work on the words as they are
@@ -678,12 +680,42 @@ struct NttBody {
 
     // forward output left lazy for a dyadic product, but every word < 2^60 + 2^29 (mul60's bound on its SECOND operand):
     // only the differences (y') need the 3-instruction reduction, the sums are reduced already
-    static DPF_HD void fwd_reduce_partner(u64 (&x)[E], const LimbConst& lc) {
-        static_assert(Arith::kFold, "FoldArith only");
+    static DPF_HD void fwd_reduce_partner(u64 (&x)[E], const LimbConst& lc_in) {
+        static_assert(Arith::kFoldCore, "fold policies only");
+        const auto& lc = Arith::ntt_lc(lc_in);
         constexpr CtfPlan<LOGE> plan = ctf_plan<NPH - 1>();
 #pragma clang loop unroll(full)
         for (int k = 0; k < E; ++k)
             if (plan.out[k] > kRedB) x[k] = FoldArith::reduce(x[k], lc);
+    }
+
+    // ---------------- lazy products of forward outputs (the fused multiply's tensor step, in registers) ----------------
+    // prod(a, b): a = a forward output as the transform left it, b = one that went through prod_partner.  Sums of two products (prod_add) feed the
+    // inverse transform of a RAW_INV body with IN = kProdInvIn.  FoldScaledArith: a product of two scaled words carries the scale twice; the inverse
+    // then runs on last-stage twiddles with s^-1 folded in (DevTables::last2).
+    static constexpr bool kLazyProducts = Arith::kFoldCore || Arith::kF64;
+    static constexpr int kProdInvIn = Arith::kF64 ? 2 * kUnit : 2 * kMulB;
+    static_assert(!Arith::kF64 || (LOGN + 1) * kUnit / 2 <= kWord / 2, "F64Arith: |a b / q| <= (log2 N + 1) q / 2 must stay below 2^50 for the quotient estimate");
+    static DPF_HD void prod_partner(u64 (&y)[E], const LimbConst& lc) {
+        if constexpr (Arith::kF64) {
+            const double q = Arith::qd(lc), qi = Arith::qinv(lc);
+#pragma clang loop unroll(full)
+            for (int k = 0; k < E; ++k) y[k] = Arith::b(Arith::reduce(Arith::f(y[k]), q, qi));   // |y| <= q / 2 + 1
+        } else fwd_reduce_partner(y, lc);
+    }
+    static DPF_HD u64 prod(u64 a, u64 b, const LimbConst& lc) {
+        if constexpr (Arith::kF64) {
+            // |a| < (log2 N + 1) q, |b| <= q / 2 + 1: the quotient estimate is within 0.375 of a b / q, so |result| < 0.875 q + 1; both fma exact (modarith.h)
+            const double x = Arith::f(a), y = Arith::f(b), q = Arith::qd(lc);
+            const double p = x * y;
+            const double e = __builtin_fma(x, y, -p);
+            const double h = Arith::rint_mul(p, Arith::qinv(lc));
+            return Arith::b(__builtin_fma(-h, q, p) + e);
+        } else return FoldArith::mul60(a, b, (u32)lc.d);
+    }
+    static DPF_HD u64 prod_add(u64 p, u64 r) {
+        if constexpr (Arith::kF64) return Arith::b(Arith::f(p) + Arith::f(r));
+        else return chk_add(p, r);
     }
 
     // ---------------- inverse (Gentleman-Sande) phase; forward phase list walked backwards -------
@@ -703,7 +735,7 @@ struct NttBody {
         constexpr Phase ph = G::phase(P);
         constexpr GsPlan<LOGE> plan = gs_plan<P, IN>();
         const auto& lc = Arith::ntt_lc(lc_in);
-        if constexpr (P == NPH - 1) enter(x, lc_in);
+        if constexpr (P == NPH - 1 && !RAW_INV) enter(x, lc_in);
         if constexpr (Arith::kF64) {
             static_assert(IN <= kWord / 2, "F64Arith: the first butterfly's operands must fit the plan's cap");
             const double q = Arith::qd(lc), qi = Arith::qinv(lc);

@@ -404,45 +404,65 @@ extern "C" int emu_ntt_halves(int arith, int inverse, u64 q, u64 psi, const u64*
 // the same per-thread transform code and the same dyadic sequence, so that the bound plans and the relaxed mul60
 // precondition (lazy forward outputs < 14 q times partially reduced b-side factors) are checked on the CPU with the
 // wrap-around / precondition counters armed.  out3 = (c0, c1, c2) of one limb.
-template <int LOGN, int LOGE>
-static int emu_ct_mul_fold(u64 q, u64 psi, const u64* a0, const u64* a1, const u64* b0, const u64* b1, u64* out3) {
-    typedef NttBody<FoldArith, LOGN, LOGE> B;
+template <class Arith, int LOGN, int LOGE>
+static int emu_ct_mul_lazy(u64 q, u64 psi, const u64* a0, const u64* a1, const u64* b0, const u64* b1, u64* out3) {
+    typedef NttBody<Arith, LOGN, LOGE> B;
+    typedef NttBody<Arith, LOGN, LOGE, 0, kUnit, true> BI;   // inverse of register-resident products (kernels.h ct_mul_quad_kernel / ct_mul_dual_kernel)
     HostLimbTables t;
     int rc = build_limb_tables(LOGN, q, psi, t);
     if (rc) return rc;
-    if (!fold_eligible(q)) return 2000;
+    if (!class_ok<Arith>(q)) return 2000;
     constexpr int E = B::E, T = B::T, N = B::G::N;
-    static_assert(B::kFwdOutBound <= kLimitPartner, "lazy forward outputs must satisfy mul60's bound");
-    auto twf = TwTab<FoldArith>::make(t.rp, t.rp_sh, q), twi = TwTab<FoldArith>::make(t.irp, t.irp_sh, q);
+    static_assert(!Arith::kFoldCore || B::kFwdOutBound <= kLimitPartner, "lazy forward outputs must satisfy mul60's bound");
+    auto twf = TwTab<Arith>::make(t.rp, t.rp_sh, q), twi = TwTab<Arith>::make(t.irp, t.irp_sh, q);
     permute_window0(twf, LOGN, LOGE, B::G::kPermStages);
     permute_window0(twi, LOGN, LOGE, B::G::kPermStages);
-    const auto wl = TwTab<FoldArith>::one(t.w_last, t.w_last_sh, q), wn = TwTab<FoldArith>::one(t.lc.ninv, t.lc.ninv_sh, q);
-    const LimbConst& lc = t.lc;
+    // FoldScaledArith: the products carry the scale twice; the inverse's last stage folds one s^-1 in (DevTables::last2)
+    const u64 sinv = (Arith::kFoldCore && !Arith::kFold) ? h_powmod((1ull << fold_scaled_shift(q)) % q, q - 2, q) : 1;
+    const u64 wlv = h_mulmod(t.w_last, sinv, q), wnv = h_mulmod(t.lc.ninv, sinv, q);
+    const auto wl = TwTab<Arith>::one(wlv, h_shoup(wlv, q), q), wn = TwTab<Arith>::one(wnv, h_shoup(wnv, q), q);
+    const LimbConst lc = class_lc<Arith>(t.lc);
     std::vector<u64> lds(B::G::lds_words());
-    auto fwd = [&](const u64* src, bool reduce_out) {
+    auto fwd = [&](const u64* src, bool partner) {
         std::vector<u64> regs((size_t)T * E);
         auto X = [&](int tid) -> u64(&)[E] { return *reinterpret_cast<u64(*)[E]>(&regs[(size_t)tid * E]); };
         for (int tid = 0; tid < T; ++tid) B::load_top(tid, X(tid), src);
         FwdSteps<B, 0>::run(regs, lds, twf.data(), lc);
-        if (reduce_out) for (int tid = 0; tid < T; ++tid) B::fwd_reduce_partner(X(tid), lc);
+        if (partner) for (int tid = 0; tid < T; ++tid) B::prod_partner(X(tid), lc);
         return regs;
     };
     auto inv = [&](std::vector<u64> regs, u64* dst) {
         auto X = [&](int tid) -> u64(&)[E] { return *reinterpret_cast<u64(*)[E]>(&regs[(size_t)tid * E]); };
-        InvSteps<B, B::NPH - 1, 2 * kMulB>::run(regs, lds, twi.data(), wl, wn, lc);
+        InvSteps<BI, B::NPH - 1, B::kProdInvIn>::run(regs, lds, twi.data(), wl, wn, lc);
         for (int tid = 0; tid < T; ++tid) { B::inv_canon(X(tid), lc); B::store_top(tid, X(tid), dst); }
     };
-    const u32 d = (u32)lc.d;
     std::vector<u64> S0 = fwd(a0, false), S1 = fwd(b0, true), x((size_t)N);
-    for (int i = 0; i < N; ++i) x[i] = FoldArith::mul60(S0[i], S1[i], d);
+    for (int i = 0; i < N; ++i) x[i] = B::prod(S0[i], S1[i], lc);
     inv(x, out3);
     std::vector<u64> S2 = fwd(b1, true);
-    for (int i = 0; i < N; ++i) S0[i] = FoldArith::mul60(S0[i], S2[i], d);
+    for (int i = 0; i < N; ++i) S0[i] = B::prod(S0[i], S2[i], lc);
     x = fwd(a1, false);
-    for (int i = 0; i < N; ++i) { S0[i] = chk_add(S0[i], FoldArith::mul60(x[i], S1[i], d)); S2[i] = FoldArith::mul60(x[i], S2[i], d); }
+    for (int i = 0; i < N; ++i) { S0[i] = B::prod_add(S0[i], B::prod(x[i], S1[i], lc)); S2[i] = B::prod(x[i], S2[i], lc); }
     inv(S0, out3 + N);
     inv(S2, out3 + 2 * N);
     return 0;
+}
+template <int LOGN, int LOGE>
+static int emu_ct_mul_fold(u64 q, u64 psi, const u64* a0, const u64* a1, const u64* b0, const u64* b1, u64* out3) {
+    return emu_ct_mul_lazy<FoldArith, LOGN, LOGE>(q, psi, a0, a1, b0, b1, out3);
+}
+// the lazy-product path of the round-6 classes (arith 2 F64, 3 FoldScaled; 1 Fold)
+extern "C" int emu_ct_mul_lazy_class(int arith, int log2n, u64 q, u64 psi, const u64* a0, const u64* a1, const u64* b0, const u64* b1, u64* out3) {
+#define CASE(LN)                                                                                                           \
+    if (log2n == LN) {                                                                                                     \
+        if (arith == 1) return emu_ct_mul_lazy<FoldArith, LN, 4>(q, psi, a0, a1, b0, b1, out3);                            \
+        if (arith == 2) return emu_ct_mul_lazy<F64Arith, LN, 4>(q, psi, a0, a1, b0, b1, out3);                             \
+        if (arith == 3) return emu_ct_mul_lazy<FoldScaledArith, LN, 4>(q, psi, a0, a1, b0, b1, out3);                      \
+        return -1;                                                                                                         \
+    }
+    CASE(8) CASE(10) CASE(12) CASE(13)
+#undef CASE
+    return -1;
 }
 
 extern "C" int emu_ct_mul(int log2n, u64 q, u64 psi, const u64* a0, const u64* a1, const u64* b0, const u64* b1, u64* out3) {
