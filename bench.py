@@ -234,6 +234,13 @@ def dry_run(args):
         gathered = allgather_partials(torch.from_numpy(partial.view(np.int64)))                # the one collective
         return msum(gathered.numpy().view(np.uint64)), gathered
 
+    def step_allreduce():   # SURVEY.md 8(e)'s alternative: 64-bit sum all-reduce of the partials (world * q < 2^64), then one mod-q pass
+        partial = msum(product(lo + i) for i in range(B))
+        t = torch.from_numpy(partial.view(np.int64).copy())
+        if dist.is_initialized():
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        return t.numpy().view(np.uint64) % q
+
     def fence():
         if dist.is_initialized():
             dist.barrier()
@@ -258,7 +265,8 @@ def dry_run(args):
         elapsed = float(t.item())
     want = msum(product(i) for i in range(world * B))   # world-size-1 recomputation of the same global batch
     assert shard_bounds(world * B, world, rank) == (lo, lo + B)
-    ok = torch.tensor([int(np.array_equal(total, want) and gathered.shape[0] == world)])
+    ar_total = step_allreduce()
+    ok = torch.tensor([int(np.array_equal(total, want) and gathered.shape[0] == world and np.array_equal(ar_total, want))])
     if dist.is_initialized():
         dist.all_reduce(ok, op=dist.ReduceOp.MIN)
     rates = [B * args.steps / e for e in per_rank]
@@ -270,7 +278,8 @@ def dry_run(args):
                          "batch_per_gpu": B, "global_batch": B * world, "parallelism": f"batch-sharded x{world}, one process per rank", "collective": "torch.distributed all_gather_into_tensor (gloo)"},
               "per_rank_ct_mul_per_s": {"min": min(rates), "max": max(rates), "ranks": len(rates)},
               "allgather_us": {"median": gather_us[len(gather_us) // 2], "min": gather_us[0], "max": gather_us[-1]},
-              "reduce_consistent": bool(ok.item()), "global_sum_matches_world1": bool(ok.item()), "native_comm_id_shipped": id_ok}
+              "reduce_consistent": bool(ok.item()), "global_sum_matches_world1": bool(ok.item()), "native_comm_id_shipped": id_ok,
+              "collective_ab": {"allreduce_total_equals_allgather_total": bool(ok.item()), "what": "all-gather + local sum against sum all-reduce + one mod-q pass (gloo)"}}
     if dist.is_initialized() and world > 1:   # the rank-0 programs of the N>1 report, stood in by canned output; the host-side wait is real
         def fake(argv, timeout):
             if argv[0] == "sharded_ct_mul":
@@ -908,6 +917,27 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # SURVEY.md section 8(e)'s alternative exchange, measured next to the timed one whenever there is more than one rank (after the timed region: `value`
+    # is the all-gather step's): the SAME step with a 64-bit sum all-reduce of the partials + one mod-q pass instead of all-gather + local sum.
+    collective_ab = None
+    if world > 1:
+        pipe_ar = ShardedMultiplyReduce(ev, B, comm=comm, main=main, collective="allreduce")
+        pipe_ar.outs = pipe.outs                                   # same output buffers: no second 6 GiB
+        for _ in range(max(1, args.warmup)):
+            pipe_ar.step(a, b)
+        fence()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            k_ar = pipe_ar.step(a, b)
+        fence()
+        t_ar = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=dev)
+        dist.all_reduce(t_ar, op=dist.ReduceOp.MAX)
+        same = torch.tensor([int(torch.equal(pipe_ar.totals[k_ar], totals[last]))], device=dev)
+        dist.all_reduce(same, op=dist.ReduceOp.MIN)
+        collective_ab = {"allgather_ms_per_step": elapsed / args.steps * 1e3, "allreduce_ms_per_step": float(t_ar.item()) / args.steps * 1e3,
+                         "allreduce_total_equals_allgather_total": bool(same.item()),
+                         "what": "the timed step with ncclAllReduce(u64, sum) of one partial per rank + one mod-q pass, against all-gather + local sum (the timed `value`)"}
+
     def workgroup_timeline():
         """median microseconds per segment of a quad-form workgroup's life over a 2048-pair launch (steady-state workgroups only): the share
         spent waiting for the first operand word is what two waves per SIMD cannot hide, and what differs between the boxes of the pool"""
@@ -1028,6 +1058,8 @@ def main():
     }
 
     result["roofline"]["autotune_chosen"] = autotune.get("chosen") or autotune["at_ctx_create"].get("chosen")
+    if collective_ab is not None:
+        result["collective_ab"] = collective_ab
     rates = [B * args.steps / e for e in per_rank_elapsed]
     result["per_rank_ct_mul_per_s"] = {"min": min(rates), "max": max(rates), "ranks": len(rates)}
     detail = {}

@@ -16,6 +16,9 @@ SYMBOLS = {
     "dpfhe_ctx_limbs": ([C.c_void_p], C.c_uint32),
     "dpfhe_ctx_uses_fold": ([C.c_void_p], C.c_int),
     "dpfhe_ctx_limb_class": ([C.c_void_p, C.c_uint32], C.c_int),
+    "dpfhe_ctx_release_scratch": ([C.c_void_p, C.c_void_p, C.c_uint32], C.c_int),
+    "dpfhe_ctx_scratch_bytes": ([C.c_void_p], C.c_size_t),
+    "dpfhe_tune_cache_clear": ([], None),
     "dpfhe_ctx_set_scratch_limit": ([C.c_void_p, C.c_size_t], C.c_int),
     "dpfhe_ctx_autotune": ([C.c_void_p, _U64P, C.c_size_t, C.c_uint32, C.c_void_p], C.c_int),
     "dpfhe_ctx_tune_info": ([C.c_void_p, C.c_void_p], C.c_int),
@@ -57,6 +60,8 @@ SYMBOLS = {
     "dpfhe_comm_create": ([C.POINTER(C.c_void_p), C.POINTER(C.c_uint8), C.c_int, C.c_int, C.c_int], C.c_int),
     "dpfhe_comm_destroy": ([C.c_void_p], C.c_int),
     "dpfhe_comm_allgather": ([C.c_void_p, _U64P, _U64P, C.c_size_t, C.c_void_p], C.c_int),
+    "dpfhe_comm_allreduce_sum": ([C.c_void_p, C.c_void_p, _U64P, C.c_size_t, C.c_void_p], C.c_int),
+    "dpfhe_canonicalize_sum": ([C.c_void_p, _U64P, C.c_size_t, C.c_void_p], C.c_int),
     "dpfhe_strerror": ([C.c_int], C.c_char_p),
     "dpfhe_last_error": ([], C.c_char_p),
 }
@@ -70,7 +75,7 @@ class TuneInfo(C.Structure):
                 ("probe_reps", C.c_uint32), ("probe_us", C.c_float * 8)]
 
 
-TUNE_SOURCES = ("default", "cached dpfhe_ctx_autotune of this shape", "dpfhe_ctx_autotune", "forced")
+TUNE_SOURCES = ("default", "retired (1)", "dpfhe_ctx_autotune", "forced", "cached dpfhe_ctx_autotune of this shape")   # include/dpfhe.h DPFHE_TUNE_*
 
 
 class DpfheError(RuntimeError):

@@ -98,15 +98,16 @@ struct dpfhe_ctx {
     MixedTables mixed{};                              // the batched transforms' one-launch view (kernels.h ntt_classes_kernel)
     // scratch of the composed large-ring operations: a pool of this context's own (created on first use) that keeps what it has been
     // given until the context goes - the default pool hands its memory back at every synchronisation and pays the mapping again
-    struct ScratchArena { hipStream_t stream; u64* p; size_t words; };
-    std::vector<ScratchArena> scratch_arenas;   // one per stream that ever ran a composed operation (StreamScratch below)
+    struct ScratchArena { hipStream_t stream; u64* p; size_t words; uint64_t last_use; };
+    std::vector<ScratchArena> scratch_arenas;   // one per stream that ran a composed operation (StreamScratch below); at most kMaxScratchArenas, least recently used evicted
+    uint64_t scratch_clock = 0;                 // guarded by scratch_mutex
     std::mutex scratch_mutex;
     // which form of the fused multiply dpfhe_ct_mul(flags = 0) launches (launch.h CtMulVariant): the default of the ring degree until
     // dpfhe_ctx_autotune or dpfhe_ctx_set_ct_mul_variant says otherwise.  Both forms give the same words.
     std::atomic<int> ct_mul_variant{0};
     dpfhe_tune_info tune{};           // guarded by tune_mutex (the launch path reads ct_mul_variant only)
     mutable std::mutex tune_mutex;
-    size_t scratch_limit_words = (size_t)1024 << 17;   // slice size of the composed large-ring operations (dpfhe_ctx_set_scratch_limit)
+    std::atomic<size_t> scratch_limit_words{(size_t)1024 << 17};   // slice size of the composed large-ring operations (dpfhe_ctx_set_scratch_limit; read on the compute path)
 };
 
 
@@ -208,6 +209,11 @@ static void tune_at_create(dpfhe_ctx* c) {
     }
     c->tune = t;
     c->ct_mul_variant.store(t.chosen);
+}
+
+extern "C" void dpfhe_tune_cache_clear(void) {
+    std::lock_guard<std::mutex> lk(g_tune_cache_mutex);
+    g_tune_cache.clear();
 }
 
 extern "C" int dpfhe_ctx_autotune(dpfhe_ctx* c, uint64_t* d_work, size_t work_words, uint32_t reps, void* stream) {
@@ -494,7 +500,7 @@ extern "C" int dpfhe_ctx_destroy(dpfhe_ctx* c) {
 extern "C" int dpfhe_ctx_set_scratch_limit(dpfhe_ctx* c, size_t mib) {
     if (!c) return fail(DPFHE_INVALID_ARGUMENT, "dpfhe_ctx_set_scratch_limit", "null context");
     if (mib == 0 || mib > ((size_t)1 << 20)) return fail(DPFHE_INVALID_ARGUMENT, "dpfhe_ctx_set_scratch_limit", "limit must be in [1 MiB, 1 TiB]");
-    c->scratch_limit_words = mib << 17;
+    c->scratch_limit_words.store(mib << 17, std::memory_order_relaxed);
     return DPFHE_SUCCESS;
 }
 extern "C" uint32_t dpfhe_ctx_log2n(const dpfhe_ctx* c) { return c ? c->log2n : 0; }
@@ -656,17 +662,21 @@ extern "C" int dpfhe_multiply_plain(dpfhe_ctx* c, uint64_t* o, const uint64_t* a
 
 // ------------------------------------------------------------------------------------------------
 // ---- ring degrees above 8192: the fused kernels stop there (kernels_large.h); the same operations composed from the batched transforms
-// and one-pass streaming kernels.  Scratch comes from the stream-ordered allocator (hipMallocFromPoolAsync / hipFreeAsync on the caller's
-// stream: no synchronisation, the memory returns to the context's pool when the stream gets there).
+// and one-pass streaming kernels.  Their scratch comes from per-stream arenas (StreamScratch below).
 static const uint32_t kFusedMaxLog2N = 13;
 
 // Scratch of the composed large-ring operations: one ARENA per (context, stream), a plain hipMalloc made the first time that stream runs a
 // composed operation and grown (hipStreamSynchronize of that stream + hipFree + hipMalloc) only when a larger slice than ever before arrives;
-// kept until dpfhe_ctx_destroy.  Work on one stream is ordered, so consecutive calls share their stream's arena without a fence; different
+// kept until dpfhe_ctx_destroy, dpfhe_ctx_release_scratch or eviction.  Work on one stream is ordered, so consecutive calls share their stream's arena without a fence; different
 // streams never share one.  Steady state: no allocation, no synchronisation.
 // (Rounds 2-4 took the scratch from a stream-ordered memory pool - hipMallocFromPoolAsync / hipFreeAsync.  Round 5 found blocks of tens of MiB from
 // that pool giving wrong results and millisecond allocation times in a process without PyTorch - the C++ programs; tools/gpu_r05_f.sh -, while the
 // same calls under PyTorch were exact: the arena has no such dependence on the runtime's allocator state.)
+// The arena is created and grown on the CONTEXT's device whatever the calling thread's current device is (round 6: the advisor's finding - one caller
+// allocated before it took the device guard).  A context keeps at most kMaxScratchArenas arenas: a caller that rotates through a pool of streams evicts
+// the least recently used one (its stream is synchronised first); dpfhe_ctx_release_scratch hands an arena back explicitly (a stream about to be
+// destroyed, a phase that will not run composed operations again).
+static const size_t kMaxScratchArenas = 16;
 struct StreamScratch {
     u64* p = nullptr;
     dpfhe_ctx* c;
@@ -676,24 +686,61 @@ struct StreamScratch {
         std::lock_guard<std::mutex> lock(c->scratch_mutex);
         dpfhe_ctx::ScratchArena* arena = nullptr;
         for (auto& a : c->scratch_arenas) if (a.stream == s) arena = &a;
-        if (arena && arena->words >= words) { p = arena->p; return DPFHE_SUCCESS; }
+        if (arena && arena->words >= words) { arena->last_use = ++c->scratch_clock; p = arena->p; return DPFHE_SUCCESS; }
+        DeviceGuard guard(c->device);   // everything below touches the device: the context's, not the caller's current one
+        if (guard.err != hipSuccess) return fail(DPFHE_DEVICE_ERROR, what, hipGetErrorString(guard.err));
         if (arena && arena->p) {   // growth: the stream's earlier launches may still be using the old block
             hipError_t e = hipStreamSynchronize(s);
             if (e != hipSuccess) return fail(DPFHE_DEVICE_ERROR, what, hipGetErrorString(e));
             (void)hipFree(arena->p);
             arena->p = nullptr; arena->words = 0;
         }
+        if (!arena && c->scratch_arenas.size() >= kMaxScratchArenas) {   // evict the least recently used arena (another stream's: wait for that stream)
+            size_t lru = 0;
+            for (size_t i = 1; i < c->scratch_arenas.size(); ++i) if (c->scratch_arenas[i].last_use < c->scratch_arenas[lru].last_use) lru = i;
+            if (c->scratch_arenas[lru].p) {
+                if (hipStreamSynchronize(c->scratch_arenas[lru].stream) != hipSuccess) (void)hipGetLastError();   // a destroyed stream: hipFree below synchronises the device anyway
+                (void)hipFree(c->scratch_arenas[lru].p);
+            }
+            c->scratch_arenas.erase(c->scratch_arenas.begin() + (long)lru);
+        }
         const size_t gran = (size_t)1 << 21;                                    // 16 MiB steps
         const size_t want = (words + gran - 1) / gran * gran;
         u64* q = nullptr;
         hipError_t e = hipMalloc(reinterpret_cast<void**>(&q), want * sizeof(u64));
         if (e != hipSuccess) { (void)hipGetLastError(); return fail(DPFHE_OUT_OF_MEMORY, what, hipGetErrorString(e)); }
-        if (arena) { arena->p = q; arena->words = want; }
-        else c->scratch_arenas.push_back(dpfhe_ctx::ScratchArena{s, q, want});
+        if (arena) { arena->p = q; arena->words = want; arena->last_use = ++c->scratch_clock; }
+        else c->scratch_arenas.push_back(dpfhe_ctx::ScratchArena{s, q, want, ++c->scratch_clock});
         p = q;
         return DPFHE_SUCCESS;
     }
 };
+
+extern "C" int dpfhe_ctx_release_scratch(dpfhe_ctx* c, void* stream, uint32_t flags) {
+    if (!c) return fail(DPFHE_INVALID_ARGUMENT, "dpfhe_ctx_release_scratch", "null context");
+    if (flags & ~(uint32_t)DPFHE_SCRATCH_ALL) return fail(DPFHE_INVALID_ARGUMENT, "dpfhe_ctx_release_scratch", "unknown flag");
+    DPFHE_ON_DEVICE(c, "dpfhe_ctx_release_scratch");
+    std::lock_guard<std::mutex> lock(c->scratch_mutex);
+    int rc = DPFHE_SUCCESS;
+    for (size_t i = 0; i < c->scratch_arenas.size();) {
+        dpfhe_ctx::ScratchArena& a = c->scratch_arenas[i];
+        if (!(flags & DPFHE_SCRATCH_ALL) && a.stream != static_cast<hipStream_t>(stream)) { ++i; continue; }
+        if (a.p) {
+            hipError_t e = hipStreamSynchronize(a.stream);   // the stream's composed operations may still be reading the block
+            if (e != hipSuccess) { (void)hipGetLastError(); rc = fail(DPFHE_DEVICE_ERROR, "dpfhe_ctx_release_scratch", hipGetErrorString(e)); }
+            (void)hipFree(a.p);
+        }
+        c->scratch_arenas.erase(c->scratch_arenas.begin() + (long)i);
+    }
+    return rc;
+}
+extern "C" size_t dpfhe_ctx_scratch_bytes(const dpfhe_ctx* c) {
+    if (!c) return 0;
+    std::lock_guard<std::mutex> lock(const_cast<dpfhe_ctx*>(c)->scratch_mutex);
+    size_t w = 0;
+    for (const auto& a : c->scratch_arenas) w += a.words;
+    return w * sizeof(u64);
+}
 
 static int ct_mul_composed_slice(dpfhe_ctx* c, uint64_t* d_out3, const uint64_t* d_a2, const uint64_t* d_b2, size_t batch, uint32_t flags, hipStream_t s) {
     const size_t L = c->n_limbs, n = (size_t)1 << c->log2n, poly = L * n;
@@ -744,7 +791,7 @@ static int key_switch_composed_slice(dpfhe_ctx* c, uint64_t* d_out2, const uint6
 // Large batches go through in slices whose scratch stays below the context's scratch limit (the slices run back to back on the caller's stream and reuse
 // the pool's block): the scratch of a composed operation is 4 (multiply) or L^2 / 2 (key switch) times its input.
 static size_t slice_items(const dpfhe_ctx* c, size_t batch, size_t scratch_words_per_item) {   // 1 GiB of scratch unless dpfhe_ctx_set_scratch_limit said otherwise
-    const size_t fit = c->scratch_limit_words / scratch_words_per_item;
+    const size_t fit = c->scratch_limit_words.load(std::memory_order_relaxed) / scratch_words_per_item;
     return fit == 0 ? 1 : (fit < batch ? fit : batch);
 }
 static int ct_mul_composed(dpfhe_ctx* c, uint64_t* d_out3, const uint64_t* d_a2, const uint64_t* d_b2, size_t batch, uint32_t flags, hipStream_t s) {
@@ -1020,7 +1067,8 @@ extern "C" int dpfhe_rotate_hybrid_hoisted(dpfhe_ctx* c, uint64_t* d_out2, const
     if (c->n_limbs < 2) return fail(DPFHE_INVALID_STATE, what, "the extended context needs at least one data limb and the special prime");
     if (c->log2n > 14) return fail(DPFHE_INVALID_STATE, what, "available up to N = 16384");
     if (batch == 0 || n_items == 0) return DPFHE_SUCCESS;
-    if (!d_out2 || !d_in2 || !galois_elts || !d_keys || !d_work || !d_rotated0 || !d_digits || misaligned(d_out2) || misaligned(d_in2) || misaligned(d_keys) ||
+    const bool composed = c->log2n > (uint32_t)kMaxFusedLog2N;   // N = 16384: the deferred-division pipeline below never touches d_work / d_rotated0 - they may be NULL
+    if (!d_out2 || !d_in2 || !galois_elts || !d_keys || (!composed && (!d_work || !d_rotated0)) || !d_digits || misaligned(d_out2) || misaligned(d_in2) || misaligned(d_keys) ||
         misaligned(d_work) || misaligned(d_rotated0) || misaligned(d_digits))
         return fail(DPFHE_INVALID_ARGUMENT, what, "null or misaligned buffer");
     const size_t L = c->n_limbs, Ld = L - 1, T = n_items, total = batch * T;
@@ -1028,19 +1076,21 @@ extern "C" int dpfhe_rotate_hybrid_hoisted(dpfhe_ctx* c, uint64_t* d_out2, const
     const unsigned two_n = 2u << c->log2n;
     for (size_t i = 0; i < batch; ++i)
         if (!(galois_elts[i] & 1u) || galois_elts[i] >= two_n) return fail(DPFHE_INVALID_ARGUMENT, what, "galois elements must be odd and < 2N");
-    const size_t in_words = T * 2 * Ld * (size_t)n, out_words = total * 2 * Ld * n, work_words = total * 2 * L * n, rot_words = total * Ld * n, dig_words = T * Ld * L * (size_t)n;
+    const size_t in_words = T * 2 * Ld * (size_t)n, out_words = total * 2 * Ld * n, work_words = d_work ? total * 2 * L * n : 0, rot_words = d_rotated0 ? total * Ld * n : 0,
+                 dig_words = T * Ld * L * (size_t)n;
     if (overlaps(d_out2, out_words, d_in2, in_words) || overlaps(d_out2, out_words, d_work, work_words) || overlaps(d_out2, out_words, d_rotated0, rot_words) ||
         overlaps(d_work, work_words, d_rotated0, rot_words) || overlaps(d_digits, dig_words, d_work, work_words) || overlaps(d_digits, dig_words, d_out2, out_words) ||
         overlaps(d_digits, dig_words, d_rotated0, rot_words) || overlaps(d_digits, dig_words, d_in2, in_words) || overlaps(d_rotated0, rot_words, d_in2, in_words))
         return fail(DPFHE_INVALID_ARGUMENT, what, "buffers must not overlap");
     const size_t key_words = Ld * 2 * L * (size_t)n;
     const int chunks = (n + 511) / 512;
-    if (c->log2n > (uint32_t)kMaxFusedLog2N) {
+    if (composed) {
+        DPFHE_ON_DEVICE(c, what);
         // N = 16384 (round 5): no fused hoisted kernel - the deferred-division pipeline instead: dpfhe_rotate_hoisted_qp gives, per rotation and item,
         // P sigma_g(ct) + its key-switching term in the NTT domain over Q P; one inverse transform and the division by P per term finish it (the same words:
         // tests/test_rlwe_semantics.py).  Scratch (the Q P terms + the transformed inputs) from the stream's arena, rotations in slices under the scratch limit;
         // d_work / d_rotated0 are not used on this path.
-        const size_t item_qp = T * 2 * L * (size_t)n, fit = c->scratch_limit_words / item_qp;
+        const size_t item_qp = T * 2 * L * (size_t)n, fit = c->scratch_limit_words.load(std::memory_order_relaxed) / item_qp;
         const size_t per = fit > 2 ? (fit - 2 < batch ? fit - 2 : batch) : 1;     // (+ block 0 and the transformed inputs)
         for (size_t r0 = 0; r0 < batch; r0 += per) {
             const size_t m = batch - r0 < per ? batch - r0 : per;
@@ -1050,7 +1100,6 @@ extern "C" int dpfhe_rotate_hybrid_hoisted(dpfhe_ctx* c, uint64_t* d_out2, const
             u64* qp = ws.p;
             u64* in_ntt = qp + (m + 1) * item_qp;
             if (int rc = dpfhe_rotate_hoisted_qp(c, qp, d_in2, T, galois_elts + r0, d_keys + r0 * key_words, in_ntt, d_digits, m, stream)) return rc;
-            DPFHE_ON_DEVICE(c, what);
             hipStream_t s = static_cast<hipStream_t>(stream);
             if (int rc = ntt_launch(c, true, qp + item_qp, qp + item_qp, m * T * 2 * L, s)) return rc;
             const size_t rblocks = m * T * 2 * Ld * (size_t)chunks;
@@ -1433,6 +1482,19 @@ extern "C" int dpfhe_reduce_sum(dpfhe_ctx* c, uint64_t* d_out, const uint64_t* d
     return check_launch("reduce_sum kernel launch");
 }
 
+// words that are sums of at most 15 canonical residues (< 15 q < 2^64) -> canonical, in place: the one pass after an all-reduce of partial ciphertexts
+extern "C" int dpfhe_canonicalize_sum(dpfhe_ctx* c, uint64_t* d_io, size_t n_rns_polys, void* stream) {
+    if (!c) return fail(DPFHE_INVALID_ARGUMENT, "dpfhe_canonicalize_sum", "null context");
+    if (n_rns_polys == 0) return DPFHE_SUCCESS;
+    if (!d_io || misaligned(d_io)) return fail(DPFHE_INVALID_ARGUMENT, "dpfhe_canonicalize_sum", "null or misaligned buffer");
+    const int n = 1 << c->log2n, chunks = (n + 511) / 512;
+    const size_t blocks = n_rns_polys * c->n_limbs * (size_t)chunks;
+    if (blocks > kMaxGrid) return fail(DPFHE_INVALID_ARGUMENT, "dpfhe_canonicalize_sum", "batch too large for one launch");
+    DPFHE_ON_DEVICE(c, "dpfhe_canonicalize_sum");
+    hipLaunchKernelGGL(reduce_final_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), d_io, c->fold ? c->foldt.lc : c->shoup.lc, (int)c->n_limbs, n, chunks);
+    return check_launch("canonicalize_sum kernel launch");
+}
+
 // ------------------------------------------------------------------------------------------------
 // exact base extension / scale-and-round between limb ranges of one context (kernels_misc.h base_extend_kernel)
 static int base_extend_common(dpfhe_ctx* c, int mode, uint64_t* d_out, size_t out_stride_limbs, const uint64_t* d_in, size_t in_stride_limbs, uint32_t src0, uint32_t ns,
@@ -1537,6 +1599,7 @@ struct Rccl {
     int (*CommInitRank)(ncclComm_t*, int, NcclUniqueId, int) = nullptr;
     int (*CommDestroy)(ncclComm_t) = nullptr;
     int (*AllGather)(const void*, void*, size_t, int, ncclComm_t, hipStream_t) = nullptr;
+    int (*AllReduce)(const void*, void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
     const char* (*GetErrorString)(int) = nullptr;
     bool ok = false;
 };
@@ -1550,8 +1613,9 @@ Rccl& rccl() {
         x.CommInitRank = reinterpret_cast<decltype(x.CommInitRank)>(dlsym(x.h, "ncclCommInitRank"));
         x.CommDestroy = reinterpret_cast<decltype(x.CommDestroy)>(dlsym(x.h, "ncclCommDestroy"));
         x.AllGather = reinterpret_cast<decltype(x.AllGather)>(dlsym(x.h, "ncclAllGather"));
+        x.AllReduce = reinterpret_cast<decltype(x.AllReduce)>(dlsym(x.h, "ncclAllReduce"));
         x.GetErrorString = reinterpret_cast<decltype(x.GetErrorString)>(dlsym(x.h, "ncclGetErrorString"));
-        x.ok = x.GetUniqueId && x.CommInitRank && x.CommDestroy && x.AllGather;
+        x.ok = x.GetUniqueId && x.CommInitRank && x.CommDestroy && x.AllGather && x.AllReduce;
         return x;
     }();
     return r;
@@ -1610,6 +1674,24 @@ extern "C" int dpfhe_comm_allgather(dpfhe_comm* c, uint64_t* d_recv, const uint6
     int rc = rccl().AllGather(d_send, d_recv, words_per_rank, kNcclUint64, c->comm, static_cast<hipStream_t>(stream));
     if (rc) return rccl_fail("ncclAllGather", rc);
     return DPFHE_SUCCESS;
+}
+
+// SURVEY.md section 8(e)'s alternative to the all-gather, ready for the first multi-GPU lease: ncclAllReduce(ncclUint64, ncclSum) of the ranks' partial
+// ciphertexts in place, then ONE mod-q pass - safe because world_size * q < 2^64 for world_size <= 15 (q < 2^60).  Same words as all-gather + local sum.
+extern "C" int dpfhe_comm_allreduce_sum(dpfhe_comm* c, dpfhe_ctx* ctx, uint64_t* d_io, size_t n_rns_polys, void* stream) {
+    if (!c || !ctx || !d_io) return fail(DPFHE_INVALID_ARGUMENT, "dpfhe_comm_allreduce_sum", "null argument");
+    if (c->world > 15) return fail(DPFHE_INVALID_STATE, "dpfhe_comm_allreduce_sum", "the lazy sum of more than 15 residues below 2^60 does not fit 64 bits");
+    if (c->device != ctx->device) return fail(DPFHE_INVALID_ARGUMENT, "dpfhe_comm_allreduce_sum", "communicator and context live on different devices");
+    if (n_rns_polys == 0) return DPFHE_SUCCESS;
+    {
+        DeviceGuard guard(c->device);
+        if (guard.err != hipSuccess) return fail(DPFHE_DEVICE_ERROR, "dpfhe_comm_allreduce_sum", hipGetErrorString(guard.err));
+        const size_t words = n_rns_polys * ctx->n_limbs << ctx->log2n;
+        const int ncclSum = 0;   // rccl.h ncclRedOp_t
+        int rc = rccl().AllReduce(d_io, d_io, words, kNcclUint64, ncclSum, c->comm, static_cast<hipStream_t>(stream));
+        if (rc) return rccl_fail("ncclAllReduce", rc);
+    }
+    return dpfhe_canonicalize_sum(ctx, d_io, n_rns_polys, stream);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -105,14 +105,16 @@ const FheParams& Context::params() const { return impl_->params; }
 int Context::device_id() const { return impl_->device_id; }
 bool Context::uses_fold() const { return dpfhe_ctx_uses_fold(impl_->h) != 0; }
 int Context::limb_class(uint32_t limb) const { return dpfhe_ctx_limb_class(impl_->h, limb); }
+void Context::release_scratch(void* stream, bool all_streams) { check(dpfhe_ctx_release_scratch(impl_->h, stream, all_streams ? DPFHE_SCRATCH_ALL : 0), "dpfhe_ctx_release_scratch"); }
+size_t Context::scratch_bytes() const { return dpfhe_ctx_scratch_bytes(impl_->h); }
 void* Context::handle() const { return impl_->h; }
 Context::TuneInfo Context::tune_info() const {
     dpfhe_tune_info t{};
     check(dpfhe_ctx_tune_info(impl_->h, &t), "dpfhe_ctx_tune_info");
-    static const char* const src[] = {"default", "cached dpfhe_ctx_autotune of this shape", "dpfhe_ctx_autotune", "forced"};
+    static const char* const src[] = {"default", "?", "dpfhe_ctx_autotune", "forced", "cached dpfhe_ctx_autotune of this shape"};   // include/dpfhe.h DPFHE_TUNE_*
     TuneInfo r;
     r.chosen = dpfhe_ct_mul_variant_name(t.chosen);
-    r.source = (t.source >= 0 && t.source < 4) ? src[t.source] : "?";
+    r.source = (t.source >= 0 && t.source < 5) ? src[t.source] : "?";
     r.probe_pairs = t.probe_pairs;
     r.probe_reps = t.probe_reps;
     for (int v = 0; v < t.n_variants && v < 8; ++v)

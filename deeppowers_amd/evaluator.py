@@ -60,6 +60,16 @@ class Context:
     def uses_fold(self) -> bool:
         return bool(self._lib.dpfhe_ctx_uses_fold(self._h))
 
+    def release_scratch(self, stream=None, all_streams: bool = False) -> None:
+        """hand back the scratch arena the composed large-ring operations keep for `stream` (a torch stream, None = the current one), or every arena of the
+        context (dpfhe_ctx_release_scratch); scratch_bytes = what the context holds"""
+        sp = 0 if all_streams else (stream.cuda_stream if stream is not None else torch.cuda.current_stream(self.device).cuda_stream)
+        _cabi.check(self._lib.dpfhe_ctx_release_scratch(self._h, C.c_void_p(sp), 1 if all_streams else 0), "dpfhe_ctx_release_scratch")
+
+    @property
+    def scratch_bytes(self) -> int:
+        return int(self._lib.dpfhe_ctx_scratch_bytes(self._h))
+
     ARITH_NAMES = ("shoup", "fold", "f64", "fold_scaled")
 
     @property
@@ -73,7 +83,7 @@ class Context:
         t = _cabi.TuneInfo()
         _cabi.check(self._lib.dpfhe_ctx_tune_info(self._h, C.byref(t)), "dpfhe_ctx_tune_info")
         name = lambda v: self._lib.dpfhe_ct_mul_variant_name(v).decode()
-        return {"chosen": name(t.chosen), "n_variants": t.n_variants, "source": _cabi.TUNE_SOURCES[t.source] if 0 <= t.source < 4 else str(t.source),
+        return {"chosen": name(t.chosen), "n_variants": t.n_variants, "source": _cabi.TUNE_SOURCES[t.source] if 0 <= t.source < len(_cabi.TUNE_SOURCES) else str(t.source),
                 "probe_pairs": t.probe_pairs, "probe_reps": t.probe_reps,
                 "probe_us": {name(v): round(float(t.probe_us[v]), 2) for v in range(t.n_variants) if t.probe_us[v] >= 0}}
 
@@ -246,6 +256,12 @@ class Evaluator:
 
     def negate(self, a: Ciphertext, stream=None) -> Ciphertext:
         return Ciphertext(self.negate_words(a.data, stream=stream), a.is_ntt)
+
+    def canonicalize_sum_(self, t: torch.Tensor, stream=None) -> torch.Tensor:
+        """in place: words that are sums of at most 15 canonical residues -> canonical residues (dpfhe_canonicalize_sum: the pass after an all-reduce of partials)"""
+        self._chk(t)
+        _cabi.check(self._lib.dpfhe_canonicalize_sum(self.ctx.handle, t.data_ptr(), self._npolys(t), self._sp(stream)), "dpfhe_canonicalize_sum")
+        return t
 
     def reduce_sum(self, cts: Ciphertext, out: torch.Tensor | None = None, stream=None) -> Ciphertext:
         """Modular sum over the batch dimension(s) -> one ciphertext (the shard-local partial)."""

@@ -84,6 +84,17 @@ class NativeComm:
         _cabi.check(self._lib.dpfhe_comm_allgather(self._h, out.data_ptr(), partial.data_ptr(), partial.numel(), s.cuda_stream), "dpfhe_comm_allgather")
         return out
 
+    def allreduce_sum(self, ctx, partial: torch.Tensor, stream=None) -> torch.Tensor:
+        """in place: every rank's `partial` ([..., L, N] canonical residues of `ctx`) becomes the sum of all ranks' partials mod q - ncclAllReduce(u64, sum)
+        + one mod-q pass (dpfhe_comm_allreduce_sum; world <= 15).  The words all-gather + local sum give."""
+        from . import _cabi
+        if partial.dtype != torch.int64 or not partial.is_cuda or not partial.is_contiguous():
+            raise _cabi.DpfheError(2000, "allreduce_sum: contiguous int64 CUDA tensor expected")
+        s = torch.cuda.current_stream(partial.device) if stream is None else stream
+        n_rns = partial.numel() // (ctx.params.n_limbs * ctx.params.n)
+        _cabi.check(self._lib.dpfhe_comm_allreduce_sum(self._h, ctx.handle, partial.data_ptr(), n_rns, s.cuda_stream), "dpfhe_comm_allreduce_sum")
+        return partial
+
     def close(self):
         if getattr(self, "_h", None):
             self._lib.dpfhe_comm_destroy(self._h)
@@ -131,8 +142,12 @@ class ShardedMultiplyReduce:
     Two output buffers and two HIP streams: the (VALU-bound) multiply of step i+1 runs on `main` while the (HBM-bound)
     shard-local reduce + all-gather + final sum of step i run on `side`.  No allocation after construction."""
 
-    def __init__(self, ev, batch: int, group=None, comm: NativeComm | None = None, main=None):
-        self.ev, self.group, self.comm = ev, group, comm
+    def __init__(self, ev, batch: int, group=None, comm: NativeComm | None = None, main=None, collective: str = "allgather"):
+        """collective: "allgather" (one partial per rank gathered, summed locally - the north star's exchange) or "allreduce" (SURVEY.md 8(e)'s alternative:
+        a 64-bit sum all-reduce of the partials in place + one mod-q pass; world <= 15).  Same words either way."""
+        if collective not in ("allgather", "allreduce"):
+            raise ValueError("collective must be 'allgather' or 'allreduce'")
+        self.ev, self.group, self.comm, self.collective = ev, group, comm, collective
         ctx = ev.ctx
         self.world = comm.world if comm is not None else (dist.get_world_size(group) if dist.is_initialized() else 1)
         p = ctx.params
@@ -165,6 +180,18 @@ class ShardedMultiplyReduce:
             part = ev.reduce_sum(c, out=self.partials[k], stream=self.side)
             if self.gather_events is not None:
                 self.gather_events[0].record(self.side)
+            if self.collective == "allreduce" and self.world > 1:
+                # the lazy sum of the ranks' partials (each < q < 2^60, world <= 15: no 64-bit wrap), then one pass to canonical residues
+                self.totals[k].copy_(part.data)
+                if self.comm is not None:
+                    self.comm.allreduce_sum(ev.ctx, self.totals[k], stream=self.side)
+                else:
+                    dist.all_reduce(self.totals[k], op=dist.ReduceOp.SUM, group=self.group)
+                    ev.canonicalize_sum_(self.totals[k], stream=self.side)
+                if self.gather_events is not None:
+                    self.gather_events[1].record(self.side)
+                self.red_done[k].record(self.side)
+                return k
             if self.comm is not None:
                 g = self.comm.allgather(part.data, out=self.gathered[k], stream=self.side)
             elif dist.is_initialized():

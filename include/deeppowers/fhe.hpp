@@ -67,6 +67,9 @@ public:
     bool uses_fold() const;
     // arithmetic of limb i in the batched transforms and the fused multiply (dpfhe_ctx_limb_class): 0 Shoup, 1 fold, 2 f64, 3 fold-scaled
     int limb_class(uint32_t limb) const;
+    // scratch arenas of the composed large-ring operations, one per stream (dpfhe_ctx_release_scratch / dpfhe_ctx_scratch_bytes)
+    void release_scratch(void* stream = nullptr, bool all_streams = false);
+    size_t scratch_bytes() const;
     void* handle() const;  // dpfhe_ctx*
     void synchronize() const;
     // set-up call: slice size (MiB of scratch) of the operations composed from the batched transforms at N >= 16384 (dpfhe_ctx_set_scratch_limit; default 1024)

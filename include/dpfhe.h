@@ -75,6 +75,17 @@ int dpfhe_ctx_destroy(dpfhe_ctx* ctx);
 /* set-up call (before the context is shared between threads): the composed large-ring operations (log2_n >= 14) slice their batches so that
  * one slice's scratch stays below `mib` MiB (default 1024).  The library reads NO environment variable. */
 int dpfhe_ctx_set_scratch_limit(dpfhe_ctx* ctx, size_t mib);
+/* The composed operations take their scratch from one ARENA per (context, stream): a device allocation made at that stream's first composed call (<= the
+ * scratch limit above, in 16 MiB steps), grown only for a larger slice than ever before (growth synchronises that stream), reused without allocation or
+ * synchronisation from then on.  A context keeps at most 16 arenas - the least recently used one is released (after synchronising ITS stream) when a
+ * 17th stream arrives - and all of them until dpfhe_ctx_destroy unless told otherwise:
+ *   dpfhe_ctx_release_scratch(ctx, stream, 0)                  releases the arena of `stream` (NULL = the default stream), after synchronising it - call it
+ *                                                               before destroying a stream that ran composed operations, or when a phase is over;
+ *   dpfhe_ctx_release_scratch(ctx, NULL, DPFHE_SCRATCH_ALL)    releases every arena of the context.
+ * dpfhe_ctx_scratch_bytes: device bytes the context's arenas hold right now.  Thread-safe (one mutex per context). */
+enum { DPFHE_SCRATCH_ALL = 1 };
+int dpfhe_ctx_release_scratch(dpfhe_ctx* ctx, void* stream, uint32_t flags);
+size_t dpfhe_ctx_scratch_bytes(const dpfhe_ctx* ctx);
 uint32_t dpfhe_ctx_log2n(const dpfhe_ctx* ctx);
 uint32_t dpfhe_ctx_limbs(const dpfhe_ctx* ctx);
 /* 1 if every limb is of the form 2^60 - d, d < 2^24, and the fold-reduction kernels are in use */
@@ -98,7 +109,12 @@ int dpfhe_ctx_limb_class(const dpfhe_ctx* ctx, uint32_t limb);
  * (7 L N) synthetic ciphertext pairs; contents are overwritten; synchronises `stream`) and keeps the default unless the other form is
  * >= 3 % faster.  It changes the context: call it before the context is shared between threads.  Other contexts (generic primes, other
  * ring degrees) have one form; the call is a no-op there. */
-enum { DPFHE_TUNE_DEFAULT = 0, DPFHE_TUNE_CACHED = 1, DPFHE_TUNE_EXPLICIT = 2, DPFHE_TUNE_FORCED = 3 };
+/* DPFHE_TUNE_CACHED: a PROCESS-WIDE cache, keyed (device, log2_n, n_limbs), remembers what the last explicit dpfhe_ctx_autotune of that shape found;
+ * contexts of the same shape created LATER in the process start from it (so behaviour depends on call order: both forms give the same words, only the
+ * speed can differ).  dpfhe_tune_cache_clear() empties it.  (Value 1 was DPFHE_TUNE_AT_CREATE until round 4 and is retired: the cached state got a
+ * fresh number so that an old caller never misreads it.) */
+enum { DPFHE_TUNE_DEFAULT = 0, DPFHE_TUNE_EXPLICIT = 2, DPFHE_TUNE_FORCED = 3, DPFHE_TUNE_CACHED = 4 };
+void dpfhe_tune_cache_clear(void);
 typedef struct dpfhe_tune_info {
     int32_t chosen;        /* form in use (index for dpfhe_ct_mul_variant_name) */
     int32_t n_variants;    /* forms this context can run (0: one form, nothing measured) */
@@ -272,6 +288,14 @@ int dpfhe_comm_unique_id(uint8_t out_id[128]);
 int dpfhe_comm_create(dpfhe_comm** out, const uint8_t id[128], int rank, int world_size, int device_id);
 int dpfhe_comm_destroy(dpfhe_comm* comm);
 int dpfhe_comm_allgather(dpfhe_comm* comm, uint64_t* d_recv, const uint64_t* d_send, size_t words_per_rank, void* stream);
+/* (SURVEY.md section 8(b) lists this exchange as `dpfhe_allgather_partials`; it is exported under the dpfhe_comm_* names above, with the communicator's
+ *  life cycle next to it.)
+ * The alternative SURVEY.md section 8(e) asks to have measured: ncclAllReduce(ncclUint64, ncclSum) of the ranks' partial ciphertexts IN PLACE, then one
+ * mod-q pass (dpfhe_canonicalize_sum) - world_size <= 15, since 15 q < 2^64 for q < 2^60.  The result is what all-gather + the local sum give.
+ * dpfhe_canonicalize_sum alone: words that are sums of at most 15 canonical residues -> canonical residues, in place (the pass after a
+ * torch.distributed all_reduce of the partials). */
+int dpfhe_comm_allreduce_sum(dpfhe_comm* comm, dpfhe_ctx* ctx, uint64_t* d_io, size_t n_rns_polys, void* stream);
+int dpfhe_canonicalize_sum(dpfhe_ctx* ctx, uint64_t* d_io, size_t n_rns_polys, void* stream);
 
 const char* dpfhe_strerror(int code);
 /* text of the last HIP/RCCL failure on the calling thread ("" if none) */

@@ -1,4 +1,5 @@
-"""Generates tests/golden/*.json from the Python big-int oracle (oracle/pyoracle.py).
+"""Generates tests/golden/*.json from the Python big-int oracle (oracle/pyoracle.py) - and, round 6, one fixture from sympy alone
+(sympy_restatement: a third, builder-independent route to the same words).
 
 The reference holds no golden vectors for this path ("Golden vectors /
 known-answer tests: none of any kind"), so these are known answers of the mathematical definition,
@@ -118,6 +119,66 @@ def n4096_ntt_digest():
     return res
 
 
+def sympy_restatement():
+    """A THIRD restatement, written by neither this build's oracle authors nor its kernel authors: sympy's polynomial ring over GF(q) and sympy's
+    number-theoretic transform (sympy 1.14, already in the image; tests/test_params.py uses it for primality).  Nothing of oracle/ is called to
+    PRODUCE these values (pyoracle only draws the inputs and is compared afterwards):
+      * N = 256, two limbs (a pinned 60-bit prime and the 30-bit prime): the ct x ct tensor product as sympy Poly products over GF(q) reduced by X^N + 1;
+      * N = 64, the same two primes: the forward negacyclic NTT (i) by evaluating the sympy polynomial at psi^(2 brv(k) + 1) and (ii) through
+        sympy.discrete.transforms.ntt of the psi-twisted sequence, re-indexed from sympy's root of unity to ours."""
+    import sympy
+    from sympy import GF, Poly, symbols
+    from sympy.discrete.transforms import ntt as sympy_ntt
+    from sympy.ntheory import primitive_root
+    x = symbols("x")
+
+    def poly(c, q):
+        return Poly(list(reversed(c)), x, domain=GF(q, symmetric=False))
+
+    def coeffs(pl, n, q):
+        c = [int(v) % q for v in reversed(pl.all_coeffs())]
+        return c + [0] * (n - len(c))
+
+    out = {"sympy_version": sympy.__version__}
+    # ---- ct x ct at N = 256, two limbs, batch 2 ----
+    log2n, n = 8, 256
+    moduli = [PRIMES_60[2][0], PRIME_30]
+    g = po.SplitMix64(2560)
+    A, B, Cc = [], [], []
+    for _ in range(2):
+        a = [[g.words_mod(n, q) for q in moduli] for _ in range(2)]
+        b = [[g.words_mod(n, q) for q in moduli] for _ in range(2)]
+        c = [[None] * len(moduli) for _ in range(3)]
+        for l, q in enumerate(moduli):
+            m = Poly(x**n + 1, x, domain=GF(q, symmetric=False))
+            a0, a1, b0, b1 = (poly(v[l], q) for v in (a[0], a[1], b[0], b[1]))
+            c[0][l] = coeffs((a0 * b0).rem(m), n, q)
+            c[1][l] = coeffs((a0 * b1 + a1 * b0).rem(m), n, q)
+            c[2][l] = coeffs((a1 * b1).rem(m), n, q)
+        A += po.flatten_ct(a); B += po.flatten_ct(b); Cc += po.flatten_ct(c)
+    out["ct_mul_n256"] = {"log2n": log2n, "moduli": moduli, "psi": [pow(PRIMES_60[2][2], 8192 // n, moduli[0]), pow(PSI_30_N1024, 1024 // n, moduli[1])],
+                          "batch": 2, "a": A, "b": B, "c": Cc}
+    # ---- forward NTT at N = 64 ----
+    log2n, n = 6, 64
+    vecs = []
+    for q, psi in ((PRIMES_60[2][0], pow(PRIMES_60[2][2], 8192 // n, PRIMES_60[2][0])), (PRIME_30, pow(PSI_30_N1024, 1024 // n, PRIME_30))):
+        a = po.SplitMix64(640 + (q & 0xFF)).words_mod(n, q)
+        pa = poly(a, q)
+        brv = lambda k: int(format(k, "0%db" % log2n)[::-1], 2)
+        by_eval = [int(pa.eval(pow(psi, 2 * brv(k) + 1, q))) % q for k in range(n)]
+        # (ii) cyclic transform of the twisted sequence with sympy's own root rt = g^((q-1)/n); ours is omega = psi^2 = rt^t
+        twisted = [a[j] * pow(psi, j, q) % q for j in range(n)]
+        cyc = [int(v) % q for v in sympy_ntt(twisted, prime=q)]
+        rt = pow(primitive_root(q), (q - 1) // n, q)
+        omega = psi * psi % q
+        t = next(t for t in range(1, n, 2) if pow(rt, t, q) == omega)      # omega^(j k) = rt^(j (t k)):  ours[k] = sympy[t k mod n]
+        by_ntt = [cyc[(t * brv(k)) % n] for k in range(n)]
+        assert by_eval == by_ntt, "sympy's two routes disagree"
+        vecs.append({"log2n": log2n, "q": q, "psi": psi, "a": a, "ntt": by_eval})
+    out["ntt_n64"] = vecs
+    return out
+
+
 if __name__ == "__main__":
     data = {
         "small_ntt": small_ntt_vectors(),
@@ -126,6 +187,7 @@ if __name__ == "__main__":
         "identities": identities(),
         "rns_ct_mul_n256": rns_ct_mul_n256(),
         "n4096_ntt_digest": n4096_ntt_digest(),
+        "sympy_restatement": sympy_restatement(),
     }
     for k, v in data.items():
         with open(os.path.join(HERE, k + ".json"), "w") as f:

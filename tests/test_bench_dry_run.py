@@ -36,6 +36,7 @@ def test_bench_dry_run_walks_every_collective(world):
     r = _line(run.stdout)
     assert r["dry_run"] is True and r["n_gpus"] == world and r["steps"] == 3 and r["warmup"] == 1 and r["scaling"] == "weak"
     assert r["reduce_consistent"] is True and r["global_sum_matches_world1"] is True and r["native_comm_id_shipped"] is True
+    assert r["collective_ab"]["allreduce_total_equals_allgather_total"] is True   # SURVEY.md 8(e)'s alternative exchange gives the same words
     assert r["per_rank_ct_mul_per_s"]["ranks"] == world and 0 < r["per_rank_ct_mul_per_s"]["min"] <= r["per_rank_ct_mul_per_s"]["max"]
     assert r["allgather_us"]["min"] <= r["allgather_us"]["median"] <= r["allgather_us"]["max"]
     assert r["config"]["global_batch"] == world * r["config"]["batch_per_gpu"]

@@ -161,3 +161,29 @@ def test_key_switching_on_a_context_with_classes_still_matches_the_oracle():
         assert np.array_equal(got, orc.keyswitch_hybrid(ct, key, 3, threads=0))
     finally:
         ctx.close()
+
+
+@pytest.mark.gpu
+def test_sympy_fixture_replayed_on_the_device(golden_dir):
+    """tests/golden/sympy_restatement.json (sympy's GF(q)[X] arithmetic alone) against the HIP path directly: a 60-bit fold limb next to the 30-bit prime
+    (f64 class), N = 256 - the device words must be sympy's words, with no oracle of this build in between."""
+    import json
+    import os
+    from deeppowers_amd.evaluator import Ciphertext, Context, Evaluator, to_device, to_host
+    with open(os.path.join(golden_dir, "sympy_restatement.json")) as f:
+        v = json.load(f)["ct_mul_n256"]
+    p = FheParams(v["log2n"], tuple(v["moduli"]), tuple(v["psi"]))
+    ctx = Context(p, 0)
+    ev = Evaluator(ctx)
+    try:
+        assert ctx.limb_classes == ("fold", "f64")
+        n, L = p.n, p.n_limbs
+        a = np.array(v["a"], np.uint64).reshape(v["batch"], 2, L, n)
+        b = np.array(v["b"], np.uint64).reshape(v["batch"], 2, L, n)
+        c = np.array(v["c"], np.uint64).reshape(v["batch"], 3, L, n)
+        A, B = Ciphertext(to_device(a, ctx.device)), Ciphertext(to_device(b, ctx.device))
+        assert np.array_equal(to_host(ev.multiply(A, B).data), c)
+        got = ev.ntt_inverse(ev.multiply(A, B, out_ntt=True).data)
+        assert np.array_equal(to_host(got), c)
+    finally:
+        ctx.close()

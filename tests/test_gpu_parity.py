@@ -134,7 +134,7 @@ def test_n256_bigint_fixture_mixed_fold_and_30bit_limbs(golden_dir):
     p = FheParams(v["log2n"], tuple(v["moduli"]), tuple(v["psi"]))
     ctx = Context(p, 0)
     ev = Evaluator(ctx)
-    assert not ctx.uses_fold  # one limb is the 30-bit prime -> generic path for the whole context
+    assert not ctx.uses_fold and ctx.limb_classes == ("fold", "f64")   # round 6: the arithmetic is chosen per limb - the 30-bit prime no longer drags the 60-bit one along
     shape = (v["batch"], 2, 2, 256)
     a = np.array(v["a"], np.uint64).reshape(shape)
     b = np.array(v["b"], np.uint64).reshape(shape)
@@ -560,6 +560,18 @@ def test_native_comm_world_size_one_through_the_step(rigs):
     g = comm.allgather(pipe.partials[k], stream=pipe.side)
     torch.cuda.synchronize()
     assert g.shape == (1, 3, L, n) and torch.equal(g[0], pipe.partials[k])
+    # SURVEY.md 8(e)'s alternative exchange through the same communicator: ncclAllReduce(u64, sum) in place + one mod-q pass (dpfhe_comm_allreduce_sum).
+    # World size 1: the sum of one partial is the partial; fed a LAZY word (3 q + r) the mod-q pass must bring it back to r.
+    lazy = pipe.partials[k].clone()
+    qcol = torch.tensor(r.p.moduli, dtype=torch.int64, device=lazy.device).view(1, L, 1)
+    lazy += 3 * qcol
+    comm.allreduce_sum(r.ctx, lazy, stream=pipe.side)
+    torch.cuda.synchronize()
+    assert torch.equal(lazy, pipe.partials[k])
+    pipe2 = ShardedMultiplyReduce(r.ev, batch, comm=comm, collective="allreduce")   # (world 1: the step takes the plain path, same totals)
+    k2 = pipe2.step(a, b)
+    torch.cuda.synchronize()
+    assert torch.equal(pipe2.totals[k2], pipe.totals[k])
     comm.close()
 
 

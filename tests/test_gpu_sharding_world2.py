@@ -43,6 +43,12 @@ def _worker(rank, world, port, total, out_dir):
     assert gathered.shape[0] == world and torch.equal(gathered[rank], partial.data.cpu())
     total_ct = ev.reduce_sum(Ciphertext(gathered.to(ctx.device)))
     torch.cuda.synchronize()
+    # SURVEY.md 8(e)'s alternative exchange: 64-bit sum all-reduce of the partials (gloo, host memory) + ONE mod-q pass on the device - the same words
+    lazy = partial.data.cpu().clone()
+    dist.all_reduce(lazy, op=dist.ReduceOp.SUM)
+    ar = ev.canonicalize_sum_(lazy.to(ctx.device))
+    torch.cuda.synchronize()
+    assert torch.equal(ar, total_ct.data), "all-reduce + mod-q pass differs from all-gather + local sum"
     np.save(os.path.join(out_dir, f"r{rank}.npy"), to_host(total_ct.data))
     np.save(os.path.join(out_dir, f"p{rank}.npy"), to_host(partial.data))
     ctx.close()

@@ -93,6 +93,33 @@ def test_rns_ct_mul_small(golden_dir):
     assert np.array_equal(orc.ct_mul(a, b, threads=0).ravel(), c)  # all threads
 
 
+def test_sympy_restatement_agrees_with_both_oracles(golden_dir):
+    """tests/golden/sympy_restatement.json was produced by sympy ALONE (Poly products over GF(q) reduced by X^N + 1; Poly.eval and
+    sympy.discrete.transforms.ntt for the transform - make_golden.py sympy_restatement): a third, builder-independent route to the same words.
+    The Python big-int oracle and the C oracle (both of its multiply paths, single- and multi-threaded) must reproduce it word for word.
+    (It cannot turn "parity unpinned" into "pinned" - the reference holds no vector - but the oracle no longer rests on one author's arithmetic.)"""
+    v = load(golden_dir, "sympy_restatement")
+    cm = v["ct_mul_n256"]
+    n, moduli, L = 1 << cm["log2n"], cm["moduli"], len(cm["moduli"])
+    orc = Oracle(cm["log2n"], moduli, cm["psi"])
+    a, b, c = u64(cm["a"]), u64(cm["b"]), u64(cm["c"])
+    assert np.array_equal(orc.ct_mul(a, b).ravel(), c)
+    assert np.array_equal(orc.ct_mul(a, b, schoolbook=True).ravel(), c)
+    assert np.array_equal(orc.ct_mul(a, b, threads=0).ravel(), c)
+    A, B, C3 = a.reshape(cm["batch"], 2, L, n), b.reshape(cm["batch"], 2, L, n), c.reshape(cm["batch"], 3, L, n)
+    for i in range(cm["batch"]):   # the pure-Python big-int oracle, both of ITS routes
+        ai = [[[int(w) for w in A[i, comp, l]] for l in range(L)] for comp in range(2)]
+        bi = [[[int(w) for w in B[i, comp, l]] for l in range(L)] for comp in range(2)]
+        want = [[[int(w) for w in C3[i, comp, l]] for l in range(L)] for comp in range(3)]
+        assert po.ct_mul_schoolbook(ai, bi, moduli) == want
+        assert po.ct_mul_ntt(ai, bi, moduli, cm["psi"]) == want
+    for t in v["ntt_n64"]:
+        o1 = Oracle(t["log2n"], [t["q"]], [t["psi"]])
+        assert np.array_equal(o1.ntt_fwd(u64(t["a"])), u64(t["ntt"]))
+        assert np.array_equal(o1.ntt_inv(u64(t["ntt"])), u64(t["a"]))
+        assert po.ntt_forward(t["a"], t["q"], t["psi"]) == t["ntt"] and po.ntt_forward_definition(t["a"], t["q"], t["psi"]) == t["ntt"]
+
+
 def test_n4096_ntt_digests(golden_dir):
     orc = Oracle.from_params(FheParams.n4096_l4())
     for v in load(golden_dir, "n4096_ntt_digest"):
