@@ -344,7 +344,7 @@ extern "C" int dpfhe_ctx_create(dpfhe_ctx** out, uint32_t log2_n, uint32_t n_lim
                  o_last = up(o_inv + tab), o_top_fwd = up(o_last + L * n_sub * 2 * tw_sz), o_top_inv = up(o_top_fwd + L * n_sub * tw_sz),
                  o_top_last = up(o_top_inv + L * n_sub * tw_sz), o_resc = up(o_top_last + L * 2 * tw_sz);
     // N = 8192: the "halves" tables next to the one-piece ones (ntt_halves.h; the fused kernels keep the one-piece layout)
-    const bool halves = (DPFHE_N13_HALVES || DPFHE_RELIN13_HALVES) && log2_n == 13 && fold;   // the halves tables (launch.h): large batched transforms at N = 8192
+    const bool halves = log2_n == 13 && fold;   // the halves tables (launch.h): large batched transforms at N = 8192
     const size_t o_hfwd = up(o_resc + L * sizeof(RescaleConst)), o_hinv = halves ? up(o_hfwd + tab) : o_hfwd, o_htop_fwd = halves ? up(o_hinv + tab) : o_hfwd,
                  o_htop_last = halves ? up(o_htop_fwd + L * tw_sz) : o_hfwd, total = halves ? up(o_htop_last + L * 2 * tw_sz) : o_hfwd;
     std::vector<unsigned char> blob(total, 0);
@@ -515,18 +515,9 @@ static_assert(DPFHE_ARITH_SHOUP == kClassShoup && DPFHE_ARITH_FOLD == kClassFold
 
 // ------------------------------------------------------------------------------------------------
 // words per thread of the FoldArith matvec kernels: 2 right-hand-side polynomials per workgroup / 4 (kernels_misc.h matvec_fold_kernel)
-#ifndef DPFHE_MATVEC_WPT2
-#define DPFHE_MATVEC_WPT2 2
-#endif
-#ifndef DPFHE_MATVEC_WPT4
-#define DPFHE_MATVEC_WPT4 1
-#endif
-#ifndef DPFHE_MATVEC_WD
-#define DPFHE_MATVEC_WD 1     // columns of W lookahead in the multi-right-hand-side product (tools/ab_variant.sh mvwd2 -DDPFHE_MATVEC_WD=2 ... for A/B runs)
-#endif
-#ifndef DPFHE_MATVEC_RT4
-#define DPFHE_MATVEC_RT4 4    // rows per workgroup of the 4-polynomial (2-token) kernel; tools/ab_variant.sh mvrt8 -DDPFHE_MATVEC_RT4=8 for A/B runs
-#endif
+constexpr int kMatvecWpt2 = 2, kMatvecWpt4 = 1;
+constexpr int kMatvecWd = 1;     // columns of W lookahead in the multi-right-hand-side product (2 measured no faster: profiles/r04_ab_matvec_full.txt)
+constexpr int kMatvecRt4 = 4;    // rows per workgroup of the 4-polynomial (2-token) kernel (8 measured slower)
 
 static int check_launch(const char* what) {
     hipError_t e = hipGetLastError();
@@ -1335,16 +1326,13 @@ extern "C" int dpfhe_matvec_plain(dpfhe_ctx* c, uint64_t* d_y, const uint64_t* d
     DPFHE_ON_DEVICE(c, "dpfhe_matvec_plain");
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (c->fold) {   // column accumulators split at bit 30 (kernels_misc.h matvec_fold_kernel): 4 multiply-adds per term
-        constexpr int WPT = DPFHE_MATVEC_WPT2;
+        constexpr int WPT = kMatvecWpt2;
         const int chunks = (n + 256 * WPT - 1) / (256 * WPT);
         const size_t slabs = c->n_limbs * (size_t)chunks, rtiles = (rows + RT - 1) / RT;
         const size_t blocks = ((slabs + 7) / 8) * 8 * rtiles;
         if (blocks > kMaxGrid) return fail(DPFHE_INVALID_ARGUMENT, "dpfhe_matvec_plain", "too many rows for one launch");
-#ifndef DPFHE_MATVEC_NTW
-#define DPFHE_MATVEC_NTW 1
-#endif
         // a W beyond the 256 MiB Infinity Cache is a read-once stream (every tile goes to exactly one workgroup here): non-temporal loads
-        const bool ntw = DPFHE_MATVEC_NTW && rows * cols * ((size_t)c->n_limbs << c->log2n) * sizeof(u64) > ((size_t)256 << 20);
+        const bool ntw = rows * cols * ((size_t)c->n_limbs << c->log2n) * sizeof(u64) > ((size_t)256 << 20);
         // (the branch-free FULL form of the kernel, which the multi-right-hand-side product takes, measured SLOWER here: 1412 against 1258 us on configs[2] -
         // this launch streams 6 GiB of W from HBM with two right-hand-side polynomials per workgroup and lives on memory-level parallelism, not on issue slots)
         if (ntw) hipLaunchKernelGGL((matvec_fold_kernel<RT, 2, WPT, true>), dim3((unsigned)blocks), dim3(256), 0, s, d_y, d_W, d_x, c->foldt.lc, (int)c->n_limbs, n, chunks, rows,
@@ -1381,9 +1369,6 @@ extern "C" int dpfhe_matvec_plain_multi(dpfhe_ctx* c, uint64_t* d_y, const uint6
     // HBM by every group), see MEASUREMENTS.md for the XCD-grouped launch.
     const size_t pairs = n_rhs / 2;
     if (c->fold) {   // split-at-bit-30 column accumulators (kernels_misc.h matvec_fold_kernel), same grouping and block-id layout
-#ifndef DPFHE_MATVEC_FULL
-#define DPFHE_MATVEC_FULL 1
-#endif
 #define MVF_LAUNCH(RT, C, WPT, GROUPS, XS, YS)                                                                                                          \
     {                                                                                                                                                    \
         const int chunks = (n + 256 * (WPT) - 1) / (256 * (WPT));                                                                                        \
@@ -1391,21 +1376,21 @@ extern "C" int dpfhe_matvec_plain_multi(dpfhe_ctx* c, uint64_t* d_y, const uint6
         const size_t blocks = ((slabs + 7) / 8) * 8 * rtiles * (GROUPS);                                                                                 \
         if (blocks > kMaxGrid) return fail(DPFHE_INVALID_ARGUMENT, what, "too many rows for one launch");                                             \
         /* whole row tiles and whole periods (a packed layer's products): the branch-free form, see kernels_misc.h */                                    \
-        if (DPFHE_MATVEC_FULL && rows % (RT) == 0 && cols % FoldArith::kDot30Period == 0)                                                                \
-            hipLaunchKernelGGL((matvec_fold_kernel<RT, C, WPT, false, DPFHE_MATVEC_WD, true>), dim3((unsigned)blocks), dim3(256), 0, s, YS, d_W, XS, c->foldt.lc, (int)c->n_limbs, n, chunks, rows, \
+        if (rows % (RT) == 0 && cols % FoldArith::kDot30Period == 0)                                                                \
+            hipLaunchKernelGGL((matvec_fold_kernel<RT, C, WPT, false, kMatvecWd, true>), dim3((unsigned)blocks), dim3(256), 0, s, YS, d_W, XS, c->foldt.lc, (int)c->n_limbs, n, chunks, rows, \
                                cols, n_rhs * 2, (unsigned)(GROUPS), (unsigned)tiles);                                                                    \
         else                                                                                                                                             \
-            hipLaunchKernelGGL((matvec_fold_kernel<RT, C, WPT, false, DPFHE_MATVEC_WD>), dim3((unsigned)blocks), dim3(256), 0, s, YS, d_W, XS, c->foldt.lc, (int)c->n_limbs, n, chunks, rows, cols, \
+            hipLaunchKernelGGL((matvec_fold_kernel<RT, C, WPT, false, kMatvecWd>), dim3((unsigned)blocks), dim3(256), 0, s, YS, d_W, XS, c->foldt.lc, (int)c->n_limbs, n, chunks, rows, cols, \
                                n_rhs * 2, (unsigned)(GROUPS), (unsigned)tiles);                                                                          \
     }
         if (pairs) {
-            MVF_LAUNCH(DPFHE_MATVEC_RT4, 4, DPFHE_MATVEC_WPT4, pairs, d_x, d_y)
+            MVF_LAUNCH(kMatvecRt4, 4, kMatvecWpt4, pairs, d_x, d_y)
             if (int e = check_launch("matvec_multi kernel launch")) return e;
         }
         if (n_rhs & 1) {
             const uint64_t* xs = d_x + (n_rhs - 1) * 2 * poly;
             uint64_t* ys = d_y + (n_rhs - 1) * 2 * poly;
-            MVF_LAUNCH(4, 2, DPFHE_MATVEC_WPT2, 1, xs, ys)
+            MVF_LAUNCH(4, 2, kMatvecWpt2, 1, xs, ys)
             if (int e = check_launch("matvec_multi kernel launch")) return e;
         }
 #undef MVF_LAUNCH

@@ -1405,9 +1405,7 @@ PackedLinear::PackedLinear(const Context& ctx, const BatchEncoder& enc, HybridKe
     // A hoisted baby step (gathers + key inner products, no transform) costs about a third of a giant step (Ld transforms per limb + its
     // share of the inverse transform and the division by P), so the split leans towards baby steps: n1 = 2 sqrt(m) when m allows.
     int shift = kBabyShiftDefault;
-#ifdef DPFHE_EXPERIMENTS   // split sweeps only (profiles/r03_bsgs_split_sweep.txt): a library's behaviour does not depend on its environment
-    if (const char* e = std::getenv("DPFHE_BSGS_BABY_SHIFT")) shift = std::atoi(e);
-#endif
+    // (the split sweep behind this default: profiles/r03_bsgs_split_sweep.txt)
     for (; shift > 0 && n1 * 2 < I.m; --shift) n1 <<= 1;
     for (; shift < 0 && n1 > 2; ++shift) n1 >>= 1;
     I.n1 = n1; I.n2 = I.m / n1;

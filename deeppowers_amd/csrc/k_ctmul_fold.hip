@@ -4,7 +4,7 @@ template int launch_ct_mul<FoldArith>(int, unsigned, u64*, const u64*, const u64
 template int launch_relin<FoldArith>(int, int, u64*, const u64*, const u64*, size_t, unsigned, size_t, const DevTables<FoldArith>&, hipStream_t);
 template int launch_hoisted_ks<FoldArith>(int, u64*, const u64*, const u64*, size_t, const unsigned*, size_t, size_t, const DevTables<FoldArith>&, hipStream_t);
 }
-#ifdef DPFHE_RELIN_TRACE   // diagnostic builds only: 8 words per workgroup of the last traced launch (kernels.h relin_kernel TRACE)
+#ifdef DPFHE_DIAGNOSTICS   // diagnostic builds only: 8 words per workgroup of the last traced launch (kernels.h relin_kernel TRACE)
 extern "C" int dpfhe_debug_relin_trace_read(unsigned long long* host, size_t max_blocks) {
     if (!dpfhe::g_relin_trace || !host) return -1;
     if (hipDeviceSynchronize() != hipSuccess) return -2;

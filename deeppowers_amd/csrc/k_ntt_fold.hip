@@ -3,7 +3,7 @@ namespace dpfhe {
 template int launch_ntt<FoldArith>(int, bool, u64*, const u64*, size_t, const DevTables<FoldArith>&, hipStream_t);
 template int launch_ntt_inv_galois<FoldArith>(int, u64*, const u64*, const unsigned*, size_t, size_t, const DevTables<FoldArith>&, hipStream_t);
 }
-#ifdef DPFHE_NTT_TRACE   // diagnostic builds only: 8 words per workgroup of the last traced forward transform (kernels_trace.h)
+#ifdef DPFHE_DIAGNOSTICS   // diagnostic builds only: 8 words per workgroup of the last traced forward transform (kernels_trace.h)
 extern "C" int dpfhe_debug_ntt_trace_read(unsigned long long* host, size_t max_blocks) {
     if (!dpfhe::g_ntt_trace || !host) return -1;
     if (hipDeviceSynchronize() != hipSuccess) return -2;

@@ -432,11 +432,9 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE)) void ntt_inv_galois_kernel(u64*
 //   4 forward NTTs -> register-resident dyadic tensor product -> 3 inverse NTTs, as three rounds of
 //   [forward, forward, inverse].  HBM traffic: 4 reads + 3 writes of a residue poly.
 // ------------------------------------------------------------------------------------------------
-#ifndef DPFHE_CTMUL_OCC
-#define DPFHE_CTMUL_OCC 2
-#endif
+constexpr int kCtMulOcc = 2;   // workgroups per CU the generic fused multiply's register budget is sized for
 template <class Arith, int LOGN, int LOGE, bool IN_NTT, bool OUT_NTT>
-__global__ __launch_bounds__(1 << (LOGN - LOGE), (LOGE <= 3 && LOGN - LOGE <= 9) ? 4 : DPFHE_CTMUL_OCC) void ct_mul_kernel(u64* __restrict__ out3, const u64* __restrict__ a2,
+__global__ __launch_bounds__(1 << (LOGN - LOGE), (LOGE <= 3 && LOGN - LOGE <= 9) ? 4 : kCtMulOcc) void ct_mul_kernel(u64* __restrict__ out3, const u64* __restrict__ a2,
                                                                         const u64* __restrict__ b2, DevTables<Arith> tb) {
     typedef NttBody<Arith, LOGN, LOGE> B;
     static_assert(LOGE == kFusedLoge, "the fused kernels read the fused twiddle layout (DevTables::fwd4 / inv4)");
@@ -470,10 +468,7 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE), (LOGE <= 3 && LOGN - LOGE <= 9)
         if (IN_NTT) { B::load_bot(tid, x, src); return; }
         B::template load_top<true>(tid, x, src);   // streamed once: non-temporal
         if (!first) lds_barrier();
-#ifndef DPFHE_FUSED_EARLY_TW
-#define DPFHE_FUSED_EARLY_TW 0
-#endif
-        FwdChain<B, 0>::template run<DPFHE_FUSED_EARLY_TW != 0>(tid, x, lds, twf, lc);
+        FwdChain<B, 0>::template run<false>(tid, x, lds, twf, lc);   // (early twiddle requests spill here)
         if (!Arith::kFold) B::fwd_canon(x, lc);
         else if (reduce_out) {
             if constexpr (kLazy) B::fwd_reduce_partner(x, lc);
@@ -681,17 +676,15 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE), 2) void ct_mul_quad_kernel(u64*
         z[k] = B::prod(a1, b1, lc);
     }
     const u64 ts3 = trace_stamp<TRACE>(z[E - 1]);
-#ifndef DPFHE_CTMUL_NT_STORE
-#define DPFHE_CTMUL_NT_STORE 1
-#endif
+    constexpr bool kNtStore = true;   // the 3 GiB of products are written once and read by another kernel much later: around the Infinity Cache (-2.4 %)
     InvChain3<BI, B::NPH - 1, kInvIn>::run(tid, x, y, z, lds, lds + W, tb.inv4 + (size_t)limb * N, last, lc);
     const u64 ts4 = trace_stamp<TRACE>(z[E - 1]);
     B::inv_canon(x, lc);
-    B::template store_top<DPFHE_CTMUL_NT_STORE != 0>(tid, x, dst);
+    B::template store_top<kNtStore>(tid, x, dst);
     B::inv_canon(y, lc);
-    B::template store_top<DPFHE_CTMUL_NT_STORE != 0>(tid, y, dst + cstride);
+    B::template store_top<kNtStore>(tid, y, dst + cstride);
     B::inv_canon(z, lc);
-    B::template store_top<DPFHE_CTMUL_NT_STORE != 0>(tid, z, dst + 2 * cstride);
+    B::template store_top<kNtStore>(tid, z, dst + 2 * cstride);
     if constexpr (TRACE) {
         const u64 ts5 = trace_stamp<TRACE>((u64)tid);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -823,6 +816,7 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE), (Arith::kFold ? 2 : 1)) void re
             // key polynomials are NTT-domain tiles: transposed through LDS (rows private to the wave) where that measured
             // faster (N = 8192: -7 %), in registers otherwise (N = 4096: the LDS path is 5 % slower at 2 waves per SIMD)
             constexpr bool kLdsKeys = B::kLdsIO && LOGN >= 13;
+            // (key tiles with the non-temporal hint - so that the L2 would rather keep the digits - measured 6.6 % slower and 3.7 % MORE fabric reads: profiles/r06_giant_traffic.txt)
             if constexpr (kLdsKeys) B::load_bot_lds(tid, e, k0, lds); else B::load_bot(tid, e, k0);
             u64 tr_d = 0;
             if constexpr (TRACE) {

@@ -103,9 +103,6 @@ __global__ __launch_bounds__(256) void copy_kernel(U64x2* __restrict__ dst, cons
 // No workspace, no per-call allocation.
 // ------------------------------------------------------------------------------------------------
 constexpr int kReduceSplits = 15;
-#ifndef DPFHE_REDUCE_NT
-#define DPFHE_REDUCE_NT 0
-#endif
 
 // Work item = (512-word chunk of a residue polynomial, batch split); a workgroup walks the items with stride gridDim.x,
 // so the launch size caps how much of the chip (and of the HBM bandwidth) the reduction takes at once.
@@ -126,12 +123,7 @@ __global__ __launch_bounds__(256) void reduce_partial_kernel(u64* out, const u64
             U64x2 v[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-#if DPFHE_REDUCE_NT
-                const u64* pp = src + (it + u) * words_per_item;   // read once, far beyond the Infinity Cache: do not allocate there
-                v[u].a = __builtin_nontemporal_load(pp); v[u].b = __builtin_nontemporal_load(pp + 1);
-#else
-                v[u] = *reinterpret_cast<const U64x2*>(src + (it + u) * words_per_item);
-#endif
+                v[u] = *reinterpret_cast<const U64x2*>(src + (it + u) * words_per_item);   // (non-temporal loads measured no faster here: plain)
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) { s0 = csub(s0 + v[u].a, q); s1 = csub(s1 + v[u].b, q); }
@@ -212,21 +204,12 @@ __global__ __launch_bounds__(256) void matvec_kernel(u64* y, const u64* W, const
     const u64* wp = W + (row0 * cols * L + limb) * n + w0;
     const u64* xp = x + (size_t)limb * n + w0;
     size_t since = 0;
-#ifndef DPFHE_MATVEC_PIPELINE
-#define DPFHE_MATVEC_PIPELINE 0   // 1: request column j + 1 before the products of column j - measured SLOWER here (1.46 vs 1.38 ms at configs[2]: the 10 extra registers cost the 4th wave per SIMD); the multi-right-hand-side kernel below does pipeline
-#endif
+    // (requesting column j + 1 before the products of column j measured SLOWER here - 1.46 against 1.38 ms at configs[2]: the 10 extra registers cost the 4th wave per SIMD - removed)
     U64x2 x0 = *reinterpret_cast<const U64x2*>(xp), x1 = *reinterpret_cast<const U64x2*>(xp + L * n), w[RT];
 #pragma unroll
     for (int r = 0; r < RT; ++r) w[r] = (row0 + r < rows) ? *reinterpret_cast<const U64x2*>(wp + r * rstride) : U64x2{0, 0};
     for (size_t j = 0; j < cols; ++j) {
-        U64x2 x0n, x1n, wn[RT];
-        if (DPFHE_MATVEC_PIPELINE) {
-            const size_t jn = j + 1 < cols ? j + 1 : j;
-            x0n = *reinterpret_cast<const U64x2*>(xp + jn * xstride);
-            x1n = *reinterpret_cast<const U64x2*>(xp + jn * xstride + L * n);
-#pragma unroll
-            for (int r = 0; r < RT; ++r) wn[r] = (row0 + r < rows) ? *reinterpret_cast<const U64x2*>(wp + r * rstride + jn * wstride) : U64x2{0, 0};
-        } else if (j > 0) {
+        if (j > 0) {
             x0 = *reinterpret_cast<const U64x2*>(xp + j * xstride);
             x1 = *reinterpret_cast<const U64x2*>(xp + j * xstride + L * n);
 #pragma unroll
@@ -236,11 +219,6 @@ __global__ __launch_bounds__(256) void matvec_kernel(u64* y, const u64* W, const
         for (int r = 0; r < RT; ++r) {
             acc_mac(acc[r][0][0], w[r].a, x0.a); acc_mac(acc[r][0][1], w[r].b, x0.b);
             acc_mac(acc[r][1][0], w[r].a, x1.a); acc_mac(acc[r][1][1], w[r].b, x1.b);
-        }
-        if (DPFHE_MATVEC_PIPELINE) {
-            x0 = x0n; x1 = x1n;
-#pragma unroll
-            for (int r = 0; r < RT; ++r) w[r] = wn[r];
         }
         if (++since == 128) {  // 128 products of < 2^120 stay below 2^128 next to a reduced value
 #pragma unroll
@@ -371,10 +349,7 @@ __device__ __forceinline__ WordVec<WPT> load_words(const u64* p, bool in_range) 
 // compile time and the loads of column j + 1 are waited for where column j + 1 first uses them.  With the checks in place every column was its
 // own block that ended in register copies of the next operands behind s_waitcnt vmcnt(0): the one-column lookahead the source asks for
 // did not exist in the binary.
-#ifndef DPFHE_MATVEC_FULL_DEPTH
-#define DPFHE_MATVEC_FULL_DEPTH 1
-#endif
-constexpr int kMatvecFullDepth = DPFHE_MATVEC_FULL_DEPTH;   // columns of lookahead of the FULL form (both operands)
+constexpr int kMatvecFullDepth = 1;   // columns of lookahead of the FULL form (both operands)
 template <int RT, int C, int WPT, bool NTW = false, int WD = 1, bool FULL = false>
 __global__ __launch_bounds__(256) void matvec_fold_kernel(u64* y, const u64* W, const u64* x, const LimbConst* lcs, int n_limbs, int n,
                                                           int chunks, size_t rows, size_t cols, size_t polys_per_col, unsigned n_groups,

@@ -1,12 +1,10 @@
-// kernels_trace.h - DIAGNOSTIC builds only (-DDPFHE_NTT_TRACE=1; =2 forces the halves form of N = 8192 at every batch size; tools/ab_variant.sh; read back by tools/ntt_trace.py): the batched forward transform
+// kernels_trace.h - DIAGNOSTIC builds only (-DDPFHE_DIAGNOSTICS; tools/ab_variant.sh diag -DDPFHE_DIAGNOSTICS; read back by tools/ntt_trace.py): the batched forward transform
 // with per-workgroup s_memrealtime stamps (100 MHz), for the workgroup timelines of DESIGN.md section 5.  Thread 0 of every workgroup writes 8 words:
 //   0 start, 1 first operand word in registers, 2 all operand words arrived, 3 transform + canonicalisation done, 4 stores issued, 5 stores drained,
 //   6 HW_ID | XCC_ID << 32, 7 unused.   Same words out as the untraced kernels; not part of the library.
 #pragma once
 #include "kernels.h"
-#if DPFHE_N13_HALVES
 #include "kernels_halves.h"
-#endif
 
 namespace dpfhe {
 
@@ -54,9 +52,8 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE)) void ntt_fwd_trace_kernel(u64* 
     ntt_trace_write(trace, t0, t1, t2, t3, t4);
 }
 
-#if DPFHE_N13_HALVES
 template <class Arith>
-__global__ __launch_bounds__(256, DPFHE_HALVES_OCC) void ntt_fwd_halves_trace_kernel(u64* __restrict__ out, const u64* __restrict__ in, DevTables<Arith> tb, u64* __restrict__ trace) {
+__global__ __launch_bounds__(256, kHalvesOcc) void ntt_fwd_halves_trace_kernel(u64* __restrict__ out, const u64* __restrict__ in, DevTables<Arith> tb, u64* __restrict__ trace) {
     typedef Halves13<Arith> H;
     typedef typename H::B B;
     constexpr int E = H::E, N = H::N, N2 = H::N2;
@@ -77,12 +74,12 @@ __global__ __launch_bounds__(256, DPFHE_HALVES_OCC) void ntt_fwd_halves_trace_ke
     for (int k = 0; k < E; ++k) dep |= lo[k] | hi[k];
     const u64 t2 = trace_stamp<true>(dep);
     H::fwd_column(lo, hi, wtop, lc);
-    FwdChain<B, 0>::template run<DPFHE_HALVES_OCC <= 3>(tid, lo, lds, tw, lc);
+    FwdChain<B, 0>::template run<kHalvesOcc <= 3>(tid, lo, lds, tw, lc);
     B::fwd_canon(lo, lc);
     B::store_bot_lds(tid, lo, out + p * N, lds);
     asm volatile("" : "+v"(tid));
     lds_barrier();
-    FwdChain<B, 0>::template run<DPFHE_HALVES_OCC <= 3>(tid, hi, lds, tw + N2, lc);
+    FwdChain<B, 0>::template run<kHalvesOcc <= 3>(tid, hi, lds, tw + N2, lc);
     B::fwd_canon(hi, lc);
     dep = 0;
 #pragma unroll
@@ -92,6 +89,5 @@ __global__ __launch_bounds__(256, DPFHE_HALVES_OCC) void ntt_fwd_halves_trace_ke
     const u64 t4 = trace_stamp<true>((u64)tid);
     ntt_trace_write(trace, t0, t1, t2, t3, t4);
 }
-#endif
 
 }  // namespace dpfhe

@@ -13,29 +13,17 @@ namespace dpfhe {
 // 16 everywhere keeps one twiddle layout per context)
 // N = 16384 (128 KiB of LDS per polynomial): 1024 threads, one workgroup per CU (16 words per thread measured 5 % faster
 // than 32 on the forward transform); the fused kernels stop at N = 8192.
-#ifndef DPFHE_NTT12_LOGE
-#define DPFHE_NTT12_LOGE 4   // tools/ab_variant.sh ntt12e5 -DDPFHE_NTT12_LOGE=5: 32 words per thread at N = 4096 (A/B only)
-#endif
-constexpr int ntt_loge(int log2n) { return log2n == 12 ? DPFHE_NTT12_LOGE : 4; }
+constexpr int ntt_loge(int /*log2n*/) { return 4; }   // (32 words per thread at N = 4096 measured equal to slower - round 4 A/B, closed)
 constexpr int kMaxLog2N = 16, kMaxFusedLog2N = 13;
 // N > 16384: split transform - log2(N1) top stages in ntt_top_kernel, then N1 transforms of N2 = 4096 points each
 constexpr int kSplitLog2N2 = 12;
 constexpr int split_log_n1(int log2n) { return log2n > 14 ? log2n - kSplitLog2N2 : 0; }
-#ifndef DPFHE_FUSED_LOGE
-#define DPFHE_FUSED_LOGE 4   // words-per-thread exponent of the fused kernels (tools/ab_variant.sh builds -DDPFHE_FUSED_LOGE=3 for A/B runs)
-#endif
-constexpr int kFusedLoge = DPFHE_FUSED_LOGE;
+constexpr int kFusedLoge = 4;   // words-per-thread exponent of the fused kernels (8 per thread measured slower - round 3 A/B, closed)
 // N = 8192 on the N = 4096 body ("halves": ntt_halves.h, kernels_halves.h - a register column stage + two 4096-point sub-transforms through one LDS
 // buffer, 256-thread workgroups, three to a CU).  Round 5, measured (profiles/r05_ntt13_batch_sweep.txt, r05_ntt_workgroup_timelines.txt, r05_halves_*.txt):
 //  * batched transforms: 2.5-9 % FASTER than the 512-thread kernels from 384 RNS polynomials (2304 workgroups) up - the 512-thread kernel keeps only 1.7 of
 //    its 2 workgroups per CU resident -, 4 % slower at 256 and below (two lockstep generations): launch_ntt picks the form by batch size, FoldArith contexts;
-//  * giant-step key inner products as one workgroup per (item, limb, half): 3 % slower at the packed layers' size - A/B builds only (-DDPFHE_RELIN13_HALVES=1).
-#ifndef DPFHE_N13_HALVES
-#define DPFHE_N13_HALVES 1
-#endif
-#ifndef DPFHE_RELIN13_HALVES
-#define DPFHE_RELIN13_HALVES 0
-#endif
+//  * giant-step key inner products as one workgroup per (item, limb, half): 3 % slower at the packed layers' size (profiles/r05_halves_relin_ab.txt) - removed in round 6.
 constexpr size_t kHalvesMinPolys = 2304;   // residue polynomials per launch from which the halves form of the N = 8192 transforms wins (measured crossover: 1536 loses, 2304 wins)
 constexpr int kMaxGaloisBatch = 64;   // Galois elements travel as kernel arguments, this many per launch
 

@@ -4,10 +4,8 @@
 
 #include "kernels.h"
 #include "launch.h"
-#if DPFHE_N13_HALVES || DPFHE_RELIN13_HALVES
 #include "kernels_halves.h"
-#endif
-#ifdef DPFHE_NTT_TRACE   // diagnostic builds only
+#ifdef DPFHE_DIAGNOSTICS   // diagnostic builds only (tools/ab_variant.sh diag -DDPFHE_DIAGNOSTICS): per-workgroup timestamp kernels, their buffers and read-back entries
 #include "kernels_trace.h"
 #endif
 
@@ -43,12 +41,12 @@ static_assert(sizeof(u64) * Geo<14, 4>::lds_words() <= kLdsBytesPerCu, "the N = 
         case 9: MACRO(9, 4); break;         \
         case 10: MACRO(10, 4); break;       \
         case 11: MACRO(11, 4); break;       \
-        case 12: MACRO(12, DPFHE_NTT12_LOGE); break; \
+        case 12: MACRO(12, 4); break;       \
         case 13: MACRO(13, 4); break;       \
         case 14: MACRO(14, 4); break;       \
         default: return -1;                 \
     }
-static_assert(ntt_loge(12) == DPFHE_NTT12_LOGE && ntt_loge(13) == 4 && ntt_loge(8) == 4 && ntt_loge(14) == 4, "launch.h ntt_loge must match DPFHE_NTT_GEO_SWITCH");
+static_assert(ntt_loge(12) == 4 && ntt_loge(13) == 4 && ntt_loge(8) == 4 && ntt_loge(14) == 4, "launch.h ntt_loge must match DPFHE_NTT_GEO_SWITCH");
 
 template <class Arith, int LOG_N1>
 static void launch_ntt_split(bool inverse, u64* out, const u64* in, size_t npolys, const DevTables<Arith>& tb, hipStream_t s) {
@@ -73,34 +71,31 @@ int launch_ntt(int log2n, bool inverse, u64* out, const u64* in, size_t npolys, 
     // batches whose input + output cannot stay in the 256 MiB Infinity Cache stream around it (FoldArith, the two production ring degrees)
     const size_t touched = (npolys << log2n) * sizeof(u64) * (out == in ? 1 : 2);
     const bool nt = Arith::kFold && (log2n == 12 || log2n == 13) && touched > ((size_t)256 << 20);
-#ifdef DPFHE_NTT_TRACE   // diagnostic builds only: the forward transform at N = 4096 / 8192 with per-workgroup timestamps (kernels_trace.h, tools/ntt_trace.py)
+#ifdef DPFHE_DIAGNOSTICS   // the forward transform at N = 4096 / 8192 with per-workgroup timestamps (kernels_trace.h, tools/ntt_trace.py)
     if constexpr (Arith::kFold) {
-        if (!inverse && (log2n == 12 || log2n == 13) && npolys <= 65536) {
+        if (!inverse && (log2n == 12 || log2n == 13) && npolys <= 65536 && !tb.n_active) {
             if (!g_ntt_trace) { if (hipMalloc(&g_ntt_trace, sizeof(u64) * 8 * 65536) != hipSuccess) return -1; }
             g_ntt_trace_blocks = (unsigned)npolys;
-#if DPFHE_N13_HALVES
-            if (log2n == 13 && tb.hfwd && (npolys >= kHalvesMinPolys || DPFHE_NTT_TRACE > 1)) { hipLaunchKernelGGL((ntt_fwd_halves_trace_kernel<Arith>), dim3((unsigned)npolys), dim3(256), 0, s, out, in, tb, g_ntt_trace); return 0; }
-#endif
+            if (log2n == 13 && tb.hfwd && npolys >= kHalvesMinPolys) { hipLaunchKernelGGL((ntt_fwd_halves_trace_kernel<Arith>), dim3((unsigned)npolys), dim3(256), 0, s, out, in, tb, g_ntt_trace); return 0; }
             if (log2n == 12) hipLaunchKernelGGL((ntt_fwd_trace_kernel<Arith, 12, 4>), dim3((unsigned)npolys), dim3(Geo<12, 4>::T), 0, s, out, in, tb, g_ntt_trace);
             else hipLaunchKernelGGL((ntt_fwd_trace_kernel<Arith, 13, 4>), dim3((unsigned)npolys), dim3(Geo<13, 4>::T), 0, s, out, in, tb, g_ntt_trace);
             return 0;
         }
     }
 #endif
-#if DPFHE_N13_HALVES   // N = 8192, large batches, FoldArith: 256-thread workgroups on the N = 4096 body (launch.h)
+    // N = 8192, large batches, FoldArith: 256-thread workgroups on the N = 4096 body (launch.h)
     if constexpr (Arith::kFold) {
-    if (log2n == 13 && tb.hfwd && !tb.n_active && npolys >= kHalvesMinPolys) {
-        if (inverse) {
-            if (nt && Arith::kFold) hipLaunchKernelGGL((ntt_inv_halves_kernel<Arith, Arith::kFold>), dim3((unsigned)npolys), dim3(256), 0, s, out, in, tb);
-            else hipLaunchKernelGGL((ntt_inv_halves_kernel<Arith, false>), dim3((unsigned)npolys), dim3(256), 0, s, out, in, tb);
-        } else {
-            if (nt && Arith::kFold) hipLaunchKernelGGL((ntt_fwd_halves_kernel<Arith, Arith::kFold>), dim3((unsigned)npolys), dim3(256), 0, s, out, in, tb);
-            else hipLaunchKernelGGL((ntt_fwd_halves_kernel<Arith, false>), dim3((unsigned)npolys), dim3(256), 0, s, out, in, tb);
+        if (log2n == 13 && tb.hfwd && !tb.n_active && npolys >= kHalvesMinPolys) {
+            if (inverse) {
+                if (nt) hipLaunchKernelGGL((ntt_inv_halves_kernel<Arith, true>), dim3((unsigned)npolys), dim3(256), 0, s, out, in, tb);
+                else hipLaunchKernelGGL((ntt_inv_halves_kernel<Arith, false>), dim3((unsigned)npolys), dim3(256), 0, s, out, in, tb);
+            } else {
+                if (nt) hipLaunchKernelGGL((ntt_fwd_halves_kernel<Arith, true>), dim3((unsigned)npolys), dim3(256), 0, s, out, in, tb);
+                else hipLaunchKernelGGL((ntt_fwd_halves_kernel<Arith, false>), dim3((unsigned)npolys), dim3(256), 0, s, out, in, tb);
+            }
+            return 0;
         }
-        return 0;
     }
-    }
-#endif
 #define NTT_CASE(LN, LE)                                                                                                              \
     if constexpr (Arith::kFold && (LN == 12 || LN == 13)) {                                                                           \
         if (nt) {                                                                                                                     \
@@ -118,26 +113,15 @@ int launch_ntt(int log2n, bool inverse, u64* out, const u64* in, size_t npolys, 
 
 template <class Arith, bool IN_NTT, bool OUT_NTT>
 static int launch_ct_mul_dom(int log2n, u64* out3, const u64* a2, const u64* b2, size_t blocks, const DevTables<Arith>& tb, hipStream_t s) {
-    // the fused kernel keeps up to four transformed polynomials in registers: always E = 16 words per thread
-#ifndef DPFHE_CTMUL_DUAL
-#define DPFHE_CTMUL_DUAL 1
-#endif
-#ifndef DPFHE_CTMUL_DUAL_MAXLOGN
-#define DPFHE_CTMUL_DUAL_MAXLOGN 13
-#endif
-    // coefficient domain in and out, N <= 4096: all four forward and all three inverse transforms share their twiddle fetches
+    // the fused kernel keeps up to four transformed polynomials in registers: always E = 16 words per thread.
+    // Coefficient domain in and out, N <= 4096: all four forward and all three inverse transforms share their twiddle fetches
     // (ct_mul_quad_kernel); N = 8192 or NTT-domain output: transforms in pairs (ct_mul_dual_kernel; at N = 8192 the quad form
-    // measured equal to slightly slower: one 8-wave workgroup per CU, three barriers per all-to-all exchange)
-#ifndef DPFHE_CTMUL_QUAD
-#define DPFHE_CTMUL_QUAD 1
-#endif
-#ifndef DPFHE_CTMUL_QUAD_MAXLOGN
-#define DPFHE_CTMUL_QUAD_MAXLOGN 12   // tools/ab_variant.sh quad13 -DDPFHE_CTMUL_QUAD_MAXLOGN=13 builds the N = 8192 form for A/B runs
-#endif
+    // measured equal to slightly slower: one 8-wave workgroup per CU, three barriers per all-to-all exchange - profiles/r03_ab_quad13.txt)
+    constexpr int kQuadMaxLogN = 12, kDualMaxLogN = 13;
 #define CT_CASE(LN, LE)                                                                                                                              \
-    if constexpr (DPFHE_CTMUL_QUAD && Arith::kFoldCore && !IN_NTT && !OUT_NTT && LN <= DPFHE_CTMUL_QUAD_MAXLOGN)   /* (F64Arith's quad form spills: pairs) */           \
+    if constexpr (Arith::kFoldCore && !IN_NTT && !OUT_NTT && LN <= kQuadMaxLogN)   /* (F64Arith's quad form spills: pairs) */                                           \
         hipLaunchKernelGGL((ct_mul_quad_kernel<Arith, LN, kFusedLoge>), dim3((unsigned)blocks), dim3(Geo<LN, kFusedLoge>::T), 0, s, out3, a2, b2, tb, (u64*)nullptr); \
-    else if constexpr (DPFHE_CTMUL_DUAL && (Arith::kFoldCore || Arith::kF64) && !IN_NTT && LN <= DPFHE_CTMUL_DUAL_MAXLOGN)                                                                     \
+    else if constexpr ((Arith::kFoldCore || Arith::kF64) && !IN_NTT && LN <= kDualMaxLogN)                                                                                                     \
         hipLaunchKernelGGL((ct_mul_dual_kernel<Arith, LN, kFusedLoge, OUT_NTT>), dim3((unsigned)blocks), dim3(Geo<LN, kFusedLoge>::T), 0, s, out3, a2, b2, tb); \
     else                                                                                                                                             \
         hipLaunchKernelGGL((ct_mul_kernel<Arith, LN, kFusedLoge, IN_NTT, OUT_NTT>), dim3((unsigned)blocks), dim3(Geo<LN, kFusedLoge>::T), 0, s, out3, a2, b2, tb)
@@ -188,49 +172,31 @@ int launch_ct_mul_trace(int log2n, u64* out3, const u64* a2, const u64* b2, size
     }
 }
 
-#ifdef DPFHE_RELIN_TRACE
+#ifdef DPFHE_DIAGNOSTICS
 inline u64* g_relin_trace = nullptr;
 inline unsigned g_relin_trace_blocks = 0;
 #endif
 template <class Arith>
 int launch_relin(int log2n, int mode, u64* out2, const u64* in3, const u64* evk, size_t key_stride, unsigned key_group, size_t blocks,
                  const DevTables<Arith>& tb, hipStream_t s) {
-#ifndef DPFHE_RELIN_SHARED
-#define DPFHE_RELIN_SHARED 1
-#endif
     // 4..7 digits at N <= 4096: digit transforms side by side (relin_shared_kernel: -10 % on relinearize at N=4096, L=4; at N=8192,
     // where one workgroup owns the CU and the key tiles are what it streams, the same form measured -1 %: not instantiated)
     if (mode < 0 || mode > 4) return -1;
     const int n_digits = mode >= 2 ? tb.n_limbs - 1 : tb.n_limbs;
     // items that share a key (key_group > 1) are laid out per XCD: kernels.h relin_kernel
     const unsigned kg = key_group ? key_group : 1u;
-    unsigned n_outer = (kg > 1 && blocks % ((size_t)kg * tb.n_limbs) == 0) ? (unsigned)(blocks / kg) : 0u;   // whole groups only
+    // (round 6: items with a key each and NO sharing - one token's rotations - take the key-major order too: all limbs of an item on one XCD, so that its
+    //  digits cross the fabric once, not once per XCD - profiles/r06_giant_traffic.txt, shape (15, 1).  Items that share ONE key (key_stride 0) keep the plain
+    //  order, in which an XCD only ever touches the key tiles of its own limbs.)
+    unsigned n_outer = ((kg > 1 || key_stride != 0) && blocks % ((size_t)kg * tb.n_limbs) == 0) ? (unsigned)(blocks / kg) : 0u;   // whole groups only
     unsigned grid = n_outer ? ((n_outer + 7u) / 8u) * 8u * kg : (unsigned)blocks;
-#ifndef DPFHE_RELIN_KEY_MAJOR
-#define DPFHE_RELIN_KEY_MAJOR 1
-#endif
     // eight keys or more: one key (all its limbs and items) per XCD at a time, so that the items' digits are fetched once, not once per limb
-    if (DPFHE_RELIN_KEY_MAJOR && n_outer && n_outer / (unsigned)tb.n_limbs >= 8u) {
+    if (n_outer && n_outer / (unsigned)tb.n_limbs >= 8u) {
         const unsigned n_keys = n_outer / (unsigned)tb.n_limbs;
         grid = ((n_keys + 7u) / 8u) * 8u * (unsigned)tb.n_limbs * kg;
         n_outer |= kRelinRotMajor;
     }
-#if DPFHE_RELIN13_HALVES   // A/B builds only (launch.h): one 256-thread workgroup per (item, limb, half of the NTT domain) - kernels_halves.h relin_half_kernel
-    if (log2n == 13 && mode == 4 && tb.hfwd) {
-        const unsigned VL = 2u * (unsigned)tb.n_limbs;
-        const size_t vblocks = blocks * 2;
-        unsigned h_outer = (kg > 1 && vblocks % ((size_t)kg * VL) == 0) ? (unsigned)(vblocks / kg) : 0u;
-        unsigned h_grid = h_outer ? ((h_outer + 7u) / 8u) * 8u * kg : (unsigned)vblocks;
-        if (DPFHE_RELIN_KEY_MAJOR && h_outer && h_outer / VL >= 8u) {
-            const unsigned n_keys = h_outer / VL;
-            h_grid = ((n_keys + 7u) / 8u) * 8u * VL * kg;
-            h_outer |= kRelinRotMajor;
-        }
-        hipLaunchKernelGGL((relin_half_kernel<Arith>), dim3(h_grid), dim3(256), 0, s, out2, in3, evk, key_stride, kg, h_outer, tb);
-        return 0;
-    }
-#endif
-#ifdef DPFHE_RELIN_TRACE   // diagnostic builds only (tools/ab_variant.sh reltrace -DDPFHE_RELIN_TRACE; tools/relin_trace.py reads the buffer back)
+#ifdef DPFHE_DIAGNOSTICS   // (tools/relin_trace.py reads the buffer back)
     if constexpr (Arith::kFold) {
         if (log2n == 13 && mode == 4) {
             if (!g_relin_trace) { if (hipMalloc(&g_relin_trace, sizeof(u64) * 8 * 65536) != hipSuccess) return -1; }
@@ -241,7 +207,7 @@ int launch_relin(int log2n, int mode, u64* out2, const u64* in3, const u64* evk,
     }
 #endif
 #define RL_ONE(LN, M)                                                                                                                                    \
-    if constexpr (DPFHE_RELIN_SHARED && Arith::kFold && LN >= 10 && LN <= 12) {                                                                          \
+    if constexpr (Arith::kFold && LN >= 10 && LN <= 12) {                                                                          \
         if (n_digits >= 4 && n_digits <= 7) {                                                                                                            \
             hipLaunchKernelGGL((relin_shared_kernel<Arith, LN, kFusedLoge, M>), dim3(grid), dim3(Geo<LN, kFusedLoge>::T), 0, s, out2, in3, evk,          \
                                key_stride, kg, n_outer, tb);                                                                                             \
@@ -270,11 +236,9 @@ int launch_hoisted_ks(int log2n, u64* work, const u64* digits, const u64* keys, 
     // few workgroups (one token): one per (rotation, limb, key component), half the serial chain each; many (several tokens, Ld <= 7 so
     // that the lazy sums fit): one per (rotation, limb) doing both components - the digit words are gathered once and the two inverse
     // transforms share their twiddles (kernels.h hoisted_ks2_kernel)
-#ifndef DPFHE_HOISTED_MERGE_MIN
-#define DPFHE_HOISTED_MERGE_MIN 512
-#endif
+    constexpr size_t kHoistedMergeMin = 512;
     const unsigned tiles1 = (unsigned)(count * (size_t)tb.n_limbs);                 // (rotation, limb)
-    const bool merged = Arith::kFold && tb.n_limbs - 1 <= 7 && (size_t)tiles1 * n_items >= (size_t)DPFHE_HOISTED_MERGE_MIN;
+    const bool merged = Arith::kFold && tb.n_limbs - 1 <= 7 && (size_t)tiles1 * n_items >= kHoistedMergeMin;
     const unsigned tiles = merged ? tiles1 : tiles1 * 2u;                           // ... x key component when split
     const unsigned blocks = ((tiles + 7u) / 8u) * 8u * (unsigned)n_items;           // x token, ids laid out per XCD (kernels.h)
 #define HK_CASE(LN, LE)                                                                                                                                  \

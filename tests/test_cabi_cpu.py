@@ -28,6 +28,33 @@ def test_every_header_symbol_is_exported_and_bound(lib):
     assert declared == set(_cabi.SYMBOLS), declared ^ set(_cabi.SYMBOLS)
     for name in declared:
         assert getattr(lib, name) is not None
+    # ... and the library exports NOTHING else (round 6: linked with a version script, csrc/exports.map - no mangled __device_stub__ / template symbols)
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", _cabi.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = {l.split()[-1] for l in out.splitlines() if l.strip()}
+    assert exported == declared, sorted(exported ^ declared)[:10]
+
+
+def test_product_sources_carry_no_ab_switches():
+    """Round 6: the losing arms of closed A/B experiments are deleted, tuning constants are constexpr, and the diagnostic (timestamp) kernels sit behind ONE
+    macro, DPFHE_DIAGNOSTICS.  What may remain: that macro's guards and the emulator's DPFHE_EMU_CHECK - at most 8 preprocessor conditionals on DPFHE_* in csrc/."""
+    import glob
+    hits = []
+    for path in glob.glob(os.path.join(ROOT, "deeppowers_amd", "csrc", "*")):
+        if not os.path.isfile(path) or not path.endswith((".h", ".hip", ".cpp")):
+            continue
+        for i, l in enumerate(open(path, errors="replace").read().split("\n")):
+            if re.match(r"\s*#\s*if.*DPFHE_", l):
+                hits.append((os.path.basename(path), i + 1, l.strip()[:60]))
+    assert len(hits) <= 8, hits
+    assert all("DPFHE_DIAGNOSTICS" in h[2] or "DPFHE_EMU_CHECK" in h[2] for h in hits), hits
+
+
+def test_null_entry_points_of_round_6(lib):
+    assert lib.dpfhe_ctx_limb_class(None, 0) == -1
+    assert lib.dpfhe_ctx_release_scratch(None, None, 0) == 2000 and lib.dpfhe_ctx_scratch_bytes(None) == 0
+    assert lib.dpfhe_canonicalize_sum(None, None, 1, None) == 2000 and lib.dpfhe_comm_allreduce_sum(None, None, None, 1, None) == 2000
+    lib.dpfhe_tune_cache_clear()
 
 
 def test_strerror_uses_reference_error_codes(lib):
@@ -108,19 +135,15 @@ def test_no_kernel_spills_to_scratch(lib):
 
 
 def test_library_sources_read_no_environment_variable():
-    """Round 5: a library's behaviour does not depend on its environment - the only getenv left in the product sources is the split-sweep switch of the
-    packed layers, compiled in only under -DDPFHE_EXPERIMENTS."""
+    """A library's behaviour does not depend on its environment: no getenv anywhere in the product sources (round 6 removed the last one, the split-sweep switch)."""
     import glob
     hits = []
     for path in glob.glob(os.path.join(ROOT, "deeppowers_amd", "csrc", "*")) + glob.glob(os.path.join(ROOT, "include", "**", "*.h*"), recursive=True):
         if not os.path.isfile(path) or path.endswith((".o", ".so", ".log")):
             continue
-        lines = open(path, errors="replace").read().split("\n")
-        for i, l in enumerate(lines):
+        for i, l in enumerate(open(path, errors="replace").read().split("\n")):
             if "getenv(" in l and not l.lstrip().startswith("//"):
-                guarded = any("#ifdef DPFHE_EXPERIMENTS" in p for p in lines[max(0, i - 3):i])
-                if not guarded:
-                    hits.append(f"{os.path.basename(path)}:{i + 1}")
+                hits.append(f"{os.path.basename(path)}:{i + 1}")
     assert not hits, hits
 
 

@@ -9,7 +9,7 @@ import subprocess
 import numpy as np
 import pytest
 
-from deeppowers_amd.params import PRIMES_60, PRIME_30, PSI_30_N1024
+from deeppowers_amd.params import PRIMES_60, PRIME_30, PSI_30_N1024, ntt_primes
 from oracle import pyoracle as po
 from oracle.cbind import Oracle
 
@@ -23,7 +23,7 @@ def emu():
     src = os.path.join(ROOT, "tools", "emulate.cpp")
     deps = [src] + [os.path.join(ROOT, "deeppowers_amd", "csrc", f) for f in ("ntt_core.h", "ntt_top.h", "ntt_halves.h", "modarith.h", "tables.h")]
     if not os.path.exists(so) or any(os.path.getmtime(d) > os.path.getmtime(so) for d in deps):
-        subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-o", so, src])
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-shared", "-fPIC", "-o", so, src])   # (F64Arith: nothing fused behind the explicit fma calls)
     lib = C.CDLL(so)
     lib.emu_ntt.argtypes = [C.c_int] * 4 + [C.c_uint64, C.c_uint64, U, U]
     lib.emu_overflows.restype = C.c_long
@@ -192,4 +192,62 @@ def test_dot30_column_accumulators_match_128_bit_arithmetic(emu):
                 a, b = np.ascontiguousarray(a), np.ascontiguousarray(b)
                 want = sum(int(x) * int(y) for x, y in zip(a, b)) % q
                 assert emu.emu_dot30(q, a.ctypes.data_as(U), b.ctypes.data_as(U), n) == want
+    assert emu.emu_overflows() == before
+
+
+# ---- round 6: the per-limb arithmetic classes (modarith.h F64Arith, FoldScaledArith) -------------------------------------------------------------------
+CLASS_CASES = [(2, bits) for bits in (20, 30, 31, 33, 40, 45, 47)] + [(3, bits) for bits in (54, 56, 57, 58, 59)]
+
+
+def _class_patterns(orc, n, q):
+    return [orc.fill(1, 77).ravel().copy(), np.full(n, q - 1, np.uint64), np.zeros(n, np.uint64),
+            np.where(np.arange(n) % 2 == 0, q - 1, 0).astype(np.uint64), np.where(np.arange(n) < n // 2, q - 1, 1).astype(np.uint64),
+            np.where(np.arange(n) % 2 == 0, q // 2, q // 2 + 1).astype(np.uint64)]
+
+
+@pytest.mark.parametrize("ln,le", [(8, 4), (10, 4), (12, 4), (13, 4), (14, 4)])
+@pytest.mark.parametrize("arith,bits", CLASS_CASES, ids=[("f64_" if a == 2 else "fold_scaled_") + str(b) for a, b in CLASS_CASES])
+def test_emulated_class_transforms_match_oracle(emu, ln, le, arith, bits):
+    """F64Arith (residues as doubles, error-free FMA products; the |y| < 2^51 precondition of every product is armed in the emulator build) and
+    FoldScaledArith (2^k - d0 carried as 2^60 - d) through the very per-thread code the kernels run, both directions, extreme residues included."""
+    n = 1 << ln
+    before = emu.emu_overflows()
+    P = ntt_primes(ln, 2, bits)
+    ran = 0
+    for q, psi in zip(P.moduli, P.psi):
+        orc = Oracle(ln, [q], [psi])
+        for a in _class_patterns(orc, n, q):
+            rc, got = run(emu, arith, ln, le, 0, q, psi, a)
+            if rc == 2000:          # a prime of this width that the class does not take (d0 2^(60-k) >= 2^24): the library runs it on another class
+                assert arith == 3
+                break
+            assert rc == 0 and np.array_equal(got, orc.ntt_fwd(a))
+            rc, got = run(emu, arith, ln, le, 1, q, psi, a)
+            assert rc == 0 and np.array_equal(got, orc.ntt_inv(a))
+            ran += 1
+    assert ran or arith == 3
+    assert emu.emu_overflows() == before, "a lazy-arithmetic precondition was broken"
+
+
+@pytest.mark.parametrize("ln", [8, 12, 13])
+@pytest.mark.parametrize("arith,bits,lazy", [(2, 30, 1), (2, 47, 1), (2, 40, 0), (3, 59, 1), (3, 57, 1), (3, 59, 0), (1, 60, 1)],
+                         ids=["f64_30_lazy", "f64_47_lazy", "f64_40_generic", "fscaled_59_lazy", "fscaled_57_lazy", "fscaled_59_generic", "fold_lazy"])
+def test_emulated_class_fused_multiply_matches_oracle(emu, ln, arith, bits, lazy):
+    """the fused multiply's two data paths for the classes: lazy products of forward outputs straight into the inverse (ct_mul_quad / ct_mul_dual, ntt_core.h
+    NttBody::prod; FoldScaledArith's products carry the scale twice and end on last2) and the generic path through canonical words (ct_mul_kernel)"""
+    n = 1 << ln
+    fn = emu.emu_ct_mul_lazy_class if lazy else emu.emu_ct_mul_class
+    fn.argtypes = [C.c_int, C.c_int, C.c_uint64, C.c_uint64, U, U, U, U, U]
+    fn.restype = C.c_int
+    before = emu.emu_overflows()
+    P = ntt_primes(ln, 1, bits)
+    q, psi = P.moduli[0], P.psi[0]
+    orc = Oracle(ln, [q], [psi])
+    for polys in (orc.fill(4, 900).reshape(4, n), np.full((4, n), q - 1, np.uint64)):
+        polys = np.ascontiguousarray(polys, dtype=np.uint64)
+        a0, a1, b0, b1 = (np.ascontiguousarray(polys[i]) for i in range(4))
+        out = np.zeros(3 * n, np.uint64)
+        assert fn(arith, ln, q, psi, *(v.ctypes.data_as(U) for v in (a0, a1, b0, b1, out))) == 0
+        want = orc.ct_mul(np.stack([a0, a1]).reshape(1, 2, 1, n), np.stack([b0, b1]).reshape(1, 2, 1, n)).reshape(3 * n)
+        assert np.array_equal(out, want)
     assert emu.emu_overflows() == before
