@@ -308,7 +308,7 @@ def digest_other(o):
         c5 = o["n8192_l6"]
         d["n8192_l6"] = {"ntt_fwd_frac": r3(c5["ntt_fwd"]["frac_of_hbm_peak"]), "ntt_inv_frac": r3(c5["ntt_inv"]["frac_of_hbm_peak"]),
                          "ct_mul_per_s": round(c5["ct_mul"]["per_s"]), "ct_mul_frac": r3(c5["ct_mul"]["frac_of_hbm_peak"])}
-    for key in ("shoup_n4096_l4", "p31_n4096_l4", "shoup49_n4096_l4"):   # the per-limb arithmetic classes at the headline shape
+    for key in ("shoup_n4096_l4", "p31_n4096_l4", "wide49_n4096_l4", "shoup55_n4096_l4"):   # the per-limb arithmetic classes at the headline shape
         if isinstance(o.get(key), dict) and "ct_mul" in o[key]:
             sg = o[key]
             d[key] = {"classes": sg.get("limb_classes"), "ntt_fwd_frac": r3(sg["ntt_fwd"]["frac_of_hbm_peak"]), "ntt_inv_frac": r3(sg["ntt_inv"]["frac_of_hbm_peak"]),
@@ -711,7 +711,8 @@ def main():
         # kernels; now every limb runs on the fastest policy its prime admits (include/dpfhe.h dpfhe_ctx_limb_class).
         #   shoup_n4096_l4  : the round-5 line's primes, 59 / 50 / 40 / 33 bits (now fold_scaled, fold_scaled, f64, f64) - name kept for continuity
         #   p31_n4096_l4    : four 31-bit primes (f64: residues as doubles inside a transform) - the reference's widest integer is INT32 (hal.hpp:27-33)
-        #   shoup49_n4096_l4: four 49-bit primes - too wide for f64, too far from 2^60 for the scaled fold: what still runs on the generic kernels
+        #   wide49_n4096_l4 : four 49-bit primes (f64_wide: doubles, with reductions inside the transforms)
+        #   shoup55_n4096_l4: four 55-bit primes too far below 2^55 for the scaled fold - what still runs on the generic kernels
         def class_line(pg, what):
             ctxg = Context(pg, local_rank)
             evg = Evaluator(ctxg)
@@ -738,10 +739,19 @@ def main():
                 return sg
             finally:
                 ctxg.close()
-        from deeppowers_amd.params import ntt_primes
+        from deeppowers_amd.params import is_prime, min_primitive_2n_root, ntt_primes
+
+        def shoup55():   # too wide for the doubles (>= 2^50), too far below 2^55 for the scaled fold ((2^55 - q) 2^5 >= 2^24)
+            qs, qq = [], (1 << 55) - ((1 << 55) - 1) % 8192
+            while len(qs) < 4:
+                if is_prime(qq) and (((1 << 55) - qq) << 5) >= (1 << 24):
+                    qs.append(qq)
+                qq -= 8192
+            return FheParams(12, tuple(qs), tuple(min_primitive_2n_root(4096, v) for v in qs))
         for key, mk, what in (("shoup_n4096_l4", FheParams.generic_n4096_l4, "primes of 59/50/40/33 bits, none 2^60 - d (classes: scaled fold x2, f64 x2)"),
                               ("p31_n4096_l4", lambda: ntt_primes(12, 4, 31), "four 31-bit primes (f64 class: error-free FMA products on doubles)"),
-                              ("shoup49_n4096_l4", lambda: ntt_primes(12, 4, 49), "four 49-bit primes (generic class: Harvey/Shoup butterflies + 128-bit Barrett products)")):
+                              ("wide49_n4096_l4", lambda: ntt_primes(12, 4, 49), "four 49-bit primes (f64_wide class: doubles with reductions inside the transforms)"),
+                              ("shoup55_n4096_l4", shoup55, "four 55-bit primes no fast class takes (generic class: Harvey/Shoup butterflies + 128-bit Barrett products)")):
             try:
                 other[key] = class_line(mk(), what)
             except Exception as e:
@@ -1117,7 +1127,7 @@ def main():
             result["roofline"].update({"shoup_ntt_fwd_frac": sg["ntt_fwd"]["frac_of_hbm_peak"], "shoup_ntt_inv_frac": sg["ntt_inv"]["frac_of_hbm_peak"],
                                        "shoup_ct_mul_per_s": sg["ct_mul"]["per_s"], "shoup_ct_mul_frac": sg["ct_mul"]["frac_of_hbm_peak"],
                                        "fold_over_shoup_ct_mul": sg["fold_over_shoup_ct_mul"]})
-        for key, pre in (("p31_n4096_l4", "p31"), ("shoup49_n4096_l4", "shoup49")):
+        for key, pre in (("p31_n4096_l4", "p31"), ("wide49_n4096_l4", "wide49"), ("shoup55_n4096_l4", "shoup55")):
             sg = other_result.get(key) or {}
             if "ct_mul" in sg:
                 result["roofline"].update({pre + "_ntt_fwd_frac": sg["ntt_fwd"]["frac_of_hbm_peak"], pre + "_ntt_inv_frac": sg["ntt_inv"]["frac_of_hbm_peak"],

@@ -94,6 +94,7 @@ struct dpfhe_ctx {
     DevTables<FoldArith> cls_fold{};                  // typed views of it; the active-limb maps are set per launch (for_each_class)
     DevTables<F64Arith> cls_f64{};
     DevTables<FoldScaledArith> cls_fscaled{};
+    DevTables<F64WideArith> cls_f64w{};
     DevTables<ShoupArith> cls_shoup{};
     MixedTables mixed{};                              // the batched transforms' one-launch view (kernels.h ntt_classes_kernel)
     // scratch of the composed large-ring operations: a pool of this context's own (created on first use) that keeps what it has been
@@ -458,7 +459,7 @@ extern "C" int dpfhe_ctx_create(dpfhe_ctx** out, uint32_t log2_n, uint32_t n_lim
                 const LimbClass k = (LimbClass)c->limb_cls[l];
                 c->cls_map |= (unsigned long long)k << (4 * l);
                 if (k == kClassFold) fill_mixed_limb<TwFold>(mb, m, (int)log2_n, l, ht[l], k, [](u64 w, u64 q) { return h_tw_fold(w, q); });
-                else if (k == kClassF64) fill_mixed_limb<TwF64>(mb, m, (int)log2_n, l, ht[l], k, [](u64 w, u64 q) { return h_make_tw<TwF64>(w, q); });
+                else if (k == kClassF64 || k == kClassF64Wide) fill_mixed_limb<TwF64>(mb, m, (int)log2_n, l, ht[l], k, [](u64 w, u64 q) { return h_make_tw<TwF64>(w, q); });
                 else if (k == kClassFoldScaled) fill_mixed_limb<TwFold>(mb, m, (int)log2_n, l, ht[l], k, [](u64 w, u64 q) { return h_tw_fold_scaled(w, q, fold_scaled_shift(q)); });
                 else fill_mixed_limb<TwShoup>(mb, m, (int)log2_n, l, ht[l], k, [](u64 w, u64 q) { return h_make_tw<TwShoup>(w, q); });
             }
@@ -475,6 +476,7 @@ extern "C" int dpfhe_ctx_create(dpfhe_ctx** out, uint32_t log2_n, uint32_t n_lim
             c->cls_fold = mixed_view<FoldArith>(b, m, L);
             c->cls_f64 = mixed_view<F64Arith>(b, m, L);
             c->cls_fscaled = mixed_view<FoldScaledArith>(b, m, L);
+            c->cls_f64w = mixed_view<F64WideArith>(b, m, L);
             c->cls_shoup = mixed_view<ShoupArith>(b, m, L);
             c->mixed.fwd = b + m.o_fwd; c->mixed.inv = b + m.o_inv; c->mixed.last = b + m.o_last;
             c->mixed.lc = reinterpret_cast<const LimbConst*>(b + m.o_lc);
@@ -511,7 +513,8 @@ extern "C" int dpfhe_ctx_limb_class(const dpfhe_ctx* c, uint32_t limb) {
     if (c->classes) return (int)c->limb_cls[limb];
     return c->fold ? DPFHE_ARITH_FOLD : DPFHE_ARITH_SHOUP;
 }
-static_assert(DPFHE_ARITH_SHOUP == kClassShoup && DPFHE_ARITH_FOLD == kClassFold && DPFHE_ARITH_F64 == kClassF64 && DPFHE_ARITH_FOLD_SCALED == kClassFoldScaled, "dpfhe.h <-> tables.h");
+static_assert(DPFHE_ARITH_SHOUP == kClassShoup && DPFHE_ARITH_FOLD == kClassFold && DPFHE_ARITH_F64 == kClassF64 && DPFHE_ARITH_FOLD_SCALED == kClassFoldScaled &&
+              DPFHE_ARITH_F64_WIDE == kClassF64Wide, "dpfhe.h <-> tables.h");
 
 // ------------------------------------------------------------------------------------------------
 // words per thread of the FoldArith matvec kernels: 2 right-hand-side polynomials per workgroup / 4 (kernels_misc.h matvec_fold_kernel)
@@ -557,6 +560,7 @@ static int for_each_class(const dpfhe_ctx* c, size_t limbs_used, Fn fn) {
     { auto tb = restrict_to(c->cls_fold, kClassFold); if (tb.n_active && !rc) rc = fn(tb); }
     { auto tb = restrict_to(c->cls_f64, kClassF64); if (tb.n_active && !rc) rc = fn(tb); }
     { auto tb = restrict_to(c->cls_fscaled, kClassFoldScaled); if (tb.n_active && !rc) rc = fn(tb); }
+    { auto tb = restrict_to(c->cls_f64w, kClassF64Wide); if (tb.n_active && !rc) rc = fn(tb); }
     { auto tb = restrict_to(c->cls_shoup, kClassShoup); if (tb.n_active && !rc) rc = fn(tb); }
     return rc;
 }

@@ -1,7 +1,10 @@
 #include "launch_impl.h"
+#include "tables.h"
 // round 6: one launch for the batched transforms of a context whose limbs run on different arithmetic classes (kernels.h ntt_classes_kernel)
 namespace dpfhe {
 int launch_ntt_classes(int log2n, bool inverse, u64* out, const u64* in, size_t npolys, const MixedTables& tb, hipStream_t s) {
+    for (int l = 0; l < tb.n_limbs; ++l)
+        if (((tb.cls_map >> (4 * l)) & 15) == (unsigned long long)kClassF64Wide) return 1;   // no arm for this class in the merged kernel (kernels.h)
 // returns 0, -1 (no geometry), or 1: this geometry has no merged kernel - launch per class instead (the forward kernels at N = 256 and N = 16384
 // spill a few registers when the four arms share one kernel; they are not instantiated)
 #define NC_CASE(LN, LE)                                                                                                                  \

@@ -327,7 +327,8 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE)) void ntt_inv_kernel(u64* __rest
 // Round 6: the batched transforms of a context whose limbs run on DIFFERENT arithmetic classes (dpfhe_cabi.hip dpfhe_ctx::classes) in ONE launch.
 // The tables of such a context live in one blob whose per-limb slots are each in their limb's own format (all twiddle types are 16 bytes, so the
 // strides agree); the limb's class is workgroup-uniform, so the kernel branches once, on a scalar, into that class's transform - the same per-thread
-// code as ntt_fwd_kernel / ntt_inv_kernel.  (One launch per class measured 54.7 / 50.6 % of HBM peak on the 59/50/40/33-bit context at configs[1]'s
+// code as ntt_fwd_kernel / ntt_inv_kernel.  Four arms - Shoup, fold, f64, scaled fold; a fifth (F64WideArith) spills a few registers at N = 2048 / 4096, so contexts
+// with such limbs AND another class launch per class (launch_ntt_classes returns 1).  (One launch per class measured 54.7 / 50.6 % of HBM peak on the 59/50/40/33-bit context at configs[1]'s
 // batch, against 69 and 59 % for its two classes alone: two half-size launches each pay their own tail.)
 // ------------------------------------------------------------------------------------------------
 template <class Arith, int LOGN, int LOGE>

@@ -321,12 +321,13 @@ struct FoldScaledArith {
 };
 
 // -------------------------------------------------------------------------------------------------
-// F64Arith - primes q < 2^47 (round 6): inside a transform a residue is an IEEE double holding a (signed) integer, and the
+// F64Arith - primes q < 2^47, F64WideArith - primes q < 2^50 (round 6): inside a transform a residue is an IEEE double holding a (signed) integer, and the
 // modular product is the error-free FMA sequence
 //     p = y w;  e = fma(y, w, -p);  h = rint(y (w/q));  r = fma(-h, q, p);  t = r + e            ( = y w - h q exactly )
 // - 6 full-rate FP64 instructions, no integer multiply.  Exactness (|y| < 2^51, 0 <= w < q < 2^47, wq = fl(w / q)):
 //   * y wq differs from y w / q by at most |y| 2^-52 <= 1/2, so |y w / q - h| <= 1 and |t| <= q;
 //   * p and h q are integers and |r| = |t - e| <= q + ulp(p)/2 < 2^53, so the second fma is exact; so is r + e.
+//   (the same two lines hold for q < 2^50: ulp(p) / 2 <= 2^48.)
 // Butterflies are plain signed additions: a forward (Cooley-Tukey) word grows by at most q per stage, 1 + log2 N <= 16 q <= 2^51
 // at the last stage - no reduction inside a forward transform at all; the inverse (Gentleman-Sande) sums double per stage and are
 // reduced where the static plan (ntt_core.h make_gs_plan, cap 16 q) says so (3 instructions).  The rounding to an integer is the
@@ -337,10 +338,16 @@ struct FoldScaledArith {
 struct alignas(16) TwF64 {
     double w, wq;   // w and fl(w / q)
 };
-struct F64Arith {
+// MAXBITS: the widest prime the instantiation takes.  A product needs |y| < 2^51, i.e. |y| < kCap q with kCap = 2^(51 - MAXBITS) - 16 at 47 bits (no
+// reduction inside a forward transform), 2 at 50 bits (F64WideArith: ntt_core.h's static plans reduce most multiplied words first, 3 instructions each:
+// about the fold arithmetic's instruction count, on full-rate FP64 instructions, for primes no other fast class takes).
+template <int MAXBITS>
+struct F64ArithT {
     typedef TwF64 Tw;
     static constexpr bool kFold = false, kFoldCore = false, kF64 = true;
-    static constexpr int kMaxBits = 47;
+    static constexpr int kMaxBits = MAXBITS;
+    static_assert(MAXBITS >= 20 && MAXBITS <= 50, "the error-free product needs q + ulp(y w) / 2 < 2^53 and a quotient estimate within 1");
+    static constexpr int kCap = 1 << (51 - MAXBITS);   // |y| < kCap q  =>  |y| < 2^51
     static DPF_HD const LimbConst& ntt_lc(const LimbConst& c) { return c; }
     static DPF_HD double f(u64 x) { return __builtin_bit_cast(double, x); }
     static DPF_HD u64 b(double x) { return __builtin_bit_cast(u64, x); }
@@ -377,6 +384,8 @@ struct F64Arith {
         return from_f(r < 0.0 ? r + q : r);
     }
 };
+typedef F64ArithT<47> F64Arith;
+typedef F64ArithT<50> F64WideArith;
 
 // canonical add / sub / negate (inputs canonical)
 DPF_HD u64 add_mod(u64 a, u64 b, u64 q) { return csub(a + b, q); }

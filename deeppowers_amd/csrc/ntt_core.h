@@ -268,6 +268,74 @@ constexpr CtfPlan<LOGE> make_ctf_plan(int lb_top, int r, int in_bound, int out_c
 }
 
 // ------------------------------------------------------------------------------------------------
+// static bound plans (F64ArithT).  Bounds are on |x|, in units of q/1024.  A product's multiplied word must stay below cap = kCap q (<= 2^51); sums of
+// two words below 4 cap (exact additions: < 2^53).  A reduction leaves |x| <= q/2 + 1, a product |x| <= q.  With kCap = 16 (primes below 2^47) the forward
+// plan of every compiled ring degree is empty; with kCap = 2 (primes below 2^50) most multiplied words are reduced first.
+// ------------------------------------------------------------------------------------------------
+constexpr int kF64Red = kUnit / 2 + 1, kF64Tw = kUnit;
+template <int LOGE>
+struct F64CtPlan {
+    bool red_y[LOGE][1 << LOGE];   // reduce the multiplied word (upper-index element k | bit) of the butterfly with lower-index element k before stage u
+    bool red_a[LOGE][1 << LOGE];   // reduce the other word first (its sum with the product would leave the exact range)
+    bool red_end[1 << LOGE];
+    int out_bound;
+};
+template <int LOGE>
+constexpr F64CtPlan<LOGE> make_f64_ct_plan(int lb_top, int r, int in_bound, int out_cap, int cap) {
+    F64CtPlan<LOGE> p{};
+    constexpr int E = 1 << LOGE;
+    int bnd[E] = {};
+    for (int k = 0; k < E; ++k) bnd[k] = in_bound;
+    for (int u = 0; u < r; ++u) {
+        const int bit = 1 << (lb_top - u);
+        for (int k = 0; k < E; ++k) {
+            if (k & bit) continue;
+            int A = bnd[k], Y = bnd[k | bit];
+            if (Y > cap) { p.red_y[u][k] = true; Y = kF64Red; }
+            if (A + kF64Tw > 4 * cap) { p.red_a[u][k] = true; A = kF64Red; }
+            bnd[k] = bnd[k | bit] = A + kF64Tw;
+        }
+    }
+    int mx = 0;
+    for (int k = 0; k < E; ++k) {
+        if (bnd[k] > out_cap) { p.red_end[k] = true; bnd[k] = kF64Red; }
+        if (bnd[k] > mx) mx = bnd[k];
+    }
+    p.out_bound = mx;
+    return p;
+}
+template <int LOGE>
+struct F64GsPlan {
+    bool red[LOGE][1 << LOGE];
+    bool red_end[1 << LOGE];
+};
+template <int LOGE>
+constexpr F64GsPlan<LOGE> make_f64_gs_plan(int lb0, int r, int in_bound, int out_bound, bool last_all_mul, int cap) {
+    F64GsPlan<LOGE> p{};
+    constexpr int E = 1 << LOGE;
+    int bnd[E] = {};
+    for (int k = 0; k < E; ++k) bnd[k] = in_bound;
+    for (int u = 0; u < r; ++u) {
+        const int bit = 1 << (lb0 + u);
+        for (int k = 0; k < E; ++k) {
+            if (k & bit) continue;
+            int bx = bnd[k], by = bnd[k | bit];
+            if (bx + by > cap) {   // the difference is multiplied (and, in the last stage, the sum too)
+                if (bx > kF64Red) { p.red[u][k] = true; bx = kF64Red; }
+                if (by > kF64Red) { p.red[u][k | bit] = true; by = kF64Red; }
+            }
+            bnd[k] = (last_all_mul && u == r - 1) ? kF64Tw : bx + by;
+            bnd[k | bit] = kF64Tw;
+        }
+    }
+    for (int k = 0; k < E; ++k) {
+        p.red_end[k] = bnd[k] > out_bound;
+        if (p.red_end[k]) bnd[k] = kF64Red;
+    }
+    return p;
+}
+
+// ------------------------------------------------------------------------------------------------
 // per-thread transform body
 // ------------------------------------------------------------------------------------------------
 // SUB = 1: the body runs as one HALF of a 2N-point transform whose column stage (the first forward / last inverse radix-2 stage) the caller
@@ -571,6 +639,26 @@ struct NttBody {
         }
     }
 
+    // F64ArithT: kF64Cap = the product's precondition in plan units; phase hand-over at 2 cap (additions stay exact below 4 cap); the last forward phase
+    // hands over at most cap, what the lazy products take (prod below) and what leave() converts
+    template <class A = Arith> static constexpr int f64_cap_of() { if constexpr (A::kF64) return A::kCap * kUnit; else return kWord; }
+    static constexpr int kF64Cap = f64_cap_of<>();
+    template <int P>
+    static constexpr F64CtPlan<LOGE> f64_ct_plan() {
+        constexpr Phase ph = G::phase(P);
+        int in = kUnit;
+        for (int i = 0; i < P; ++i) {
+            const Phase pi = G::phase(i);
+            in = make_f64_ct_plan<LOGE>(pi.b - pi.c + pi.r - 1, pi.r, in, 2 * kF64Cap, kF64Cap).out_bound;
+        }
+        return make_f64_ct_plan<LOGE>(ph.b - ph.c + ph.r - 1, ph.r, in, (P == NPH - 1) ? kF64Cap : 2 * kF64Cap, kF64Cap);
+    }
+    template <int P, int IN>
+    static constexpr F64GsPlan<LOGE> f64_gs_plan() {
+        constexpr Phase ph = G::phase(P);
+        constexpr int mid = kF64Cap / 2 > 2 * kUnit ? 2 * kUnit : kF64Cap / 2;   // two such words may meet in the next phase's first butterfly
+        return make_f64_gs_plan<LOGE>(ph.b - ph.c, ph.r, (P == NPH - 1) ? IN : mid, (P == 0) ? kF64Cap : mid, P == 0, kF64Cap);
+    }
     // bound plan of forward phase P (FoldArith): canonical input to phase 0, kCtfMid at every exchange, nothing capped after the last
     template <int P>
     static constexpr CtfPlan<LOGE> ctf_plan() {
@@ -583,14 +671,14 @@ struct NttBody {
         return make_ctf_plan<LOGE>(ph.b - ph.c + ph.r - 1, ph.r, in, (P == NPH - 1) ? kWord : kCtfMid);
     }
     // bound of every word a forward transform hands to a dyadic product when its output is left lazy
-    static constexpr int kFwdOutBound = Arith::kFoldCore ? ctf_plan<NPH - 1>().out_bound : Arith::kF64 ? (LOGN + 1) * kUnit : 4 * kUnit;
+    static constexpr int kFwdOutBound = Arith::kFoldCore ? ctf_plan<NPH - 1>().out_bound : Arith::kF64 ? f64_ct_plan<NPH - 1>().out_bound : 4 * kUnit;
     static_assert(!Arith::kFoldCore || kFwdOutBound <= kLimitPartner, "lazy forward outputs must satisfy mul60's bound");
 
     // generic policies (FoldScaledArith, F64Arith) convert a canonical word when it enters a transform and back when it leaves (Arith::enter /
     // Arith::leave); the pinned-prime and Harvey policies work on the words as they are
     static constexpr bool kConverts = Arith::kF64 || (Arith::kFoldCore && !Arith::kFold);
     static_assert(!kConverts || !SUB, "the halves form is FoldArith's");
-    static_assert(!Arith::kF64 || LOGN <= 15, "F64Arith: a forward word reaches (1 + log2 N) q <= 16 q <= 2^51 unreduced");
+
     static DPF_HD void enter(u64 (&x)[E], const LimbConst& lc) {
         if constexpr (kConverts) {
 #pragma clang loop unroll(full)
@@ -604,7 +692,8 @@ struct NttBody {
         if constexpr (P == 0) enter(x, lc_in);
         const u64 two_q = 2 * lc.q;
         if constexpr (Arith::kF64) {
-            const double q = Arith::qd(lc);
+            constexpr F64CtPlan<LOGE> plan = f64_ct_plan<P>();
+            const double q = Arith::qd(lc), qi = Arith::qinv(lc);
 #pragma clang loop unroll(full)
             for (int u = 0; u < ph.r; ++u) {
                 const int lb = ph.b + ph.r - 1 - u - ph.c;
@@ -613,12 +702,17 @@ struct NttBody {
                     if (k & (1 << lb)) continue;
                     const int kk = k | (1 << lb);
                     const Tw& w = twr[u][k >> (lb + 1)];
-                    const double a = Arith::f(x[k]);
-                    const double t = Arith::mulmod(Arith::f(x[kk]), w.w, w.wq, q);   // |t| <= q: a word grows by at most q per stage
+                    double a = Arith::f(x[k]), y = Arith::f(x[kk]);
+                    if (plan.red_a[u][k]) a = Arith::reduce(a, q, qi);
+                    if (plan.red_y[u][k]) y = Arith::reduce(y, q, qi);
+                    const double t = Arith::mulmod(y, w.w, w.wq, q);   // |t| <= q: a word grows by at most q per stage
                     x[k] = Arith::b(a + t);
                     x[kk] = Arith::b(a - t);
                 }
             }
+#pragma clang loop unroll(full)
+            for (int k = 0; k < E; ++k)
+                if (plan.red_end[k]) x[k] = Arith::b(Arith::reduce(Arith::f(x[k]), q, qi));
         } else if constexpr (Arith::kFoldCore) {
             constexpr CtfPlan<LOGE> plan = ctf_plan<P>();
 #pragma clang loop unroll(full)
@@ -695,7 +789,7 @@ struct NttBody {
     // then runs on last-stage twiddles with s^-1 folded in (DevTables::last2).
     static constexpr bool kLazyProducts = Arith::kFoldCore || Arith::kF64;
     static constexpr int kProdInvIn = Arith::kF64 ? 2 * kUnit : 2 * kMulB;
-    static_assert(!Arith::kF64 || (LOGN + 1) * kUnit / 2 <= kWord / 2, "F64Arith: |a b / q| <= (log2 N + 1) q / 2 must stay below 2^50 for the quotient estimate");
+    static_assert(!Arith::kF64 || kFwdOutBound <= kF64Cap, "F64ArithT: |a b / q| <= |a| / 2 must stay below 2^50 for the quotient estimate of a lazy product");
     static DPF_HD void prod_partner(u64 (&y)[E], const LimbConst& lc) {
         if constexpr (Arith::kF64) {
             const double q = Arith::qd(lc), qi = Arith::qinv(lc);
@@ -705,7 +799,7 @@ struct NttBody {
     }
     static DPF_HD u64 prod(u64 a, u64 b, const LimbConst& lc) {
         if constexpr (Arith::kF64) {
-            // |a| < (log2 N + 1) q, |b| <= q / 2 + 1: the quotient estimate is within 0.375 of a b / q, so |result| < 0.875 q + 1; both fma exact (modarith.h)
+            // |a| < kCap q <= 2^51, |b| <= q / 2 + 1: the quotient estimate is within 0.375 of a b / q, so |result| < 0.875 q + 1; both fma exact (modarith.h)
             const double x = Arith::f(a), y = Arith::f(b), q = Arith::qd(lc);
             const double p = x * y;
             const double e = __builtin_fma(x, y, -p);
@@ -725,19 +819,17 @@ struct NttBody {
     static constexpr GsPlan<LOGE> gs_plan() {
         constexpr Phase ph = G::phase(P);
         if (SUB) return make_gs_plan<LOGE>(ph.b - ph.c, ph.r, (P == NPH - 1) ? IN : kGsMid, (P == 0) ? kSubInvOut : kGsMid, false);
-        // (F64Arith reads the same plan: bounds are on |x| in units of q / 1024, the cap 16 q <= 2^51 is its product's precondition, a reduction leaves
-        //  |x| <= q / 2 + 1 < kRedB and a product |x| <= q < kTwB; the offsets are not used - doubles are signed)
         return make_gs_plan<LOGE>(ph.b - ph.c, ph.r, (P == NPH - 1) ? IN : kGsMid, (P == 0) ? kLimit : kGsMid, P == 0, Arith::kFold ? LOGN : 0);
     }
 
     template <int P, int IN>
     static DPF_HD void inv_phase_r(u64 (&x)[E], const TwRegs& twr, const Tw& w_last, const Tw& w_ninv, const LimbConst& lc_in) {
         constexpr Phase ph = G::phase(P);
-        constexpr GsPlan<LOGE> plan = gs_plan<P, IN>();
         const auto& lc = Arith::ntt_lc(lc_in);
         if constexpr (P == NPH - 1 && !RAW_INV) enter(x, lc_in);
         if constexpr (Arith::kF64) {
-            static_assert(IN <= kWord / 2, "F64Arith: the first butterfly's operands must fit the plan's cap");
+            constexpr F64GsPlan<LOGE> plan = f64_gs_plan<P, IN>();
+            static_assert(IN <= 2 * kF64Cap, "F64ArithT: the sum of the first butterfly's operands must be an exact addition");
             const double q = Arith::qd(lc), qi = Arith::qinv(lc);
 #pragma clang loop unroll(full)
             for (int u = 0; u < ph.r; ++u) {
@@ -766,6 +858,7 @@ struct NttBody {
             for (int k = 0; k < E; ++k)
                 if (plan.red_end[k]) x[k] = Arith::b(Arith::reduce(Arith::f(x[k]), q, qi));
         } else {
+            constexpr GsPlan<LOGE> plan = gs_plan<P, IN>();
             const u64 q = lc.q, two_q = 2 * lc.q;
 #pragma clang loop unroll(full)
             for (int u = 0; u < ph.r; ++u) {

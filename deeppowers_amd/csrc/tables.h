@@ -63,8 +63,9 @@ template <> inline TwF64 h_make_tw<TwF64>(u64 w, u64 q) { return TwF64{(double)w
 
 // ---- per-limb arithmetic classes (round 6): which policy's transform kernels a limb runs on ------------------------------------------
 // kClassFold: the pinned shape 2^60 - d; kClassF64: any prime below 2^47; kClassFoldScaled: 2^k - d0, 48 <= k < 60, d0 2^(60-k) < 2^24;
-// kClassShoup: everything else (50 ... 59-bit primes far from a power of two, 47 ... 49-bit primes).
-enum LimbClass { kClassShoup = 0, kClassFold = 1, kClassF64 = 2, kClassFoldScaled = 3, kLimbClasses = 4 };
+// kClassF64Wide: any other prime below 2^50 (doubles again, with reductions inside the transforms); kClassShoup: everything else (51 ... 59-bit primes far
+// from a power of two).
+enum LimbClass { kClassShoup = 0, kClassFold = 1, kClassF64 = 2, kClassFoldScaled = 3, kClassF64Wide = 4, kLimbClasses = 5 };
 inline int h_bit_length(u64 v) { int b = 0; while (v) { ++b; v >>= 1; } return b; }
 // the scaling shift 60 - k of a FoldScaledArith prime, 0 when q is not one
 inline int fold_scaled_shift(u64 q) {
@@ -78,6 +79,7 @@ inline LimbClass limb_class(u64 q) {
     if (q < (1ull << 60) && ((1ull << 60) - q) < (1ull << 24)) return kClassFold;
     if (f64_eligible(q)) return kClassF64;
     if (fold_scaled_shift(q)) return kClassFoldScaled;
+    if (q < (1ull << F64WideArith::kMaxBits)) return kClassF64Wide;
     return kClassShoup;
 }
 // FoldScaledArith twiddle of w (< q): w unscaled, the companion w 2^32 modulo the SCALED modulus q' = q 2^sh (modarith.h)
@@ -89,7 +91,7 @@ inline LimbConst limb_const_of_class(const LimbConst& lc, LimbClass cls) {
         const int sh = fold_scaled_shift(lc.q);
         c.d = ((1ull << (60 - sh)) - lc.q) << sh;
         c.pad1 = (u64)sh;
-    } else if (cls == kClassF64) {
+    } else if (cls == kClassF64 || cls == kClassF64Wide) {
         const double qd = (double)lc.q, qi = 1.0 / qd;
         c.d = 0;
         c.ninv = __builtin_bit_cast(u64, qd);

@@ -70,11 +70,11 @@ class Context:
     def scratch_bytes(self) -> int:
         return int(self._lib.dpfhe_ctx_scratch_bytes(self._h))
 
-    ARITH_NAMES = ("shoup", "fold", "f64", "fold_scaled")
+    ARITH_NAMES = ("shoup", "fold", "f64", "fold_scaled", "f64_wide")
 
     @property
     def limb_classes(self) -> tuple:
-        """per limb, the arithmetic the transforms and the fused multiply run it on (dpfhe_ctx_limb_class): 'shoup' | 'fold' | 'f64' | 'fold_scaled'"""
+        """per limb, the arithmetic the transforms and the fused multiply run it on (dpfhe_ctx_limb_class): 'shoup' | 'fold' | 'f64' | 'fold_scaled' | 'f64_wide'"""
         return tuple(self.ARITH_NAMES[self._lib.dpfhe_ctx_limb_class(self._h, i)] for i in range(self.params.n_limbs))
 
     # ---- which form of the fused multiply this context launches (include/dpfhe.h "A0, continued") ----

@@ -92,11 +92,12 @@ uint32_t dpfhe_ctx_limbs(const dpfhe_ctx* ctx);
 int dpfhe_ctx_uses_fold(const dpfhe_ctx* ctx);
 /* Which arithmetic the batched transforms and the fused multiply run limb `limb` on (round 6: chosen PER LIMB, not per context):
  *   DPFHE_ARITH_FOLD 2^60 - d, d < 2^24;  DPFHE_ARITH_F64 any prime below 2^47 (residues as IEEE doubles inside a transform, error-free FMA products);
- *   DPFHE_ARITH_FOLD_SCALED 2^k - d0 with 48 <= k < 60 and d0 2^(60-k) < 2^24 (carried scaled to 2^60 - d);  DPFHE_ARITH_SHOUP every other prime
- *   (Harvey / Shoup butterflies, 128-bit Barrett products).  Results are the same words whatever the class.  A context of more than 16 limbs, or
+ *   DPFHE_ARITH_FOLD_SCALED 2^k - d0 with 48 <= k < 60 and d0 2^(60-k) < 2^24 (carried scaled to 2^60 - d);  DPFHE_ARITH_F64_WIDE any other prime below 2^50
+ *   (doubles again, with reductions inside the transforms);  DPFHE_ARITH_SHOUP every other prime (51 ... 59 bits far from a power of two: Harvey / Shoup
+ *   butterflies, 128-bit Barrett products).  Results are the same words whatever the class.  A context of more than 16 limbs, or
  *   with log2_n > 14, is uniform: fold if every limb is, Shoup otherwise.  -1: null context or no such limb.
  * The reference's widest integer type is INT32 (src/core/hal/hal.hpp:27-33): its own parameter sets would land in DPFHE_ARITH_F64. */
-enum { DPFHE_ARITH_SHOUP = 0, DPFHE_ARITH_FOLD = 1, DPFHE_ARITH_F64 = 2, DPFHE_ARITH_FOLD_SCALED = 3 };
+enum { DPFHE_ARITH_SHOUP = 0, DPFHE_ARITH_FOLD = 1, DPFHE_ARITH_F64 = 2, DPFHE_ARITH_FOLD_SCALED = 3, DPFHE_ARITH_F64_WIDE = 4 };
 int dpfhe_ctx_limb_class(const dpfhe_ctx* ctx, uint32_t limb);
 
 /* -- A0, continued: which FORM of the fused multiply a context launches -------------------------------------------------

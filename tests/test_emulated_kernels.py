@@ -196,7 +196,8 @@ def test_dot30_column_accumulators_match_128_bit_arithmetic(emu):
 
 
 # ---- round 6: the per-limb arithmetic classes (modarith.h F64Arith, FoldScaledArith) -------------------------------------------------------------------
-CLASS_CASES = [(2, bits) for bits in (20, 30, 31, 33, 40, 45, 47)] + [(3, bits) for bits in (54, 56, 57, 58, 59)]
+CLASS_CASES = [(2, bits) for bits in (20, 30, 31, 33, 40, 45, 47)] + [(3, bits) for bits in (54, 56, 57, 58, 59)] + [(4, bits) for bits in (30, 47, 48, 49, 50)]
+CLASS_NAMES = {2: "f64_", 3: "fold_scaled_", 4: "f64_wide_"}
 
 
 def _class_patterns(orc, n, q):
@@ -206,10 +207,11 @@ def _class_patterns(orc, n, q):
 
 
 @pytest.mark.parametrize("ln,le", [(8, 4), (10, 4), (12, 4), (13, 4), (14, 4)])
-@pytest.mark.parametrize("arith,bits", CLASS_CASES, ids=[("f64_" if a == 2 else "fold_scaled_") + str(b) for a, b in CLASS_CASES])
+@pytest.mark.parametrize("arith,bits", CLASS_CASES, ids=[CLASS_NAMES[a] + str(b) for a, b in CLASS_CASES])
 def test_emulated_class_transforms_match_oracle(emu, ln, le, arith, bits):
-    """F64Arith (residues as doubles, error-free FMA products; the |y| < 2^51 precondition of every product is armed in the emulator build) and
-    FoldScaledArith (2^k - d0 carried as 2^60 - d) through the very per-thread code the kernels run, both directions, extreme residues included."""
+    """F64Arith / F64WideArith (residues as doubles, error-free FMA products; the |y| < 2^51 precondition of every product is armed in the emulator build;
+    the wide form's static plans reduce words inside the transforms) and FoldScaledArith (2^k - d0 carried as 2^60 - d) through the very per-thread code the
+    kernels run, both directions, extreme residues included."""
     n = 1 << ln
     before = emu.emu_overflows()
     P = ntt_primes(ln, 2, bits)
@@ -230,8 +232,9 @@ def test_emulated_class_transforms_match_oracle(emu, ln, le, arith, bits):
 
 
 @pytest.mark.parametrize("ln", [8, 12, 13])
-@pytest.mark.parametrize("arith,bits,lazy", [(2, 30, 1), (2, 47, 1), (2, 40, 0), (3, 59, 1), (3, 57, 1), (3, 59, 0), (1, 60, 1)],
-                         ids=["f64_30_lazy", "f64_47_lazy", "f64_40_generic", "fscaled_59_lazy", "fscaled_57_lazy", "fscaled_59_generic", "fold_lazy"])
+@pytest.mark.parametrize("arith,bits,lazy", [(2, 30, 1), (2, 47, 1), (2, 40, 0), (3, 59, 1), (3, 57, 1), (3, 59, 0), (1, 60, 1), (4, 50, 1), (4, 48, 1), (4, 49, 0)],
+                         ids=["f64_30_lazy", "f64_47_lazy", "f64_40_generic", "fscaled_59_lazy", "fscaled_57_lazy", "fscaled_59_generic", "fold_lazy", "f64w_50_lazy", "f64w_48_lazy",
+                              "f64w_49_generic"])
 def test_emulated_class_fused_multiply_matches_oracle(emu, ln, arith, bits, lazy):
     """the fused multiply's two data paths for the classes: lazy products of forward outputs straight into the inverse (ct_mul_quad / ct_mul_dual, ntt_core.h
     NttBody::prod; FoldScaledArith's products carry the scale twice and end on last2) and the generic path through canonical words (ct_mul_kernel)"""

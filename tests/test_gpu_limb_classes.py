@@ -1,8 +1,8 @@
 """-m gpu: the per-limb arithmetic classes (round 6; include/dpfhe.h dpfhe_ctx_limb_class) through the C ABI against the oracle.
 
 A context's limbs no longer share one arithmetic: the batched transforms and the fused multiply run each limb on the fastest policy its prime admits -
-fold (2^60 - d), f64 (any prime below 2^47: doubles inside a transform), fold_scaled (2^k - d0 carried as 2^60 - d), shoup (the rest) - one launch per class
-present.  Results must be the same words whatever the class: every case below compares whole buffers with the oracle (radix-2 Harvey NTT + u128
+fold (2^60 - d), f64 (any prime below 2^47: doubles inside a transform), fold_scaled (2^k - d0 carried as 2^60 - d), f64_wide (the other primes below 2^50),
+shoup (the rest) - in one launch for the transforms of most mixtures, one launch per class present otherwise.  Results must be the same words whatever the class: every case below compares whole buffers with the oracle (radix-2 Harvey NTT + u128
 schoolbook, a different algorithm from all four)."""
 import numpy as np
 import pytest
@@ -13,11 +13,17 @@ from oracle.cbind import Oracle
 
 
 def primes_of(log2n, widths):
-    """one prime = 1 mod 2N per requested width, distinct (the j-th largest below 2^w for the j-th request of width w)"""
+    """one prime = 1 mod 2N per requested width, distinct (the j-th largest below 2^w for the j-th request of width w); a NEGATIVE width -w asks for a
+    prime of w bits that only the generic (Shoup) class takes"""
     qs, ps, seen = [], [], {}
     for w in widths:
         j = seen.get(w, 0)
         seen[w] = j + 1
+        if w < 0:
+            sq, sp = shoup_class_primes(log2n, -w, j + 1)
+            qs.append(sq[j])
+            ps.append(sp[j])
+            continue
         p = ntt_primes(log2n, j + 1, w)
         qs.append(p.moduli[j])
         ps.append(p.psi[j])
@@ -32,7 +38,21 @@ def expected_class(q):
     k = q.bit_length()
     if 48 <= k <= 59 and (((1 << k) - q) << (60 - k)) < (1 << 24):
         return "fold_scaled"
+    if q < (1 << 50):
+        return "f64_wide"
     return "shoup"
+
+
+def shoup_class_primes(log2n, bits, count):
+    """`count` primes = 1 mod 2N of `bits` (51 ... 59) bits that NO fast class takes: too wide for the doubles, too far below 2^bits for the scaled fold"""
+    from deeppowers_amd.params import is_prime, min_primitive_2n_root
+    n = 1 << log2n
+    qs, q = [], (1 << bits) - ((1 << bits) - 1) % (2 * n)
+    while len(qs) < count:
+        if is_prime(q) and expected_class(q) == "shoup":
+            qs.append(q)
+        q -= 2 * n
+    return qs, [min_primitive_2n_root(n, v) for v in qs]
 
 
 def worst_case(x, qcol, n):
@@ -55,13 +75,18 @@ CASES = [
     ("fscaled_widths", 12, (59, 58, 57, 56)),
     ("fscaled_n8192", 13, (59, 58)),
     ("fscaled_n16384", 14, (59, 57)),
-    ("shoup_49x2", 12, (49, 49)),
-    ("all_four_classes", 12, (60, 40, 59, 49)),
+    ("shoup_55x2", 12, (-55, -55)),
+    ("f64_wide_49_48_50", 12, (49, 48, 50)),
+    ("f64_wide_n8192", 13, (50, 49)),
+    ("f64_wide_n16384", 14, (49, 50)),
+    ("f64_wide_n256", 8, (50, 48)),
+    ("all_five_classes", 12, (60, 40, 59, -53, 49)),
+    ("wide_next_to_f64_one_launch_per_class", 12, (49, 30)),
     ("seal_like_60_40_40_60", 12, (60, 40, 40, 60)),
     ("bench_mixed_59_50_40_33", 12, (59, 50, 40, 33)),
     ("config1_like_30bit_n1024", 10, (30,)),
-    ("all_four_classes_n8192", 13, (60, 33, 59, 49, 60, 46)),
-    ("all_four_classes_n2048", 11, (49, 60, 45, 58)),
+    ("all_five_classes_n8192", 13, (60, 33, 59, 49, -56, 46)),
+    ("all_five_classes_n2048", 11, (49, 60, 45, 58, -52)),
 ]
 
 
@@ -104,7 +129,7 @@ def test_limb_classes_transforms_and_fused_multiply_match_the_oracle(name, log2n
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("widths", [(30, 30, 30, 30), (59, 50, 40, 33), (59, 59, 58, 58)], ids=["f64", "mixed", "fold_scaled"])
+@pytest.mark.parametrize("widths", [(30, 30, 30, 30), (59, 50, 40, 33), (59, 59, 58, 58), (49, 49, 50, 48)], ids=["f64", "mixed", "fold_scaled", "f64_wide"])
 def test_limb_classes_full_size_whole_buffer_oracle(widths):
     """BASELINE configs[1]'s batch (1024 RNS polynomials = 4096 residue polynomials, N = 4096) and 1024 ciphertext pairs, every word against the oracle,
     plus the size-independent properties: round trip, linearity of the transform"""
@@ -139,13 +164,13 @@ def test_limb_classes_full_size_whole_buffer_oracle(widths):
 def test_key_switching_on_a_context_with_classes_still_matches_the_oracle():
     """the key-switching kernels of a non-uniform context read its complete generic tables; the transforms and the fused multiply around them run per class"""
     from deeppowers_amd.evaluator import Ciphertext, Context, Evaluator, to_device, to_host
-    p = primes_of(12, (60, 40, 59, 49))
+    p = primes_of(12, (60, 40, 59, -54, 49))
     L, n = p.n_limbs, p.n
     orc = Oracle.from_params(p)
     ctx = Context(p, 0)
     ev = Evaluator(ctx)
     try:
-        assert ctx.limb_classes == ("fold", "f64", "fold_scaled", "shoup")
+        assert ctx.limb_classes == ("fold", "f64", "fold_scaled", "shoup", "f64_wide")
         a = orc.fill(6, 6100).reshape(3, 2, L, n)
         b = orc.fill(6, 6200).reshape(3, 2, L, n)
         want = orc.ct_mul(a, b, threads=0)

@@ -1,6 +1,6 @@
 """Per-limb arithmetic classes at BASELINE's N = 4096, L = 4 (tool): forward / inverse NTT at configs[1]'s batch (1024 RNS polynomials) and the
 fused multiply at `pairs` ciphertext pairs for one context per class - fold (2^60 - d), f64 (30- and 45-bit primes), fold_scaled (59-bit),
-shoup (49-bit: too wide for f64, too far from 2^60 for the scaled fold) - and the mixed 59/50/40/33 context.  HIP events per launch.
+f64_wide (49-bit), shoup (55-bit primes too far below 2^55 for the scaled fold) - and the mixed 59/50/40/33 context.  HIP events per launch.
     python tools/class_bench.py [pairs=2048] [log2n=12]"""
 import json, os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -25,8 +25,16 @@ def mixed():
     for bits in (59, 50, 40, 33):
         p = ntt_primes(log2n, 1, bits); qs.append(p.moduli[0]); ps.append(p.psi[0])
     return FheParams(log2n, tuple(qs), tuple(ps))
+def shoup55():   # 55-bit primes that no fast class takes (too far below 2^55 for the scaled fold)
+    from deeppowers_amd.params import is_prime, min_primitive_2n_root
+    n, qs, q = 1 << log2n, [], (1 << 55) - ((1 << 55) - 1) % (2 << log2n)
+    while len(qs) < L:
+        if is_prime(q) and (((1 << 55) - q) << 5) >= (1 << 24):
+            qs.append(q)
+        q -= 2 * n
+    return FheParams(log2n, tuple(qs), tuple(min_primitive_2n_root(n, v) for v in qs))
 sets = (("fold", ntt_primes(log2n, L, 60)), ("f64_30", ntt_primes(log2n, L, 30)), ("f64_45", ntt_primes(log2n, L, 45)), ("fscaled_59", ntt_primes(log2n, L, 59)),
-        ("shoup_49", ntt_primes(log2n, L, 49)), ("mixed", mixed()))
+        ("f64wide_49", ntt_primes(log2n, L, 49)), ("shoup_55", shoup55()), ("mixed", mixed()))
 res = {}
 for name, params in sets:
     ctx = Context(params, 0); ev = Evaluator(ctx)

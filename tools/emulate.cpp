@@ -44,6 +44,7 @@ template <> struct TwTab<F64Arith> {
     }
     static TwF64 one(u64 w, u64, u64 q) { return h_make_tw<TwF64>(w, q); }
 };
+template <> struct TwTab<F64WideArith> : TwTab<F64Arith> {};
 template <> struct TwTab<FoldScaledArith> {
     static std::vector<TwFold> make(const std::vector<u64>& w, const std::vector<u64>&, u64 q) {
         std::vector<TwFold> v(w.size());
@@ -54,12 +55,12 @@ template <> struct TwTab<FoldScaledArith> {
 };
 template <class Arith> static bool class_ok(u64 q) {
     if (Arith::kFold) return fold_eligible(q);
-    if (Arith::kF64) return f64_eligible(q);
+    if constexpr (Arith::kF64) return q < (1ull << Arith::kMaxBits);
     if (Arith::kFoldCore) return fold_scaled_shift(q) != 0;
     return true;
 }
 template <class Arith> static LimbConst class_lc(const LimbConst& lc) {
-    return limb_const_of_class(lc, Arith::kFold ? kClassFold : Arith::kF64 ? kClassF64 : Arith::kFoldCore ? kClassFoldScaled : kClassShoup);
+    return limb_const_of_class(lc, Arith::kFold ? kClassFold : Arith::kF64 ? kClassF64 : Arith::kFoldCore ? kClassFoldScaled : kClassShoup);   // (F64Wide reads F64's record)
 }
 
 template <class B> static constexpr int E_of() { return B::E; }
@@ -198,11 +199,12 @@ static int emu(int inverse, u64 q, u64 psi, const u64* in, u64* out) {
     return 0;
 }
 
-// arith: 0 Shoup, 1 Fold, 2 F64, 3 FoldScaled (tables.h LimbClass).  `in`/`out` must be 16-byte aligned.  returns 0, 2000 bad args, -1 unsupported geometry
+// arith: 0 Shoup, 1 Fold, 2 F64, 3 FoldScaled, 4 F64Wide (tables.h LimbClass).  `in`/`out` must be 16-byte aligned.  returns 0, 2000 bad args, -1 unsupported geometry
 extern "C" int emu_ntt(int arith, int log2n, int loge, int inverse, u64 q, u64 psi, const u64* in, u64* out) {
 #define CASE(LN, LE)                                                                     \
     if (log2n == LN && loge == LE) {                                                     \
         if (arith == 2) return emu<F64Arith, LN, LE>(inverse, q, psi, in, out);          \
+        if (arith == 4) return emu<F64WideArith, LN, LE>(inverse, q, psi, in, out);      \
         if (arith == 3) return emu<FoldScaledArith, LN, LE>(inverse, q, psi, in, out);   \
         return arith ? emu<FoldArith, LN, LE>(inverse, q, psi, in, out) : emu<ShoupArith, LN, LE>(inverse, q, psi, in, out); \
     }
@@ -254,6 +256,7 @@ extern "C" int emu_ct_mul_class(int arith, int log2n, u64 q, u64 psi, const u64*
 #define CASE(LN)                                                                                                              \
     if (log2n == LN) {                                                                                                        \
         if (arith == 2) return emu_ct_mul_generic<F64Arith, LN, 4>(q, psi, a0, a1, b0, b1, out3);                             \
+        if (arith == 4) return emu_ct_mul_generic<F64WideArith, LN, 4>(q, psi, a0, a1, b0, b1, out3);                         \
         if (arith == 3) return emu_ct_mul_generic<FoldScaledArith, LN, 4>(q, psi, a0, a1, b0, b1, out3);                      \
         if (arith == 0) return emu_ct_mul_generic<ShoupArith, LN, 4>(q, psi, a0, a1, b0, b1, out3);                           \
         return -1;                                                                                                            \
@@ -457,6 +460,7 @@ extern "C" int emu_ct_mul_lazy_class(int arith, int log2n, u64 q, u64 psi, const
     if (log2n == LN) {                                                                                                     \
         if (arith == 1) return emu_ct_mul_lazy<FoldArith, LN, 4>(q, psi, a0, a1, b0, b1, out3);                            \
         if (arith == 2) return emu_ct_mul_lazy<F64Arith, LN, 4>(q, psi, a0, a1, b0, b1, out3);                             \
+        if (arith == 4) return emu_ct_mul_lazy<F64WideArith, LN, 4>(q, psi, a0, a1, b0, b1, out3);                         \
         if (arith == 3) return emu_ct_mul_lazy<FoldScaledArith, LN, 4>(q, psi, a0, a1, b0, b1, out3);                      \
         return -1;                                                                                                         \
     }
