@@ -88,6 +88,8 @@ struct dpfhe_ctx {
     // generic tables above stay complete (every limb), so the key-switching kernels of such a context run as before.
     // `classes` is set when L <= 16, 8 <= log2 N <= 14 and at least one limb has a faster class than the context-wide policy.
     bool classes = false;
+    int uniform_cls = kClassShoup;                    // the class ALL limbs share (kClassShoup when they differ, or when `classes` is off): which policy's KEY-SWITCHING
+                                                      // kernels the context runs (with_policy below); a mixture keeps the generic ones, on the complete generic tables
     unsigned char limb_cls[16] = {};                  // LimbClass of limb i
     unsigned long long cls_map = 0;                   // the same, 4 bits per limb
     void* class_blob = nullptr;                       // ONE blob of tables whose per-limb slots are in their limb's class format (mixed_layout)
@@ -483,6 +485,9 @@ extern "C" int dpfhe_ctx_create(dpfhe_ctx** out, uint32_t log2_n, uint32_t n_lim
             c->mixed.n_limbs = (int)L;
             c->mixed.cls_map = c->cls_map;
             c->classes = true;
+            bool same = true;
+            for (size_t l = 1; l < L; ++l) same = same && c->limb_cls[l] == c->limb_cls[0];
+            if (same) c->uniform_cls = c->limb_cls[0];
         }
     }
     tune_at_create(c);   // default form of the fused multiply, or a cached explicit probe of this shape: no device work
@@ -563,6 +568,20 @@ static int for_each_class(const dpfhe_ctx* c, size_t limbs_used, Fn fn) {
     { auto tb = restrict_to(c->cls_f64w, kClassF64Wide); if (tb.n_active && !rc) rc = fn(tb); }
     { auto tb = restrict_to(c->cls_shoup, kClassShoup); if (tb.n_active && !rc) rc = fn(tb); }
     return rc;
+}
+
+// The policy of the KEY-SWITCHING kernels (relin_kernel, hoisted_ks_kernel, ntt_inv_galois_kernel): fold for the pinned primes; the class's own for a
+// context whose limbs all share one class (round 6: the generic forms of those kernels with that class's transforms and products - an all-f64 context no
+// longer key-switches at the generic kernels' rate); the generic policy on the complete generic tables for a mixture.  fn(tables) launches.
+template <class Fn>
+static int with_policy(const dpfhe_ctx* c, Fn fn) {
+    if (c->fold) return fn(c->foldt);
+    if (c->classes) {
+        if (c->uniform_cls == kClassF64) return fn(c->cls_f64);
+        if (c->uniform_cls == kClassF64Wide) return fn(c->cls_f64w);
+        if (c->uniform_cls == kClassFoldScaled) return fn(c->cls_fscaled);
+    }
+    return fn(c->shoup);
 }
 
 // batched transform of `items` RNS polynomials over the first `limbs_used` limbs (limbs_used = 0: all); arguments validated, device selected by the caller
@@ -871,8 +890,7 @@ extern "C" int dpfhe_relinearize(dpfhe_ctx* c, uint64_t* d_out2, const uint64_t*
     DPFHE_ON_DEVICE(c, "dpfhe_relinearize");
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (c->log2n > kFusedMaxLog2N) return key_switch_composed(c, d_out2, d_in3, 3, 3, d_evk, batch, s, "dpfhe_relinearize");
-    const int rc = c->fold ? launch_relin<FoldArith>((int)c->log2n, 0, d_out2, d_in3, d_evk, 0, 1, blocks, c->foldt, s)
-                           : launch_relin<ShoupArith>((int)c->log2n, 0, d_out2, d_in3, d_evk, 0, 1, blocks, c->shoup, s);
+    const int rc = with_policy(c, [&](const auto& tb) { return launch_relin((int)c->log2n, 0, d_out2, d_in3, d_evk, 0, 1, blocks, tb, s); });
     if (rc) return fail(DPFHE_INVALID_STATE, "dpfhe_relinearize", "no kernel geometry for this log2_n");
     return check_launch("relin kernel launch");
 }
@@ -888,8 +906,7 @@ extern "C" int dpfhe_switch_key(dpfhe_ctx* c, uint64_t* d_out2, const uint64_t* 
     DPFHE_ON_DEVICE(c, "dpfhe_switch_key");
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (c->log2n > kFusedMaxLog2N) return key_switch_composed(c, d_out2, d_in2, 2, 1, d_key, batch, s, "dpfhe_switch_key");
-    const int rc = c->fold ? launch_relin<FoldArith>((int)c->log2n, 1, d_out2, d_in2, d_key, 0, 1, blocks, c->foldt, s)
-                           : launch_relin<ShoupArith>((int)c->log2n, 1, d_out2, d_in2, d_key, 0, 1, blocks, c->shoup, s);
+    const int rc = with_policy(c, [&](const auto& tb) { return launch_relin((int)c->log2n, 1, d_out2, d_in2, d_key, 0, 1, blocks, tb, s); });
     if (rc) return fail(DPFHE_INVALID_STATE, "dpfhe_switch_key", "no kernel geometry for this log2_n");
     return check_launch("switch_key kernel launch");
 }
@@ -969,8 +986,7 @@ static int hybrid_entry(dpfhe_ctx* c, const char* what, int in_comps, uint64_t* 
         if (!ntt_grid_fits(c, batch * 2 * L)) return fail(DPFHE_INVALID_ARGUMENT, what, "batch too large for one launch");
         if (int rc = ntt_launch(c, true, d_work, d_work, batch * 2 * L, s)) return rc;
     } else {
-        const int rc = c->fold ? launch_relin<FoldArith>((int)c->log2n, mode, d_work, d_in, d_key, key_stride, key_group, blocks, c->foldt, s)
-                               : launch_relin<ShoupArith>((int)c->log2n, mode, d_work, d_in, d_key, key_stride, key_group, blocks, c->shoup, s);
+        const int rc = with_policy(c, [&](const auto& tb) { return launch_relin((int)c->log2n, mode, d_work, d_in, d_key, key_stride, key_group, blocks, tb, s); });
         if (rc) return fail(DPFHE_INVALID_STATE, what, "no kernel geometry for this log2_n");
         int e = check_launch("hybrid key-switch kernel launch");
         if (e) return e;
@@ -1116,12 +1132,7 @@ extern "C" int dpfhe_rotate_hybrid_hoisted(dpfhe_ctx* c, uint64_t* d_out2, const
     if (c->fold) hipLaunchKernelGGL((lift_digits_kernel<FoldArith>), dim3(lift_grid), dim3(256), 0, s, d_digits, d_in2 + Ld * (size_t)n, 2 * Ld * (size_t)n, lc, (int)L, n, chunks);
     else hipLaunchKernelGGL((lift_digits_kernel<ShoupArith>), dim3(lift_grid), dim3(256), 0, s, d_digits, d_in2 + Ld * (size_t)n, 2 * Ld * (size_t)n, lc, (int)L, n, chunks);
     if (int e = check_launch("lift_digits kernel launch")) return e;
-    {
-        const int rc = c->fold ? launch_ntt<FoldArith>((int)c->log2n, false, d_digits, d_digits, T * Ld * L, c->foldt, s)
-                               : launch_ntt<ShoupArith>((int)c->log2n, false, d_digits, d_digits, T * Ld * L, c->shoup, s);
-        if (rc) return fail(DPFHE_INVALID_STATE, what, "no kernel geometry for this log2_n");
-        if (int e = check_launch("digit NTT launch")) return e;
-    }
+    if (int e = ntt_launch_items(c, false, d_digits, d_digits, T * Ld, 0, s)) return e;   // (per limb class where the context has them)
     // 2. sigma_g(c0) of every (rotation, item) for the final addition: [batch][T][Ld][N]; 64 output items per launch
     for (size_t first = 0; first < total; first += kMaxGaloisBatch) {
         const size_t cnt = total - first < (size_t)kMaxGaloisBatch ? total - first : (size_t)kMaxGaloisBatch;
@@ -1133,10 +1144,9 @@ extern "C" int dpfhe_rotate_hybrid_hoisted(dpfhe_ctx* c, uint64_t* d_out2, const
     // 3. permuted digits (.) keys, one inverse transform per (rotation, limb, key component, item); 64 rotations per launch
     for (size_t first = 0; first < batch; first += kMaxGaloisBatch) {
         const size_t cnt = batch - first < (size_t)kMaxGaloisBatch ? batch - first : (size_t)kMaxGaloisBatch;
-        const int rc = c->fold ? launch_hoisted_ks<FoldArith>((int)c->log2n, d_work + first * T * 2 * L * n, d_digits, d_keys + first * key_words, key_words,
-                                                              galois_elts + first, cnt, T, c->foldt, s)
-                               : launch_hoisted_ks<ShoupArith>((int)c->log2n, d_work + first * T * 2 * L * n, d_digits, d_keys + first * key_words, key_words,
-                                                               galois_elts + first, cnt, T, c->shoup, s);
+        const int rc = with_policy(c, [&](const auto& tb) {
+            return launch_hoisted_ks((int)c->log2n, d_work + first * T * 2 * L * n, d_digits, d_keys + first * key_words, key_words, galois_elts + first, cnt, T, tb, s);
+        });
         if (rc) return fail(DPFHE_INVALID_STATE, what, "no kernel geometry for this log2_n");
         if (int e = check_launch("hoisted key-switch kernel launch")) return e;
     }
@@ -1178,24 +1188,13 @@ extern "C" int dpfhe_rotate_hoisted_qp(dpfhe_ctx* c, uint64_t* d_out_qp, const u
     hipStream_t s = static_cast<hipStream_t>(stream);
     DPFHE_ON_DEVICE(c, what);
     // 1. NTT of the inputs on the data limbs (the same tables, seen as an Ld-limb context)
-    {
-        int rc;
-        if (c->fold) { DevTables<FoldArith> td = c->foldt; td.n_limbs = (int)Ld; rc = launch_ntt<FoldArith>((int)c->log2n, false, d_in_ntt, d_in2, T * 2 * Ld, td, s); }
-        else { DevTables<ShoupArith> td = c->shoup; td.n_limbs = (int)Ld; rc = launch_ntt<ShoupArith>((int)c->log2n, false, d_in_ntt, d_in2, T * 2 * Ld, td, s); }
-        if (rc) return fail(DPFHE_INVALID_STATE, what, "no kernel geometry for this log2_n");
-        if (int e = check_launch("input NTT launch")) return e;
-    }
+    if (int e = ntt_launch_items(c, false, d_in_ntt, d_in2, T * 2, Ld, s)) return e;
     // 2. digits of every item's c1, lifted to every limb and transformed
     const unsigned lift_grid = (unsigned)(T * Ld * L * (size_t)chunks);
     if (c->fold) hipLaunchKernelGGL((lift_digits_kernel<FoldArith>), dim3(lift_grid), dim3(256), 0, s, d_digits, d_in2 + Ld * (size_t)n, 2 * Ld * (size_t)n, lc, (int)L, n, chunks);
     else hipLaunchKernelGGL((lift_digits_kernel<ShoupArith>), dim3(lift_grid), dim3(256), 0, s, d_digits, d_in2 + Ld * (size_t)n, 2 * Ld * (size_t)n, lc, (int)L, n, chunks);
     if (int e = check_launch("lift_digits kernel launch")) return e;
-    {
-        const int rc = c->fold ? launch_ntt<FoldArith>((int)c->log2n, false, d_digits, d_digits, T * Ld * L, c->foldt, s)
-                               : launch_ntt<ShoupArith>((int)c->log2n, false, d_digits, d_digits, T * Ld * L, c->shoup, s);
-        if (rc) return fail(DPFHE_INVALID_STATE, what, "no kernel geometry for this log2_n");
-        if (int e = check_launch("digit NTT launch")) return e;
-    }
+    if (int e = ntt_launch_items(c, false, d_digits, d_digits, T * Ld, 0, s)) return e;   // (per limb class where the context has them)
     // 3. item block 0: the inputs themselves as P * ct over the extended basis
     const unsigned idg = (unsigned)(T * 2 * L * (size_t)chunks);
     if (c->fold) hipLaunchKernelGGL((lift_qp_kernel<FoldArith>), dim3(idg), dim3(256), 0, s, d_out_qp, d_in_ntt, lc, p_special, (int)L, n, chunks);
@@ -1247,8 +1246,7 @@ extern "C" int dpfhe_ntt_inv_galois(dpfhe_ctx* c, uint64_t* d_out, const uint64_
     for (size_t first = 0; first < n_elts; first += kMaxGaloisBatch) {
         const size_t cnt = n_elts - first < (size_t)kMaxGaloisBatch ? n_elts - first : (size_t)kMaxGaloisBatch;
         const size_t off = first * per_elt << c->log2n;
-        const int rc = c->fold ? launch_ntt_inv_galois<FoldArith>((int)c->log2n, d_out + off, d_in + off, galois_elts + first, cnt, per_elt, c->foldt, s)
-                               : launch_ntt_inv_galois<ShoupArith>((int)c->log2n, d_out + off, d_in + off, galois_elts + first, cnt, per_elt, c->shoup, s);
+        const int rc = with_policy(c, [&](const auto& tb) { return launch_ntt_inv_galois((int)c->log2n, d_out + off, d_in + off, galois_elts + first, cnt, per_elt, tb, s); });
         if (rc) return fail(DPFHE_INVALID_STATE, what, "no single-kernel transform for this log2_n");
         if (int e = check_launch("ntt_inv_galois kernel launch")) return e;
     }
@@ -1272,8 +1270,7 @@ extern "C" int dpfhe_switch_key_qp(dpfhe_ctx* c, uint64_t* d_out_qp, const uint6
     const size_t key_words = Ld * 2 * L * (size_t)n;
     if (c->log2n > kFusedMaxLog2N)   // composed from the batched transform (round 5): the digits of c1, lifted and transformed, times the group's key
         return key_products_composed(c, d_out_qp, d_in2 + Ld * (size_t)n, 2 * Ld * (size_t)n, d_keys, key_words, (unsigned)group, batch, s, what);
-    const int rc = c->fold ? launch_relin<FoldArith>((int)c->log2n, 4, d_out_qp, d_in2, d_keys, key_words, (unsigned)group, blocks, c->foldt, s)
-                           : launch_relin<ShoupArith>((int)c->log2n, 4, d_out_qp, d_in2, d_keys, key_words, (unsigned)group, blocks, c->shoup, s);
+    const int rc = with_policy(c, [&](const auto& tb) { return launch_relin((int)c->log2n, 4, d_out_qp, d_in2, d_keys, key_words, (unsigned)group, blocks, tb, s); });
     if (rc) return fail(DPFHE_INVALID_STATE, what, "no kernel geometry for this log2_n");
     return check_launch("switch_key_qp kernel launch");
 }

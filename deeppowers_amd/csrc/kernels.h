@@ -827,7 +827,7 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE), (Arith::kFold ? 2 : 1)) void re
             const u64 tr3 = trace_stamp<TRACE>(tr_d);
 #pragma unroll
             for (int k = 0; k < E; ++k)
-                acc0[k] = Arith::kFold ? acc0[k] + FoldArith::mul60(x[k], e[k], (u32)lc.d) : add_mod(acc0[k], ShoupArith::mul_var(x[k], e[k], lc), lc.q);
+                acc0[k] = Arith::kFold ? acc0[k] + FoldArith::mul60(x[k], e[k], (u32)lc.d) : add_mod(acc0[k], Arith::mul_var(x[k], e[k], lc), lc.q);
             if constexpr (TRACE) {
                 tr_d = 0;
 #pragma unroll
@@ -844,7 +844,7 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE), (Arith::kFold ? 2 : 1)) void re
             const u64 tr5 = trace_stamp<TRACE>(tr_d);
 #pragma unroll
             for (int k = 0; k < E; ++k)
-                acc1[k] = Arith::kFold ? acc1[k] + FoldArith::mul60(x[k], e[k], (u32)lc.d) : add_mod(acc1[k], ShoupArith::mul_var(x[k], e[k], lc), lc.q);
+                acc1[k] = Arith::kFold ? acc1[k] + FoldArith::mul60(x[k], e[k], (u32)lc.d) : add_mod(acc1[k], Arith::mul_var(x[k], e[k], lc), lc.q);
             if constexpr (TRACE) {
                 tr_d = 0;
 #pragma unroll
@@ -1101,7 +1101,7 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE), (Arith::kFold ? 2 : 1)) void ho
         }
 #pragma unroll
         for (int k = 0; k < E; ++k)
-            acc[k] = Arith::kFold ? acc[k] + FoldArith::mul60(x[k], e[k], (u32)lc.d) : add_mod(acc[k], ShoupArith::mul_var(x[k], e[k], lc), lc.q);
+            acc[k] = Arith::kFold ? acc[k] + FoldArith::mul60(x[k], e[k], (u32)lc.d) : add_mod(acc[k], Arith::mul_var(x[k], e[k], lc), lc.q);
 #pragma unroll
         for (int k = 0; k < E; ++k) { e[k] = en[k]; x[k] = xn[k]; }
     }

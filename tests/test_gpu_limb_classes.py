@@ -212,3 +212,57 @@ def test_sympy_fixture_replayed_on_the_device(golden_dir):
         assert np.array_equal(to_host(got), c)
     finally:
         ctx.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,log2n,widths", [("f64", 12, (30, 31, 40, 46)), ("f64_n8192", 13, (45, 46, 33)), ("f64_wide", 12, (49, 49, 48)), ("fold_scaled", 12, (59, 58, 59)),
+                                               ("fold_scaled_n8192", 13, (59, 58, 57)), ("f64_n1024", 10, (30, 30))], ids=lambda v: v if isinstance(v, str) else None)
+def test_key_switching_runs_on_the_class_of_a_uniform_context(name, log2n, widths):
+    """a context whose limbs all share ONE class key-switches on that class's kernels (dpfhe_cabi.hip with_policy: the generic forms of relin_kernel /
+    hoisted_ks_kernel / ntt_inv_galois_kernel instantiated for the class): relinearisation, the plain key switch behind an automorphism, hybrid key switching
+    with 2- and 3-component inputs, hoisted rotations - every word against the oracle"""
+    from deeppowers_amd.evaluator import Ciphertext, Context, Evaluator, to_device, to_host
+    p = primes_of(log2n, widths)
+    L, n = p.n_limbs, p.n
+    orc = Oracle.from_params(p)
+    ctx = Context(p, 0)
+    ev = Evaluator(ctx)
+    try:
+        assert len(set(ctx.limb_classes)) == 1 and ctx.limb_classes[0] == name.split("_n")[0]
+        batch = 3
+        a = orc.fill(batch * 2, 8100).reshape(batch, 2, L, n)
+        b = orc.fill(batch * 2, 8200).reshape(batch, 2, L, n)
+        want = orc.ct_mul(a, b, threads=0)
+        c = ev.multiply(Ciphertext(to_device(a, ctx.device)), Ciphertext(to_device(b, ctx.device)))
+        assert np.array_equal(to_host(c.data), want)
+        evk = orc.fill(L * 2, 8300).reshape(L, 2, L, n)
+        assert np.array_equal(to_host(ev.relinearize(c, to_device(evk, ctx.device)).data), orc.relinearize(want, evk, threads=0))
+        got = ev.apply_galois(Ciphertext(to_device(a, ctx.device)), 5, to_device(evk, ctx.device))        # automorphism + dpfhe_switch_key
+        assert np.array_equal(to_host(got.data), orc.switch_key(orc.apply_galois(a, 5), evk, threads=0))
+        Ld = L - 1
+        data = Oracle(p.log2_n, p.moduli[:-1], p.psi[:-1])
+        key = orc.fill(Ld * 2, 8400).reshape(Ld, 2, L, n)
+        for comps in (2, 3):
+            ct = data.fill(batch * comps, 8500 + comps).reshape(batch, comps, Ld, n)
+            got = to_host(ev.keyswitch_hybrid(Ciphertext(to_device(ct, ctx.device)), to_device(key, ctx.device)).data)
+            assert np.array_equal(got, orc.keyswitch_hybrid(ct, key, comps, threads=0)), comps
+        # rotations: one key per item (batched), hoisted (hoisted_ks_kernel: permuted digits, 70 rotations = two launch groups), grouped (key-major giant steps)
+        k, T = 70, 2
+        elts = [pow(3, i + 1, 2 * n) for i in range(k)]
+        elts[-1] = 2 * n - 1
+        keys = orc.fill(k * Ld * 2, 8600).reshape(k, Ld, 2, L, n)
+        dk = to_device(keys, ctx.device)
+        cts = data.fill(T * 2, 8700).reshape(T, 2, Ld, n)
+        got = to_host(ev.rotate_hybrid_batch(Ciphertext(to_device(cts[:1], ctx.device)), elts, dk).data)
+        for i in (0, 1, 63, 64, 69):
+            assert np.array_equal(got[i], orc.keyswitch_hybrid(data.apply_galois(cts[:1], elts[i]), keys[i], 2, threads=0)[0]), ("batch", i)
+        got = to_host(ev.rotate_hybrid_hoisted(Ciphertext(to_device(cts, ctx.device)), elts, dk).data).reshape(k, T, 2, Ld, n)
+        for r in (0, 22, 63, 64, 69):
+            for t in range(T):
+                assert np.array_equal(got[r, t], orc.rotate_hoisted(cts[t], [elts[r]], keys[r][None], threads=0)[0]), ("hoisted", r, t)
+        items = data.fill(k * T * 2, 8800).reshape(k * T, 2, Ld, n)
+        got = to_host(ev.rotate_hybrid_grouped(Ciphertext(to_device(items, ctx.device)), elts, T, dk).data)
+        for i in (0, 1, 2, 127, 128, k * T - 1):
+            assert np.array_equal(got[i], orc.keyswitch_hybrid(data.apply_galois(items[i][None], elts[i // T]), keys[i // T], 2, threads=0)[0]), ("grouped", i)
+    finally:
+        ctx.close()
