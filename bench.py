@@ -312,7 +312,8 @@ def digest_other(o):
         if isinstance(o.get(key), dict) and "ct_mul" in o[key]:
             sg = o[key]
             d[key] = {"classes": sg.get("limb_classes"), "ntt_fwd_frac": r3(sg["ntt_fwd"]["frac_of_hbm_peak"]), "ntt_inv_frac": r3(sg["ntt_inv"]["frac_of_hbm_peak"]),
-                      "ct_mul_per_s": round(sg["ct_mul"]["per_s"]), "ct_mul_frac": r3(sg["ct_mul"]["frac_of_hbm_peak"]), "fold_over_this_ct_mul": r3(sg["fold_over_shoup_ct_mul"])}
+                      "ct_mul_per_s": round(sg["ct_mul"]["per_s"]), "ct_mul_frac": r3(sg["ct_mul"]["frac_of_hbm_peak"]), "fold_over_this_ct_mul": r3(sg["fold_over_shoup_ct_mul"]),
+                      "relin_per_s": round(sg["relinearize"]["per_s"]) if "relinearize" in sg else None}
     pl = o.get("packed_linear") or {}
     if pl:
         e = {"all_correct": pl.get("all_correct")}
@@ -736,6 +737,14 @@ def main():
                 sg["fold_ct_mul_per_s_same_moment"] = B / t
                 sg["fold_over_shoup_ct_mul"] = sg["fold_ct_mul_per_s_same_moment"] / sg["ct_mul"]["per_s"]
                 del ag, bg
+                # the key switch that follows the metric op, on this context's classes (round 6: no longer on the generic kernels): 2048 three-component ciphertexts
+                nbr = 2048
+                c3g = Ciphertext(torch.randint(0, 2**62, (nbr, 3, L, N), generator=g, dtype=torch.int64, device=dev) % qg.view(1, 1, L, 1))
+                evkg = torch.randint(0, 2**62, (L, 2, L, N), generator=g, dtype=torch.int64, device=dev) % qg.view(1, 1, L, 1)
+                o2g = ctxg.empty(nbr, components=2)
+                t = timed(lambda: evg.relinearize(c3g, evkg, out=o2g), 6)
+                sg["relinearize"] = {"cts": nbr, "median_us": t * 1e6, "per_s": nbr / t}
+                del c3g, evkg, o2g
                 return sg
             finally:
                 ctxg.close()

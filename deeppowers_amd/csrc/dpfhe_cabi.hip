@@ -584,6 +584,16 @@ static int with_policy(const dpfhe_ctx* c, Fn fn) {
     return fn(c->shoup);
 }
 
+// relin_kernel launches (`blocks` = items x L): on the context's policy, or - a MIXTURE of classes - one launch per class present, each over its own limbs
+// (relin_kernel maps its workgroups through DevTables::active_map: the digits of every limb still enter every limb's transforms)
+static int relin_launch(const dpfhe_ctx* c, int mode, u64* out, const u64* in, const u64* evk, size_t key_stride, unsigned key_group, size_t blocks, hipStream_t s) {
+    if (c->classes && c->uniform_cls == kClassShoup) {
+        const size_t items = blocks / c->n_limbs;
+        return for_each_class(c, c->n_limbs, [&](const auto& tb) { return launch_relin((int)c->log2n, mode, out, in, evk, key_stride, key_group, items * (size_t)tb.n_active, tb, s); });
+    }
+    return with_policy(c, [&](const auto& tb) { return launch_relin((int)c->log2n, mode, out, in, evk, key_stride, key_group, blocks, tb, s); });
+}
+
 // batched transform of `items` RNS polynomials over the first `limbs_used` limbs (limbs_used = 0: all); arguments validated, device selected by the caller
 static int ntt_launch_items(dpfhe_ctx* c, bool inverse, uint64_t* out, const uint64_t* in, size_t items, size_t limbs_used, hipStream_t s) {
     const size_t Lu = limbs_used ? limbs_used : c->n_limbs;
@@ -890,7 +900,7 @@ extern "C" int dpfhe_relinearize(dpfhe_ctx* c, uint64_t* d_out2, const uint64_t*
     DPFHE_ON_DEVICE(c, "dpfhe_relinearize");
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (c->log2n > kFusedMaxLog2N) return key_switch_composed(c, d_out2, d_in3, 3, 3, d_evk, batch, s, "dpfhe_relinearize");
-    const int rc = with_policy(c, [&](const auto& tb) { return launch_relin((int)c->log2n, 0, d_out2, d_in3, d_evk, 0, 1, blocks, tb, s); });
+    const int rc = relin_launch(c, 0, d_out2, d_in3, d_evk, 0, 1, blocks, s);
     if (rc) return fail(DPFHE_INVALID_STATE, "dpfhe_relinearize", "no kernel geometry for this log2_n");
     return check_launch("relin kernel launch");
 }
@@ -906,7 +916,7 @@ extern "C" int dpfhe_switch_key(dpfhe_ctx* c, uint64_t* d_out2, const uint64_t* 
     DPFHE_ON_DEVICE(c, "dpfhe_switch_key");
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (c->log2n > kFusedMaxLog2N) return key_switch_composed(c, d_out2, d_in2, 2, 1, d_key, batch, s, "dpfhe_switch_key");
-    const int rc = with_policy(c, [&](const auto& tb) { return launch_relin((int)c->log2n, 1, d_out2, d_in2, d_key, 0, 1, blocks, tb, s); });
+    const int rc = relin_launch(c, 1, d_out2, d_in2, d_key, 0, 1, blocks, s);
     if (rc) return fail(DPFHE_INVALID_STATE, "dpfhe_switch_key", "no kernel geometry for this log2_n");
     return check_launch("switch_key kernel launch");
 }
@@ -986,7 +996,7 @@ static int hybrid_entry(dpfhe_ctx* c, const char* what, int in_comps, uint64_t* 
         if (!ntt_grid_fits(c, batch * 2 * L)) return fail(DPFHE_INVALID_ARGUMENT, what, "batch too large for one launch");
         if (int rc = ntt_launch(c, true, d_work, d_work, batch * 2 * L, s)) return rc;
     } else {
-        const int rc = with_policy(c, [&](const auto& tb) { return launch_relin((int)c->log2n, mode, d_work, d_in, d_key, key_stride, key_group, blocks, tb, s); });
+        const int rc = relin_launch(c, mode, d_work, d_in, d_key, key_stride, key_group, blocks, s);
         if (rc) return fail(DPFHE_INVALID_STATE, what, "no kernel geometry for this log2_n");
         int e = check_launch("hybrid key-switch kernel launch");
         if (e) return e;
@@ -1270,7 +1280,7 @@ extern "C" int dpfhe_switch_key_qp(dpfhe_ctx* c, uint64_t* d_out_qp, const uint6
     const size_t key_words = Ld * 2 * L * (size_t)n;
     if (c->log2n > kFusedMaxLog2N)   // composed from the batched transform (round 5): the digits of c1, lifted and transformed, times the group's key
         return key_products_composed(c, d_out_qp, d_in2 + Ld * (size_t)n, 2 * Ld * (size_t)n, d_keys, key_words, (unsigned)group, batch, s, what);
-    const int rc = with_policy(c, [&](const auto& tb) { return launch_relin((int)c->log2n, 4, d_out_qp, d_in2, d_keys, key_words, (unsigned)group, blocks, tb, s); });
+    const int rc = relin_launch(c, 4, d_out_qp, d_in2, d_keys, key_words, (unsigned)group, blocks, s);
     if (rc) return fail(DPFHE_INVALID_STATE, what, "no kernel geometry for this log2_n");
     return check_launch("switch_key_qp kernel launch");
 }

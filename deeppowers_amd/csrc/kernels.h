@@ -741,10 +741,13 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE), (Arith::kFold ? 2 : 1)) void re
     const int L = tb.n_limbs;
     size_t bi;
     int limb;
+    // La = the limbs THIS launch works on: all of them, or one arithmetic class of a mixed context (devtables.h n_active / active_map; `limb` below is then
+    // an index into the class and is mapped to the limb's number in the context right after)
+    const unsigned La = tb.n_active ? (unsigned)tb.n_active : (unsigned)L;
     if (n_outer & kRelinRotMajor) {
         // round 4: ALL workgroups of a key (L limbs x key_group items) on ONE XCD, limb-major: the items' digits (read by every limb's
         // workgroup) and the key tiles (read by every item's workgroup) both come from HBM once - the layout below fetched the digits L times
-        const unsigned n_keys = (n_outer & ~kRelinRotMajor) / (unsigned)L, per_key = (unsigned)L * key_group;
+        const unsigned n_keys = (n_outer & ~kRelinRotMajor) / La, per_key = La * key_group;
         const unsigned q = blockIdx.x >> 3, w = q % per_key, key = (q / per_key) * 8u + (blockIdx.x & 7u);
         if (key >= n_keys) return;
         limb = (int)(w / key_group);
@@ -754,12 +757,13 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE), (Arith::kFold ? 2 : 1)) void re
         // equal modulo 8 and adjacent above that, i.e. the same XCD at the same time - the key tiles come from HBM once per group
         const unsigned q = blockIdx.x >> 3, inner = q % key_group, outer = (q / key_group) * 8u + (blockIdx.x & 7u);
         if (outer >= n_outer) return;
-        limb = (int)(outer % (unsigned)L);
-        bi = (size_t)(outer / (unsigned)L) * key_group + inner;
+        limb = (int)(outer % La);
+        bi = (size_t)(outer / La) * key_group + inner;
     } else {
-        bi = blockIdx.x / (unsigned)L;
-        limb = (int)(blockIdx.x % (unsigned)L);
+        bi = blockIdx.x / La;
+        limb = (int)(blockIdx.x % La);
     }
+    if (tb.n_active) limb = (int)((tb.active_map >> (4u * (unsigned)limb)) & 15u);
     const LimbConst lc = tb.lc[limb];
     const InvLast<typename B::Tw> last = tb.last[limb];
     constexpr int kInComps = (MODE == 0 || MODE == 2) ? 3 : 2;

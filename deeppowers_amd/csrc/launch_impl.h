@@ -182,18 +182,19 @@ int launch_relin(int log2n, int mode, u64* out2, const u64* in3, const u64* evk,
     // 4..7 digits at N <= 4096: digit transforms side by side (relin_shared_kernel: -10 % on relinearize at N=4096, L=4; at N=8192,
     // where one workgroup owns the CU and the key tiles are what it streams, the same form measured -1 %: not instantiated)
     if (mode < 0 || mode > 4) return -1;
+    const unsigned La = tb.n_active ? (unsigned)tb.n_active : (unsigned)tb.n_limbs;   // limbs this launch works on (one class of a mixed context, or all): blocks = items x La
     const int n_digits = mode >= 2 ? tb.n_limbs - 1 : tb.n_limbs;
     // items that share a key (key_group > 1) are laid out per XCD: kernels.h relin_kernel
     const unsigned kg = key_group ? key_group : 1u;
     // (round 6: items with a key each and NO sharing - one token's rotations - take the key-major order too: all limbs of an item on one XCD, so that its
     //  digits cross the fabric once, not once per XCD - profiles/r06_giant_traffic.txt, shape (15, 1).  Items that share ONE key (key_stride 0) keep the plain
     //  order, in which an XCD only ever touches the key tiles of its own limbs.)
-    unsigned n_outer = ((kg > 1 || key_stride != 0) && blocks % ((size_t)kg * tb.n_limbs) == 0) ? (unsigned)(blocks / kg) : 0u;   // whole groups only
+    unsigned n_outer = ((kg > 1 || key_stride != 0) && blocks % ((size_t)kg * La) == 0) ? (unsigned)(blocks / kg) : 0u;   // whole groups only
     unsigned grid = n_outer ? ((n_outer + 7u) / 8u) * 8u * kg : (unsigned)blocks;
     // eight keys or more: one key (all its limbs and items) per XCD at a time, so that the items' digits are fetched once, not once per limb
-    if (n_outer && n_outer / (unsigned)tb.n_limbs >= 8u) {
-        const unsigned n_keys = n_outer / (unsigned)tb.n_limbs;
-        grid = ((n_keys + 7u) / 8u) * 8u * (unsigned)tb.n_limbs * kg;
+    if (n_outer && n_outer / La >= 8u) {
+        const unsigned n_keys = n_outer / La;
+        grid = ((n_keys + 7u) / 8u) * 8u * La * kg;
         n_outer |= kRelinRotMajor;
     }
 #ifdef DPFHE_DIAGNOSTICS   // (tools/relin_trace.py reads the buffer back)
@@ -208,7 +209,7 @@ int launch_relin(int log2n, int mode, u64* out2, const u64* in3, const u64* evk,
 #endif
 #define RL_ONE(LN, M)                                                                                                                                    \
     if constexpr (Arith::kFold && LN >= 10 && LN <= 12) {                                                                          \
-        if (n_digits >= 4 && n_digits <= 7) {                                                                                                            \
+        if (n_digits >= 4 && n_digits <= 7 && !tb.n_active) {                                                                                                            \
             hipLaunchKernelGGL((relin_shared_kernel<Arith, LN, kFusedLoge, M>), dim3(grid), dim3(Geo<LN, kFusedLoge>::T), 0, s, out2, in3, evk,          \
                                key_stride, kg, n_outer, tb);                                                                                             \
             break;                                                                                                                                       \

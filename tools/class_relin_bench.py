@@ -15,7 +15,7 @@ def shoup55():
 
 nb, L, N = 2048, 4, 4096
 for name, p in (("fold", ntt_primes(12, L, 60)), ("f64_31", ntt_primes(12, L, 31)), ("f64_45", ntt_primes(12, L, 45)), ("f64wide_49", ntt_primes(12, L, 49)),
-                ("fscaled_59", ntt_primes(12, L, 59)), ("shoup_55", shoup55()), ("fold", ntt_primes(12, L, 60))):
+                ("fscaled_59", ntt_primes(12, L, 59)), ("shoup_55", shoup55()), ("mixed", FheParams.generic_n4096_l4()), ("fold", ntt_primes(12, L, 60))):
     ctx = Context(p, 0); ev = Evaluator(ctx); dev = ctx.device
     g = torch.Generator(device=dev).manual_seed(3)
     q = torch.tensor(p.moduli, dtype=torch.int64, device=dev)
@@ -29,5 +29,5 @@ for name, p in (("fold", ntt_primes(12, L, 60)), ("f64_31", ntt_primes(12, L, 31
         s.record(); ev.relinearize(c3, evk, out=o2); e.record()
     torch.cuda.synchronize()
     ts = sorted(s.elapsed_time(e) * 1e3 for s, e in evs)
-    print(f"RELIN {name:11s} {ctx.limb_classes[0]:11s} median {ts[3]:8.1f} us -> {nb / ts[3]:6.3f} M relin/s", flush=True)
+    print(f"RELIN {name:11s} {'/'.join(sorted(set(ctx.limb_classes))):20s} median {ts[3]:8.1f} us -> {nb / ts[3]:6.3f} M relin/s", flush=True)
     ctx.close()
