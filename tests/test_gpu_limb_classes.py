@@ -266,3 +266,38 @@ def test_key_switching_runs_on_the_class_of_a_uniform_context(name, log2n, width
             assert np.array_equal(got[i], orc.keyswitch_hybrid(data.apply_galois(items[i][None], elts[i // T]), keys[i // T], 2, threads=0)[0]), ("grouped", i)
     finally:
         ctx.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("widths", [(36, 45, 40), (59, 57, 45), (49, 50)], ids=["f64", "mixed", "f64_wide_and_scaled"])
+def test_large_ring_composed_operations_on_limb_classes(widths):
+    """N = 16384 has no fused kernels: dpfhe_ct_mul / dpfhe_relinearize / hybrid key switching are composed from the batched transforms (per limb class, the
+    mixtures in one launch) and the streaming kernels (generic products on canonical words) - every word against the oracle"""
+    from deeppowers_amd.evaluator import Ciphertext, Context, Evaluator, to_device, to_host
+    p = primes_of(14, widths)
+    L, n = p.n_limbs, p.n
+    orc = Oracle.from_params(p)
+    ctx = Context(p, 0)
+    ev = Evaluator(ctx)
+    try:
+        assert ctx.limb_classes == tuple(expected_class(q) for q in p.moduli)
+        qcol = np.array(p.moduli, np.uint64)[:, None]
+        a = worst_case(orc.fill(4, 9100).reshape(2, 2, L, n), qcol, n)
+        b = worst_case(orc.fill(4, 9200).reshape(2, 2, L, n), qcol, n)
+        want = orc.ct_mul(a, b, threads=0)
+        A, B = Ciphertext(to_device(a, ctx.device)), Ciphertext(to_device(b, ctx.device))
+        c = ev.multiply(A, B)
+        assert np.array_equal(to_host(c.data), want)
+        assert np.array_equal(to_host(ev.ntt_inverse(ev.multiply(A, B, out_ntt=True).data)), want)
+        evk = orc.fill(L * 2, 9300).reshape(L, 2, L, n)
+        assert np.array_equal(to_host(ev.relinearize(c, to_device(evk, ctx.device)).data), orc.relinearize(want, evk, threads=0))
+        Ld = L - 1
+        data = Oracle(p.log2_n, p.moduli[:-1], p.psi[:-1])
+        key = orc.fill(Ld * 2, 9400).reshape(Ld, 2, L, n)
+        ct = data.fill(2 * 2, 9500).reshape(2, 2, Ld, n)
+        got = to_host(ev.keyswitch_hybrid(Ciphertext(to_device(ct, ctx.device)), to_device(key, ctx.device)).data)
+        assert np.array_equal(got, orc.keyswitch_hybrid(ct, key, 2, threads=0))
+        ctx.release_scratch(all_streams=True)
+        assert ctx.scratch_bytes == 0
+    finally:
+        ctx.close()
