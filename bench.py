@@ -940,22 +940,24 @@ def main():
     # is the all-gather step's): the SAME step with a 64-bit sum all-reduce of the partials + one mod-q pass instead of all-gather + local sum.
     collective_ab = None
     if world > 1:
-        pipe_ar = ShardedMultiplyReduce(ev, B, comm=comm, main=main, collective="allreduce")
-        pipe_ar.outs = pipe.outs                                   # same output buffers: no second 6 GiB
-        for _ in range(max(1, args.warmup)):
-            pipe_ar.step(a, b)
-        fence()
-        t1 = time.perf_counter()
-        for _ in range(args.steps):
-            k_ar = pipe_ar.step(a, b)
-        fence()
-        t_ar = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=dev)
-        dist.all_reduce(t_ar, op=dist.ReduceOp.MAX)
-        same = torch.tensor([int(torch.equal(pipe_ar.totals[k_ar], totals[last]))], device=dev)
-        dist.all_reduce(same, op=dist.ReduceOp.MIN)
-        collective_ab = {"allgather_ms_per_step": elapsed / args.steps * 1e3, "allreduce_ms_per_step": float(t_ar.item()) / args.steps * 1e3,
-                         "allreduce_total_equals_allgather_total": bool(same.item()),
-                         "what": "the timed step with ncclAllReduce(u64, sum) of one partial per rank + one mod-q pass, against all-gather + local sum (the timed `value`)"}
+        try:   # (every rank walks the same path: an exception here is raised on all of them, so the ranks stay in step)
+            pipe_ar = ShardedMultiplyReduce(ev, B, comm=comm, main=main, collective="allreduce", outs=pipe.outs)   # same output buffers: no second 6 GiB
+            for _ in range(max(1, args.warmup)):
+                pipe_ar.step(a, b)
+            fence()
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                k_ar = pipe_ar.step(a, b)
+            fence()
+            t_ar = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=dev)
+            dist.all_reduce(t_ar, op=dist.ReduceOp.MAX)
+            same = torch.tensor([int(torch.equal(pipe_ar.totals[k_ar], totals[last]))], device=dev)
+            dist.all_reduce(same, op=dist.ReduceOp.MIN)
+            collective_ab = {"allgather_ms_per_step": elapsed / args.steps * 1e3, "allreduce_ms_per_step": float(t_ar.item()) / args.steps * 1e3,
+                             "allreduce_total_equals_allgather_total": bool(same.item()),
+                             "what": "the timed step with ncclAllReduce(u64, sum) of one partial per rank + one mod-q pass, against all-gather + local sum (the timed `value`)"}
+        except Exception as e:
+            collective_ab = {"error": repr(e)[:200]}
 
     def workgroup_timeline():
         """median microseconds per segment of a quad-form workgroup's life over a 2048-pair launch (steady-state workgroups only): the share

@@ -594,6 +594,13 @@ static int relin_launch(const dpfhe_ctx* c, int mode, u64* out, const u64* in, c
     return with_policy(c, [&](const auto& tb) { return launch_relin((int)c->log2n, mode, out, in, evk, key_stride, key_group, blocks, tb, s); });
 }
 
+// the same choice for kernels whose workgroups map through DevTables::active_map (hoisted_ks_kernel, ntt_inv_galois_kernel): a mixture of classes launches once per class
+template <class Fn>
+static int with_policy_or_classes(const dpfhe_ctx* c, Fn fn) {
+    if (c->classes && c->uniform_cls == kClassShoup) return for_each_class(c, c->n_limbs, fn);
+    return with_policy(c, fn);
+}
+
 // batched transform of `items` RNS polynomials over the first `limbs_used` limbs (limbs_used = 0: all); arguments validated, device selected by the caller
 static int ntt_launch_items(dpfhe_ctx* c, bool inverse, uint64_t* out, const uint64_t* in, size_t items, size_t limbs_used, hipStream_t s) {
     const size_t Lu = limbs_used ? limbs_used : c->n_limbs;
@@ -1154,7 +1161,7 @@ extern "C" int dpfhe_rotate_hybrid_hoisted(dpfhe_ctx* c, uint64_t* d_out2, const
     // 3. permuted digits (.) keys, one inverse transform per (rotation, limb, key component, item); 64 rotations per launch
     for (size_t first = 0; first < batch; first += kMaxGaloisBatch) {
         const size_t cnt = batch - first < (size_t)kMaxGaloisBatch ? batch - first : (size_t)kMaxGaloisBatch;
-        const int rc = with_policy(c, [&](const auto& tb) {
+        const int rc = with_policy_or_classes(c, [&](const auto& tb) {
             return launch_hoisted_ks((int)c->log2n, d_work + first * T * 2 * L * n, d_digits, d_keys + first * key_words, key_words, galois_elts + first, cnt, T, tb, s);
         });
         if (rc) return fail(DPFHE_INVALID_STATE, what, "no kernel geometry for this log2_n");
@@ -1256,7 +1263,7 @@ extern "C" int dpfhe_ntt_inv_galois(dpfhe_ctx* c, uint64_t* d_out, const uint64_
     for (size_t first = 0; first < n_elts; first += kMaxGaloisBatch) {
         const size_t cnt = n_elts - first < (size_t)kMaxGaloisBatch ? n_elts - first : (size_t)kMaxGaloisBatch;
         const size_t off = first * per_elt << c->log2n;
-        const int rc = with_policy(c, [&](const auto& tb) { return launch_ntt_inv_galois((int)c->log2n, d_out + off, d_in + off, galois_elts + first, cnt, per_elt, tb, s); });
+        const int rc = with_policy_or_classes(c, [&](const auto& tb) { return launch_ntt_inv_galois((int)c->log2n, d_out + off, d_in + off, galois_elts + first, cnt, per_elt, tb, s); });
         if (rc) return fail(DPFHE_INVALID_STATE, what, "no single-kernel transform for this log2_n");
         if (int e = check_launch("ntt_inv_galois kernel launch")) return e;
     }

@@ -397,8 +397,14 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE)) void ntt_inv_galois_kernel(u64*
     static_assert(B::G::highest_cross_wave_exchange() >= 0 || B::G::T <= 64, "in-place safety relies on the transform's workgroup barrier");
     __shared__ __attribute__((aligned(16))) u64 lds[B::G::lds_words()];
     const int tid = threadIdx.x;
-    const size_t p = blockIdx.x;
-    const int limb = (int)(p % (size_t)tb.n_limbs);
+    // (a launch over one class of a mixed context: blockIdx.x counts (polynomial, class limb) pairs; polys_per_elt is then per class too)
+    size_t p = blockIdx.x;
+    int limb = (int)(p % (size_t)tb.n_limbs);
+    if (tb.n_active) {
+        size_t item;
+        block_item_limb(tb, blockIdx.x, item, limb);
+        p = item * (size_t)tb.n_limbs + (size_t)limb;
+    }
     const unsigned g = elts.v[blockIdx.x / polys_per_elt];
     const LimbConst lc = tb.lc[limb];
     const typename B::Tw* tw = tb.inv + (size_t)limb * N;
@@ -1056,8 +1062,10 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE), (Arith::kFold ? 2 : 1)) void ho
     const unsigned q = blockIdx.x >> 3, token = q % n_items, tile = (q / n_items) * 8u + (blockIdx.x & 7u);
     if (tile >= n_tiles) return;
     const int comp = (int)(tile & 1u);
-    const size_t rot = (tile >> 1) / (unsigned)L;
-    const int limb = (int)((tile >> 1) % (unsigned)L);
+    const unsigned La = tb.n_active ? (unsigned)tb.n_active : (unsigned)L;   // limbs this launch works on (one class of a mixed context, or all)
+    const size_t rot = (tile >> 1) / La;
+    int limb = (int)((tile >> 1) % La);
+    if (tb.n_active) limb = (int)((tb.active_map >> (4u * (unsigned)limb)) & 15u);
     const size_t item = rot * n_items + token;        // output / work item
     digits += (size_t)token * (size_t)(L - 1) * L * N;
     const LimbConst lc = tb.lc[limb];

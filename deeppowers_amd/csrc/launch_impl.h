@@ -238,8 +238,9 @@ int launch_hoisted_ks(int log2n, u64* work, const u64* digits, const u64* keys, 
     // that the lazy sums fit): one per (rotation, limb) doing both components - the digit words are gathered once and the two inverse
     // transforms share their twiddles (kernels.h hoisted_ks2_kernel)
     constexpr size_t kHoistedMergeMin = 512;
-    const unsigned tiles1 = (unsigned)(count * (size_t)tb.n_limbs);                 // (rotation, limb)
-    const bool merged = Arith::kFold && tb.n_limbs - 1 <= 7 && (size_t)tiles1 * n_items >= kHoistedMergeMin;
+    const unsigned La = tb.n_active ? (unsigned)tb.n_active : (unsigned)tb.n_limbs;  // limbs this launch works on (one class of a mixed context, or all)
+    const unsigned tiles1 = (unsigned)(count * (size_t)La);                         // (rotation, limb)
+    const bool merged = Arith::kFold && !tb.n_active && tb.n_limbs - 1 <= 7 && (size_t)tiles1 * n_items >= kHoistedMergeMin;
     const unsigned tiles = merged ? tiles1 : tiles1 * 2u;                           // ... x key component when split
     const unsigned blocks = ((tiles + 7u) / 8u) * 8u * (unsigned)n_items;           // x token, ids laid out per XCD (kernels.h)
 #define HK_CASE(LN, LE)                                                                                                                                  \
@@ -261,6 +262,8 @@ int launch_ntt_inv_galois(int log2n, u64* out, const u64* in, const unsigned* el
     if (tb.n_sub != 1 || n_elts > (size_t)kMaxGaloisBatch) return -1;   // split transforms (N > 16384) have no gather form; callers chunk by kMaxGaloisBatch
     GaloisElts ge{};
     for (size_t i = 0; i < n_elts; ++i) ge.v[i] = elts[i];
+    // polys_per_elt counts residue polynomials over ALL limbs; a class launch covers n_active of every n_limbs of them
+    if (tb.n_active) polys_per_elt = polys_per_elt / (size_t)tb.n_limbs * (size_t)tb.n_active;
     const unsigned grid = (unsigned)(n_elts * polys_per_elt);
 #define NG_CASE(LN, LE) \
     hipLaunchKernelGGL((ntt_inv_galois_kernel<Arith, LN, LE>), dim3(grid), dim3(Geo<LN, LE>::T), 0, s, out, in, ge, (unsigned)polys_per_elt, tb)

@@ -142,7 +142,7 @@ class ShardedMultiplyReduce:
     Two output buffers and two HIP streams: the (VALU-bound) multiply of step i+1 runs on `main` while the (HBM-bound)
     shard-local reduce + all-gather + final sum of step i run on `side`.  No allocation after construction."""
 
-    def __init__(self, ev, batch: int, group=None, comm: NativeComm | None = None, main=None, collective: str = "allgather"):
+    def __init__(self, ev, batch: int, group=None, comm: NativeComm | None = None, main=None, collective: str = "allgather", outs=None):
         """collective: "allgather" (one partial per rank gathered, summed locally - the north star's exchange) or "allreduce" (SURVEY.md 8(e)'s alternative:
         a 64-bit sum all-reduce of the partials in place + one mod-q pass; world <= 15).  Same words either way."""
         if collective not in ("allgather", "allreduce"):
@@ -151,7 +151,7 @@ class ShardedMultiplyReduce:
         ctx = ev.ctx
         self.world = comm.world if comm is not None else (dist.get_world_size(group) if dist.is_initialized() else 1)
         p = ctx.params
-        self.outs = [ctx.empty(batch, components=3) for _ in range(2)]
+        self.outs = list(outs) if outs is not None else [ctx.empty(batch, components=3) for _ in range(2)]   # (outs: two caller buffers [batch][3][L][N] to reuse)
         self.partials = [ctx.empty(components=3) for _ in range(2)]
         self.gathered = [torch.empty((self.world, 3, p.n_limbs, p.n), dtype=torch.int64, device=ctx.device) for _ in range(2)]
         self.totals = [ctx.empty(components=3) for _ in range(2)]

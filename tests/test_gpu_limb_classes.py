@@ -184,6 +184,22 @@ def test_key_switching_on_a_context_with_classes_still_matches_the_oracle():
         ct = data.fill(3 * 3, 6500).reshape(3, 3, Ld, n)
         got = to_host(ev.keyswitch_hybrid(Ciphertext(to_device(ct, ctx.device)), to_device(key, ctx.device)).data)
         assert np.array_equal(got, orc.keyswitch_hybrid(ct, key, 3, threads=0))
+        # hoisted rotations (hoisted_ks_kernel, one launch per class) and the Galois inverse transform (ntt_inv_galois_kernel, per class) on the mixture
+        k, T = 70, 2
+        elts = [pow(3, i + 1, 2 * n) for i in range(k)]
+        keys = orc.fill(k * Ld * 2, 6600).reshape(k, Ld, 2, L, n)
+        cts = data.fill(T * 2, 6700).reshape(T, 2, Ld, n)
+        got = to_host(ev.rotate_hybrid_hoisted(Ciphertext(to_device(cts, ctx.device)), elts, to_device(keys, ctx.device)).data).reshape(k, T, 2, Ld, n)
+        for r in (0, 22, 63, 64, 69):
+            for t in range(T):
+                assert np.array_equal(got[r, t], orc.rotate_hoisted(cts[t], [elts[r]], keys[r][None], threads=0)[0]), ("hoisted", r, t)
+        ge = [pow(3, 5 * i, 2 * n) for i in range(70)]
+        x = orc.fill(70 * 2, 6800).reshape(70, 2, L, n)
+        wantg = np.stack([orc.apply_galois(orc.ntt_inv(x[e]), ge[e]) for e in range(70)])
+        d = to_device(x, ctx.device)
+        assert np.array_equal(to_host(ev.ntt_inverse_galois(d, ge)), wantg)
+        ev.ntt_inverse_galois(d, ge, out=d)
+        assert np.array_equal(to_host(d), wantg)
     finally:
         ctx.close()
 
