@@ -4,6 +4,8 @@
 
 namespace dpfhe {
 
+struct QuartersTop;   // ntt_quarters.h
+
 template <class Tw>
 struct InvLast {  // per limb: last inverse stage twiddles with N^-1 folded in
     Tw w_last;    // psi^-brv(1) * N^-1
@@ -31,6 +33,13 @@ struct DevTables {
     const typename Arith::Tw* hinv;         // [L][2][4096]
     const typename Arith::Tw* htop_fwd;     // [L]
     const InvLast<typename Arith::Tw>* htop_last;  // [L]  {psi^-brv(1) N^-1, N^-1}
+    // N = 16384 in "quarters" form (ntt_quarters.h; FoldArith contexts, null elsewhere): per limb the four 4096-point sub-tree tables (roots 4..7 of the
+    // N = 16384 table) in the (12, 4) kernel layout, the forward column stages' twiddles, the inverse ones' (psi^-brv(2), psi^-brv(3)) and the last stage
+    const typename Arith::Tw* qfwd;         // [L][4][4096]
+    const typename Arith::Tw* qinv;         // [L][4][4096]
+    const struct QuartersTop* qtop_fwd;     // [L]
+    const typename Arith::Tw* qtop_inv;     // [L][2]
+    const InvLast<typename Arith::Tw>* qtop_last;  // [L]  {psi^-brv(1) N^-1, N^-1}
     const InvLast<typename Arith::Tw>* last;  // [L]
     // FoldScaledArith class only: the same with s^-1 = 2^-(60-k) folded in - the last stage of an inverse transform whose input is a PRODUCT of two
     // scaled words (the fused multiply's lazy tensor step).  Null elsewhere.

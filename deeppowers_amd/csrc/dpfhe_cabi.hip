@@ -25,6 +25,7 @@
 #include "kernels_misc.h"
 #include "launch.h"
 #include "ntt_core.h"
+#include "ntt_quarters.h"
 #include "tables.h"
 
 using namespace dpfhe;
@@ -349,7 +350,12 @@ extern "C" int dpfhe_ctx_create(dpfhe_ctx** out, uint32_t log2_n, uint32_t n_lim
     // N = 8192: the "halves" tables next to the one-piece ones (ntt_halves.h; the fused kernels keep the one-piece layout)
     const bool halves = log2_n == 13 && fold;   // the halves tables (launch.h): large batched transforms at N = 8192
     const size_t o_hfwd = up(o_resc + L * sizeof(RescaleConst)), o_hinv = halves ? up(o_hfwd + tab) : o_hfwd, o_htop_fwd = halves ? up(o_hinv + tab) : o_hfwd,
-                 o_htop_last = halves ? up(o_htop_fwd + L * tw_sz) : o_hfwd, total = halves ? up(o_htop_last + L * 2 * tw_sz) : o_hfwd;
+                 o_htop_last = halves ? up(o_htop_fwd + L * tw_sz) : o_hfwd, o_q0 = halves ? up(o_htop_last + L * 2 * tw_sz) : o_hfwd;
+    // N = 16384, FoldArith: the "quarters" tables next to the one-piece ones (ntt_quarters.h: four sub-tree tables per limb + the column stages' twiddles)
+    const bool quarters = log2_n == 14 && fold;
+    const size_t o_qfwd = o_q0, o_qinv = quarters ? up(o_qfwd + tab) : o_q0, o_qtop_fwd = quarters ? up(o_qinv + tab) : o_q0,
+                 o_qtop_inv = quarters ? up(o_qtop_fwd + L * sizeof(QuartersTop)) : o_q0, o_qtop_last = quarters ? up(o_qtop_inv + L * 2 * tw_sz) : o_q0,
+                 total = quarters ? up(o_qtop_last + L * 2 * tw_sz) : o_q0;
     std::vector<unsigned char> blob(total, 0);
     auto fill = [&](auto tw_tag) {
         typedef decltype(tw_tag) Tw;
@@ -369,6 +375,18 @@ extern "C" int dpfhe_ctx_create(dpfhe_ctx** out, uint32_t log2_n, uint32_t n_lim
                     pack(ht[l].irp, (int)log2_n, loge, (geo ? o_inv : o_inv4) + l * n * tw_sz);
                 }
                 lasts[l] = InvLast<Tw>{h_make_tw<Tw>(ht[l].w_last, q), h_make_tw<Tw>(ht[l].lc.ninv, q)};
+                if constexpr (std::is_same<Tw, TwFold>::value) {
+                    if (quarters) {
+                        for (size_t r = 0; r < 4; ++r) {
+                            pack(subtree_table(ht[l].rp, 14, 2, r), 12, 4, o_qfwd + (l * 4 + r) * (n / 4) * tw_sz);
+                            pack(subtree_table(ht[l].irp, 14, 2, r), 12, 4, o_qinv + (l * 4 + r) * (n / 4) * tw_sz);
+                        }
+                        reinterpret_cast<QuartersTop*>(&blob[o_qtop_fwd])[l] = QuartersTop{h_tw_fold(ht[l].rp[1], q), h_tw_fold(ht[l].rp[2], q), h_tw_fold(ht[l].rp[3], q)};
+                        reinterpret_cast<TwFold*>(&blob[o_qtop_inv])[2 * l] = h_tw_fold(ht[l].irp[2], q);
+                        reinterpret_cast<TwFold*>(&blob[o_qtop_inv])[2 * l + 1] = h_tw_fold(ht[l].irp[3], q);
+                        reinterpret_cast<InvLast<TwFold>*>(&blob[o_qtop_last])[l] = InvLast<TwFold>{h_tw_fold(ht[l].w_last, q), h_tw_fold(ht[l].lc.ninv, q)};
+                    }
+                }
                 if (halves) {
                     for (size_t r = 0; r < 2; ++r) {
                         pack(subtree_table(ht[l].rp, 13, 1, r), 12, 4, o_hfwd + (l * 2 + r) * (n / 2) * tw_sz);
@@ -429,6 +447,11 @@ extern "C" int dpfhe_ctx_create(dpfhe_ctx** out, uint32_t log2_n, uint32_t n_lim
         c->foldt.top_last = reinterpret_cast<const InvLast<TwFold>*>(d + o_top_last);
         c->foldt.n_sub = (int)n_sub;
         c->foldt.n_limbs = (int)n_limbs;
+        if (quarters) {
+            c->foldt.qfwd = reinterpret_cast<const TwFold*>(d + o_qfwd); c->foldt.qinv = reinterpret_cast<const TwFold*>(d + o_qinv);
+            c->foldt.qtop_fwd = reinterpret_cast<const QuartersTop*>(d + o_qtop_fwd); c->foldt.qtop_inv = reinterpret_cast<const TwFold*>(d + o_qtop_inv);
+            c->foldt.qtop_last = reinterpret_cast<const InvLast<TwFold>*>(d + o_qtop_last);
+        }
         if (halves) {
             c->foldt.hfwd = reinterpret_cast<const TwFold*>(d + o_hfwd); c->foldt.hinv = reinterpret_cast<const TwFold*>(d + o_hinv);
             c->foldt.htop_fwd = reinterpret_cast<const TwFold*>(d + o_htop_fwd); c->foldt.htop_last = reinterpret_cast<const InvLast<TwFold>*>(d + o_htop_last);

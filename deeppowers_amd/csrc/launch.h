@@ -25,6 +25,11 @@ constexpr int kFusedLoge = 4;   // words-per-thread exponent of the fused kernel
 //    its 2 workgroups per CU resident -, 4 % slower at 256 and below (two lockstep generations): launch_ntt picks the form by batch size, FoldArith contexts;
 //  * giant-step key inner products as one workgroup per (item, limb, half): 3 % slower at the packed layers' size (profiles/r05_halves_relin_ab.txt) - removed in round 6.
 constexpr size_t kHalvesMinPolys = 2304;   // residue polynomials per launch from which the halves form of the N = 8192 transforms wins (measured crossover: 1536 loses, 2304 wins)
+// N = 16384 on the N = 4096 body ("quarters": ntt_quarters.h, kernels_quarters.h - two register column stages + four 4096-point sub-transforms through one LDS
+// buffer, 256-thread workgroups, two to a CU).  Round 6, measured against the 1024-thread kernel on one box, alternated (profiles/r06_ntt14_quarters_sweep.txt):
+// 5-13 % faster from 1536 workgroups up (forward 122 against 138 us at 512 RNS polynomials x 3 limbs, 458 against 493-502 at 2048; inverse 5-7 %), equal at 768,
+// slower below (a workgroup lives four sub-transforms long: 28.7 against 21.4 us at 192).  launch_ntt picks the form by batch size, FoldArith contexts.
+constexpr size_t kQuartersMinPolys = 768;
 constexpr int kMaxGaloisBatch = 64;   // Galois elements travel as kernel arguments, this many per launch
 
 // return 0, or -1 when log2n has no compiled geometry.  Launch errors are left in hipGetLastError().

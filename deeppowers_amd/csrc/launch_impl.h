@@ -5,6 +5,7 @@
 #include "kernels.h"
 #include "launch.h"
 #include "kernels_halves.h"
+#include "kernels_quarters.h"
 #ifdef DPFHE_DIAGNOSTICS   // diagnostic builds only (tools/ab_variant.sh diag -DDPFHE_DIAGNOSTICS): per-workgroup timestamp kernels, their buffers and read-back entries
 #include "kernels_trace.h"
 #endif
@@ -83,6 +84,20 @@ int launch_ntt(int log2n, bool inverse, u64* out, const u64* in, size_t npolys, 
         }
     }
 #endif
+    // N = 16384, FoldArith: 256-thread workgroups on the N = 4096 body, two to a CU (ntt_quarters.h)
+    if constexpr (Arith::kFold) {
+        if (log2n == 14 && tb.qfwd && !tb.n_active && npolys >= kQuartersMinPolys) {
+            const bool nt14 = touched > ((size_t)256 << 20);
+            if (inverse) {
+                if (nt14) hipLaunchKernelGGL((ntt_inv_quarters_kernel<true>), dim3((unsigned)npolys), dim3(256), 0, s, out, in, tb);
+                else hipLaunchKernelGGL((ntt_inv_quarters_kernel<false>), dim3((unsigned)npolys), dim3(256), 0, s, out, in, tb);
+            } else {
+                if (nt14) hipLaunchKernelGGL((ntt_fwd_quarters_kernel<true>), dim3((unsigned)npolys), dim3(256), 0, s, out, in, tb);
+                else hipLaunchKernelGGL((ntt_fwd_quarters_kernel<false>), dim3((unsigned)npolys), dim3(256), 0, s, out, in, tb);
+            }
+            return 0;
+        }
+    }
     // N = 8192, large batches, FoldArith: 256-thread workgroups on the N = 4096 body (launch.h)
     if constexpr (Arith::kFold) {
         if (log2n == 13 && tb.hfwd && !tb.n_active && npolys >= kHalvesMinPolys) {

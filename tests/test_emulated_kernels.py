@@ -21,7 +21,7 @@ U = C.POINTER(C.c_uint64)
 def emu():
     so = os.path.join(ROOT, "tools", "libemu.so")
     src = os.path.join(ROOT, "tools", "emulate.cpp")
-    deps = [src] + [os.path.join(ROOT, "deeppowers_amd", "csrc", f) for f in ("ntt_core.h", "ntt_top.h", "ntt_halves.h", "modarith.h", "tables.h")]
+    deps = [src] + [os.path.join(ROOT, "deeppowers_amd", "csrc", f) for f in ("ntt_core.h", "ntt_top.h", "ntt_halves.h", "ntt_quarters.h", "modarith.h", "tables.h")]
     if not os.path.exists(so) or any(os.path.getmtime(d) > os.path.getmtime(so) for d in deps):
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-shared", "-fPIC", "-o", so, src])   # (F64Arith: nothing fused behind the explicit fma calls)
     lib = C.CDLL(so)
@@ -254,3 +254,25 @@ def test_emulated_class_fused_multiply_matches_oracle(emu, ln, arith, bits, lazy
         want = orc.ct_mul(np.stack([a0, a1]).reshape(1, 2, 1, n), np.stack([b0, b1]).reshape(1, 2, 1, n)).reshape(3 * n)
         assert np.array_equal(out, want)
     assert emu.emu_overflows() == before
+
+
+def test_emulated_quarters_transform_matches_oracle(emu):
+    """N = 16384 as two register column stages + four 4096-point sub-transforms through one LDS buffer (ntt_quarters.h, the 256-thread kernels of
+    kernels_quarters.h) == the oracle's one-piece transform, worst-case residues included, no 64-bit wrap of the lazy arithmetic."""
+    n = 16384
+    emu.emu_ntt_quarters.argtypes = [C.c_int, C.c_uint64, C.c_uint64, U, U]
+    emu.emu_ntt_quarters.restype = C.c_int
+    before = emu.emu_overflows()
+    for limb in (1, 2, 4):   # the pinned primes that are 1 mod 32768
+        q = PRIMES_60[limb][0]
+        psi = po.min_primitive_2n_root(n, q)
+        orc = Oracle(14, [q], [psi])
+        for a in (orc.fill(1, 91 + limb).ravel().copy(), np.full(n, q - 1, np.uint64), np.where(np.arange(n) % 2 == 0, q - 1, 0).astype(np.uint64),
+                  np.where(np.arange(n) < n // 2, q - 1, 1).astype(np.uint64), np.where(np.arange(n) % 4 < 2, q - 1, 0).astype(np.uint64)):
+            a = np.ascontiguousarray(a, dtype=np.uint64)
+            for inv, ref in ((0, orc.ntt_fwd), (1, orc.ntt_inv)):
+                out = np.zeros_like(a)
+                assert emu.emu_ntt_quarters(inv, q, psi, a.ctypes.data_as(U), out.ctypes.data_as(U)) == 0
+                assert np.array_equal(out, ref(a)), (limb, inv)
+    assert emu.emu_overflows() == before, "lazy arithmetic wrapped around 2^64"
+    assert emu.emu_ntt_quarters(0, PRIME_30, PSI_30_N1024, None, None) == 2000   # FoldArith only

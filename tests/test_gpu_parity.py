@@ -462,6 +462,34 @@ def test_n8192_large_batches_take_the_halves_form_and_match_the_oracle(rigs):
     assert torch.equal(y, xd)
 
 
+def test_n16384_large_batches_take_the_quarters_form_and_match_the_oracle(rigs):
+    """N = 16384, 3 limbs of the pinned chain: from 768 residue polynomials per launch the batched transforms run in "quarters" form (launch.h kQuartersMinPolys:
+    two register column stages + four 4096-point sub-transforms through one LDS buffer, 256-thread workgroups, two to a CU); below, the 1024-thread kernel.
+    Both sides of the threshold, out of place and in place, EVERY word against the oracle; round trip; the two forms agree on a shared prefix of the batch."""
+    r = rigs("fold14")
+    L, n = r.p.n_limbs, r.p.n
+    g = torch.Generator(device="cpu").manual_seed(31)
+    q = torch.tensor(r.p.moduli, dtype=torch.int64).view(1, L, 1)
+    big, small = 300, 255                                  # 900 and 765 residue polynomials: above and just below the threshold
+    x = (torch.randint(0, 2**62, (big, L, n), generator=g, dtype=torch.int64) % q)
+    x[0, :, : n // 2] = q.view(L, 1) - 1                   # worst-case residues in one polynomial
+    x[1, :, 1::2] = q.view(L, 1) - 1
+    xd = x.to(r.ctx.device)
+    X = r.ev.ntt_forward(xd)
+    want = r.orc.ntt_fwd(to_host(xd), threads=0)
+    assert np.array_equal(to_host(X), want)
+    assert torch.equal(r.ev.ntt_inverse(X), xd)                                           # round trip through the quarters inverse
+    assert np.array_equal(to_host(r.ev.ntt_inverse(xd)), r.orc.ntt_inv(to_host(xd), threads=0))   # inverse of non-image data
+    Xs = r.ev.ntt_forward(xd[:small].contiguous())                                        # the 1024-thread kernel on a prefix: the same words
+    assert torch.equal(Xs, X[:small])
+    assert torch.equal(r.ev.ntt_inverse(X[:small].contiguous()), xd[:small])
+    y = xd.clone()
+    r.ev.ntt_forward_(y)
+    assert torch.equal(y, X)
+    r.ev.ntt_inverse_(y)
+    assert torch.equal(y, xd)
+
+
 def test_ct_mul_large_batch_checksum_of_checksums(rigs):
     """2048 ct-muls at N=4096/L=4: sum of outputs == output of ... (bilinearity): sum_i a_i (x) b == (sum_i a_i) (x) b."""
     r = rigs("n4096")

@@ -78,3 +78,57 @@ def test_random_parameter_set_matches_the_oracle(seed):
         assert np.array_equal(r.reshape(3, L, n), orc.reduce_sum(want, 3).reshape(3, L, n))
     finally:
         ctx.close()
+
+
+# ---- round 6: hypothesis-driven limb widths (every arithmetic class and every mixture of them) ---------------------------------------------------------
+from hypothesis import HealthCheck, given, settings, strategies as st  # noqa: E402
+
+
+def _kth_prime(log2n, bits, k):
+    p = ntt_primes(log2n, k + 1, bits)
+    return p.moduli[k], p.psi[k]
+
+
+@pytest.mark.gpu
+@settings(max_examples=25, deadline=None, derandomize=True, suppress_health_check=list(HealthCheck))
+@given(log2n=st.integers(8, 13), widths=st.lists(st.tuples(st.integers(20, 60), st.integers(0, 3)), min_size=1, max_size=6, unique=True), seed=st.integers(0, 2**31))
+def test_random_limb_widths_every_class_matches_the_oracle(log2n, widths, seed):
+    """(width k, index j) -> the j-th largest prime = 1 mod 2N below 2^k: 20 ... 60 bits, so every limb class (f64, f64_wide, fold_scaled, fold, shoup) and every
+    mixture of them turns up; transforms, the fused multiply in both output domains and relinearisation against the oracle, extreme residues included"""
+    from deeppowers_amd.evaluator import Ciphertext, Context, Evaluator, to_device, to_host
+    n = 1 << log2n
+    qs, psis = [], []
+    for bits, j in widths:
+        if bits < log2n + 8:                      # too few primes = 1 mod 2N below 2^bits
+            bits = log2n + 8 + bits % 8
+        q, psi = _kth_prime(log2n, bits, j)
+        if q in qs:
+            continue
+        qs.append(q)
+        psis.append(psi)
+    p = FheParams(log2n, tuple(qs), tuple(psis))
+    L = p.n_limbs
+    orc = Oracle.from_params(p)
+    ctx = Context(p, 0)
+    ev = Evaluator(ctx)
+    try:
+        qcol = np.array(p.moduli, np.uint64)[None, :, None]
+        batch = 1 + seed % 3
+        x = orc.fill(batch, seed % 100000).reshape(batch, L, n)
+        x[0, :, : n // 4] = qcol[0] - np.uint64(1)
+        X = ev.ntt_forward(to_device(x, ctx.device))
+        assert np.array_equal(to_host(X), orc.ntt_fwd(x, threads=0)), ctx.limb_classes
+        assert np.array_equal(to_host(ev.ntt_inverse(to_device(x, ctx.device))), orc.ntt_inv(x, threads=0)), ctx.limb_classes
+        a = orc.fill(batch * 2, seed % 100000 + 1).reshape(batch, 2, L, n)
+        b = orc.fill(batch * 2, seed % 100000 + 2).reshape(batch, 2, L, n)
+        a[0, :, :, -(n // 4):] = qcol - np.uint64(1)
+        b[0, :, :, -(n // 4):] = qcol - np.uint64(1)
+        want = orc.ct_mul(a, b, threads=0)
+        A, B = Ciphertext(to_device(a, ctx.device)), Ciphertext(to_device(b, ctx.device))
+        c = ev.multiply(A, B)
+        assert np.array_equal(to_host(c.data), want), ctx.limb_classes
+        assert np.array_equal(to_host(ev.ntt_inverse(ev.multiply(A, B, out_ntt=True).data)), want), ctx.limb_classes
+        evk = orc.fill(L * 2, seed % 100000 + 3).reshape(L, 2, L, n)
+        assert np.array_equal(to_host(ev.relinearize(c, to_device(evk, ctx.device)).data), orc.relinearize(want, evk, threads=0)), ctx.limb_classes
+    finally:
+        ctx.close()

@@ -10,6 +10,7 @@
 
 #include "../deeppowers_amd/csrc/ntt_core.h"
 #include "../deeppowers_amd/csrc/ntt_halves.h"
+#include "../deeppowers_amd/csrc/ntt_quarters.h"
 #include "../deeppowers_amd/csrc/ntt_top.h"
 #include "../deeppowers_amd/csrc/tables.h"
 
@@ -398,6 +399,51 @@ static int emu_halves(int inverse, u64 q, u64 psi, const u64* in, u64* out) {
     }
     return 0;
 }
+// N = 16384 as two column stages in registers + four 4096-point sub-transforms through ONE LDS buffer (ntt_quarters.h; kernels_quarters.h runs exactly these
+// steps on the device): 256 emulated threads hold q0..q3, the sub-transforms run on the sub-tree tables rooted at nodes 4..7.  FoldArith.
+extern "C" int emu_ntt_quarters(int inverse, u64 q, u64 psi, const u64* in, u64* out) {
+    typedef Quarters14 Q;
+    typedef Q::B B;
+    HostLimbTables t;
+    int rc = build_limb_tables(Q::LOGN, q, psi, t);
+    if (rc) return rc;
+    if (!fold_eligible(q)) return 2000;
+    constexpr int E = B::E, T = B::T, N2 = Q::N2;
+    std::vector<u64> r[4], lds(B::G::lds_words(), 0xDEADBEEFDEADBEEFull);
+    for (auto& v : r) v.assign((size_t)T * E, 0);
+    auto X = [&](std::vector<u64>& v, int tid) -> u64(&)[E] { return *reinterpret_cast<u64(*)[E]>(&v[(size_t)tid * E]); };
+    std::vector<TwFold> tw[4];
+    for (size_t i = 0; i < 4; ++i) {
+        const std::vector<u64> words = subtree_table(inverse ? t.irp : t.rp, Q::LOGN, 2, i);
+        tw[i].resize(words.size());
+        for (size_t j = 0; j < words.size(); ++j) tw[i][j] = h_tw_fold(words[j], q);
+        permute_window0(tw[i], Q::LOGN2, Q::LOGE, B::G::kPermStages);
+    }
+    if (!inverse) {
+        const QuartersTop top{h_tw_fold(t.rp[1], q), h_tw_fold(t.rp[2], q), h_tw_fold(t.rp[3], q)};
+        for (int tid = 0; tid < T; ++tid) {
+            for (int i = 0; i < 4; ++i) B::load_top(tid, X(r[i], tid), in + (size_t)i * N2);
+            Q::fwd_columns(X(r[0], tid), X(r[1], tid), X(r[2], tid), X(r[3], tid), top, t.lc);
+        }
+        for (int i = 0; i < 4; ++i) {
+            FwdSteps<B, 0>::run(r[i], lds, tw[i].data(), t.lc);
+            for (int tid = 0; tid < T; ++tid) { B::fwd_canon(X(r[i], tid), t.lc); B::store_bot(tid, X(r[i], tid), out + (size_t)i * N2); }
+        }
+    } else {
+        const InvLast<TwFold> last{h_tw_fold(t.w_last, q), h_tw_fold(t.lc.ninv, q)};
+        const TwFold wi2 = h_tw_fold(t.irp[2], q), wi3 = h_tw_fold(t.irp[3], q), unused = h_tw_fold(1, q);
+        for (int i = 0; i < 4; ++i) {
+            for (int tid = 0; tid < T; ++tid) B::load_bot(tid, X(r[i], tid), in + (size_t)i * N2);
+            InvSteps<B, B::NPH - 1, kUnit>::run(r[i], lds, tw[i].data(), unused, unused, t.lc);
+        }
+        for (int tid = 0; tid < T; ++tid) {
+            Q::inv_columns(X(r[0], tid), X(r[1], tid), X(r[2], tid), X(r[3], tid), wi2, wi3, last, t.lc);
+            for (int i = 0; i < 4; ++i) { B::inv_canon(X(r[i], tid), t.lc); B::store_top(tid, X(r[i], tid), out + (size_t)i * N2); }
+        }
+    }
+    return 0;
+}
+
 extern "C" int emu_ntt_halves(int arith, int inverse, u64 q, u64 psi, const u64* in, u64* out) {
     return arith ? emu_halves<FoldArith>(inverse, q, psi, in, out) : emu_halves<ShoupArith>(inverse, q, psi, in, out);
 }
