@@ -319,9 +319,10 @@ def digest_other(o):
         e = {"all_correct": pl.get("all_correct")}
         if pl.get("layers"):
             e["ms_per_token"] = {f"{l.get('layer', '?')}@{l.get('tokens_per_apply', l.get('tokens', '?'))}": r3(l.get("ms_per_token")) for l in pl["layers"]}
-        for blk in ("ffn_block", "transformer_block", "activated_ffn", "activated_block", "activated_block_n16384", "activated_stack"):
+        for blk in ("ffn_block", "transformer_block", "activated_ffn", "activated_block", "activated_block_n16384", "activated_block_two_tokens_per_ct",
+                    "activated_block_n16384_two_tokens_per_ct", "activated_stack"):
             if isinstance(pl.get(blk), dict):
-                e[blk] = {x: pl[blk].get(x) for x in ("ms_per_token", "ms_per_token_per_block", "correct", "blocks", "correct_blocks", "data_limbs", "tokens", "error", "budget_bits", "log2_n",
+                e[blk] = {x: pl[blk].get(x) for x in ("ms_per_token", "ms_per_token_per_block", "correct", "blocks", "correct_blocks", "data_limbs", "tokens", "tokens_per_ciphertext", "error", "budget_bits", "log2_n",
                                                       "modulus_bits_under_key_switching", "he_standard_128bit_budget_bits",
                                                       "levels", "limbs_per_level") if pl[blk].get(x) is not None}
         ks = pl.get("kernels") or {}
@@ -811,6 +812,15 @@ def main():
             other["packed_linear"]["activated_block"] = got[0] if got and run.returncode == 0 else {"error": (run.stdout + run.stderr)[-300:]}
             # ... and the same block on a ring with a SECURITY MARGIN (round 5): N = 16384, six primes = 1 mod 2^15 - 360 bits under key switching against the
             # 438 bits of 128-bit security there; no fused kernel above N = 8192: every key switch and the multiply composed from the batched transforms
+            # round 6: two tokens per ciphertext (the slot rows carry two tokens: PackedLinear tokens_per_ciphertext = 2), 16 tokens in 8 ciphertexts, both rings
+            for key2, ring in (("activated_block_two_tokens_per_ct", "13"), ("activated_block_n16384_two_tokens_per_ct", "14")):
+                try:
+                    run2 = subprocess.run([example("encrypted_gpt2_block_act"), "16", "2", "json", "ladder", ring, "2"], capture_output=True, text=True, timeout=600)
+                    d2 = json.loads([l for l in run2.stdout.splitlines() if l.startswith("{")][0])
+                    other["packed_linear"][key2] = {"ms_per_token": d2["ms_per_token"], "correct": d2["correct"], "tokens": d2["tokens"],
+                                                    "tokens_per_ciphertext": d2["tokens_per_ciphertext"], "log2_n": d2["log2_n"], "budget_bits": d2["budget_bits"]}
+                except Exception as e:
+                    other["packed_linear"][key2] = {"error": repr(e)[:160]}
             run = subprocess.run([example("encrypted_gpt2_block_act"), "8", "2", "json", "ladder", "14"], capture_output=True, text=True, timeout=600)
             got = [json.loads(l) for l in run.stdout.splitlines() if l.startswith("{")]
             other["packed_linear"]["activated_block_n16384"] = got[0] if got and run.returncode == 0 else {"error": (run.stdout + run.stderr)[-300:]}

@@ -1342,7 +1342,8 @@ public:
     size_t out_dim = 0, in_dim = 0;
     size_t n = 0;        // input period: the input vector repeats every n slots of a row (power of two >= in_dim)
     size_t m = 0;        // diagonals per pass = output period (n, or the padded out_dim of a wide-input layer)
-    size_t copies = 0;   // independent n-slot windows per ciphertext = N / n
+    size_t tpc = 1;      // tokens per ciphertext: 2 = the two slot rows carry two tokens (the windows of ONE row share the output blocks)
+    size_t copies = 0;   // independent n-slot windows that share the output blocks = N / n (tpc = 2: of one row, N / 2 / n)
     size_t blocks = 0;   // output row blocks of m rows
     size_t passes = 0;   // output ciphertexts
     bool replicate = false;   // one block: every window computes it (the output is again a periodic vector)
@@ -1371,7 +1372,7 @@ public:
     // which output row a slot of pass `pass` holds (or npos)
     size_t row_of_slot(size_t pass, size_t slot) const {
         const size_t row = enc->row_size(), r = slot % row, rho = slot / row;
-        const size_t c = r / n + rho * (row / n);
+        const size_t c = r / n + (tpc == 2 ? 0 : rho * (row / n));
         const size_t b = replicate || m < n ? 0 : pass * copies + c;
         const size_t R = b * m + r % m;
         return R < out_dim ? R : (size_t)-1;
@@ -1383,8 +1384,9 @@ PackedLinear::PackedLinear(const Context& ctx, const BatchEncoder& enc, HybridKe
     if (d < 2 || (d & (d - 1))) throw Exception(ErrorCode::INVALID_ARGUMENT, "PackedLinear: d must be a power of two dividing N/2");
 }
 
-PackedLinear::PackedLinear(const Context& ctx, const BatchEncoder& enc, HybridKeySwitcher& ks, const uint64_t* W, size_t out_dim, size_t in_dim)
+PackedLinear::PackedLinear(const Context& ctx, const BatchEncoder& enc, HybridKeySwitcher& ks, const uint64_t* W, size_t out_dim, size_t in_dim, size_t tokens_per_ciphertext)
     : impl_(new Impl) {
+    if (tokens_per_ciphertext != 1 && tokens_per_ciphertext != 2) throw Exception(ErrorCode::INVALID_ARGUMENT, "PackedLinear: one or two tokens per ciphertext");
     const FheParams& p = ctx.params();
     const size_t N = p.n(), L = p.n_limbs(), row = N / 2;
     if (!W || out_dim == 0 || in_dim == 0) throw Exception(ErrorCode::INVALID_ARGUMENT, "PackedLinear: empty matrix");
@@ -1394,7 +1396,8 @@ PackedLinear::PackedLinear(const Context& ctx, const BatchEncoder& enc, HybridKe
     I.ctx = &ctx; I.enc = &enc; I.ks = &ks; I.out_dim = out_dim; I.in_dim = in_dim;
     I.n = pow2(in_dim) < 2 ? 2 : pow2(in_dim);
     if (I.n > row) throw Exception(ErrorCode::INVALID_ARGUMENT, "PackedLinear: in_dim (padded to a power of two) must be <= N/2");
-    I.copies = N / I.n;
+    I.tpc = tokens_per_ciphertext;
+    I.copies = (I.tpc == 2 ? row : N) / I.n;
     const size_t mo = pow2(out_dim) < 2 ? 2 : pow2(out_dim);
     I.m = mo < I.n ? mo : I.n;                                  // wide-input layer: only m wrapped diagonals, folded afterwards
     I.blocks = (out_dim + I.m - 1) / I.m;
@@ -1476,6 +1479,26 @@ void PackedLinear::pack_input(const uint64_t* x, uint64_t* slots) const {
         slots[s] = c < impl_->in_dim ? x[c] : 0;
     }
 }
+size_t PackedLinear::tokens_per_ciphertext() const { return impl_->tpc; }
+void PackedLinear::pack_input_rows(const uint64_t* x0, const uint64_t* x1, uint64_t* slots) const {
+    const size_t N = impl_->enc->slot_count(), row = N / 2;
+    for (size_t s = 0; s < N; ++s) {
+        const size_t c = (s % row) % impl_->n;
+        slots[s] = c < impl_->in_dim ? (s < row ? x0[c] : x1[c]) : 0;
+    }
+}
+void PackedLinear::unpack_output_rows(const uint64_t* slots, uint64_t* y0, uint64_t* y1) const {
+    const size_t N = impl_->enc->slot_count(), row = N / 2;
+    for (size_t rho = 0; rho < 2; ++rho) {
+        std::vector<char> seen(impl_->out_dim, 0);
+        uint64_t* y = rho ? y1 : y0;
+        for (size_t pass = 0; pass < impl_->passes; ++pass)
+            for (size_t s = rho * row; s < (rho + 1) * row; ++s) {
+                const size_t R = impl_->row_of_slot(pass, s);
+                if (R != (size_t)-1 && !seen[R]) { y[R] = slots[pass * N + s]; seen[R] = 1; }
+            }
+    }
+}
 void PackedLinear::unpack_output(const uint64_t* slots, uint64_t* y) const {
     const size_t N = impl_->enc->slot_count();
     std::vector<char> seen(impl_->out_dim, 0);
@@ -1544,7 +1567,7 @@ class PackedSelect::Impl {
 public:
     const Context* ctx = nullptr;
     HybridKeySwitcher* ks = nullptr;
-    size_t offset = 0;
+    size_t offset = 0, tpc = 1;
     uint32_t shift_elt = 0, swap_elt = 0;
     std::vector<uint32_t> spread_elts;          // right rotations by period, 2 period, ... up to half a slot row
     std::unique_ptr<Plaintext> mask;            // NTT domain: 1 on slots [0, length) of row 0, 0 elsewhere
@@ -1558,20 +1581,21 @@ public:
     }
 };
 
-PackedSelect::PackedSelect(const Context& ctx, const BatchEncoder& enc, HybridKeySwitcher& ks, size_t offset, size_t length, size_t period) : impl_(new Impl) {
+PackedSelect::PackedSelect(const Context& ctx, const BatchEncoder& enc, HybridKeySwitcher& ks, size_t offset, size_t length, size_t period, size_t tokens_per_ciphertext) : impl_(new Impl) {
+    if (tokens_per_ciphertext != 1 && tokens_per_ciphertext != 2) throw Exception(ErrorCode::INVALID_ARGUMENT, "PackedSelect: one or two tokens per ciphertext");
     const FheParams& p = ctx.params();
     const size_t N = p.n(), row = N / 2, L = p.n_limbs();
     if (enc.slot_count() != N || length == 0 || period < length || (period & (period - 1)) || period > row || offset + length > row)
         throw Exception(ErrorCode::INVALID_ARGUMENT, "PackedSelect: slice of slot row 0, period a power of two in [length, N/2]");
     Impl& I = *impl_;
-    I.ctx = &ctx; I.ks = &ks; I.offset = offset;
+    I.ctx = &ctx; I.ks = &ks; I.offset = offset; I.tpc = tokens_per_ciphertext;
     if (offset) { I.shift_elt = enc.galois_element((int)offset); ks.add_galois_element(I.shift_elt); }
     for (size_t sft = period; sft < row; sft <<= 1) { I.spread_elts.push_back(enc.galois_element(-(int)sft)); ks.add_galois_element(I.spread_elts.back()); }
     I.swap_elt = (uint32_t)(2 * N - 1);
-    ks.add_galois_element(I.swap_elt);
+    if (I.tpc == 1) ks.add_galois_element(I.swap_elt);
     std::vector<uint64_t> slots(N, 0), host(L * N);
     std::vector<int64_t> coeffs(N);
-    for (size_t i = 0; i < length; ++i) slots[i] = 1;
+    for (size_t i = 0; i < length; ++i) { slots[i] = 1; if (I.tpc == 2) slots[row + i] = 1; }   // (two tokens: the same slice of row 1)
     enc.encode(slots.data(), coeffs.data());
     for (size_t l = 0; l < L; ++l)
         for (size_t c = 0; c < N; ++c) host[l * N + c] = lift_signed(coeffs[c], p.moduli[l]);
@@ -1583,7 +1607,7 @@ PackedSelect::PackedSelect(const Context& ctx, const BatchEncoder& enc, HybridKe
     ctx.synchronize();
 }
 PackedSelect::~PackedSelect() = default;
-size_t PackedSelect::key_switches_per_apply() const { return (impl_->offset ? 1 : 0) + impl_->spread_elts.size() + 1; }
+size_t PackedSelect::key_switches_per_apply() const { return (impl_->offset ? 1 : 0) + impl_->spread_elts.size() + (impl_->tpc == 1 ? 1 : 0); }
 
 void PackedSelect::apply(const Ciphertext& x, Ciphertext& y, Stream* s) const {
     Impl& I = *impl_;
@@ -1611,8 +1635,19 @@ void PackedSelect::apply(const Ciphertext& x, Ciphertext& y, Stream* s) const {
         check(dpfhe_add(h, out.data(), have->data(), tmp->data(), T * 2, s), "dpfhe_add");
         out.set_ntt(false);
     };
-    for (uint32_t g : I.spread_elts) rotate_add(g, *have);
-    rotate_add(I.swap_elt, y);
+    if (I.tpc == 1) {
+        for (uint32_t g : I.spread_elts) rotate_add(g, *have);
+        rotate_add(I.swap_elt, y);
+    } else {   // two tokens per ciphertext: every row keeps its own token - spread inside the rows only, the last step writes y
+        const FheParams& p = I.ctx->params();
+        if (I.spread_elts.empty()) {
+            hip_check(hipMemcpyAsync(y.data(), have->data(), T * 2 * p.n_limbs() * p.n() * sizeof(uint64_t), hipMemcpyDeviceToDevice, static_cast<hipStream_t>(s)), "hipMemcpyAsync");
+            y.set_ntt(false);
+        } else {
+            for (size_t i = 0; i + 1 < I.spread_elts.size(); ++i) rotate_add(I.spread_elts[i], *have);
+            rotate_add(I.spread_elts.back(), y);
+        }
+    }
 }
 
 class PackedTransformerBlock::Impl {

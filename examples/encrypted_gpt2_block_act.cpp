@@ -6,7 +6,9 @@
 // to two limbs, the activation is an EXACT ciphertext x ciphertext multiply (ExactMultiplier: the fused tensor-product kernel, i.e. the
 // metric op, inside the forward) + relinearisation, and W_down and the residual run on two limbs.  Every stage is decrypted and compared
 // with the plaintext computation; the noise budget is reported after every stage (six levels: qkv, the v mask, W_o, W_up, the square, W_down).
-//   usage: encrypted_gpt2_block_act [tokens = 4] [reps = 2] [json | text] [ladder | flat] [log2_n = 13 | 14]
+//   usage: encrypted_gpt2_block_act [tokens = 4] [reps = 2] [json | text] [ladder | flat] [log2_n = 13 | 14] [tokens_per_ciphertext = 1 | 2]
+// tokens_per_ciphertext = 2 (round 6): the two slot rows of a ciphertext carry two tokens (PackedLinear's two-token packing): the same kernels, half the
+// ciphertexts - every stage is still decrypted and compared for BOTH rows.
 // STAND-INS (what this is not): x^2 for GELU, no LayerNorm, attention = v (exact at one position only), ONE of the reference's 12 blocks, no LM head.
 // SECURITY: at N = 8192 the 360-bit modulus under key switching is far beyond the 218 bits the Homomorphic Encryption Standard allows at 128-bit security
 // (ternary secret, sigma = 3.2): that ring is BASELINE configs[4]'s, a performance shape, not a deployable parameter set.  log2_n = 14 runs the same block
@@ -49,6 +51,9 @@ int main(int argc, char** argv) {
     const bool ladder = argc > 4 && !std::strcmp(argv[4], "ladder");
     const int log2n = argc > 5 ? std::atoi(argv[5]) : 13;
     if (log2n != 13 && log2n != 14) { std::fprintf(stderr, "log2_n must be 13 or 14\n"); return 1; }
+    const size_t tpc = argc > 6 ? (size_t)std::atol(argv[6]) : 1;
+    if ((tpc != 1 && tpc != 2) || T % tpc) { std::fprintf(stderr, "tokens_per_ciphertext must be 1 or 2 and divide the token count\n"); return 1; }
+    const size_t C = T / tpc;   // ciphertexts per application
     const int lv_attn = ladder ? 4 : 5, lv_up = ladder ? 3 : 5;
     try {
         FheParams p5 = log2n == 14 ? FheParams::n16384(6) : FheParams::n8192_l6();
@@ -90,13 +95,13 @@ int main(int argc, char** argv) {
         }
 
         auto t0 = std::chrono::steady_clock::now();
-        PackedLinear lqkv(*ctx[5], *be[5], *hks[5], Wqkv.data(), 3 * D, D);
-        PackedLinear lo(*ctx[lv_attn], *be[lv_attn], *hks[lv_attn], Wo.data(), D, D);
-        PackedLinear lup(*ctx[lv_up], *be[lv_up], *hks[lv_up], Wu.data(), H, D);
-        PackedLinear ldown(*ctx[2], *be[2], *hks[2], Wd.data(), D, H);
-        PackedSelect take_v(*ctx[lv_attn], *be[lv_attn], *hks[lv_attn], 2 * D, D, lo.input_period());
+        PackedLinear lqkv(*ctx[5], *be[5], *hks[5], Wqkv.data(), 3 * D, D, tpc);
+        PackedLinear lo(*ctx[lv_attn], *be[lv_attn], *hks[lv_attn], Wo.data(), D, D, tpc);
+        PackedLinear lup(*ctx[lv_up], *be[lv_up], *hks[lv_up], Wu.data(), H, D, tpc);
+        PackedLinear ldown(*ctx[2], *be[2], *hks[2], Wd.data(), D, H, tpc);
+        PackedSelect take_v(*ctx[lv_attn], *be[lv_attn], *hks[lv_attn], 2 * D, D, lo.input_period(), tpc);
         const uint32_t row_swap = (uint32_t)(2 * n - 1);
-        hks[lv_up]->add_galois_element(row_swap);
+        if (tpc == 1) hks[lv_up]->add_galois_element(row_swap);
         // W_up leaves its 3072 outputs in slots 0 .. 3071 of row 0; W_down reads its input replicated with period 4096 over BOTH slot rows.  The row swap
         // fills row 1; a row longer than that period (N = 16384: 8192 slots) also needs the copies inside the row: one more rotation per doubling
         std::vector<uint32_t> spread;
@@ -104,26 +109,28 @@ int main(int argc, char** argv) {
         const double setup_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
 
         std::vector<uint64_t> slots(n);
-        std::vector<int64_t> coeffs(T * n);
-        for (size_t tk = 0; tk < T; ++tk) {
-            lqkv.pack_input(&x[tk * D], slots.data());
-            be[5]->encode(slots.data(), &coeffs[tk * n]);
+        std::vector<int64_t> coeffs(C * n);
+        for (size_t c = 0; c < C; ++c) {   // ciphertext c carries token c (one per ciphertext) or tokens 2 c | 2 c + 1 in its two slot rows
+            if (tpc == 1) lqkv.pack_input(&x[c * D], slots.data());
+            else lqkv.pack_input_rows(&x[(2 * c) * D], &x[(2 * c + 1) * D], slots.data());
+            be[5]->encode(slots.data(), &coeffs[c * n]);
         }
         // one set of buffers per level; down(from, to, in) walks `in` down the ladder through them and returns the ciphertext at level `to`
         std::unique_ptr<Ciphertext> lad_a[6], lad_b[6], lad_c[6];
-        for (int l = 2; l <= 5; ++l) { lad_a[l].reset(new Ciphertext(*ctx[l], 2, T)); lad_b[l].reset(new Ciphertext(*ctx[l], 2, T)); lad_c[l].reset(new Ciphertext(*ctx[l], 2, T)); }
+        for (int l = 2; l <= 5; ++l) { lad_a[l].reset(new Ciphertext(*ctx[l], 2, C)); lad_b[l].reset(new Ciphertext(*ctx[l], 2, C)); lad_c[l].reset(new Ciphertext(*ctx[l], 2, C)); }
         auto down = [&](const Ciphertext& in, int from, int to, std::unique_ptr<Ciphertext> (&buf)[6]) -> const Ciphertext& {
             const Ciphertext* cur = &in;
             for (int l = from; l > to; --l) { ev[l]->rescale(*cur, *buf[l - 1]); cur = buf[l - 1].get(); }
             return *cur;
         };
-        Ciphertext cx(*ctx[5], 2, T), cqkv(*ctx[5], 2, T);
-        Ciphertext ca(*ctx[lv_attn], 2, T), co(*ctx[lv_attn], 2, T), ch1(*ctx[lv_attn], 2, T);
-        Ciphertext cu(*ctx[lv_up], 2, T), cus(*ctx[lv_up], 2, T), cur(*ctx[lv_up], 2, T);
-        Ciphertext sq3(*ctx[2], 3, T), sq(*ctx[2], 2, T), cdn(*ctx[2], 2, T), ch2(*ctx[2], 2, T);
+        Ciphertext cx(*ctx[5], 2, C), cqkv(*ctx[5], 2, C);
+        Ciphertext ca(*ctx[lv_attn], 2, C), co(*ctx[lv_attn], 2, C), ch1(*ctx[lv_attn], 2, C);
+        Ciphertext cu(*ctx[lv_up], 2, C), cus(*ctx[lv_up], 2, C), cur(*ctx[lv_up], 2, C);
+        Ciphertext sq3(*ctx[2], 3, C), sq(*ctx[2], 2, C), cdn(*ctx[2], 2, C), ch2(*ctx[2], 2, C);
         enc.encrypt_exact(coeffs.data(), TM, cx);
-        const std::vector<uint32_t> swaps(T, row_swap);
+        const std::vector<uint32_t> swaps(C, row_swap);
         const Ciphertext* u2 = nullptr;
+        const Ciphertext* w_in = nullptr;   // W_up's outputs in W_down's input packing (at W_up's level)
         auto block = [&] {
             lqkv.apply(cx, cqkv);                                          // q | k | v at slots 0 .. 3d-1 of row 0, five limbs               (gpt_model.cpp:793)
             const Ciphertext& qkv_l = down(cqkv, 5, lv_attn, lad_a);       // (ladder: to four limbs)
@@ -133,14 +140,19 @@ int main(int argc, char** argv) {
             ev[lv_attn]->add(x_l, co, ch1);                                // h1 = x + W_o a
             const Ciphertext& h1_l = down(ch1, lv_attn, lv_up, lad_c);     // (ladder: to three limbs)
             lup.apply(h1_l, cu);                                           // W_up h1                                                            (gpt_model.cpp:848)
-            hks[lv_up]->apply_galois_many(cu, swaps, cus);
-            ev[lv_up]->add(cu, cus, cur);                                  // W_down's input packing
             Ciphertext *packed = &cur, *spare = &cu;
+            if (tpc == 1) {
+                hks[lv_up]->apply_galois_many(cu, swaps, cus);
+                ev[lv_up]->add(cu, cus, cur);                              // W_down's input packing: both rows
+            } else {
+                packed = &cu; spare = &cur;                                // two tokens per ciphertext: every row already holds ITS token's W_up outputs
+            }
             for (uint32_t e : spread) {                                    // (N = 16384 only: the period-4096 copies inside a slot row)
-                hks[lv_up]->apply_galois_many(*packed, std::vector<uint32_t>(T, e), cus);
+                hks[lv_up]->apply_galois_many(*packed, std::vector<uint32_t>(C, e), cus);
                 ev[lv_up]->add(*packed, cus, *spare);
                 std::swap(packed, spare);
             }
+            w_in = packed;
             u2 = &down(*packed, lv_up, 2, lad_a);                          // modulus switch to two limbs
             mul.multiply(*u2, *u2, sq3);                                   // the activation (exact multiply around the fused ct x ct kernel)
             hks[2]->relinearize(sq3, sq);
@@ -155,38 +167,45 @@ int main(int argc, char** argv) {
         ctx[5]->synchronize();
         const double ms_per_token = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() * 1e3 / reps / (double)T;
 
-        std::vector<uint64_t> dm(T * n), got(n), expect(n), yv(D);
+        std::vector<uint64_t> dm(C * n), got(n), expect(n), yv(D), yw(D);
         size_t bad_h1 = 0, bad_act = 0, bad = 0;
         dec[lv_attn]->decrypt_exact(ch1, TM, dm.data());
-        for (size_t tk = 0; tk < T; ++tk) {
-            be[lv_attn]->decode(dm.data() + tk * n, got.data());
-            lup.pack_input(&h1[tk * D], expect.data());
+        for (size_t c = 0; c < C; ++c) {
+            be[lv_attn]->decode(dm.data() + c * n, got.data());
+            if (tpc == 1) lup.pack_input(&h1[c * D], expect.data());
+            else lup.pack_input_rows(&h1[(2 * c) * D], &h1[(2 * c + 1) * D], expect.data());
             for (size_t i = 0; i < n; ++i) bad_h1 += got[i] != expect[i];
         }
         dec[2]->decrypt_exact(sq, TM, dm.data());
-        for (size_t tk = 0; tk < T; ++tk) {
-            be[2]->decode(dm.data() + tk * n, got.data());
-            ldown.pack_input(&act[tk * H], expect.data());
+        for (size_t c = 0; c < C; ++c) {
+            be[2]->decode(dm.data() + c * n, got.data());
+            if (tpc == 1) ldown.pack_input(&act[c * H], expect.data());
+            else ldown.pack_input_rows(&act[(2 * c) * H], &act[(2 * c + 1) * H], expect.data());
             for (size_t i = 0; i < n; ++i) bad_act += got[i] != expect[i];
         }
         dec[2]->decrypt_exact(ch2, TM, dm.data());
-        for (size_t tk = 0; tk < T; ++tk) {
-            be[2]->decode(dm.data() + tk * n, got.data());
-            ldown.unpack_output(got.data(), yv.data());
-            for (size_t r = 0; r < D; ++r) bad += yv[r] != h2[tk * D + r];
+        for (size_t c = 0; c < C; ++c) {
+            be[2]->decode(dm.data() + c * n, got.data());
+            if (tpc == 1) {
+                ldown.unpack_output(got.data(), yv.data());
+                for (size_t r = 0; r < D; ++r) bad += yv[r] != h2[c * D + r];
+            } else {
+                ldown.unpack_output_rows(got.data(), yv.data(), yw.data());
+                for (size_t r = 0; r < D; ++r) bad += (yv[r] != h2[(2 * c) * D + r]) + (yw[r] != h2[(2 * c + 1) * D + r]);
+            }
         }
         const double b[8] = {dec[5]->noise_budget_bits(cx, TM), dec[5]->noise_budget_bits(cqkv, TM), dec[lv_attn]->noise_budget_bits(ca, TM), dec[lv_attn]->noise_budget_bits(ch1, TM),
-                             dec[lv_up]->noise_budget_bits(cur, TM), dec[2]->noise_budget_bits(*u2, TM), dec[2]->noise_budget_bits(sq, TM), dec[2]->noise_budget_bits(ch2, TM)};
+                             dec[lv_up]->noise_budget_bits(*w_in, TM), dec[2]->noise_budget_bits(*u2, TM), dec[2]->noise_budget_bits(sq, TM), dec[2]->noise_budget_bits(ch2, TM)};
         const size_t ks = lqkv.key_switches_per_apply() + take_v.key_switches_per_apply() + lo.key_switches_per_apply() + lup.key_switches_per_apply() + 1 +
-                          ldown.key_switches_per_apply() + 1;
+                          ldown.key_switches_per_apply() + (tpc == 1 ? 1 : 0);
         const bool ok = !(bad || bad_act || bad_h1);
         char levels[96];
         std::snprintf(levels, sizeof levels, "qkv 5, v + W_o %d, W_up %d, square + W_down 2 limbs", lv_attn, lv_up);
         if (json)
             std::printf("{\"block\": \"transformer_block_square_activation\", \"hidden\": %zu, \"inner\": %zu, \"log2_n\": %d, \"modulus_bits_under_key_switching\": 360, \"he_standard_128bit_budget_bits\": %d, \"levels\": \"%s\", "
-                        "\"plain_modulus\": %llu, \"tokens\": %zu, \"key_switches_per_token\": %zu, \"ct_ct_multiplies_per_token\": 1, \"setup_s\": %.2f, \"ms_per_token\": %.3f, "
+                        "\"plain_modulus\": %llu, \"tokens\": %zu, \"tokens_per_ciphertext\": %zu, \"key_switches_per_token\": %zu, \"ct_ct_multiplies_per_token\": 1, \"setup_s\": %.2f, \"ms_per_token\": %.3f, "
                         "\"budget_bits\": [%.0f, %.0f, %.0f, %.0f, %.0f, %.0f, %.0f, %.0f], \"correct\": %s}\n",
-                        D, H, log2n, log2n == 14 ? 438 : 218, levels, (unsigned long long)TM, T, ks, setup_s, ms_per_token, b[0], b[1], b[2], b[3], b[4], b[5], b[6], b[7], ok ? "true" : "false");
+                        D, H, log2n, log2n == 14 ? 438 : 218, levels, (unsigned long long)TM, T, tpc, ks, setup_s, ms_per_token, b[0], b[1], b[2], b[3], b[4], b[5], b[6], b[7], ok ? "true" : "false");
         else
             std::printf("transformer block with a square activation (%s), %zu token(s) per application, %zu key switches + one ct x ct multiply per token; setup %.2f s, %.3f ms per token\n"
                         "  noise budget (bits): fresh %.0f -> qkv %.0f -> v hand-over %.0f -> h1 %.0f -> W_up hand-over %.0f -> 2 limbs %.0f -> squared %.0f -> h2 %.0f\n"

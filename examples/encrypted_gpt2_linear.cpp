@@ -3,7 +3,8 @@
 // Z_65537 by the diagonal method with baby-step / giant-step rotations (deeppowers::fhe::PackedLinear).
 // The layer shapes are the reference's matmul sites (/root/reference/src/core/execution/models/gpt_model.cpp:793 QKV 768 -> 2304,
 // :848 FFN 768 -> 3072 -> 768, :883 logits 768 -> 50257; hidden_size 768, vocab 50257 at execution/model.hpp:47-50).
-//   usage: encrypted_gpt2_linear [layer = all | square | qkv | ffn_up | ffn_down | lm_head | <out>x<in>] [reps = 2] [json | text] [tokens = 1] [log2_n = 13 | 14]
+//   usage: encrypted_gpt2_linear [layer = all | square | qkv | ffn_up | ffn_down | lm_head | <out>x<in>] [reps = 2] [json | text] [tokens = 1] [log2_n = 13 | 14] [tokens_per_ciphertext = 1 | 2]
+// tokens_per_ciphertext = 2 (round 6): the two slot rows of a ciphertext carry two tokens (PackedLinear's two-token packing) - the same kernels on half the ciphertexts.
 // WHAT THIS IS: single dense layers (matrix x encrypted vector over Z_65537), nothing else of the model.  SECURITY: at the default N = 8192 the 360-bit modulus
 // under key switching is beyond the 218 bits of 128-bit security at that ring (Homomorphic Encryption Standard): a performance shape (BASELINE configs[4]).
 // log2_n = 14: the same layer at N = 16384 on six primes that are 1 mod 2^15 (round 5: the packed pipeline's rotations above N = 8192 are composed
@@ -30,6 +31,9 @@ int main(int argc, char** argv) {
     const size_t T = argc > 4 ? (size_t)std::atol(argv[4]) : 1;
     const int log2n = argc > 5 ? std::atoi(argv[5]) : 13;
     if (log2n != 13 && log2n != 14) { std::fprintf(stderr, "log2_n must be 13 or 14\n"); return 1; }
+    const size_t tpc = argc > 6 ? (size_t)std::atol(argv[6]) : 1;
+    if ((tpc != 1 && tpc != 2) || T % tpc) { std::fprintf(stderr, "tokens_per_ciphertext must be 1 or 2 and divide the token count\n"); return 1; }
+    const size_t C = T / tpc;   // ciphertexts per application
     std::vector<Shape> shapes;
     const Shape known[] = {{"square", 768, 768}, {"qkv", 2304, 768}, {"ffn_up", 3072, 768}, {"ffn_down", 768, 3072}, {"lm_head", 50257, 768}};
     for (const Shape& k : known)
@@ -66,16 +70,17 @@ int main(int argc, char** argv) {
                     want[tk * sh.out + r] = (uint64_t)(acc % t);
                 }
             auto t0 = std::chrono::steady_clock::now();
-            PackedLinear layer(ctx, be, hks, W.data(), sh.out, sh.in);     // encodes + transforms the diagonals, generates the rotation keys
+            PackedLinear layer(ctx, be, hks, W.data(), sh.out, sh.in, tpc);     // encodes + transforms the diagonals, generates the rotation keys
             const double setup_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
             const size_t outs = layer.output_ciphertexts();
-            std::vector<uint64_t> slots(n), dm(outs * T * n), got(outs * n), y(sh.out);
-            std::vector<int64_t> coeffs(T * n);
-            for (size_t tk = 0; tk < T; ++tk) {
-                layer.pack_input(&x[tk * sh.in], slots.data());
-                be.encode(slots.data(), &coeffs[tk * n]);
+            std::vector<uint64_t> slots(n), dm(outs * C * n), got(outs * n), y(sh.out), y1(sh.out);
+            std::vector<int64_t> coeffs(C * n);
+            for (size_t c = 0; c < C; ++c) {   // ciphertext c: token c, or tokens 2 c | 2 c + 1 in its two slot rows
+                if (tpc == 1) layer.pack_input(&x[c * sh.in], slots.data());
+                else layer.pack_input_rows(&x[(2 * c) * sh.in], &x[(2 * c + 1) * sh.in], slots.data());
+                be.encode(slots.data(), &coeffs[c * n]);
             }
-            Ciphertext cx(ctx, 2, T), cy(ctx, 2, outs * T);
+            Ciphertext cx(ctx, 2, C), cy(ctx, 2, outs * C);
             enc.encrypt_exact(coeffs.data(), t, cx);
             layer.apply(cx, cy);                                // warm-up (code objects, allocator)
             ctx.synchronize();
@@ -85,15 +90,20 @@ int main(int argc, char** argv) {
             const double apply_ms = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() * 1e3 / reps / (double)T;
             dec.decrypt_exact(cy, t, dm.data());
             size_t bad = 0;
-            for (size_t tk = 0; tk < T; ++tk) {
-                for (size_t o = 0; o < outs; ++o) be.decode(dm.data() + (o * T + tk) * n, got.data() + o * n);
-                layer.unpack_output(got.data(), y.data());
-                for (size_t r = 0; r < sh.out; ++r) bad += y[r] != want[tk * sh.out + r];
+            for (size_t c = 0; c < C; ++c) {
+                for (size_t o = 0; o < outs; ++o) be.decode(dm.data() + (o * C + c) * n, got.data() + o * n);
+                if (tpc == 1) {
+                    layer.unpack_output(got.data(), y.data());
+                    for (size_t r = 0; r < sh.out; ++r) bad += y[r] != want[c * sh.out + r];
+                } else {
+                    layer.unpack_output_rows(got.data(), y.data(), y1.data());
+                    for (size_t r = 0; r < sh.out; ++r) bad += (y[r] != want[(2 * c) * sh.out + r]) + (y1[r] != want[(2 * c + 1) * sh.out + r]);
+                }
             }
             if (json)
                 std::printf("{\"layer\": \"%s\", \"out_dim\": %zu, \"in_dim\": %zu, \"log2_n\": %d, \"data_limbs\": %zu, \"plain_modulus\": %llu, \"baby_steps\": %zu, "
-                            "\"giant_steps\": %zu, \"output_ciphertexts\": %zu, \"key_switches\": %zu, \"tokens_per_apply\": %zu, \"setup_s\": %.2f, \"ms_per_token\": %.3f, \"correct\": %s}\n",
-                            sh.name, sh.out, sh.in, log2n, p.n_limbs(), (unsigned long long)t, layer.baby_steps(), layer.giant_steps(), outs, layer.key_switches_per_apply(), T,
+                            "\"giant_steps\": %zu, \"output_ciphertexts\": %zu, \"key_switches\": %zu, \"tokens_per_apply\": %zu, \"tokens_per_ciphertext\": %zu, \"setup_s\": %.2f, \"ms_per_token\": %.3f, \"correct\": %s}\n",
+                            sh.name, sh.out, sh.in, log2n, p.n_limbs(), (unsigned long long)t, layer.baby_steps(), layer.giant_steps(), outs, layer.key_switches_per_apply(), T, tpc,
                             setup_s, apply_ms, bad ? "false" : "true");
             else
                 std::printf("%-8s %5zu <- %4zu: period %zu, %zu baby x %zu giant steps, %zu output ciphertext(s), %zu key switches, %zu token(s) per apply; setup %.2f s, apply %.3f ms per token: %s\n",

@@ -449,7 +449,11 @@ private:
 class PackedLinear {
 public:
     // W: out_dim * in_dim values < t, row-major.  The needed Galois keys are added to `ks`.
-    PackedLinear(const Context& data_ctx, const BatchEncoder& enc, HybridKeySwitcher& ks, const uint64_t* W, size_t out_dim, size_t in_dim);
+    // tokens_per_ciphertext = 2 (round 6): the two slot ROWS of a ciphertext carry two different tokens - row 0 repeats token A's vector with period n, row 1
+    // token B's.  Every rotation of the diagonal method is a row rotation and the diagonals are the same for both rows, so the layer computes W x_A in row 0 and
+    // W x_B in row 1 with the very same kernels: half the cost per token.  It needs the layer's output blocks to fit the windows of ONE row
+    // (ceil(out_dim / n) <= N / (2 n) for one output ciphertext: GPT-2 small's layers do at N = 8192 and N = 16384); pack_input_rows / unpack_output_rows.
+    PackedLinear(const Context& data_ctx, const BatchEncoder& enc, HybridKeySwitcher& ks, const uint64_t* W, size_t out_dim, size_t in_dim, size_t tokens_per_ciphertext = 1);
     // square d x d (d a power of two dividing N/2)
     PackedLinear(const Context& data_ctx, const BatchEncoder& enc, HybridKeySwitcher& ks, const uint64_t* W, size_t d);
     ~PackedLinear();
@@ -467,6 +471,10 @@ public:
     // output_ciphertexts() * N decoded slots -> y (out_dim values)
     void pack_input(const uint64_t* x, uint64_t* slots) const;
     void unpack_output(const uint64_t* slots, uint64_t* y) const;
+    size_t tokens_per_ciphertext() const;
+    // two tokens per ciphertext: x0 -> slot row 0, x1 -> slot row 1 (each repeated with the input period); and back from output_ciphertexts() * N slots
+    void pack_input_rows(const uint64_t* x0, const uint64_t* x1, uint64_t* slots) const;
+    void unpack_output_rows(const uint64_t* slots, uint64_t* y0, uint64_t* y1) const;
     // x: T items (T tokens, each packed with pack_input), y: output_ciphertexts() * T items, output ciphertext o of token t at item
     // o * T + t; 2 components, coefficient domain.  All tokens share ONE pass over the rotation keys and the diagonals (hoisted
     // baby steps per token, one multi-right-hand-side matvec, the giant steps' key inner products summed before ONE division by P).
@@ -487,7 +495,8 @@ private:
 // everything else; costs one multiplicative level of noise, like a layer), log2(N/2 / period) rotate-and-add steps, one row swap.
 class PackedSelect {
 public:
-    PackedSelect(const Context& data_ctx, const BatchEncoder& enc, HybridKeySwitcher& ks, size_t offset, size_t length, size_t period);
+    // tokens_per_ciphertext = 2: the slice is taken in BOTH slot rows (each row carries its own token) and re-packed inside its row - no row swap at the end
+    PackedSelect(const Context& data_ctx, const BatchEncoder& enc, HybridKeySwitcher& ks, size_t offset, size_t length, size_t period, size_t tokens_per_ciphertext = 1);
     ~PackedSelect();
     PackedSelect(const PackedSelect&) = delete;
     PackedSelect& operator=(const PackedSelect&) = delete;

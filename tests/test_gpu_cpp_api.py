@@ -177,6 +177,27 @@ def test_example_whole_block_with_activation_on_a_128_bit_secure_ring():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("log2n", [13, 14])
+def test_example_whole_block_two_tokens_per_ciphertext(log2n):
+    """Round 6: the two slot ROWS of a ciphertext carry two different tokens (PackedLinear / PackedSelect tokens_per_ciphertext = 2: every rotation of the
+    diagonal method is a row rotation and the diagonals are the same for both rows, so the same kernels compute W x_A in row 0 and W x_B in row 1): the
+    whole activated block on 4 tokens in 2 ciphertexts - h1, the activation and h2 of BOTH rows of every ciphertext decrypt to the plaintext forward, at
+    N = 8192 and on the 128-bit-secure ring N = 16384; and a single packed layer (QKV: three output blocks in the windows of one row) the same way."""
+    import json
+    out = subprocess.run([build_example("encrypted_gpt2_block_act"), "4", "1", "json", "ladder", str(log2n), "2"], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0 and out.stdout.strip().endswith("OK"), out.stdout[-1500:] + out.stderr[-500:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
+    b = d["budget_bits"]
+    assert d["correct"] is True and d["log2_n"] == log2n and d["tokens"] == 4 and d["tokens_per_ciphertext"] == 2
+    assert len(b) == 8 and b[0] > b[1] > b[2] > b[3] > b[4] > 0 and b[5] > b[6] > b[7] > 20, b
+    for layer in ("qkv", "ffn_down"):
+        out = subprocess.run([build_example("encrypted_gpt2_linear"), layer, "1", "json", "4", str(log2n), "2"], capture_output=True, text=True, timeout=900)
+        assert out.returncode == 0 and out.stdout.strip().endswith("OK"), out.stdout[-1500:] + out.stderr[-500:]
+        d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
+        assert d["correct"] is True and d["tokens_per_ciphertext"] == 2 and d["tokens_per_apply"] == 4 and d["output_ciphertexts"] == 1
+
+
+@pytest.mark.gpu
 def test_example_two_blocks_on_a_modulus_chain():
     """configs[4] as a forward pass, DEEPER than one block: two blocks with the square activation chained on seven data limbs (420 bits); the limb
     count of every level is planned from a budget model (no secret key involved) and falls 7 -> 2 over the twelve levels; the first block's
