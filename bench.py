@@ -320,7 +320,7 @@ def digest_other(o):
         if pl.get("layers"):
             e["ms_per_token"] = {f"{l.get('layer', '?')}@{l.get('tokens_per_apply', l.get('tokens', '?'))}": r3(l.get("ms_per_token")) for l in pl["layers"]}
         for blk in ("ffn_block", "transformer_block", "activated_ffn", "activated_block", "activated_block_n16384", "activated_block_two_tokens_per_ct",
-                    "activated_block_n16384_two_tokens_per_ct", "activated_stack"):
+                    "activated_block_n16384_two_tokens_per_ct", "activated_stack", "activated_stack_two_tokens_per_ct"):
             if isinstance(pl.get(blk), dict):
                 e[blk] = {x: pl[blk].get(x) for x in ("ms_per_token", "ms_per_token_per_block", "correct", "blocks", "correct_blocks", "data_limbs", "tokens", "tokens_per_ciphertext", "error", "budget_bits", "log2_n",
                                                       "modulus_bits_under_key_switching", "he_standard_128bit_budget_bits",
@@ -827,6 +827,13 @@ def main():
             # ... and THREE such blocks in a row on ten data limbs (600 bits), the limb count of every level planned from a budget model and falling
             # 10 -> 2 over the 18 levels, the activations as exact multiplies at eight-, five- and two-limb levels; every block's output decrypted
             # and compared (examples/encrypted_gpt2_stack.cpp; gpt_model.cpp:626-672, the layer loop)
+            try:   # round 6: the same three blocks with two tokens per ciphertext (16 tokens in 8 ciphertexts)
+                run2 = subprocess.run([example("encrypted_gpt2_stack"), "16", "1", "json", "10", "0", "2"], capture_output=True, text=True, timeout=600)
+                d2 = json.loads([l for l in run2.stdout.splitlines() if l.startswith("{")][0])
+                other["packed_linear"]["activated_stack_two_tokens_per_ct"] = {k_: d2.get(k_) for k_ in ("ms_per_token", "ms_per_token_per_block", "correct", "blocks", "correct_blocks", "data_limbs",
+                                                                                                           "tokens", "tokens_per_ciphertext", "log2_n")}
+            except Exception as e:
+                other["packed_linear"]["activated_stack_two_tokens_per_ct"] = {"error": repr(e)[:160]}
             run = subprocess.run([example("encrypted_gpt2_stack"), "8", "1", "json", "10"], capture_output=True, text=True, timeout=600)
             got = [json.loads(l) for l in run.stdout.splitlines() if l.startswith("{")]
             other["packed_linear"]["activated_stack"] = got[0] if got and run.returncode == 0 else {"error": (run.stdout + run.stderr)[-300:]}

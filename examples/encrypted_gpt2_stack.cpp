@@ -56,6 +56,10 @@ int main(int argc, char** argv) {
     const int LD = argc > 4 ? std::atoi(argv[4]) : 7;
     int want_blocks = argc > 5 ? std::atoi(argv[5]) : 0;
     if (LD < 3 || LD > 10 || T == 0) { std::printf("data_limbs must be in [3, 10], tokens > 0\n"); return 2; }
+    // round 6: two tokens per ciphertext (argv[6] = 2): the two slot rows of a ciphertext carry two tokens (PackedLinear's two-token packing)
+    const size_t tpc = argc > 6 ? (size_t)std::atol(argv[6]) : 1;
+    if ((tpc != 1 && tpc != 2) || T % tpc) { std::printf("tokens_per_ciphertext must be 1 or 2 and divide the token count\n"); return 2; }
+    const size_t C = T / tpc;   // ciphertexts per application
     try {
         const FheParams chain = FheParams::n8192(20);
         // the special prime of the hybrid key switches: the first prime of the chain that is not a data limb
@@ -99,7 +103,7 @@ int main(int argc, char** argv) {
         auto layer = [&](int kind, int l) -> PackedLinear& {
             if (!lv[l].lin[kind]) {
                 const auto t0 = std::chrono::steady_clock::now();
-                lv[l].lin[kind].reset(new PackedLinear(*lv[l].ctx, *lv[l].be, hks(l), Wm[kind].data(), dims[kind][0], dims[kind][1]));
+                lv[l].lin[kind].reset(new PackedLinear(*lv[l].ctx, *lv[l].be, hks(l), Wm[kind].data(), dims[kind][0], dims[kind][1], tpc));
                 setup_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
             }
             return *lv[l].lin[kind];
@@ -110,7 +114,7 @@ int main(int argc, char** argv) {
         std::map<std::string, std::unique_ptr<Ciphertext>> pool;
         auto buf = [&](const std::string& tag, int l, size_t comps = 2) -> Ciphertext& {
             auto& p = pool[tag + "@" + std::to_string(l) + "x" + std::to_string(comps)];
-            if (!p) p.reset(new Ciphertext(*lv[l].ctx, comps, T));
+            if (!p) p.reset(new Ciphertext(*lv[l].ctx, comps, C));
             return *p;
         };
         // walks `in` (level `from`) down to level `to` through this tag's buffers
@@ -132,10 +136,10 @@ int main(int argc, char** argv) {
         std::vector<const Ciphertext*> h2_ct;              // per block: its output ciphertext and level
         std::vector<int> h2_level;
         int blocks_done = 0;
-        const std::vector<uint32_t> swaps(T, row_swap);
+        const std::vector<uint32_t> swaps(C, row_swap);
 
         // ---- one pass over the stack: `measure` (first pass only) reads the budgets and records the schedule --------------------------------
-        Ciphertext cx(*lv[LD].ctx, 2, T);
+        Ciphertext cx(*lv[LD].ctx, 2, C);
         double fresh_bits = 0;
         auto forward = [&](bool measure) {
             const Ciphertext* cur = &cx;
@@ -159,7 +163,7 @@ int main(int argc, char** argv) {
                 int l2 = choose(est, l1);
                 const Ciphertext& qkv_l = down(cqkv, l1, l2, B + "qkvd");
                 // (every 768-wide layer input shares one packing, so the qkv layer's period is W_o's)
-                if (!lv[l2].take_v) lv[l2].take_v.reset(new PackedSelect(*lv[l2].ctx, *lv[l2].be, hks(l2), 2 * D, D, layer(QKV, l1).input_period()));
+                if (!lv[l2].take_v) lv[l2].take_v.reset(new PackedSelect(*lv[l2].ctx, *lv[l2].be, hks(l2), 2 * D, D, layer(QKV, l1).input_period(), tpc));
                 Ciphertext& ca = buf(B + "a", l2);
                 lv[l2].take_v->apply(qkv_l, ca);                                              // attention over one position: its output is v
                 est = std::min(est, cap_bits(l2)) - kCost[MASK];
@@ -178,14 +182,19 @@ int main(int argc, char** argv) {
                 const Ciphertext& h1_l4 = down(ch1, l3, l4, B + "h1d");
                 Ciphertext &cu = buf(B + "u", l4), &cus = buf(B + "us", l4), &cur2 = buf(B + "ur", l4);
                 layer(WUP, l4).apply(h1_l4, cu);                                              // gpt_model.cpp:848
-                hks(l4).add_galois_element(row_swap);
-                hks(l4).apply_galois_many(cu, swaps, cus);
-                lv[l4].ev->add(cu, cus, cur2);
+                const Ciphertext* w_in = &cur2;
+                if (tpc == 1) {
+                    hks(l4).add_galois_element(row_swap);
+                    hks(l4).apply_galois_many(cu, swaps, cus);
+                    lv[l4].ev->add(cu, cus, cur2);
+                } else {
+                    w_in = &cu;   // two tokens per ciphertext: every row already holds ITS token's W_up outputs (a row of 4096 slots is W_down's whole input window)
+                }
                 est = std::min(est, cap_bits(l4)) - kCost[WUP];
-                note("W_up", cur2, l4);
+                note("W_up", *w_in, l4);
                 // the activation: exact multiply at the level the chain is on + relinearisation
                 int l5 = std::min(choose(est, l4), 9);                                        // (a multiply's workspace is 2 l + 1 <= 19 limbs)
-                const Ciphertext& u_l5 = down(cur2, l4, l5, B + "urd");
+                const Ciphertext& u_l5 = down(*w_in, l4, l5, B + "urd");
                 if (!lv[l5].mul) {
                     lv[l5].work.reset(new Context(FheParams::n8192((size_t)(2 * l5 + 1)), 0));
                     lv[l5].mul.reset(new ExactMultiplier(*lv[l5].work, *lv[l5].ctx, TM));
@@ -215,10 +224,14 @@ int main(int argc, char** argv) {
 
         // encrypt
         std::vector<uint64_t> slots(n);
-        std::vector<int64_t> coeffs(T * n);
+        std::vector<int64_t> coeffs(C * n);
         {
             PackedLinear& lq = layer(QKV, LD);
-            for (size_t tk = 0; tk < T; ++tk) { lq.pack_input(&x[tk * D], slots.data()); lv[LD].be->encode(slots.data(), &coeffs[tk * n]); }
+            for (size_t c = 0; c < C; ++c) {
+                if (tpc == 1) lq.pack_input(&x[c * D], slots.data());
+                else lq.pack_input_rows(&x[(2 * c) * D], &x[(2 * c + 1) * D], slots.data());
+                lv[LD].be->encode(slots.data(), &coeffs[c * n]);
+            }
         }
         enc.encrypt_exact(coeffs.data(), TM, cx);
         fresh_bits = lv[LD].dec->noise_budget_bits(cx, TM);
@@ -249,17 +262,22 @@ int main(int argc, char** argv) {
             h2_plain.push_back(out);
             xp = out;
         }
-        std::vector<uint64_t> dm(T * n), got(n), yv(D);
+        std::vector<uint64_t> dm(C * n), got(n), yv(D), yw(D);
         std::vector<size_t> bad(blocks_done, 0);
         int correct_blocks = 0;
         for (int b = 0; b < blocks_done; ++b) {
             const int l = h2_level[b];
             lv[l].dec->decrypt_exact(*h2_ct[b], TM, dm.data());
             PackedLinear& ld = layer(WDOWN, l);
-            for (size_t tk = 0; tk < T; ++tk) {
-                lv[l].be->decode(dm.data() + tk * n, got.data());
-                ld.unpack_output(got.data(), yv.data());
-                for (size_t r = 0; r < D; ++r) bad[b] += yv[r] != h2_plain[b][tk * D + r];
+            for (size_t c = 0; c < C; ++c) {
+                lv[l].be->decode(dm.data() + c * n, got.data());
+                if (tpc == 1) {
+                    ld.unpack_output(got.data(), yv.data());
+                    for (size_t r = 0; r < D; ++r) bad[b] += yv[r] != h2_plain[b][c * D + r];
+                } else {
+                    ld.unpack_output_rows(got.data(), yv.data(), yw.data());
+                    for (size_t r = 0; r < D; ++r) bad[b] += (yv[r] != h2_plain[b][(2 * c) * D + r]) + (yw[r] != h2_plain[b][(2 * c + 1) * D + r]);
+                }
             }
             if (!bad[b] && correct_blocks == b) ++correct_blocks;
         }
@@ -279,10 +297,10 @@ int main(int argc, char** argv) {
         }
         if (json)
             std::printf("{\"stack\": \"transformer_blocks_square_activation\", \"hidden\": %zu, \"inner\": %zu, \"log2_n\": 13, \"data_limbs\": %d, \"blocks\": %d, "
-                        "\"correct_blocks\": %d, \"limbs_per_level\": \"%s\", \"plain_modulus\": %llu, \"tokens\": %zu, \"key_switches_per_token\": %zu, "
+                        "\"correct_blocks\": %d, \"limbs_per_level\": \"%s\", \"plain_modulus\": %llu, \"tokens\": %zu, \"tokens_per_ciphertext\": %zu, \"key_switches_per_token\": %zu, "
                         "\"ct_ct_multiplies_per_token\": %d, \"setup_s\": %.2f, \"first_pass_s\": %.2f, \"ms_per_token\": %.3f, \"ms_per_token_per_block\": %.3f, "
                         "\"fresh_budget_bits\": %.0f, \"budget_bits\": [%s], \"planned_bits\": [%s], \"correct\": %s}\n",
-                        D, H, LD, blocks_done, correct_blocks, lev.c_str(), (unsigned long long)TM, T, ks, blocks_done, setup_s, first_pass_s, ms_per_token,
+                        D, H, LD, blocks_done, correct_blocks, lev.c_str(), (unsigned long long)TM, T, tpc, ks, blocks_done, setup_s, first_pass_s, ms_per_token,
                         blocks_done ? ms_per_token / blocks_done : 0.0, fresh_bits, bits.c_str(), ests.c_str(), ok ? "true" : "false");
         else {
             std::printf("%d transformer block(s) with a square activation on %d data limbs, %zu token(s) per application: %zu key switches + %d ct x ct multiplies per token; "

@@ -195,6 +195,11 @@ def test_example_whole_block_two_tokens_per_ciphertext(log2n):
         assert out.returncode == 0 and out.stdout.strip().endswith("OK"), out.stdout[-1500:] + out.stderr[-500:]
         d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
         assert d["correct"] is True and d["tokens_per_ciphertext"] == 2 and d["tokens_per_apply"] == 4 and d["output_ciphertexts"] == 1
+    if log2n == 13:   # ... and two blocks in a row on the modulus chain (the deeper demonstration), both rows of both blocks' outputs
+        out = subprocess.run([build_example("encrypted_gpt2_stack"), "4", "1", "json", "7", "0", "2"], capture_output=True, text=True, timeout=1500)
+        assert out.returncode == 0 and out.stdout.strip().endswith("OK"), out.stdout[-1500:] + out.stderr[-500:]
+        d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
+        assert d["correct"] is True and d["tokens_per_ciphertext"] == 2 and d["blocks"] >= 2 and d["correct_blocks"] == d["blocks"]
 
 
 @pytest.mark.gpu
