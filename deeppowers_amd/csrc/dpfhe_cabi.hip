@@ -1109,6 +1109,9 @@ extern "C" int dpfhe_rotate_hybrid_grouped(dpfhe_ctx* c, uint64_t* d_out2, const
     return rotate_batch_impl(c, "dpfhe_rotate_hybrid_grouped", d_out2, d_in2, n_elts * group, galois_elts, n_elts, group, d_keys, d_work, d_rotated, n_elts * group, stream);
 }
 
+static int rotate_hoisted_qp_impl(dpfhe_ctx* c, uint64_t* d_out_qp, const uint64_t* d_in2, size_t n_items, const uint32_t* galois_elts, const uint64_t* d_keys,
+                                  uint64_t* d_in_ntt, uint64_t* d_digits, size_t batch, void* stream, bool prepared);
+
 // N3, hoisted: `batch` rotations of ONE ciphertext; the digit decomposition of c1 and its Ld*L forward transforms are done once
 // (d_digits), every rotation is a permutation of those words in the NTT domain + its key inner product + two inverse transforms
 extern "C" int dpfhe_rotate_hybrid_hoisted(dpfhe_ctx* c, uint64_t* d_out2, const uint64_t* d_in2, size_t n_items, const uint32_t* galois_elts, const uint64_t* d_keys,
@@ -1143,14 +1146,14 @@ extern "C" int dpfhe_rotate_hybrid_hoisted(dpfhe_ctx* c, uint64_t* d_out2, const
         // d_work / d_rotated0 are not used on this path.
         const size_t item_qp = T * 2 * L * (size_t)n, fit = c->scratch_limit_words.load(std::memory_order_relaxed) / item_qp;
         const size_t per = fit > 2 ? (fit - 2 < batch ? fit - 2 : batch) : 1;     // (+ block 0 and the transformed inputs)
+        if (per * T * 2 * Ld * (size_t)chunks > kMaxGrid || !ntt_grid_fits(c, per * T * 2 * L)) return fail(DPFHE_INVALID_ARGUMENT, what, "batch too large for one launch (lower the scratch limit)");
+        StreamScratch ws(c, static_cast<hipStream_t>(stream));       // one arena for every slice: the transformed inputs and digits are prepared by the first slice only
+        if (int rc = ws.alloc((per + 1) * item_qp + in_words, what)) return rc;
+        u64* qp = ws.p;
+        u64* in_ntt = qp + (per + 1) * item_qp;
         for (size_t r0 = 0; r0 < batch; r0 += per) {
             const size_t m = batch - r0 < per ? batch - r0 : per;
-            if (m * T * 2 * Ld * (size_t)chunks > kMaxGrid || !ntt_grid_fits(c, m * T * 2 * L)) return fail(DPFHE_INVALID_ARGUMENT, what, "batch too large for one launch (lower the scratch limit)");
-            StreamScratch ws(c, static_cast<hipStream_t>(stream));
-            if (int rc = ws.alloc((m + 1) * item_qp + in_words, what)) return rc;
-            u64* qp = ws.p;
-            u64* in_ntt = qp + (m + 1) * item_qp;
-            if (int rc = dpfhe_rotate_hoisted_qp(c, qp, d_in2, T, galois_elts + r0, d_keys + r0 * key_words, in_ntt, d_digits, m, stream)) return rc;
+            if (int rc = rotate_hoisted_qp_impl(c, qp, d_in2, T, galois_elts + r0, d_keys + r0 * key_words, in_ntt, d_digits, m, stream, r0 != 0)) return rc;
             hipStream_t s = static_cast<hipStream_t>(stream);
             if (int rc = ntt_launch(c, true, qp + item_qp, qp + item_qp, m * T * 2 * L, s)) return rc;
             const size_t rblocks = m * T * 2 * Ld * (size_t)chunks;
@@ -1200,8 +1203,9 @@ extern "C" int dpfhe_rotate_hybrid_hoisted(dpfhe_ctx* c, uint64_t* d_out2, const
 // ------------------------------------------------------------------------------------------------
 // N3, round 3: baby-step / giant-step sums with the division by P DEFERRED (the rotated terms stay in the NTT domain over Q P)
 // ------------------------------------------------------------------------------------------------
-extern "C" int dpfhe_rotate_hoisted_qp(dpfhe_ctx* c, uint64_t* d_out_qp, const uint64_t* d_in2, size_t n_items, const uint32_t* galois_elts, const uint64_t* d_keys,
-                                       uint64_t* d_in_ntt, uint64_t* d_digits, size_t batch, void* stream) {
+// (prepared = true: d_in_ntt, d_digits and item block 0 already hold what steps 1-3 write - a later slice of dpfhe_rotate_hybrid_hoisted at N = 16384)
+static int rotate_hoisted_qp_impl(dpfhe_ctx* c, uint64_t* d_out_qp, const uint64_t* d_in2, size_t n_items, const uint32_t* galois_elts, const uint64_t* d_keys,
+                                  uint64_t* d_in_ntt, uint64_t* d_digits, size_t batch, void* stream, bool prepared) {
     const char* what = "dpfhe_rotate_hoisted_qp";
     if (!c) return fail(DPFHE_INVALID_ARGUMENT, what, "null context");
     if (c->n_limbs < 2) return fail(DPFHE_INVALID_STATE, what, "the extended context needs at least one data limb and the special prime");
@@ -1227,19 +1231,21 @@ extern "C" int dpfhe_rotate_hoisted_qp(dpfhe_ctx* c, uint64_t* d_out_qp, const u
     const u64 p_special = c->p_special;
     hipStream_t s = static_cast<hipStream_t>(stream);
     DPFHE_ON_DEVICE(c, what);
-    // 1. NTT of the inputs on the data limbs (the same tables, seen as an Ld-limb context)
-    if (int e = ntt_launch_items(c, false, d_in_ntt, d_in2, T * 2, Ld, s)) return e;
-    // 2. digits of every item's c1, lifted to every limb and transformed
-    const unsigned lift_grid = (unsigned)(T * Ld * L * (size_t)chunks);
-    if (c->fold) hipLaunchKernelGGL((lift_digits_kernel<FoldArith>), dim3(lift_grid), dim3(256), 0, s, d_digits, d_in2 + Ld * (size_t)n, 2 * Ld * (size_t)n, lc, (int)L, n, chunks);
-    else hipLaunchKernelGGL((lift_digits_kernel<ShoupArith>), dim3(lift_grid), dim3(256), 0, s, d_digits, d_in2 + Ld * (size_t)n, 2 * Ld * (size_t)n, lc, (int)L, n, chunks);
-    if (int e = check_launch("lift_digits kernel launch")) return e;
-    if (int e = ntt_launch_items(c, false, d_digits, d_digits, T * Ld, 0, s)) return e;   // (per limb class where the context has them)
-    // 3. item block 0: the inputs themselves as P * ct over the extended basis
-    const unsigned idg = (unsigned)(T * 2 * L * (size_t)chunks);
-    if (c->fold) hipLaunchKernelGGL((lift_qp_kernel<FoldArith>), dim3(idg), dim3(256), 0, s, d_out_qp, d_in_ntt, lc, p_special, (int)L, n, chunks);
-    else hipLaunchKernelGGL((lift_qp_kernel<ShoupArith>), dim3(idg), dim3(256), 0, s, d_out_qp, d_in_ntt, lc, p_special, (int)L, n, chunks);
-    if (int e = check_launch("lift_qp kernel launch")) return e;
+    if (!prepared) {
+        // 1. NTT of the inputs on the data limbs (the same tables, seen as an Ld-limb context)
+        if (int e = ntt_launch_items(c, false, d_in_ntt, d_in2, T * 2, Ld, s)) return e;
+        // 2. digits of every item's c1, lifted to every limb and transformed
+        const unsigned lift_grid = (unsigned)(T * Ld * L * (size_t)chunks);
+        if (c->fold) hipLaunchKernelGGL((lift_digits_kernel<FoldArith>), dim3(lift_grid), dim3(256), 0, s, d_digits, d_in2 + Ld * (size_t)n, 2 * Ld * (size_t)n, lc, (int)L, n, chunks);
+        else hipLaunchKernelGGL((lift_digits_kernel<ShoupArith>), dim3(lift_grid), dim3(256), 0, s, d_digits, d_in2 + Ld * (size_t)n, 2 * Ld * (size_t)n, lc, (int)L, n, chunks);
+        if (int e = check_launch("lift_digits kernel launch")) return e;
+        if (int e = ntt_launch_items(c, false, d_digits, d_digits, T * Ld, 0, s)) return e;   // (per limb class where the context has them)
+        // 3. item block 0: the inputs themselves as P * ct over the extended basis
+        const unsigned idg = (unsigned)(T * 2 * L * (size_t)chunks);
+        if (c->fold) hipLaunchKernelGGL((lift_qp_kernel<FoldArith>), dim3(idg), dim3(256), 0, s, d_out_qp, d_in_ntt, lc, p_special, (int)L, n, chunks);
+        else hipLaunchKernelGGL((lift_qp_kernel<ShoupArith>), dim3(idg), dim3(256), 0, s, d_out_qp, d_in_ntt, lc, p_special, (int)L, n, chunks);
+        if (int e = check_launch("lift_qp kernel launch")) return e;
+    }
     // 4. the rotations: permuted digit segments x key segments as a stream (kernels_misc.h hoisted_qp_stream_kernel), 64 rotations per launch
     for (size_t first = 0; first < batch; first += kMaxGaloisBatch) {
         const size_t cnt = batch - first < (size_t)kMaxGaloisBatch ? batch - first : (size_t)kMaxGaloisBatch;
@@ -1268,6 +1274,11 @@ extern "C" int dpfhe_rotate_hoisted_qp(dpfhe_ctx* c, uint64_t* d_out_qp, const u
         if (int e = check_launch("hoisted_qp kernel launch")) return e;
     }
     return DPFHE_SUCCESS;
+}
+
+extern "C" int dpfhe_rotate_hoisted_qp(dpfhe_ctx* c, uint64_t* d_out_qp, const uint64_t* d_in2, size_t n_items, const uint32_t* galois_elts, const uint64_t* d_keys,
+                                       uint64_t* d_in_ntt, uint64_t* d_digits, size_t batch, void* stream) {
+    return rotate_hoisted_qp_impl(c, d_out_qp, d_in2, n_items, galois_elts, d_keys, d_in_ntt, d_digits, batch, stream, false);
 }
 
 extern "C" int dpfhe_ntt_inv_galois(dpfhe_ctx* c, uint64_t* d_out, const uint64_t* d_in, size_t rns_polys_per_elt, const uint32_t* galois_elts, size_t n_elts, void* stream) {
