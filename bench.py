@@ -1066,11 +1066,11 @@ def main():
             "arith": "fold(2^60-d)" if ctx.uses_fold else "shoup",
             "autotune": autotune,
         },
-        # `frac` keeps the contract's meaning (algorithmic bytes / launch time / HBM peak); the kernel's real bound is VALU issue,
-        # so both fractions are first-class: frac_hbm (= frac) and frac_alu (butterflies/s over the register-only ceiling).
+        # `bound` / `peak` / `frac` keep the contract's meaning (the roofline priced against: algorithmic bytes / launch time / HBM peak); what limits
+        # the kernel in practice is VALU issue (`limited_by`), so both fractions are first-class: frac_hbm (= frac) and frac_alu (butterflies/s over the register-only ceiling).
         "roofline": {
             "kernel": {"quad": "ct_mul_quad_kernel<FoldArith,12,4>", "dual": "ct_mul_dual_kernel<FoldArith,12,4,false>"}.get(autotune.get("chosen"), "ct_mul_quad_kernel<FoldArith,12,4>"),
-            "bound": "valu", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+            "bound": "hbm", "limited_by": "valu issue at the board's power cap (see frac_alu, power)", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
             "frac": achieved / HBM_PEAK, "frac_hbm": achieved / HBM_PEAK, "frac_alu": (bfly_per_s / alu_peak) if alu_peak else None,
             "traffic": traffic,
             "traffic_source": ("measured in this run: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (two separate passes of tools/live_traffic.py after the timed region: 2048-pair launches of the same kernel form), (2 x FETCH_SIZE + WRITE_SIZE) x 1024 per ct-mul x batch"

@@ -699,7 +699,7 @@ def test_bench_distributed_path_world_size_one():
     d = json.loads(line)
     assert d["n_gpus"] == 1 and d["reduce_consistent"] is True and d["value"] > 0 and d["unit"] == "ct-mul/s"
     assert set(("roofline", "config", "metric", "ms_per_step", "scaling", "dtype", "data", "allgather_us")) <= set(d)
-    assert d["roofline"]["bound"] == "valu" and d["roofline"]["frac_hbm"] == d["roofline"]["frac"] and d["allgather_us"]["median"] > 0
+    assert d["roofline"]["bound"] == "hbm" and "valu" in d["roofline"]["limited_by"] and d["roofline"]["frac_hbm"] == d["roofline"]["frac"] and d["allgather_us"]["median"] > 0
     # what the driver's record keeps: the NTT verdict inside `roofline`, the form of the multiply and its measurements inside `config`
     nv, at = d["roofline"]["ntt"], d["config"]["autotune"]
     assert 0 < nv["fwd_frac"] < 1 and 0 < nv["inv_frac"] < 1 and nv["round_trip_exact"] is True and "sustained_2s" in nv

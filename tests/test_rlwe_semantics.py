@@ -540,6 +540,11 @@ def test_gpu_hoisted_rotations_bit_exact(name):
     for r in (0, 21, 22, 63, 64, 69):
         for t in range(T):
             assert np.array_equal(got[r, t], orc.rotate_hoisted(cts[t], [elts[r]], keys[r][None], threads=0)[0]), (r, t)
+    if name == "fold14":   # the same call in slices of 3 rotations (23 slices + 1 rotation): inputs and digits are prepared by the first slice only
+        ctx.set_scratch_limit(12)
+        again = to_host(ev.rotate_hybrid_hoisted(Ciphertext(to_device(cts, ctx.device)), elts, dk).data).reshape(k, T, 2, Ld, n)
+        assert np.array_equal(again, got), "sliced hoisted rotations differ from the one-slice run"
+        ctx.set_scratch_limit(1024)
     items = data.fill(k * T * 2, 705).reshape(k * T, 2, Ld, n)
     got = to_host(ev.rotate_hybrid_grouped(Ciphertext(to_device(items, ctx.device)), elts, T, dk).data)
     for i in (0, 1, 2, 3, 63, 64, 65, 191, 192, k * T - 1):
