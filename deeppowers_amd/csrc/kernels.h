@@ -592,9 +592,7 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE), 2) void ct_mul_dual_kernel(u64*
             for (int k = 0; k < E; ++k) {
                 const u64 a0 = D0[k], b0 = D1[k];
                 if constexpr (kLazy) {
-                    D0[k] = B::prod(a0, b0, lc);
-                    D1[k] = B::prod_add(B::prod(a0, y[k], lc), B::prod(x[k], b0, lc));
-                    D2[k] = B::prod(x[k], y[k], lc);
+                    B::tensor(a0, x[k], b0, y[k], D0[k], D1[k], D2[k], lc);
                 } else {
                     D0[k] = Arith::mul_var(a0, b0, lc);
                     D1[k] = add_mod(Arith::mul_var(a0, y[k], lc), Arith::mul_var(x[k], b0, lc), lc.q);
@@ -678,9 +676,7 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE), 2) void ct_mul_quad_kernel(u64*
 #pragma unroll
     for (int k = 0; k < E; ++k) {
         const u64 a0 = x[k], b0 = y[k], a1 = z[k], b1 = w[k];
-        x[k] = B::prod(a0, b0, lc);
-        y[k] = B::prod_add(B::prod(a0, b1, lc), B::prod(a1, b0, lc));
-        z[k] = B::prod(a1, b1, lc);
+        B::tensor(a0, a1, b0, b1, x[k], y[k], z[k], lc);
     }
     const u64 ts3 = trace_stamp<TRACE>(z[E - 1]);
     constexpr bool kNtStore = true;   // the 3 GiB of products are written once and read by another kernel much later: around the Infinity Cache (-2.4 %)
@@ -1092,7 +1088,6 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE), (Arith::kFold ? 2 : 1)) void ho
 #pragma unroll
         for (int k = 0; k < E; ++k) x[k] = d[src[k]];
     }
-    int lazy_terms = 0;
 #pragma unroll 1
     for (int j = 0; j < Ld; ++j) {
         u64 en[E], xn[E];
@@ -1103,25 +1098,13 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE), (Arith::kFold ? 2 : 1)) void ho
 #pragma unroll
             for (int k = 0; k < E; ++k) xn[k] = d[src[k]];
         }
-        if (Arith::kFold) {
-            if (lazy_terms == 13) {
-#pragma unroll
-                for (int k = 0; k < E; ++k) acc[k] = FoldArith::reduce(acc[k], lc);
-                lazy_terms = 1;
-            }
-            ++lazy_terms;
-        }
 #pragma unroll
         for (int k = 0; k < E; ++k)
-            acc[k] = Arith::kFold ? acc[k] + FoldArith::mul60(x[k], e[k], (u32)lc.d) : add_mod(acc[k], Arith::mul_var(x[k], e[k], lc), lc.q);
+            acc[k] = Arith::kFold ? FoldArith::mac_var(acc[k], x[k], e[k], lc) : add_mod(acc[k], Arith::mul_var(x[k], e[k], lc), lc.q);
 #pragma unroll
         for (int k = 0; k < E; ++k) { e[k] = en[k]; x[k] = xn[k]; }
     }
-    if (Arith::kFold) {
-#pragma unroll
-        for (int k = 0; k < E; ++k) acc[k] = FoldArith::reduce(acc[k], lc);
-    }
-    constexpr int kInvIn = Arith::kFold ? 2 * kMulB : kUnit;
+    constexpr int kInvIn = Arith::kFold ? kRedB : kUnit;
     InvChain<B, B::NPH - 1, kInvIn>::run(tid, acc, lds, tb.inv4 + (size_t)limb * N, last, lc);
     B::inv_canon(acc, lc);
     B::store_top(tid, acc, work + ((item * 2 + comp) * L + limb) * N);
@@ -1175,7 +1158,7 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE), 2) void hoisted_ks2_kernel(u64*
         u64 e1[E], xn[E];
         B::load_bot(tid, e1, evk + (((size_t)j * 2 + 1) * L + limb) * N);
 #pragma unroll
-        for (int k = 0; k < E; ++k) acc0[k] += FoldArith::mul60(x[k], e[k], (u32)lc.d);
+        for (int k = 0; k < E; ++k) acc0[k] = FoldArith::mac_var(acc0[k], x[k], e[k], lc);
         const int jn = j + 1 < Ld ? j + 1 : j;
         B::load_bot(tid, e, evk + (((size_t)jn * 2 + 0) * L + limb) * N);
         {
@@ -1184,13 +1167,11 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE), 2) void hoisted_ks2_kernel(u64*
             for (int k = 0; k < E; ++k) xn[k] = d[src[k]];
         }
 #pragma unroll
-        for (int k = 0; k < E; ++k) acc1[k] += FoldArith::mul60(x[k], e1[k], (u32)lc.d);
+        for (int k = 0; k < E; ++k) acc1[k] = FoldArith::mac_var(acc1[k], x[k], e1[k], lc);
 #pragma unroll
         for (int k = 0; k < E; ++k) x[k] = xn[k];
     }
-#pragma unroll
-    for (int k = 0; k < E; ++k) { acc0[k] = FoldArith::reduce(acc0[k], lc); acc1[k] = FoldArith::reduce(acc1[k], lc); }
-    InvChain2<B, B::NPH - 1, 2 * kMulB>::run(tid, acc0, acc1, lds, lds + W, tb.inv4 + (size_t)limb * N, last, lc);
+    InvChain2<B, B::NPH - 1, kRedB>::run(tid, acc0, acc1, lds, lds + W, tb.inv4 + (size_t)limb * N, last, lc);
     B::inv_canon(acc0, lc);
     B::store_top(tid, acc0, work + ((item * 2 + 0) * L + limb) * N);
     B::inv_canon(acc1, lc);

@@ -208,6 +208,60 @@ struct FoldArith {
         const u64 R = mad32((u32)(H >> 32), 4 * (u32)c.d, L);
         return reduce(R, c);
     }
+    // ---- variable x variable products through the twiddle chain (round 6) ------------------------------------------------------
+    // One factor b (reduced: b < 2^60 + 2^29) is turned into a twiddle on the fly, then every product with it costs mul_tw's 9 instructions
+    // instead of mul60's ~25 (hipcc builds mul60's {hi, 0} addends and fold124's shifted words with v_mov / v_alignbit), and a sum of two
+    // products comes for free through the chain's addend.  8 instructions per factor, shared by all its products:
+    //   halves of b:               a = b mod 2^30,  bh = b >> 30 (<= 2^30)
+    //   companion b 2^32 mod q:    b 2^32 = (b mod 2^29) 2^32 + (b >> 29) 2^61  ==  (b mod 2^29) 2^32 + (b >> 29) 2d   (< 2^61 + 2^57), halves as', bh' (< 2^31 + 2^27)
+    // The chain with these wider halves, for ANY 64-bit y and addend < 2^62 - 2^58:
+    //   H = y0 bh + y1 bh' < 2^62 + 2^63 + 2^59;   L = H.lo 2^30 + y0 a + y1 as' + addend < 3 2^62 + addend;   R = L + H.hi 4d < 2^64  (H.hi 4d < 2^58)
+    // (mul_ptw_add checks them exactly under the emulator).
+    static DPF_HD Tw prod_tw(u64 b, const LimbConst& c) {
+        DPFHE_EMU_ASSERT(b < (1ull << 60) + (1ull << 29));
+        const u32 lo = (u32)b;
+        u32 a = lo & 0x3fffffffu, bh = (u32)(b >> 30), t29 = (u32)(b >> 29), bl = lo & 0x1fffffffu;
+#if defined(__HIP_DEVICE_COMPILE__)
+        // opaque 32-bit halves: left visible, hipcc reasons about the 64-bit shifts behind them and multiplies by 34-bit values in two steps,
+        // takes the companion's low word from a separate v_mul_lo_u32, builds {0, bl} with a move (35 instead of 8 instructions)
+        asm("" : "+v"(a), "+v"(bh), "+v"(t29), "+v"(bl));
+#endif
+        const u64 bs = add_hi32(mad32(t29, 2 * (u32)c.d, 0), bl);     // (b >> 29) 2d + (b mod 2^29) 2^32 < 2^57 + 2^61: no carry out of the high word
+        u32 as = (u32)bs & 0x3fffffffu, bsh = (u32)(bs >> 30);
+#if defined(__HIP_DEVICE_COMPILE__)
+        asm("" : "+v"(as), "+v"(bsh));
+#endif
+        Tw t;
+        t.w = (u64)a | ((u64)bh << 32);
+        t.ws = (u64)as | ((u64)bsh << 32);
+        return t;
+    }
+    // addend + y b mod q for the twiddle prod_tw made of b; result < 2^60 + 16 d
+    static DPF_HD u64 mul_ptw_add(u64 y, const Tw& t, const LimbConst& c, u64 addend) {
+        const u32 y0 = (u32)y, y1 = (u32)(y >> 32);
+        const u32 a = (u32)t.w, b = (u32)(t.w >> 32), as = (u32)t.ws, bs = (u32)(t.ws >> 32);
+#if defined(DPFHE_EMU_CHECK) && !defined(__HIPCC__)
+        {
+            typedef unsigned __int128 u128;
+            const u128 He = (u128)y0 * b + (u128)y1 * bs;
+            DPFHE_EMU_ASSERT(He >> 64 == 0);
+            const u128 Le = (u128)((u32)(u64)He) * (1u << 30) + (u128)y0 * a + (u128)y1 * as + addend;
+            DPFHE_EMU_ASSERT((Le + (u128)(u32)((u64)He >> 32) * (4 * (u32)c.d)) >> 64 == 0);
+        }
+#endif
+        const u64 H = mad32(y1, bs, mad32(y0, b, 0));
+        u32 two30 = 1u << 30;
+#if defined(__HIP_DEVICE_COMPILE__)
+        asm("s_mov_b32 %0, 0x40000000" : "=s"(two30));
+#endif
+        const u64 L = mad32(y1, as, mad32(y0, a, mad32((u32)H, two30, addend)));
+        const u64 R = mad32((u32)(H >> 32), 4 * (u32)c.d, L);
+        return reduce(R, c);
+    }
+    static DPF_HD u64 mul_ptw(u64 y, const Tw& t, const LimbConst& c) { return mul_ptw_add(y, t, c, 0); }
+    // acc + x e mod q for a key word e < 2^60 + 2^29 (canonical) and ANY 64-bit x (a lazy forward output), acc < 2^62 - 2^58: 17 instructions, result
+    // < 2^60 + 16 d - the accumulator of a key inner product stays ONE reduced word (mul60 + lazy sums: ~26 per term and a reduction every 13 terms)
+    static DPF_HD u64 mac_var(u64 acc, u64 x, u64 e, const LimbConst& c) { return mul_ptw_add(x, prod_tw(e, c), c, acc); }
     // x N^-1 mod q for N = 2^n by EXACT DIVISION instead of a twiddle product (round 4; 6 instructions against mul_tw's 9):
     // q = 1 (mod 2N), so with m = x mod N the number x - m q is divisible by N, and
     //     (x - m q) / N = (x + m d) / N - m 2^(60-n);      adding q keeps it positive:   y = ((x + m d) >> n) + (q - (m << (60 - n))).

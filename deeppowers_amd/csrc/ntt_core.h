@@ -788,7 +788,7 @@ struct NttBody {
     // inverse transform of a RAW_INV body with IN = kProdInvIn.  FoldScaledArith: a product of two scaled words carries the scale twice; the inverse
     // then runs on last-stage twiddles with s^-1 folded in (DevTables::last2).
     static constexpr bool kLazyProducts = Arith::kFoldCore || Arith::kF64;
-    static constexpr int kProdInvIn = Arith::kF64 ? 2 * kUnit : 2 * kMulB;
+    static constexpr int kProdInvIn = Arith::kF64 ? 2 * kUnit : kRedB;   // (fold: what `tensor` leaves; prod / prod_add sums stay below it only through tensor)
     static_assert(!Arith::kF64 || kFwdOutBound <= kF64Cap, "F64ArithT: |a b / q| <= |a| / 2 must stay below 2^50 for the quotient estimate of a lazy product");
     static DPF_HD void prod_partner(u64 (&y)[E], const LimbConst& lc) {
         if constexpr (Arith::kF64) {
@@ -810,6 +810,21 @@ struct NttBody {
     static DPF_HD u64 prod_add(u64 p, u64 r) {
         if constexpr (Arith::kF64) return Arith::b(Arith::f(p) + Arith::f(r));
         else return chk_add(p, r);
+    }
+    // the tensor step of one coefficient: (c0, c1, c2) = (a0 b0, a0 b1 + a1 b0, a1 b1); b0, b1 went through prod_partner.  Fold policies (round 6): each b
+    // becomes a twiddle on the fly (FoldArith::prod_tw, 8 instructions), the four products run through the twiddle chain (9 each, the sum of c1 through its
+    // addend): ~53 instructions per coefficient against ~103 with four mul60; every output is ONE reduced word (kProdInvIn = kRedB).
+    static DPF_HD void tensor(u64 a0, u64 a1, u64 b0, u64 b1, u64& c0, u64& c1, u64& c2, const LimbConst& lc) {
+        if constexpr (Arith::kFoldCore) {
+            const Tw t0 = FoldArith::prod_tw(b0, lc), t1 = FoldArith::prod_tw(b1, lc);
+            c0 = FoldArith::mul_ptw(a0, t0, lc);
+            c1 = FoldArith::mul_ptw_add(a1, t0, lc, FoldArith::mul_ptw(a0, t1, lc));
+            c2 = FoldArith::mul_ptw(a1, t1, lc);
+        } else {
+            c0 = prod(a0, b0, lc);
+            c1 = prod_add(prod(a0, b1, lc), prod(a1, b0, lc));
+            c2 = prod(a1, b1, lc);
+        }
     }
 
     // ---------------- inverse (Gentleman-Sande) phase; forward phase list walked backwards -------

@@ -276,3 +276,26 @@ def test_emulated_quarters_transform_matches_oracle(emu):
                 assert np.array_equal(out, ref(a)), (limb, inv)
     assert emu.emu_overflows() == before, "lazy arithmetic wrapped around 2^64"
     assert emu.emu_ntt_quarters(0, PRIME_30, PSI_30_N1024, None, None) == 2000   # FoldArith only
+
+
+def test_emulated_fold_products_through_the_twiddle_chain(emu):
+    """FoldArith::prod_tw + mul_ptw_add (round 6: the fused multiply's tensor step and the key products): addend + y b mod q for ANY 64-bit y, b up to
+    2^60 + 2^29 - 1 and addends up to 2^62 - 2^58, at the extremes and at random, with the exact no-wrap checks of the chain armed; d up to 2^24 - 1
+    (the scaled-fold moduli 2^60 - d are not prime: only the arithmetic modulo 2^60 - d is checked)."""
+    emu.emu_fold_ptw.argtypes = [C.c_uint64] * 4
+    emu.emu_fold_ptw.restype = C.c_uint64
+    before = emu.emu_overflows()
+    rng = np.random.default_rng(61)
+    ds = [(1 << 60) - PRIMES_60[0][0], (1 << 60) - PRIMES_60[5][0], (1 << 24) - 1, 1, (1 << 24) - (1 << 10)]
+    for d in ds:
+        q = (1 << 60) - d
+        ys = [0, 1, (1 << 64) - 1, 15 << 60, (1 << 63) + 12345, (1 << 32) - 1, ((1 << 32) - 1) << 32] + [int(v) for v in rng.integers(0, 1 << 63, 40, dtype=np.uint64)] \
+            + [int(v) | (1 << 63) for v in rng.integers(0, 1 << 63, 20, dtype=np.uint64)]
+        bs = [0, 1, q - 1, q, (1 << 60) - 1, (1 << 60) + (1 << 29) - 1, (1 << 60), (1 << 30) - 1, ((1 << 30) - 1) << 30, (1 << 29) - 1, ((1 << 31) - 1) << 29] \
+            + [int(v) for v in rng.integers(0, q, 40, dtype=np.uint64)]
+        adds = [0, (1 << 60) + 16 * d, (1 << 62) - (1 << 58) - 1, q - 1]
+        for y in ys:
+            for b in bs:
+                for add in adds:
+                    assert emu.emu_fold_ptw(d, y, b, add) == (add + y * b) % q, (d, y, b, add)
+    assert emu.emu_overflows() == before, "the chain wrapped around 2^64"

@@ -485,15 +485,12 @@ static int emu_ct_mul_lazy(u64 q, u64 psi, const u64* a0, const u64* a1, const u
         InvSteps<BI, B::NPH - 1, B::kProdInvIn>::run(regs, lds, twi.data(), wl, wn, lc);
         for (int tid = 0; tid < T; ++tid) { B::inv_canon(X(tid), lc); B::store_top(tid, X(tid), dst); }
     };
-    std::vector<u64> S0 = fwd(a0, false), S1 = fwd(b0, true), x((size_t)N);
-    for (int i = 0; i < N; ++i) x[i] = B::prod(S0[i], S1[i], lc);
-    inv(x, out3);
-    std::vector<u64> S2 = fwd(b1, true);
-    for (int i = 0; i < N; ++i) S0[i] = B::prod(S0[i], S2[i], lc);
-    x = fwd(a1, false);
-    for (int i = 0; i < N; ++i) { S0[i] = B::prod_add(S0[i], B::prod(x[i], S1[i], lc)); S2[i] = B::prod(x[i], S2[i], lc); }
-    inv(S0, out3 + N);
-    inv(S2, out3 + 2 * N);
+    // the tensor step as ct_mul_quad_kernel / ct_mul_dual_kernel run it (NttBody::tensor: fold policies turn b0, b1 into twiddles on the fly)
+    std::vector<u64> S0 = fwd(a0, false), S1 = fwd(b0, true), S2 = fwd(b1, true), S3 = fwd(a1, false), c0((size_t)N), c1((size_t)N), c2((size_t)N);
+    for (int i = 0; i < N; ++i) B::tensor(S0[i], S3[i], S1[i], S2[i], c0[i], c1[i], c2[i], lc);
+    inv(c0, out3);
+    inv(c1, out3 + N);
+    inv(c2, out3 + 2 * N);
     return 0;
 }
 template <int LOGN, int LOGE>
@@ -535,6 +532,14 @@ extern "C" int emu_lds_words(int log2n, int loge) {
     if (log2n == 13 && loge == 5) return Geo<13, 5>::lds_words();
     if (log2n == 10 && loge == 4) return Geo<10, 4>::lds_words();
     return -1;
+}
+
+// FoldArith::prod_tw / mul_ptw_add (variable x variable products through the twiddle chain): addend + y b mod q through the very code the
+// kernels run, canonicalised; d is passed so that the scaled-fold moduli (q' = 2^60 - d, not prime) can be checked as well.
+extern "C" u64 emu_fold_ptw(u64 d, u64 y, u64 b, u64 addend) {
+    LimbConst lc{};
+    lc.q = (1ull << 60) - d; lc.d = d;
+    return FoldArith::canon(FoldArith::mul_ptw_add(y, FoldArith::prod_tw(b, lc), lc, addend), lc);
 }
 
 // FoldArith::dot30_* (the plaintext matvec's column accumulators): dot product of canonical residues through the very code
