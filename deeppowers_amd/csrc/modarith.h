@@ -236,19 +236,18 @@ struct FoldArith {
         t.ws = (u64)as | ((u64)bsh << 32);
         return t;
     }
+    // (emulator only) the chain below in exact arithmetic: neither H nor R = L + H.hi 4d leaves 64 bits
+    static DPF_HD bool ptw_fits(u32 y0, u32 y1, u32 a, u32 b, u32 as, u32 bs, u64 addend, u32 d) {
+        typedef unsigned __int128 u128;
+        const u128 H = (u128)y0 * b + (u128)y1 * bs;
+        const u128 L = (u128)((u32)(u64)H) * (1u << 30) + (u128)y0 * a + (u128)y1 * as + addend;
+        return (H >> 64) == 0 && ((L + (u128)(u32)((u64)H >> 32) * (4 * d)) >> 64) == 0;
+    }
     // addend + y b mod q for the twiddle prod_tw made of b; result < 2^60 + 16 d
     static DPF_HD u64 mul_ptw_add(u64 y, const Tw& t, const LimbConst& c, u64 addend) {
         const u32 y0 = (u32)y, y1 = (u32)(y >> 32);
         const u32 a = (u32)t.w, b = (u32)(t.w >> 32), as = (u32)t.ws, bs = (u32)(t.ws >> 32);
-#if defined(DPFHE_EMU_CHECK) && !defined(__HIPCC__)
-        {
-            typedef unsigned __int128 u128;
-            const u128 He = (u128)y0 * b + (u128)y1 * bs;
-            DPFHE_EMU_ASSERT(He >> 64 == 0);
-            const u128 Le = (u128)((u32)(u64)He) * (1u << 30) + (u128)y0 * a + (u128)y1 * as + addend;
-            DPFHE_EMU_ASSERT((Le + (u128)(u32)((u64)He >> 32) * (4 * (u32)c.d)) >> 64 == 0);
-        }
-#endif
+        DPFHE_EMU_ASSERT(ptw_fits(y0, y1, a, b, as, bs, addend, (u32)c.d));
         const u64 H = mad32(y1, bs, mad32(y0, b, 0));
         u32 two30 = 1u << 30;
 #if defined(__HIP_DEVICE_COMPILE__)
