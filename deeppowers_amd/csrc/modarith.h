@@ -11,7 +11,8 @@
 //                lets butterflies run without per-stage corrections (static bound plans in
 //                ntt_core.h).  Twiddle multiplies use a split companion table (w and w 2^32 mod q in
 //                30-bit halves): 7 v_mad_u64_u32 + 2 cheap ops, every addend a natural 64-bit
-//                register pair.  Variable x variable products (dyadic) use mul60: 7 + 8 ops.
+//                register pair.  Variable x variable products: mul60 (7 multiply-adds + the folds' shifts), or one
+//                factor turned into such a twiddle on the fly (prod_tw / mul_ptw_add: the fused multiply's tensor step).
 //
 // Everything is written on 32-bit halves through mad32(a,b,c) = a*b + c, which is exactly one
 // v_mad_u64_u32 on gfx950 (there is no 64x64 vector multiply on CDNA4).
