@@ -595,7 +595,8 @@ static int for_each_class(const dpfhe_ctx* c, size_t limbs_used, Fn fn) {
 
 // The policy of the KEY-SWITCHING kernels (relin_kernel, hoisted_ks_kernel, ntt_inv_galois_kernel): fold for the pinned primes; the class's own for a
 // context whose limbs all share one class (round 6: the generic forms of those kernels with that class's transforms and products - an all-f64 context no
-// longer key-switches at the generic kernels' rate); the generic policy on the complete generic tables for a mixture.  fn(tables) launches.
+// longer key-switches at the generic kernels' rate); the generic policy on the complete generic tables otherwise (a MIXTURE of classes does not come here for
+// its transform-bearing kernels: relin_launch / with_policy_or_classes below launch once per class).  fn(tables) launches.
 template <class Fn>
 static int with_policy(const dpfhe_ctx* c, Fn fn) {
     if (c->fold) return fn(c->foldt);
