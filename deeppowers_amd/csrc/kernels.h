@@ -637,7 +637,7 @@ __device__ __forceinline__ u64 trace_stamp(u64 dep) {
     if constexpr (TRACE) asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) : "v"(dep) : "memory");
     return t;
 }
-template <class Arith, int LOGN, int LOGE, bool TRACE = false>
+template <class Arith, int LOGN, int LOGE, bool TRACE = false, bool OUT_NTT = false>
 __global__ __launch_bounds__(1 << (LOGN - LOGE), 2) void ct_mul_quad_kernel(u64* __restrict__ out3, const u64* __restrict__ a2,
                                                                          const u64* __restrict__ b2, DevTables<Arith> tb, u64* __restrict__ trace = nullptr) {
     typedef NttBody<Arith, LOGN, LOGE> B;
@@ -679,6 +679,17 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE), 2) void ct_mul_quad_kernel(u64*
         B::tensor(a0, a1, b0, b1, x[k], y[k], z[k], lc);
     }
     const u64 ts3 = trace_stamp<TRACE>(z[E - 1]);
+    if constexpr (OUT_NTT) {
+        // round 6: the products stay in the NTT domain (DPFHE_OUT_NTT: a caller that sums them there and transforms the total back - the inverse transform
+        // is linear - never runs 3 of the 7 transforms per pair): canonical words in forward-output order
+        static_assert(Arith::kFold && !TRACE, "the pinned primes (the products of a scaled-fold limb carry the scale twice)");
+#pragma unroll
+        for (int k = 0; k < E; ++k) { x[k] = FoldArith::canon_small(x[k], lc); y[k] = FoldArith::canon_small(y[k], lc); z[k] = FoldArith::canon_small(z[k], lc); }
+        B::store_bot(tid, x, dst);
+        B::store_bot(tid, y, dst + cstride);
+        B::store_bot(tid, z, dst + 2 * cstride);
+        return;
+    }
     constexpr bool kNtStore = true;   // the 3 GiB of products are written once and read by another kernel much later: around the Infinity Cache (-2.4 %)
     InvChain3<BI, B::NPH - 1, kInvIn>::run(tid, x, y, z, lds, lds + W, tb.inv4 + (size_t)limb * N, last, lc);
     const u64 ts4 = trace_stamp<TRACE>(z[E - 1]);

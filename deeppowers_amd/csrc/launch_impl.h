@@ -136,6 +136,8 @@ static int launch_ct_mul_dom(int log2n, u64* out3, const u64* a2, const u64* b2,
 #define CT_CASE(LN, LE)                                                                                                                              \
     if constexpr (Arith::kFoldCore && !IN_NTT && !OUT_NTT && LN <= kQuadMaxLogN)   /* (F64Arith's quad form spills: pairs) */                                           \
         hipLaunchKernelGGL((ct_mul_quad_kernel<Arith, LN, kFusedLoge>), dim3((unsigned)blocks), dim3(Geo<LN, kFusedLoge>::T), 0, s, out3, a2, b2, tb, (u64*)nullptr); \
+    else if constexpr (Arith::kFold && !IN_NTT && OUT_NTT && LN <= kQuadMaxLogN)   /* round 6: four shared forward transforms + the lazy tensor step, products left in the NTT domain */ \
+        hipLaunchKernelGGL((ct_mul_quad_kernel<Arith, LN, kFusedLoge, false, true>), dim3((unsigned)blocks), dim3(Geo<LN, kFusedLoge>::T), 0, s, out3, a2, b2, tb, (u64*)nullptr); \
     else if constexpr ((Arith::kFoldCore || Arith::kF64) && !IN_NTT && LN <= kDualMaxLogN)                                                                                                     \
         hipLaunchKernelGGL((ct_mul_dual_kernel<Arith, LN, kFusedLoge, OUT_NTT>), dim3((unsigned)blocks), dim3(Geo<LN, kFusedLoge>::T), 0, s, out3, a2, b2, tb); \
     else                                                                                                                                             \

@@ -142,12 +142,16 @@ class ShardedMultiplyReduce:
     Two output buffers and two HIP streams: the (VALU-bound) multiply of step i+1 runs on `main` while the (HBM-bound)
     shard-local reduce + all-gather + final sum of step i run on `side`.  No allocation after construction."""
 
-    def __init__(self, ev, batch: int, group=None, comm: NativeComm | None = None, main=None, collective: str = "allgather", outs=None):
+    def __init__(self, ev, batch: int, group=None, comm: NativeComm | None = None, main=None, collective: str = "allgather", outs=None, sum_in_ntt_domain: bool = False):
         """collective: "allgather" (one partial per rank gathered, summed locally - the north star's exchange) or "allreduce" (SURVEY.md 8(e)'s alternative:
-        a 64-bit sum all-reduce of the partials in place + one mod-q pass; world <= 15).  Same words either way."""
+        a 64-bit sum all-reduce of the partials in place + one mod-q pass; world <= 15).  Same words either way.
+        sum_in_ntt_domain: for a caller who needs ONLY the sum - the inverse transform is linear, so the products are left in the NTT domain
+        (dpfhe_ct_mul with DPFHE_OUT_NTT: 4 forward transforms + the tensor step per pair), summed there, and the total alone is transformed back: the
+        same total, 3 of 7 transforms per pair never run.  NOT the metric op (whose products are coefficient-domain ciphertexts): outs[k] then holds
+        NTT-domain products."""
         if collective not in ("allgather", "allreduce"):
             raise ValueError("collective must be 'allgather' or 'allreduce'")
-        self.ev, self.group, self.comm, self.collective = ev, group, comm, collective
+        self.ev, self.group, self.comm, self.collective, self.sum_in_ntt_domain = ev, group, comm, collective, bool(sum_in_ntt_domain)
         ctx = ev.ctx
         self.world = comm.world if comm is not None else (dist.get_world_size(group) if dist.is_initialized() else 1)
         p = ctx.params
@@ -171,7 +175,7 @@ class ShardedMultiplyReduce:
         self.main.wait_event(self.red_done[k])              # the reduce that read outs[k] two steps ago has finished
         if timing is not None:
             timing[0].record(self.main)
-        c = ev.multiply(a, b, out=self.outs[k], stream=self.main)
+        c = ev.multiply(a, b, out=self.outs[k], out_ntt=True if self.sum_in_ntt_domain else None, stream=self.main)
         if timing is not None:
             timing[1].record(self.main)
         self.mul_done[k].record(self.main)
@@ -190,6 +194,8 @@ class ShardedMultiplyReduce:
                     ev.canonicalize_sum_(self.totals[k], stream=self.side)
                 if self.gather_events is not None:
                     self.gather_events[1].record(self.side)
+                if self.sum_in_ntt_domain:
+                    ev.ntt_inverse_(self.totals[k], stream=self.side)
                 self.red_done[k].record(self.side)
                 return k
             if self.comm is not None:
@@ -202,5 +208,7 @@ class ShardedMultiplyReduce:
             if self.gather_events is not None:
                 self.gather_events[1].record(self.side)
             ev.reduce_sum(Ciphertext(g, c.is_ntt), out=self.totals[k], stream=self.side)
+            if self.sum_in_ntt_domain:
+                ev.ntt_inverse_(self.totals[k], stream=self.side)   # the ONE inverse transform of the step: 3 L residue polynomials
         self.red_done[k].record(self.side)
         return k

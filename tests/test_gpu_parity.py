@@ -810,3 +810,31 @@ print("SLICED-OK")
     env = dict(os.environ, PYTHONPATH=root)
     run = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env, cwd=root)
     assert run.returncode == 0 and "SLICED-OK" in run.stdout, run.stdout + run.stderr
+
+
+def test_sum_in_ntt_domain_gives_the_same_total():
+    """ShardedMultiplyReduce(sum_in_ntt_domain=True): products left in the NTT domain (dpfhe_ct_mul, DPFHE_OUT_NTT), summed there, ONE inverse transform of
+    the total - the inverse transform is linear and every word canonical, so the total equals the coefficient-domain pipeline's and the oracle's word for word."""
+    from deeppowers_amd.evaluator import Ciphertext, Context, Evaluator, to_device, to_host
+    from deeppowers_amd.sharding import ShardedMultiplyReduce
+    p = FheParams.n4096_l4()
+    orc = Oracle.from_params(p)
+    batch = 37
+    a = orc.fill(batch * 2, 311).reshape(batch, 2, p.n_limbs, p.n)
+    b = orc.fill(batch * 2, 312).reshape(batch, 2, p.n_limbs, p.n)
+    a[0, :, :, : p.n // 2] = np.array(p.moduli, np.uint64)[None, :, None] - np.uint64(1)
+    ctx = Context(p, 0)
+    ev = Evaluator(ctx)
+    try:
+        da, db = Ciphertext(to_device(a, ctx.device)), Ciphertext(to_device(b, ctx.device))
+        plain = ShardedMultiplyReduce(ev, batch)
+        k0 = plain.step(da, db)
+        lazy = ShardedMultiplyReduce(ev, batch, sum_in_ntt_domain=True)
+        k1 = k1b = lazy.step(da, db)
+        k1b = lazy.step(da, db)          # second buffer as well
+        torch.cuda.synchronize()
+        want = orc.reduce_sum(orc.ct_mul(a, b, threads=0).ravel(), 3)
+        got0, got1, got1b = (to_host(t).reshape(want.shape) for t in (plain.totals[k0], lazy.totals[k1], lazy.totals[k1b]))
+        assert np.array_equal(got0, want) and np.array_equal(got1, want) and np.array_equal(got1b, want)
+    finally:
+        ctx.close()
