@@ -565,7 +565,9 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE), 2) void ct_mul_dual_kernel(u64*
     const u64* src_b = b2 + ((bi * 2) * L + limb) * N;
     u64* dst = out3 + ((bi * 3) * L + limb) * N;
     const size_t cstride = L * N;
-    constexpr bool kLazy = B::kLazyProducts && !OUT_NTT;   // products of forward outputs as the transforms left them, straight into the inverse (ntt_core.h prod)
+    // products of forward outputs as the transforms left them (ntt_core.h tensor), straight into the inverse - or, FoldArith with NTT-domain output (round 6),
+    // canonicalised and stored
+    constexpr bool kLazy = B::kLazyProducts && (!OUT_NTT || Arith::kFold);
     typedef NttBody<Arith, LOGN, LOGE, 0, kUnit, kLazy> BI;  // the inverse transforms' body: no entry conversion in front of lazy products
     constexpr bool kScaledProducts = kLazy && Arith::kFoldCore && !Arith::kFold;   // FoldScaledArith: the products carry the scale twice
     const InvLast<typename B::Tw> last = kScaledProducts ? tb.last2[limb] : tb.last[limb];
@@ -602,6 +604,10 @@ __global__ __launch_bounds__(1 << (LOGN - LOGE), 2) void ct_mul_dual_kernel(u64*
         }
     }
     if (OUT_NTT) {
+        if constexpr (kLazy) {
+#pragma unroll
+            for (int k = 0; k < E; ++k) { D0[k] = FoldArith::canon_small(D0[k], lc); D1[k] = FoldArith::canon_small(D1[k], lc); D2[k] = FoldArith::canon_small(D2[k], lc); }
+        }
         B::store_bot(tid, D0, dst);
         B::store_bot(tid, D1, dst + cstride);
         B::store_bot(tid, D2, dst + 2 * cstride);
