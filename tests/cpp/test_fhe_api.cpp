@@ -17,6 +17,7 @@ void orc_fill_splitmix(const orc_ctx* c, uint64_t* out, size_t n_rns_polys, uint
 void orc_ct_mul(const orc_ctx* c, uint64_t* out3, const uint64_t* a2, const uint64_t* b2, size_t batch, int threads);
 void orc_ntt_fwd(const orc_ctx* c, uint64_t* io, size_t n_rns_polys, int threads);
 void orc_relinearize(const orc_ctx* c, uint64_t* out2, const uint64_t* in3, const uint64_t* evk, size_t batch, int threads);
+void orc_reduce_sum(const orc_ctx* c, uint64_t* out, const uint64_t* in, size_t count, size_t comps);
 void orc_matvec_plain(const orc_ctx* c, uint64_t* y, const uint64_t* W, const uint64_t* x, size_t rows, size_t cols, size_t comps, int threads);
 }
 
@@ -45,6 +46,20 @@ static void run(const FheParams& p, size_t batch) {
     ctx.synchronize();
     C.copy_to_host(got.data());
     CHECK(std::memcmp(got.data(), want.data(), want.size() * 8) == 0);
+
+    // the SUM of the products taken in the NTT domain (coefficient-domain operands, NTT-domain products, ONE inverse transform of the sum): the inverse
+    // transform is linear, so this is the sum of the coefficient-domain products word for word
+    {
+        std::vector<uint64_t> s_want(3 * L * n), s_got(s_want.size());
+        orc_reduce_sum(orc, s_want.data(), want.data(), batch, 3);
+        Ciphertext Cs(ctx, 3, batch, /*is_ntt=*/true), S(ctx, 3, 1, /*is_ntt=*/true);
+        ev.multiply(A, B, Cs);
+        ev.reduce_sum(Cs, S);
+        ev.transform_from_ntt_inplace(S);
+        ctx.synchronize();
+        S.copy_to_host(s_got.data());
+        CHECK(!S.is_ntt() && s_got == s_want);
+    }
 
     // NTT-domain route: transform, multiply with an NTT-domain output, transform back
     ev.transform_to_ntt_inplace(A);
